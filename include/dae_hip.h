@@ -1,0 +1,172 @@
+/*
+ * dae_hip.h -- C ABI of libdae_hip.so: the MI355X (gfx950) implementation of the
+ * multi-hot denoising-autoencoder scoring path of hojinYang/spotify_recSys_challenge_2018.
+ *
+ * The reference has no FFI: its boundary is `sess.run(model.y_pred | [optimizer, cost], feed_dict)`
+ * on the TF1 graph built in models/DAEs.py.  Each entry point below names the graph section
+ * (reference file:line) it replaces.  A reference maintainer binds these with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; dae_last_error(ctx) gives the message;
+ *   - all data pointers are CALLER-OWNED DEVICE pointers (e.g. torch tensors); the library only
+ *     allocates scratch inside the ctx (grown lazily, never inside a steady-state call once sized);
+ *   - all work is enqueued on the ctx stream (dae_set_stream), no hidden synchronisation;
+ *   - one ctx is not thread-safe; independent ctxs are;
+ *   - indices are int32, values fp32; rows = playlists, columns = item ids (tracks then artists).
+ *
+ * Numerics contract (DESIGN.md "canonical order"): the fp32 path is bit-reproducible and equals
+ * oracle/dae_oracle.c bit-for-bit: encode = fmaf chain over the de-duplicated non-zeros in
+ * ascending column order; decode = fmaf chain over k = 0..H-1 (v_mfma_f32_32x32x2_f32 is exactly
+ * that chain); ranking key = (fp32 logit desc, column index asc); scores = dae canonical sigmoid.
+ */
+#ifndef DAE_HIP_H
+#define DAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dae_ctx dae_ctx;
+
+/* error codes */
+#define DAE_OK            0
+#define DAE_ERR_ARG      -1   /* bad argument (shape, alignment, null pointer)           */
+#define DAE_ERR_HIP      -2   /* a HIP runtime call failed                                */
+#define DAE_ERR_NOMEM    -3   /* scratch allocation failed                                */
+#define DAE_ERR_STATE    -4   /* call sequence error (e.g. weights not prepacked)         */
+
+/* what dae_decode_topk / dae_topk_* write into out_score */
+#define DAE_OUT_SCORE     0   /* canonical sigmoid(logit)  (what the reference ranks on)  */
+#define DAE_OUT_LOGIT     1   /* raw fp32 logit (needed when shards are merged later)     */
+
+/* decode arithmetic */
+#define DAE_DTYPE_F32     0   /* v_mfma_f32_32x32x2_f32, exact fp32, bit-equal to oracle  */
+#define DAE_DTYPE_BF16    1   /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (cfg 5)        */
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* library ABI version (major*1000 + minor). */
+int dae_version(void);
+
+/* Create a context bound to HIP device `device`.  Replaces tf.Session() (main_challenge.py:66,
+ * main_train.py:172). */
+int dae_create(int device, dae_ctx** out);
+int dae_destroy(dae_ctx* ctx);
+
+/* Stream all later calls are enqueued on (a hipStream_t passed as void*; NULL = default stream). */
+int dae_set_stream(dae_ctx* ctx, void* hip_stream);
+
+/* Last error message of this ctx (never NULL). dae_last_error(NULL) = last creation error. */
+const char* dae_last_error(const dae_ctx* ctx);
+
+/* Bytes of device scratch currently held by the ctx. */
+size_t dae_scratch_bytes(const dae_ctx* ctx);
+
+/* Per-kernel timing for roofline reporting: when enabled, the dominant kernel of each
+ * dae_decode_* call is bracketed by hipEvents on the ctx stream.  dae_profile_read
+ * synchronises those events and returns total milliseconds and the launch count, then resets. */
+int dae_profile_enable(dae_ctx* ctx, int on);
+int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches);
+
+/* Geometry of the last dae_decode_topk issued from the calling thread, for roofline accounting:
+ * {R_TILE, n_row_groups, blocks_per_row_group, sample_stride S, n_sample_tiles (phase A),
+ *  n_filter_tiles (phase B), fused(0/1), n_tiles}.  A tile is 32 vocabulary columns. */
+int dae_last_plan(int32_t out[8]);
+
+/* ---- input: COO -> CSR (DAEs.py:33-38 SparseTensor + sparse_tensor_to_dense) --------------- */
+
+/* The reference feeds COO (row, col) pairs with duplicates and ASSIGNMENT semantics
+ * (last occurrence wins).  The host shim (models/DAEs.py of this repo) de-duplicates and sorts
+ * them into CSR (row_ptr[B+1], col ascending per row, val).  All encode/train entry points take
+ * that CSR. */
+
+/* ---- encode (DAEs.py:40-42 dropout+normalise, :64-70 encoder) ----------------------------- */
+
+/* h[r,:] = hidden_dropout( sigmoid( sum_c (x[r,c]/(s_r+1e-10)) * W_enc[c,:] + b_enc ) )
+ *   x      = input_dropout(CSR row r), s_r = sum of surviving weights.
+ *   ikp/kp = input / hidden keep probabilities (1.0 = identity, the inference setting);
+ *   seed   = counter-based RNG seed for both dropouts (ignored when ikp == kp == 1).
+ * W_enc [V,H] row-major fp32, b_enc [H], h_out [B,H] row-major fp32.  H % 4 == 0. */
+int dae_encode(dae_ctx* ctx,
+               const int32_t* row_ptr, const int32_t* col, const float* val,
+               const float* W_enc, const float* b_enc,
+               int V, int H, int B,
+               float ikp, float kp, uint32_t seed,
+               float* h_out);
+
+/* ---- decoder weights ------------------------------------------------------------------------ */
+
+/* Re-tile W_dec[col_lo:col_hi, :] (row-major [V,H] fp32, DAEs.py:123 / tied :54) and
+ * b_dec[col_lo:col_hi] into the MFMA operand order the decode kernels stream (DESIGN.md "HBM
+ * layout").  Call once per weight update (model load / after a training epoch); the packed copy
+ * lives in the ctx.  dtype selects the fp32 or bf16 packed image (both may be resident). */
+int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec,
+                        int V, int H, int col_lo, int col_hi, int dtype);
+
+/* ---- decode (DAEs.py:73-77 tied / :141-145 untied) ---------------------------------------- */
+
+/* out[r, c-col_lo] = (apply_sigmoid ? sigmoid : id)( h[r,:] . W_dec[c,:] + b_dec[c] )
+ * for c in the prepacked range.  out is [B, ld_out] fp32 with ld_out >= col_hi-col_lo.
+ * This is the reference's y_pred (main_train.py:66, main_challenge.py:80). */
+int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype,
+                     int apply_sigmoid, float* out, int64_t ld_out);
+
+/* ---- rank (main_challenge.py:26-36, :87; metrics.py:59-68) ------------------------------- */
+
+/* Fused decode + top-k over the prepacked column range restricted to track columns
+ * (c < n_tracks, main_challenge.py:87), excluding each row's seed tracks
+ * (seed_row_ptr[B+1], seed_col sorted ascending & unique per row; may be NULL = no seeds).
+ * Order: logit descending, then column index ascending.  Writes k entries per row:
+ * out_idx[r, i] = GLOBAL column id (or -1 when fewer than k candidates exist, as the reference's
+ * cand[:500] of a short list), out_score per `out_kind`.  1 <= k <= 1024. */
+int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype,
+                    int n_tracks,
+                    const int32_t* seed_row_ptr, const int32_t* seed_col,
+                    int k, int out_kind,
+                    float* out_score, int32_t* out_idx);
+
+/* Unfused ranking of caller-provided dense logits/scores [B, ld] whose column 0 is global
+ * column `col_base`; ranks columns [0, ncols).  Same order/seed rules as dae_decode_topk.
+ * (parity path: dae_decode_dense + dae_topk_dense must equal dae_decode_topk.) */
+int dae_topk_dense(dae_ctx* ctx, const float* logits, int64_t ld, int B, int ncols, int col_base,
+                   const int32_t* seed_row_ptr, const int32_t* seed_col,
+                   int k, int out_kind, float* out_score, int32_t* out_idx);
+
+/* Merge G per-shard candidate lists (as produced with DAE_OUT_LOGIT, gathered by RCCL
+ * all-gather into cand_logit/cand_idx [G, B, k]) into the global top-k.  idx == -1 entries are
+ * ignored. */
+int dae_topk_merge(dae_ctx* ctx, int G, int B, int k,
+                   const float* cand_logit, const int32_t* cand_idx,
+                   int out_kind, float* out_score, int32_t* out_idx);
+
+/* ---- training step (DAEs.py:98-102) ------------------------------------------------------ */
+
+/* Forward + loss + backward for one batch.  x_* = input CSR (after the host coin flip
+ * tracks-only / artists-only, main_train.py:202-213), y_* = target CSR (values are the y_ones
+ * of the feed).  n_batch = the fixed graph batch the mean divides by (DAEs.py:100).
+ * tied != 0: W_dec aliases W_enc (DAE_tied); gW_dec is then ignored and gW_enc receives both
+ * gradients.  Gradients are dense fp32 buffers the caller owns (overwritten).
+ * cost_out: device scalar = mean_rows(L) + reg_lambda * l2 (DAEs.py:79-82/:147-150, :100). */
+int dae_train_forward_backward(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+        int V, int H, int B, int n_batch, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec,
+        float* cost_out);
+
+/* TF1 AdamOptimizer update (DAEs.py:102): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+ * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr_t*m/(sqrt(v)+eps).  Dense over n elements.
+ * t = 1-based step count. */
+int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad,
+                  int64_t n, float lr, float beta1, float beta2, float eps, int t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAE_HIP_H */

@@ -1,0 +1,175 @@
+"""ctypes binding of libdae_hip.so (C ABI: include/dae_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
+
+DAE_OUT_SCORE, DAE_OUT_LOGIT = 0, 1
+DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
+
+# every symbol include/dae_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = [
+    "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
+    "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
+    "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
+    "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward", "dae_adam_step",
+]
+
+_lib = None
+
+
+class DaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdae_hip.so; raise loudly if it has not been built (python -m <pkg>.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DaeError(
+            "libdae_hip.so not found at %s -- build it with "
+            "`python -m spotify_recsys_challenge_2018_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the scoring path." % LIB_PATH)
+    # torch must come first: it brings its own libamdhip64; loading ours before it puts two HIP
+    # runtimes in the process and the second one finds no device.
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    c_int, c_i64, c_f, c_u32, vp = (ctypes.c_int, ctypes.c_int64, ctypes.c_float,
+                                    ctypes.c_uint32, ctypes.c_void_p)
+    lib.dae_version.restype = c_int
+    lib.dae_create.argtypes = [c_int, ctypes.POINTER(vp)]
+    lib.dae_destroy.argtypes = [vp]
+    lib.dae_set_stream.argtypes = [vp, vp]
+    lib.dae_last_error.argtypes = [vp]
+    lib.dae_last_error.restype = ctypes.c_char_p
+    lib.dae_scratch_bytes.argtypes = [vp]
+    lib.dae_scratch_bytes.restype = ctypes.c_size_t
+    lib.dae_profile_enable.argtypes = [vp, c_int]
+    lib.dae_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
+    lib.dae_last_plan.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
+    lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
+    lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
+    lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
+    lib.dae_topk_dense.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
+    lib.dae_topk_merge.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]
+    lib.dae_train_forward_backward.argtypes = (
+        [vp] + [vp] * 6 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 5)
+    lib.dae_adam_step.argtypes = [vp, vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_int]
+    for name in EXPORTS:
+        if name not in ("dae_last_error", "dae_scratch_bytes"):
+            getattr(lib, name).restype = c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Context:
+    """Owns one dae_ctx bound to a device + the caller's current torch stream."""
+
+    def __init__(self, device_index=0):
+        import torch
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise DaeError("no GPU visible: the DAE scoring path runs only on MI355X (gfx950)")
+        h = ctypes.c_void_p()
+        rc = self.lib.dae_create(int(device_index), ctypes.byref(h))
+        if rc != 0:
+            raise DaeError("dae_create failed (%d): %s"
+                           % (rc, self.lib.dae_last_error(None).decode()))
+        self.h = h
+        self.device_index = int(device_index)
+        self.bind_stream()
+
+    def bind_stream(self):
+        import torch
+        s = torch.cuda.current_stream(self.device_index).cuda_stream
+        self.check(self.lib.dae_set_stream(self.h, ctypes.c_void_p(s)))
+
+    def check(self, rc):
+        if rc != 0:
+            raise DaeError("libdae_hip error %d: %s"
+                           % (rc, self.lib.dae_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thin wrappers (torch CUDA tensors in, results written into caller tensors) ------------
+    def encode(self, row_ptr, col, val, W_enc, b_enc, h_out, ikp=1.0, kp=1.0, seed=0):
+        V, H = W_enc.shape
+        B = row_ptr.numel() - 1
+        self.check(self.lib.dae_encode(self.h, _ptr(row_ptr), _ptr(col), _ptr(val), _ptr(W_enc),
+                                       _ptr(b_enc), V, H, B, float(ikp), float(kp),
+                                       int(seed) & 0xFFFFFFFF, _ptr(h_out)))
+
+    def prepack_decoder(self, W_dec, b_dec, col_lo=0, col_hi=None, dtype=DAE_DTYPE_F32):
+        V, H = W_dec.shape
+        if col_hi is None:
+            col_hi = V
+        self.check(self.lib.dae_prepack_decoder(self.h, _ptr(W_dec), _ptr(b_dec), V, H,
+                                                int(col_lo), int(col_hi), int(dtype)))
+
+    def decode_dense(self, h, out, apply_sigmoid=True, dtype=DAE_DTYPE_F32):
+        B, H = h.shape
+        self.check(self.lib.dae_decode_dense(self.h, _ptr(h), B, H, int(dtype),
+                                             1 if apply_sigmoid else 0, _ptr(out),
+                                             int(out.stride(0))))
+
+    def decode_topk(self, h, n_tracks, seed_row_ptr, seed_col, k, out_score, out_idx,
+                    out_kind=DAE_OUT_SCORE, dtype=DAE_DTYPE_F32):
+        B, H = h.shape
+        self.check(self.lib.dae_decode_topk(self.h, _ptr(h), B, H, int(dtype), int(n_tracks),
+                                            _ptr(seed_row_ptr), _ptr(seed_col), int(k),
+                                            int(out_kind), _ptr(out_score), _ptr(out_idx)))
+
+    def topk_dense(self, logits, ncols, col_base, seed_row_ptr, seed_col, k, out_score, out_idx,
+                   out_kind=DAE_OUT_SCORE):
+        B = logits.shape[0]
+        self.check(self.lib.dae_topk_dense(self.h, _ptr(logits), int(logits.stride(0)), B,
+                                           int(ncols), int(col_base), _ptr(seed_row_ptr),
+                                           _ptr(seed_col), int(k), int(out_kind),
+                                           _ptr(out_score), _ptr(out_idx)))
+
+    def topk_merge(self, cand_logit, cand_idx, out_score, out_idx, out_kind=DAE_OUT_SCORE):
+        G, B, k = cand_logit.shape
+        self.check(self.lib.dae_topk_merge(self.h, G, B, k, _ptr(cand_logit), _ptr(cand_idx),
+                                           int(out_kind), _ptr(out_score), _ptr(out_idx)))
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.dae_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_int()
+        self.check(self.lib.dae_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def last_plan(self):
+        arr = (ctypes.c_int32 * 8)()
+        self.lib.dae_last_plan(arr)
+        keys = ["R_TILE", "n_rg", "nb_rg", "S", "n_sample_tiles", "n_filter_tiles", "fused",
+                "n_tiles"]
+        return dict(zip(keys, list(arr)))
+
+    def scratch_bytes(self):
+        return int(self.lib.dae_scratch_bytes(self.h))

@@ -1,0 +1,359 @@
+// api.hip -- the C ABI of libdae_hip.so (include/dae_hip.h): context, scratch, and the launch
+// sequences of the scoring path.  No kernel lives here.
+#include <stdarg.h>
+
+#include <climits>
+
+#include "dae_internal.h"
+
+thread_local std::string g_dae_create_err;
+
+int dae_fail(dae_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_dae_create_err = buf;
+    return code;
+}
+
+int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes)
+{
+    if (bytes <= b.bytes && b.p) return DAE_OK;
+    if (bytes == 0) bytes = 16;
+    if (b.p) {
+        // growing: drain the stream first, the old buffer may still be in use
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return dae_fail(ctx, DAE_ERR_HIP, "sync before regrow: %s", hipGetErrorString(e));
+        (void)hipFree(b.p);
+        ctx->scratch_total -= b.bytes;
+        b.p = nullptr; b.bytes = 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return dae_fail(ctx, DAE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    b.p = p; b.bytes = bytes;
+    ctx->scratch_total += bytes;
+    return DAE_OK;
+}
+
+namespace {
+
+struct Plan {            // geometry of the last dae_decode_topk call (dae_last_plan)
+    int R_TILE, n_rg, nb_rg, S, n_samp, n_other, fused, ntiles;
+};
+thread_local Plan g_plan = {0, 0, 0, 0, 0, 0, 0, 0};
+
+int prof_begin(dae_ctx* ctx)
+{
+    if (!ctx->prof_on) return DAE_OK;
+    if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t ev;
+            DAE_HIP_CHECK(ctx, hipEventCreate(&ev));
+            ctx->prof_ev.push_back(ev);
+        }
+    }
+    DAE_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used], ctx->stream));
+    return DAE_OK;
+}
+int prof_end(dae_ctx* ctx)
+{
+    if (!ctx->prof_on) return DAE_OK;
+    DAE_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used + 1], ctx->stream));
+    ctx->prof_used += 2;
+    return DAE_OK;
+}
+
+const dae_packed* packed_for(dae_ctx* ctx, int dtype, int H)
+{
+    const dae_packed* pk = dtype == DAE_DTYPE_F32 ? &ctx->pk_f32 : &ctx->pk_bf16;
+    if (!pk->valid) { dae_fail(ctx, DAE_ERR_STATE, "decoder weights not prepacked for dtype %d", dtype); return nullptr; }
+    if (pk->H != H) { dae_fail(ctx, DAE_ERR_ARG, "H=%d does not match prepacked H=%d", H, pk->H); return nullptr; }
+    return pk;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dae_version(void) { return 1000; }
+
+int dae_create(int device, dae_ctx** out)
+{
+    if (!out) return dae_fail(nullptr, DAE_ERR_ARG, "out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return dae_fail(nullptr, DAE_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return dae_fail(nullptr, DAE_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return dae_fail(nullptr, DAE_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return dae_fail(nullptr, DAE_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return dae_fail(nullptr, DAE_ERR_HIP, "device %d is %s; this library is built for gfx950 only",
+                        device, prop.gcnArchName);
+    dae_ctx* c = new dae_ctx();
+    c->device = device;
+    *out = c;
+    return DAE_OK;
+}
+
+int dae_destroy(dae_ctx* ctx)
+{
+    if (!ctx) return DAE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias,
+                       &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
+                       &ctx->cand_cnt, &ctx->dense_tmp, &ctx->train_a, &ctx->train_b,
+                       &ctx->train_c, &ctx->train_d};
+    for (dae_buf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
+    delete ctx;
+    return DAE_OK;
+}
+
+int dae_set_stream(dae_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return DAE_OK;
+}
+
+const char* dae_last_error(const dae_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_dae_create_err.c_str();
+}
+
+size_t dae_scratch_bytes(const dae_ctx* ctx) { return ctx ? ctx->scratch_total : 0; }
+
+int dae_profile_enable(dae_ctx* ctx, int on)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    ctx->prof_on = on != 0;
+    ctx->prof_used = 0;
+    return DAE_OK;
+}
+
+int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        DAE_HIP_CHECK(ctx, hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float ms = 0.f;
+        DAE_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        tot += ms; ++n;
+    }
+    ctx->prof_used = 0;
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    return DAE_OK;
+}
+
+/* geometry of the last dae_decode_topk on this thread:
+ * {R_TILE, n_rg, nb_rg, S, n_sample_tiles, n_filter_tiles, fused(0/1), ntiles} */
+int dae_last_plan(int32_t out[8])
+{
+    if (!out) return DAE_ERR_ARG;
+    out[0] = g_plan.R_TILE; out[1] = g_plan.n_rg; out[2] = g_plan.nb_rg; out[3] = g_plan.S;
+    out[4] = g_plan.n_samp; out[5] = g_plan.n_other; out[6] = g_plan.fused; out[7] = g_plan.ntiles;
+    return DAE_OK;
+}
+
+int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+               const float* W_enc, const float* b_enc, int V, int H, int B,
+               float ikp, float kp, uint32_t seed, float* h_out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !W_enc || !b_enc || !h_out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (H <= 0 || (H % 4) != 0) return dae_fail(ctx, DAE_ERR_ARG, "H=%d must be a positive multiple of 4", H);
+    if (B < 0 || V <= 0) return dae_fail(ctx, DAE_ERR_ARG, "bad shape B=%d V=%d", B, V);
+    if (!(ikp > 0.f && ikp <= 1.f) || !(kp > 0.f && kp <= 1.f))
+        return dae_fail(ctx, DAE_ERR_ARG, "keep probabilities must be in (0,1]");
+    if ((reinterpret_cast<uintptr_t>(W_enc) | reinterpret_cast<uintptr_t>(b_enc) |
+         reinterpret_cast<uintptr_t>(h_out)) % 16)
+        return dae_fail(ctx, DAE_ERR_ARG, "W_enc, b_enc, h_out must be 16-byte aligned");
+    return dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, ikp, kp, seed, h_out);
+}
+
+int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, int V, int H,
+                        int col_lo, int col_hi, int dtype)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!W_dec || !b_dec) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (H <= 0 || V <= 0 || col_lo < 0 || col_hi > V || col_lo >= col_hi)
+        return dae_fail(ctx, DAE_ERR_ARG, "bad shape V=%d H=%d cols=[%d,%d)", V, H, col_lo, col_hi);
+    if (dtype == DAE_DTYPE_F32) return dae_launch_prepack_f32(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
+    return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+}
+
+int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int apply_sigmoid,
+                     float* out, int64_t ld_out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!h || !out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    const dae_packed* pk = packed_for(ctx, dtype, H);
+    if (!pk) return DAE_ERR_STATE;
+    const int ncols = pk->col_hi - pk->col_lo;
+    if (ld_out < ncols) return dae_fail(ctx, DAE_ERR_ARG, "ld_out=%lld < %d columns", (long long)ld_out, ncols);
+    if (B <= 0) return DAE_OK;
+    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
+    int rc = dae_launch_pack_h(ctx, h, B, H, g);
+    if (rc) return rc;
+    dae_tileset ts{pk->ntiles, 1, 0};
+    rc = prof_begin(ctx); if (rc) return rc;
+    rc = dae_launch_decode_dense_f32(ctx, g, B, ts, apply_sigmoid, INT_MAX, out, ld_out, 0);
+    if (rc) return rc;
+    return prof_end(ctx);
+}
+
+int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
+                    const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
+                    float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!h || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
+    if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
+        return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
+    const dae_packed* pk = packed_for(ctx, dtype, H);
+    if (!pk) return DAE_ERR_STATE;
+    if (B <= 0) return DAE_OK;
+
+    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
+    int rc = dae_launch_pack_h(ctx, h, B, H, g);
+    if (rc) return rc;
+
+    const int ntiles = pk->ntiles;
+    const int n_valid_col = n_tracks < pk->col_hi ? n_tracks : pk->col_hi;       // global bound
+    int nrank = n_valid_col - pk->col_lo;                                         // ranked columns
+    if (nrank < 0) nrank = 0;
+
+    // ---- plan: how many tiles form the threshold sample (phase A) ---------------------------------
+    const int n_ws = g.nb_rg * g.waves;                 // wave slots per row group
+    int rounds = (int)(((double)ntiles / 8.0) / n_ws + 0.5);
+    if (rounds < 1) rounds = 1;
+    int S = (ntiles + rounds * n_ws - 1) / (rounds * n_ws);
+    const bool fused = S >= 2 && nrank > 0;
+    const int n_samp = fused ? (ntiles + S - 1) / S : ntiles;
+    const int n_other = ntiles - n_samp;
+    g_plan = Plan{g.R_TILE, g.n_rg, g.nb_rg, fused ? S : 1, n_samp, n_other, fused ? 1 : 0, ntiles};
+
+    dae_topk_args ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.B = B; ta.k = k;
+    ta.bitmap_base = pk->col_lo; ta.bitmap_n = nrank;
+    ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
+
+    // phase A (or the whole problem when it is small): dense logits of the sampled tiles
+    const int64_t ld_s = (int64_t)n_samp * 32;
+    rc = dae_reserve(ctx, ctx->sample, (size_t)B * ld_s * sizeof(float));
+    if (rc) return rc;
+    float* sample = static_cast<float*>(ctx->sample.p);
+    dae_tileset tsA{n_samp, fused ? S : 1, fused ? 1 : 0};
+    if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
+    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1);
+    if (rc) return rc;
+    if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
+
+    dae_dense_src ds{sample, ld_s, (int)ld_s, pk->col_lo, fused ? S : 1};
+    if (!fused) {
+        ta.out_kind = out_kind; ta.out_score = out_score; ta.out_idx = out_idx;
+        return dae_launch_topk_dense(ctx, ds, ta);
+    }
+
+    rc = dae_reserve(ctx, ctx->tau, (size_t)g.Bpad * sizeof(float));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, ctx->sample_top, (size_t)g.Bpad * k * sizeof(uint2));
+    if (rc) return rc;
+    ta.out_kind = DAE_OUT_LOGIT;
+    ta.out_pairs = static_cast<uint2*>(ctx->sample_top.p);
+    ta.out_tau = static_cast<float*>(ctx->tau.p);
+    rc = dae_launch_topk_dense(ctx, ds, ta);
+    if (rc) return rc;
+
+    // phase B: everything else through the threshold filter
+    const int items_per_wave = (n_other + n_ws - 1) / n_ws;
+    const int cap = items_per_wave * g.waves * 32;
+    rc = dae_reserve(ctx, ctx->cand, (size_t)g.nb_rg * g.Bpad * cap * sizeof(uint2));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
+    if (rc) return rc;
+    dae_tileset tsB{n_other, S, 2};
+    rc = prof_begin(ctx); if (rc) return rc;
+    rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
+                                      n_valid_col, static_cast<uint2*>(ctx->cand.p),
+                                      static_cast<int*>(ctx->cand_cnt.p), cap);
+    if (rc) return rc;
+    rc = prof_end(ctx); if (rc) return rc;
+
+    // final: exact top-k of (sample winners) U (filter survivors), seeds removed
+    dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), nullptr, 0, k, 0, 1, k};
+    dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
+                      (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
+    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
+    ta.out_score = out_score; ta.out_idx = out_idx;
+    return dae_launch_topk_pairs(ctx, g0, g1, ta);
+}
+
+int dae_topk_dense(dae_ctx* ctx, const float* logits, int64_t ld, int B, int ncols, int col_base,
+                   const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
+                   float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!logits || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (ncols < 0 || ld < ncols) return dae_fail(ctx, DAE_ERR_ARG, "bad ncols/ld");
+    if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
+        return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
+    dae_topk_args ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.B = B; ta.k = k; ta.out_kind = out_kind;
+    ta.bitmap_base = col_base; ta.bitmap_n = ncols;
+    ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
+    ta.out_score = out_score; ta.out_idx = out_idx;
+    dae_dense_src ds{logits, ld, ncols, col_base, 1};
+    return dae_launch_topk_dense(ctx, ds, ta);
+}
+
+int dae_topk_merge(dae_ctx* ctx, int G, int B, int k, const float* cand_logit,
+                   const int32_t* cand_idx, int out_kind, float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!cand_logit || !cand_idx || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (G < 1) return dae_fail(ctx, DAE_ERR_ARG, "G=%d", G);
+    dae_topk_args ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.B = B; ta.k = k; ta.out_kind = out_kind;
+    ta.out_score = out_score; ta.out_idx = out_idx;
+    return dae_launch_topk_soa(ctx, G, cand_logit, cand_idx, ta);
+}
+
+int dae_train_forward_backward(dae_ctx* ctx,
+        const int32_t*, const int32_t*, const float*, const int32_t*, const int32_t*, const float*,
+        const float*, const float*, const float*, const float*,
+        int, int, int, int, int, float, float, uint32_t, float,
+        float*, float*, float*, float*, float*)
+{
+    return dae_fail(ctx, DAE_ERR_STATE, "training kernels are not in this build yet");
+}
+
+int dae_adam_step(dae_ctx* ctx, float*, float*, float*, const float*, int64_t, float, float, float,
+                  float, int)
+{
+    return dae_fail(ctx, DAE_ERR_STATE, "training kernels are not in this build yet");
+}
+
+}  // extern "C"

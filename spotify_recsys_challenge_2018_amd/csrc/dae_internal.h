@@ -1,0 +1,200 @@
+// dae_internal.h -- shared between the translation units of libdae_hip.so (gfx950 only).
+// Context object, error plumbing, canonical scalar device functions, kernel launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dae_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// geometry constants of the decode path (see DESIGN.md "HBM layout")
+// ---------------------------------------------------------------------------------------------
+constexpr int DAE_VT = 32;        // vocabulary columns per wave tile (MFMA M = 32)
+constexpr int DAE_KG = 8;         // k values per packed group (4 MFMA 32x32x2 steps)
+constexpr int DAE_HPAD = 32;      // hidden size is zero-padded to a multiple of this
+constexpr int DAE_MAX_K = 1024;   // largest top-k supported
+constexpr int DAE_NUM_CU = 256;   // MI355X
+constexpr int DAE_NUM_XCD = 8;
+
+struct dae_buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct dae_packed {            // one prepacked decoder image
+    bool valid = false;
+    int V = 0, H = 0, Hp = 0;   // Hp = H padded to DAE_HPAD
+    int col_lo = 0, col_hi = 0;
+    int ntiles = 0;            // ceil((col_hi-col_lo)/32)
+    dae_buf W;                 // fp32: [ntiles][Hp/8][64 lanes][4]   bf16: see decode_bf16.hip
+    dae_buf bias;              // [ntiles*32] fp32, zero padded
+};
+
+struct dae_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    size_t scratch_total = 0;
+
+    dae_packed pk_f32, pk_bf16;
+
+    // scratch (grown lazily, never shrunk)
+    dae_buf h_packed;          // [n_rg][Hp/8][RB][64][4] fp32 (or bf16 image)
+    dae_buf sample;            // phase-A dense logits [Bpad][n_sample_cols]
+    dae_buf tau;               // [Bpad] fp32
+    dae_buf sample_top;        // [Bpad][k] (logit, idx) pairs
+    dae_buf cand;              // [nb_rg][Bpad][cap] pairs
+    dae_buf cand_cnt;          // [nb_rg][Bpad] int
+    dae_buf dense_tmp;         // unfused fallback logits
+    dae_buf train_a, train_b, train_c, train_d;
+
+    // profiling of the dominant kernel
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+    size_t prof_used = 0;
+};
+
+extern thread_local std::string g_dae_create_err;
+
+int dae_fail(dae_ctx* ctx, int code, const char* fmt, ...);
+int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes);
+
+#define DAE_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return dae_fail((ctx), DAE_ERR_HIP, "%s failed: %s (%s:%d)", #expr,               \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                       \
+    } while (0)
+
+#define DAE_CHECK_LAUNCH(ctx, name)                                                           \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess)                                                                 \
+            return dae_fail((ctx), DAE_ERR_HIP, "launch of %s failed: %s", name,              \
+                            hipGetErrorString(_e));                                           \
+    } while (0)
+
+static inline int dae_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------------
+// canonical scalar device functions -- the SPECIFICATION is DESIGN.md "canonical order"; the
+// oracle (oracle/dae_oracle.c) restates the same arithmetic independently.  Built with
+// -ffp-contract=off: every fused multiply-add below is explicit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dae_sigmoidf(float x)
+{
+    float t = -x;
+    t = fminf(fmaxf(t, -87.0f), 87.0f);
+    float n = rintf(t * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, t);
+    r = fmaf(n, -1.42860682030941723e-6f, r);
+    float p = 1.0f / 5040.0f;
+    p = fmaf(p, r, 1.0f / 720.0f);
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    float s = __uint_as_float((uint32_t)((int)n + 127) << 23);
+    float e = p * s;
+    return 1.0f / (1.0f + e);
+}
+
+__device__ __forceinline__ uint32_t dae_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ float dae_uniform(uint32_t seed, uint32_t stream, uint32_t row,
+                                             uint32_t col)
+{
+    uint32_t x = dae_mix32(seed + 0x9E3779B9U * (stream + 1U));
+    x = dae_mix32(x ^ row);
+    x = dae_mix32(x ^ col);
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// order-preserving fp32 -> u32 (bigger key = bigger float, -0 == +0)
+__device__ __forceinline__ uint32_t dae_okey(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u << 1) == 0) u = 0;
+    return (u & 0x80000000U) ? ~u : (u | 0x80000000U);
+}
+__device__ __forceinline__ float dae_okey_inv(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000U) ? (k & 0x7FFFFFFFU) : ~k;
+    return __uint_as_float(u);
+}
+constexpr uint32_t DAE_KEY_NEG_INF = 0x007FFFFFU;   // dae_okey(-inf): "absent" marker
+
+// ---------------------------------------------------------------------------------------------
+// launchers (each defined next to its kernels)
+// ---------------------------------------------------------------------------------------------
+struct dae_rowgeom {        // how B rows are cut into row groups for the decode kernels
+    int R_TILE;             // rows per group: 128, 64 or 32 (LDS-resident h tile)
+    int n_rg;               // ceil(B / R_TILE)
+    int Bpad;               // n_rg * R_TILE
+    int nb_rg;              // thread blocks per row group
+    int grid;               // n_rg * nb_rg
+    int waves;              // waves per workgroup (4 or 8)
+};
+dae_rowgeom dae_row_geometry(int B, int Hp);
+
+// encode.hip
+int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                      const float* W_enc, const float* b_enc, int V, int H, int B,
+                      float ikp, float kp, uint32_t seed, float* h_out);
+
+// decode_f32.hip
+int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
+                           int col_lo, int col_hi);
+int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
+
+struct dae_tileset {        // which wave tiles a decode launch walks
+    int n_items;            // number of tiles in the set
+    int stride;             // S
+    int mode;               // 0: all tiles t=i; 1: sampled t=i*S; 2: the others
+};
+// dense epilogue: out[row*ld + item*32 + vl] (item = position of the tile in the set)
+int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
+                                int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
+                                int fill_pad);
+// filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
+int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
+                                 const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
+                                 int cap);
+
+// topk.hip
+struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)
+    const float* logits; int64_t ld; int n;
+    int col_base;           // global column of tile 0
+    int tile_stride;        // column = col_base + (p/32)*32*tile_stride + p%32
+};
+struct dae_pair_group {     // element (seg, r, i) = base[seg*seg_stride + r*row_stride + i]
+    const uint2* base; const int* cnt; int64_t seg_stride; int64_t row_stride;
+    int64_t cnt_seg_stride; int nseg; int fixed_cnt;
+};
+struct dae_topk_args {
+    int B, k, out_kind;           // out_kind: DAE_OUT_SCORE / DAE_OUT_LOGIT
+    int bitmap_base, bitmap_n;    // seed bitmap covers global columns [base, base+n)
+    const int32_t* seed_row_ptr; const int32_t* seed_col;
+    float* out_score; int32_t* out_idx;   // [B,k]  (may be null)
+    uint2* out_pairs;                     // [B,k] (logit bits, idx) (may be null)
+    float* out_tau;                       // [B] k-th logit or -inf (may be null)
+};
+int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);
+int dae_launch_topk_pairs(dae_ctx* ctx, const dae_pair_group& g0, const dae_pair_group& g1,
+                          const dae_topk_args& a);
+int dae_launch_topk_soa(dae_ctx* ctx, int G, const float* logit, const int32_t* idx,
+                        const dae_topk_args& a);

@@ -1,0 +1,451 @@
+// decode_f32.hip -- K2: decoder GEMM logits[r, c] = h[r,:] . W_dec[c,:] + b_dec[c] in EXACT fp32
+// on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), reference models/DAEs.py:73-77 (tied) and
+// :141-145 (untied), with two epilogues:
+//   EPI_DENSE  : store logits / sigmoid scores (the reference's y_pred, main_train.py:66)
+//   EPI_FILTER : keep only (logit, column) pairs with logit >= tau[row] -- the fused front half
+//                of the top-500 ranking (main_challenge.py:28-36); nothing dense reaches HBM.
+//
+// Structure (DESIGN.md "decode kernel"):
+//   * v_mfma_f32_32x32x2_f32 is bit-for-bit the fmaf chain acc = fma(a_k, b_k, acc) over
+//     ascending k, i.e. exactly oracle/dae_oracle.c:orc_decode.  A = W_dec tile (32 vocabulary
+//     columns x 2 k), B = h^T (2 k x 32 playlists); D[i = column][j = playlist], so every lane
+//     holds 16 different columns of ONE playlist (j = lane & 31) and the per-playlist threshold
+//     lives in one register.
+//   * the hidden tile of a row group (R_TILE playlists x H, 128 KiB at 128 x 256) is copied into
+//     LDS ONCE per persistent workgroup; the main loop has no LDS writes and no barriers.
+//   * W_dec is streamed straight from HBM into VGPRs from the prepacked image (one coalesced
+//     1 KiB global_load_dwordx4 per wave per 8 k), through a 4-deep register ring; each wave owns
+//     whole 32-column tiles, so W_dec is read exactly once per row group.
+//   * the fp32 matrix pipe issues one MFMA per 64 cycles per SIMD; with 4 independent
+//     accumulators a single wave per SIMD saturates it (MI355X_MICROARCH.md), so the workgroup
+//     is 4 waves = one per SIMD, one workgroup per CU.
+//   * blockIdx -> (row group, slot) is XCD-aware: the workgroups that walk the SAME column tiles
+//     for different row groups sit on the same XCD (blockIdx % 8), so the second..n-th read of a
+//     W tile hits that XCD's L2 instead of HBM.
+#include "dae_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EPI_DENSE = 0;
+constexpr int EPI_FILTER = 1;
+
+struct DecP {
+    const float4* Wp;      // [ntiles][G][64] float4
+    const float* bias;     // [ntiles*32]
+    const float4* hp;      // [n_rg][G][RB][64] float4
+    int G;                 // Hp / 8
+    int ncols;             // col_hi - col_lo of the prepacked image
+    int col_lo;
+    int B, n_rg, nb_rg, Bpad;
+    dae_tileset ts;
+    // dense epilogue
+    float* out; int64_t ld; int apply_sigmoid; int mask_from_col; int fill_pad; int vec_ok;
+    // filter epilogue
+    const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
+};
+
+__device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
+{
+    if (ts.mode == 0) return i;
+    if (ts.mode == 1) return i * ts.stride;
+    const int s1 = ts.stride - 1;                  // mode 2: i-th tile with t % S != 0
+    return (i / s1) * ts.stride + (i % s1) + 1;
+}
+
+// GT > 0: hidden size known at compile time (G = GT groups of 8 k) -> the k loop is fully
+// unrolled, so no loop header sits between the register-ring loads and their use (hipcc drains
+// vmcnt to 0 at every loop header; with the loop gone the waits are exact counted vmcnt(3)).
+template <int RB, int EPI, int GT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+    const int G = GT > 0 ? GT : p.G;
+    constexpr int R_TILE = RB * 32;
+
+    // XCD-aware block -> (row group, slot in row group)
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+
+    // ---- hidden tile of this row group -> LDS, once ------------------------------------------
+    const int n_h4 = RB * 64 * G;
+    {
+        const float4* src = p.hp + (size_t)rg * n_h4;
+        for (int i = tid; i < n_h4; i += NW * 64) lds4[i] = src[i];
+    }
+    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    if (EPI == EPI_FILTER) {
+        if (tid < R_TILE) lcnt[tid] = 0;
+    }
+    __syncthreads();
+
+    float tau_r[RB];
+    if (EPI == EPI_FILTER) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = rg * R_TILE + rb * 32 + j;
+            tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
+        }
+    }
+
+    const int n_ws = p.nb_rg * NW;
+    const int item0 = bir * NW + wave;
+
+    // W stream: the wave's tiles back to back; the register ring always holds the next 4 groups
+    // of that stream, so the prefetch runs across tile boundaries (and under the epilogue).
+    float4 wb0, wb1, wb2, wb3;
+    float4 bA[RB], bB[RB];
+    if (item0 < p.ts.n_items) {
+        const float4* w0 = p.Wp + (size_t)tile_of_item(p.ts, item0) * G * 64 + lane;
+        wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+    }
+
+    for (int item = item0; item < p.ts.n_items; item += n_ws) {
+        const int t = tile_of_item(p.ts, item);
+        const float4* wp = p.Wp + (size_t)t * G * 64 + lane;
+        // next tile of this wave (or this one again at the end: in-bounds, values unused)
+        const int item_n = item + n_ws < p.ts.n_items ? item + n_ws : item;
+        const float4* wn = p.Wp + (size_t)tile_of_item(p.ts, item_n) * G * 64 + lane;
+
+        // bias of the tile's 32 columns, fetched now so the epilogue never waits on memory:
+        // lane holds columns v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi, reg = 0..15
+        const float* bp = p.bias + (size_t)t * 32 + 4 * hi;
+        float4 bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const float4*>(bp + 8 * qd);
+
+        f32x16 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.0f;
+
+// one k-group (8 k = 4 MFMA steps per accumulator): consume ring slot WB with hidden fragments
+// BC, refill the slot from PF, and fetch the NEXT group's hidden fragments into BN.
+#define DAE_STEP(WB, PF, BC, BN, GNEXT)                                                        \
+    {                                                                                          \
+        const float4 a = WB;                                                                   \
+        WB = *(PF);                                                                            \
+        const float4* hl = lds4 + (size_t)(GNEXT) * (RB * 64) + lane;                          \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) BN[rb] = hl[rb * 64];                \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetches AHEAD of this group's MFMAs */\
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, BC[rb].x, acc[rb], 0, 0, 0);   \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, BC[rb].y, acc[rb], 0, 0, 0);   \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, BC[rb].z, acc[rb], 0, 0, 0);   \
+        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, BC[rb].w, acc[rb], 0, 0, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+
+        int g = 0;
+#pragma unroll
+        for (; g < G - 4; g += 4) {
+            const float4* pf = wp + (size_t)(g + 4) * 64;
+            DAE_STEP(wb0, pf,       bA, bB, g + 1)
+            DAE_STEP(wb1, pf + 64,  bB, bA, g + 2)
+            DAE_STEP(wb2, pf + 128, bA, bB, g + 3)
+            DAE_STEP(wb3, pf + 192, bB, bA, g + 4)
+        }
+        // last 4 groups of the tile: refill from the next tile, wrap the hidden fragments to g = 0
+        DAE_STEP(wb0, wn,       bA, bB, g + 1)
+        DAE_STEP(wb1, wn + 64,  bB, bA, g + 2)
+        DAE_STEP(wb2, wn + 128, bA, bB, g + 3)
+        DAE_STEP(wb3, wn + 192, bB, bA, 0)
+#undef DAE_STEP
+
+        // ---- epilogue -----------------------------------------------------------------------
+        // lane holds, for playlist j of row block rb, the columns
+        //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
+        const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
+
+        if (EPI == EPI_DENSE) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                if (row >= p.B) continue;
+                float* orow = p.out + (size_t)row * p.ld + (size_t)item * 32 + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int lc = tcol0 + 8 * qd;        // first of 4 consecutive local columns
+                    float z[4] = {acc[rb][4 * qd + 0] + bq[qd].x, acc[rb][4 * qd + 1] + bq[qd].y,
+                                  acc[rb][4 * qd + 2] + bq[qd].z, acc[rb][4 * qd + 3] + bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (p.apply_sigmoid) z[e] = dae_sigmoidf(z[e]);
+                        if (p.col_lo + lc + e >= p.mask_from_col || lc + e >= p.ncols)
+                            z[e] = -__builtin_inff();
+                    }
+                    if (lc + 3 < p.ncols || p.fill_pad) {
+                        if (p.vec_ok) {
+                            *reinterpret_cast<float4*>(orow + 8 * qd) =
+                                make_float4(z[0], z[1], z[2], z[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) orow[8 * qd + e] = z[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (lc + e < p.ncols) orow[8 * qd + e] = z[e];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float tv = tau_r[rb];
+                float z[16];
+                unsigned m = 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    z[4 * qd + 0] = acc[rb][4 * qd + 0] + bq[qd].x;
+                    z[4 * qd + 1] = acc[rb][4 * qd + 1] + bq[qd].y;
+                    z[4 * qd + 2] = acc[rb][4 * qd + 2] + bq[qd].z;
+                    z[4 * qd + 3] = acc[rb][4 * qd + 3] + bq[qd].w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lc = tcol0 + 8 * qd + e;
+                        const bool ok = (z[4 * qd + e] >= tv) && (lc < p.ncols) &&
+                                        (p.col_lo + lc < p.n_valid_col);
+                        m |= (ok ? 1u : 0u) << (4 * qd + e);
+                    }
+                }
+                if (m) {
+                    const int rloc = rb * 32 + j;
+                    const int row = rg * R_TILE + rloc;
+                    int base = atomicAdd(&lcnt[rloc], __popc(m));
+                    uint2* dst = p.cand + ((size_t)bir * p.Bpad + row) * (size_t)p.cap;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        if (m & (1u << reg)) {
+                            const int lc = tcol0 + (reg & 3) + 8 * (reg >> 2);
+                            dst[base++] = make_uint2(__float_as_uint(z[reg]),
+                                                     (unsigned)(p.col_lo + lc));
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI == EPI_FILTER) {
+        __syncthreads();
+        if (tid < R_TILE) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + tid] = lcnt[tid];
+    }
+}
+
+// ---- prepack: W_dec rows -> MFMA A-operand order ----------------------------------------------
+// out float4 index = (t*G + g)*64 + lane, lane = hi*32 + i; component e holds
+// W[col_lo + 32t + i][8g + 2e + hi]  (zero outside the matrix).
+__global__ __launch_bounds__(256) void prepack_f32_kernel(const float* __restrict__ W,
+                                                          const float* __restrict__ b, int H, int G,
+                                                          int col_lo, int col_hi, int ntiles,
+                                                          float4* __restrict__ Wp,
+                                                          float* __restrict__ bias)
+{
+    const size_t total = (size_t)ntiles * G * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
+         o += (size_t)gridDim.x * 256) {
+        const int lane = (int)(o & 63);
+        const size_t tg = o >> 6;
+        const int g = (int)(tg % G);
+        const int t = (int)(tg / G);
+        const int hi = lane >> 5, i = lane & 31;
+        const int v = col_lo + t * 32 + i;
+        float e[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int k = 8 * g + 2 * x + hi;
+            e[x] = (v < col_hi && k < H) ? W[(size_t)v * H + k] : 0.0f;
+        }
+        Wp[o] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    const int nb = ntiles * 32;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
+        const int v = col_lo + o;
+        bias[o] = v < col_hi ? b[v] : 0.0f;
+    }
+}
+
+// ---- pack h [B,H] -> MFMA B-operand order per row group ---------------------------------------
+// out float4 index = ((rg*G + g)*RB + rb)*64 + lane, lane = hi*32 + j; component e holds
+// h[rg*R_TILE + rb*32 + j][8g + 2e + hi]  (zero outside).
+__global__ __launch_bounds__(256) void pack_h_kernel(const float* __restrict__ h, int B, int H,
+                                                     int G, int RB, int n_rg,
+                                                     float4* __restrict__ hp)
+{
+    const size_t total = (size_t)n_rg * G * RB * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
+         o += (size_t)gridDim.x * 256) {
+        const int lane = (int)(o & 63);
+        size_t x = o >> 6;
+        const int rb = (int)(x % RB); x /= RB;
+        const int g = (int)(x % G);
+        const int rg = (int)(x / G);
+        const int hi = lane >> 5, jj = lane & 31;
+        const int r = (rg * RB + rb) * 32 + jj;
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 8 * g + 2 * c + hi;
+            e[c] = (r < B && k < H) ? h[(size_t)r * H + k] : 0.0f;
+        }
+        hp[o] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
+template <int RB, int EPI, int GT, int NW>
+int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
+{
+    const size_t lds = (size_t)RB * 64 * p.G * sizeof(float4) + (size_t)RB * 32 * sizeof(int);
+    static bool attr_set = false;     // per template instantiation
+    if (!attr_set) {
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(
+                               reinterpret_cast<const void*>(&decode_f32_kernel<RB, EPI, GT, NW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW>), dim3(g.grid), dim3(NW * 64), lds,
+                       ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "decode_f32_kernel");
+    return DAE_OK;
+}
+
+template <int EPI>
+int launch_decode_rb(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
+{
+    // the shipped configs all use hidden = 256 (config.ini:12): G = 32 gets the unrolled body
+    if (g.R_TILE == 128 && p.G == 32) {
+        if (g.waves == 8) return launch_decode<4, EPI, 32, 8>(ctx, g, p);
+        return launch_decode<4, EPI, 32, 4>(ctx, g, p);
+    }
+    if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "bad wave count %d", g.waves);
+    switch (g.R_TILE) {
+        case 128: return launch_decode<4, EPI, 0, 4>(ctx, g, p);
+        case 64:  return launch_decode<2, EPI, 0, 4>(ctx, g, p);
+        case 32:  return launch_decode<1, EPI, 0, 4>(ctx, g, p);
+    }
+    return dae_fail(ctx, DAE_ERR_ARG, "bad R_TILE %d", g.R_TILE);
+}
+
+int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p)
+{
+    const dae_packed& pk = ctx->pk_f32;
+    if (!pk.valid) return dae_fail(ctx, DAE_ERR_STATE, "decoder not prepacked (fp32)");
+    if (!ctx->h_packed.p) return dae_fail(ctx, DAE_ERR_STATE, "hidden tile not packed");
+    memset(&p, 0, sizeof(p));
+    p.Wp = static_cast<const float4*>(pk.W.p);
+    p.bias = static_cast<const float*>(pk.bias.p);
+    p.hp = static_cast<const float4*>(ctx->h_packed.p);
+    p.G = pk.Hp / DAE_KG;
+    p.ncols = pk.col_hi - pk.col_lo;
+    p.col_lo = pk.col_lo;
+    p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg; p.Bpad = g.Bpad;
+    p.ts = ts;
+    return DAE_OK;
+}
+
+}  // namespace
+
+// Rows are cut into groups of R_TILE playlists whose hidden tile (R_TILE x Hp fp32) stays in LDS.
+dae_rowgeom dae_row_geometry(int B, int Hp)
+{
+    dae_rowgeom g;
+    int rt = 128;
+    while (rt > 32 && (size_t)rt * Hp * 4 > 128 * 1024) rt >>= 1;   // <= 128 KiB of LDS
+    while (rt > 32 && B <= rt / 2) rt >>= 1;                        // small batches
+    g.R_TILE = rt;
+    g.n_rg = (B + rt - 1) / rt;
+    g.Bpad = g.n_rg * rt;
+    int nb = (DAE_NUM_CU / g.n_rg) / DAE_NUM_XCD * DAE_NUM_XCD;
+    if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
+    g.nb_rg = nb;
+    g.grid = g.n_rg * nb;
+    // waves per workgroup: 8 (two per SIMD, one covers the other's epilogue) on the unrolled
+    // hidden=256 body, else 4.  DAE_DECODE_WAVES=4|8 overrides (A/B on hardware).
+    g.waves = (rt == 128 && Hp == 256) ? 8 : 4;
+    if (const char* e = getenv("DAE_DECODE_WAVES")) {
+        const int w = atoi(e);
+        if ((w == 4 || w == 8) && rt == 128 && Hp == 256) g.waves = w;
+    }
+    return g;
+}
+
+int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
+                           int col_lo, int col_hi)
+{
+    dae_packed& pk = ctx->pk_f32;
+    pk.valid = false;
+    const int Hp = dae_round_up(H, DAE_HPAD);
+    if ((size_t)32 * Hp * 4 > 128 * 1024)
+        return dae_fail(ctx, DAE_ERR_ARG, "hidden size %d too large (max 1024)", H);
+    const int ntiles = (col_hi - col_lo + DAE_VT - 1) / DAE_VT;
+    const int G = Hp / DAE_KG;
+    int rc = dae_reserve(ctx, pk.W, (size_t)ntiles * G * 64 * sizeof(float4));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, pk.bias, (size_t)ntiles * 32 * sizeof(float));
+    if (rc) return rc;
+    const size_t total = (size_t)ntiles * G * 64;
+    int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(prepack_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, G,
+                       col_lo, col_hi, ntiles, static_cast<float4*>(pk.W.p),
+                       static_cast<float*>(pk.bias.p));
+    DAE_CHECK_LAUNCH(ctx, "prepack_f32_kernel");
+    pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
+    pk.valid = true;
+    return DAE_OK;
+}
+
+int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g)
+{
+    const int Hp = dae_round_up(H, DAE_HPAD);
+    const int G = Hp / DAE_KG, RB = g.R_TILE / 32;
+    const size_t total = (size_t)g.n_rg * G * RB * 64;
+    int rc = dae_reserve(ctx, ctx->h_packed, total * sizeof(float4));
+    if (rc) return rc;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_h_kernel, dim3(blocks), dim3(256), 0, ctx->stream, h, B, H, G, RB,
+                       g.n_rg, static_cast<float4*>(ctx->h_packed.p));
+    DAE_CHECK_LAUNCH(ctx, "pack_h_kernel");
+    return DAE_OK;
+}
+
+int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
+                                int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
+                                int fill_pad)
+{
+    DecP p;
+    int rc = fill_common(ctx, g, B, ts, p);
+    if (rc) return rc;
+    p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
+    // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
+    p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
+    p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
+    return launch_decode_rb<EPI_DENSE>(ctx, g, p);
+}
+
+int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
+                                 const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
+                                 int cap)
+{
+    DecP p;
+    int rc = fill_common(ctx, g, B, ts, p);
+    if (rc) return rc;
+    p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
+    return launch_decode_rb<EPI_FILTER>(ctx, g, p);
+}

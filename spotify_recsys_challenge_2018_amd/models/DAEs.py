@@ -1,0 +1,326 @@
+"""Host-side mirror of the reference's models/DAEs.py object protocol on top of the
+C ABI of libdae_hip.so.  PyTorch-ROCm is used for device memory and streams only; every hot
+operation is a hand-written HIP kernel behind include/dae_hip.h.
+
+Reference protocol (models/DAEs.py, all citations relative to /root/reference):
+    model = DAE_tied(conf) | DAE(conf)          # :13 / :114   reads conf.save/batch/n_input/...
+    model.fit()                                  # :84          builds the graph
+    sess.run(model.init_op)                      # variables -> device
+    sess.run(model.y_pred, feed_dict={model.x_positions:..., model.x_ones:...,
+             model.keep_prob: 1.0, model.input_keep_prob: 1.0})          # main_train.py:66-68
+    sess.run([model.optimizer, model.cost], feed_dict={... y_positions, y_ones, keep_prob,
+             input_keep_prob})                                           # main_train.py:204-207
+    model.save_model(sess)                       # :107-111  pickle [enc_W, dec_W, enc_b, dec_b]
+
+The same calls work here through `Session` below.  Direct methods (`predict`, `recommend`,
+`train_step`) are what the drivers of this repo use; `recommend` is the fused
+encode -> decode -> top-k path that never materialises the [batch, n_input] matrix.
+"""
+import pickle
+
+import numpy as np
+
+from .. import _lib
+
+
+class _Placeholder:
+    """Stands in for a tf.placeholder: only used as a feed_dict key."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<placeholder %s>" % self.name
+
+
+class _Fetch:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<fetch %s>" % self.name
+
+
+def coo_to_csr(positions, values, n_rows, n_cols=None):
+    """DAEs.py:33-35 semantics for the kernels: the reference scatters COO (row, col) -> value
+    into a dense matrix by ASSIGNMENT with validate_indices=False, so duplicates are the norm and
+    the LAST occurrence wins.  Returns CSR with columns ascending per row:
+    (row_ptr int32 [n_rows+1], col int32 [nnz], val float32 [nnz]).  Explicit zeros are kept out
+    (a zero entry contributes nothing to the row sum or the gather)."""
+    pos = np.asarray(positions, dtype=np.int64).reshape(-1, 2)
+    n = pos.shape[0]
+    vals = np.asarray(values, dtype=np.float32).reshape(-1)
+    if vals.size == 1 and n != 1:
+        vals = np.full(n, vals[0], dtype=np.float32)
+    if vals.size != n:
+        raise ValueError("positions (%d) and values (%d) differ in length" % (n, vals.size))
+    if n == 0:
+        return (np.zeros(n_rows + 1, dtype=np.int32), np.zeros(0, dtype=np.int32),
+                np.zeros(0, dtype=np.float32))
+    rows, cols = pos[:, 0], pos[:, 1]
+    if rows.min() < 0 or rows.max() >= n_rows:
+        raise ValueError("row index out of range [0,%d)" % n_rows)
+    if cols.min() < 0 or (n_cols is not None and cols.max() >= n_cols):
+        raise ValueError("column index out of range")
+    order = np.lexsort((np.arange(n), cols, rows))          # row, col, then feed order
+    r, c, v = rows[order], cols[order], vals[order]
+    last = np.ones(n, dtype=bool)
+    last[:-1] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])        # last duplicate of each (row, col)
+    keep = last & (v != 0.0)
+    r, c, v = r[keep], c[keep], v[keep]
+    row_ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(row_ptr, r + 1, 1)
+    row_ptr = np.cumsum(row_ptr)
+    return row_ptr.astype(np.int32), c.astype(np.int32), v.astype(np.float32)
+
+
+def seeds_to_csr(seeds, n_rows, n_tracks):
+    """Per-row seed track lists (main_challenge.py:31-35 `cand.remove(i)`) -> CSR of sorted unique
+    in-range track ids."""
+    row_ptr = np.zeros(n_rows + 1, dtype=np.int32)
+    cols = []
+    for i in range(n_rows):
+        s = seeds[i] if i < len(seeds) else []
+        u = np.unique(np.asarray(s, dtype=np.int64)) if len(s) else np.zeros(0, dtype=np.int64)
+        u = u[(u >= 0) & (u < n_tracks)]
+        cols.append(u.astype(np.int32))
+        row_ptr[i + 1] = row_ptr[i] + u.size
+    col = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int32)
+    return row_ptr, col.astype(np.int32)
+
+
+class DAE_tied:
+    """Tied-weight denoising autoencoder (reference DAEs.py:13-111)."""
+
+    tied = True
+
+    def __init__(self, conf):
+        self.save_dir = conf.save                       # DAEs.py:15
+        self.n_batch = int(conf.batch)                  # :17
+        self.n_input = int(conf.n_input)                # :18
+        self.n_hidden = int(conf.hidden)                # :19
+        self.learning_rate = float(conf.lr)             # :20
+        self.reg_lambda = float(conf.reg_lambda)        # :21
+        self.n_tracks = int(getattr(conf, "n_tracks", self.n_input))
+        self.device_index = int(getattr(conf, "device_index", 0))
+        self.init_seed = int(getattr(conf, "init_seed", 0))
+
+        # feed_dict keys (DAEs.py:23-30)
+        self.x_positions = _Placeholder("x_positions")
+        self.x_ones = _Placeholder("x_ones")
+        self.y_positions = _Placeholder("y_positions")
+        self.y_ones = _Placeholder("y_ones")
+        self.keep_prob = _Placeholder("keep_prob")
+        self.input_keep_prob = _Placeholder("input_keep_prob")
+
+        self.y_pred = None
+        self.cost = None
+        self.optimizer = None
+        self.init_op = None
+        self.weights = {}
+        self.biases = {}
+        self.d_params = []
+        self.ctx = None
+        self._adam = None
+        self._step = 0
+        self._packed_dirty = True
+        self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
+
+    # -- parameters ---------------------------------------------------------------------------------
+    def _xavier(self, rng, shape):
+        """tf.contrib.layers.xavier_initializer() (uniform): U(+-sqrt(6/(fan_in+fan_out)))."""
+        lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    def _host_init(self):
+        """DAEs.py:53-61: encoder_h Xavier, biases zero; decoder IS the encoder matrix."""
+        rng = np.random.default_rng(self.init_seed)
+        W = self._xavier(rng, (self.n_input, self.n_hidden))
+        return [W, W, np.zeros(self.n_hidden, np.float32), np.zeros(self.n_input, np.float32)]
+
+    def init_weight(self):
+        import torch
+        dev = torch.device("cuda", self.device_index)
+        enc_W, dec_W, enc_b, dec_b = self._host_init()
+        for a, shp in ((enc_W, (self.n_input, self.n_hidden)), (dec_W, (self.n_input, self.n_hidden)),
+                       (enc_b, (self.n_hidden,)), (dec_b, (self.n_input,))):
+            if tuple(a.shape) != shp:
+                raise ValueError("initial value has shape %s, expected %s" % (a.shape, shp))
+        self.weights["encoder_h"] = torch.from_numpy(np.ascontiguousarray(enc_W, np.float32)).to(dev)
+        if self.tied:
+            self.weights["decoder_h"] = self.weights["encoder_h"]
+        else:
+            self.weights["decoder_h"] = torch.from_numpy(np.ascontiguousarray(dec_W, np.float32)).to(dev)
+        self.biases["encoder_b"] = torch.from_numpy(np.ascontiguousarray(enc_b, np.float32)).to(dev)
+        self.biases["decoder_b"] = torch.from_numpy(np.ascontiguousarray(dec_b, np.float32)).to(dev)
+        self.d_params = [self.weights["encoder_h"], self.weights["decoder_h"],
+                         self.biases["encoder_b"], self.biases["decoder_b"]]
+        self._packed_dirty = True
+
+    def fit(self):
+        """DAEs.py:84-105.  Creates the device context, the parameters and the fetch handles."""
+        self.ctx = _lib.Context(self.device_index)
+        self.init_weight()
+        self.y_pred = _Fetch("y_pred")
+        self.cost = _Fetch("cost")
+        self.optimizer = _Fetch("optimizer")
+        self.init_op = _Fetch("init_op")
+        self.hidden = _Fetch("hidden")
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _to_dev(self, a, dtype):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(torch.device("cuda", self.device_index), dtype=dtype, non_blocking=False)
+
+    def _upload_csr(self, positions, values):
+        import torch
+        rp, c, v = coo_to_csr(positions, values, self.n_batch, self.n_input)
+        if c.size == 0:          # keep valid device pointers for empty batches
+            c = np.zeros(1, np.int32); v = np.zeros(1, np.float32)
+        return self._to_dev(rp, torch.int32), self._to_dev(c, torch.int32), self._to_dev(v, torch.float32)
+
+    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
+        if self._packed_dirty:
+            self.ctx.bind_stream()
+            self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0,
+                                     self.n_input, dtype)
+            self._packed_dirty = False
+
+    def encode(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
+        """DAEs.py:40-42 + :64-70 -> hidden [n_batch, n_hidden] (torch CUDA tensor)."""
+        import torch
+        self.ctx.bind_stream()
+        rp, c, v = self._upload_csr(x_positions, x_ones)
+        h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32,
+                        device=self.weights["encoder_h"].device)
+        self.ctx.encode(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"], h,
+                        ikp=input_keep_prob, kp=keep_prob, seed=seed)
+        return h
+
+    def predict(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
+        """sess.run(model.y_pred, ...) : dense scores [n_batch, n_input] float32 (host array)."""
+        import torch
+        self._ensure_packed()
+        h = self.encode(x_positions, x_ones, keep_prob, input_keep_prob, seed)
+        out = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=h.device)
+        self.ctx.decode_dense(h, out, apply_sigmoid=True)
+        return out.cpu().numpy()
+
+    def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None):
+        """Fused scoring path: encode -> decode -> top-k (track columns, seeds removed).
+        Equivalent of main_challenge.py:80-90 / main_train.py:66-89 without the dense matrix.
+        Returns (idx [n_rows,k] int32 with -1 padding, score [n_rows,k] float32)."""
+        import torch
+        self._ensure_packed()
+        h = self.encode(x_positions, x_ones)
+        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
+        if sc.size == 0:
+            sc = np.zeros(1, np.int32)
+        d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
+        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=h.device)
+        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=h.device)
+        self.ctx.decode_topk(h, self.n_tracks, d_srp, d_sc, k, score, idx)
+        n_rows = self.n_batch if n_rows is None else n_rows
+        return idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
+
+    # -- training -----------------------------------------------------------------------------------
+    def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob):
+        """sess.run([model.optimizer, model.cost], ...) (main_train.py:204-213) -> cost (float)."""
+        import torch
+        self.ctx.bind_stream()
+        dev = self.weights["encoder_h"].device
+        if self._adam is None:
+            self._grads = {}
+            self._adam = {}
+            names = ["encoder_h", "encoder_b", "decoder_b"] + ([] if self.tied else ["decoder_h"])
+            for n in names:
+                p = self.weights[n] if n in self.weights else self.biases[n]
+                self._grads[n] = torch.zeros_like(p)
+                self._adam[n] = (torch.zeros_like(p), torch.zeros_like(p))
+            self._cost = torch.zeros(1, dtype=torch.float32, device=dev)
+        xr, xc, xv = self._upload_csr(x_positions, x_ones)
+        yr, yc, yv = self._upload_csr(y_positions, y_ones)
+        seed = int(self._rng.randint(0, 2 ** 31 - 1))
+        g = self._grads
+        lib, ctx = self.ctx.lib, self.ctx
+        P = _lib._ptr
+        ctx.check(lib.dae_train_forward_backward(
+            ctx.h, P(xr), P(xc), P(xv), P(yr), P(yc), P(yv),
+            P(self.weights["encoder_h"]), P(self.biases["encoder_b"]),
+            P(self.weights["decoder_h"]), P(self.biases["decoder_b"]),
+            self.n_input, self.n_hidden, self.n_batch, self.n_batch, 1 if self.tied else 0,
+            float(input_keep_prob), float(keep_prob), seed, float(self.reg_lambda),
+            P(g["encoder_h"]), P(g["encoder_b"]),
+            P(g["decoder_h"]) if not self.tied else None, P(g["decoder_b"]), P(self._cost)))
+        self._step += 1
+        for n, grad in g.items():
+            p = self.weights[n] if n in self.weights else self.biases[n]
+            m, v = self._adam[n]
+            ctx.check(lib.dae_adam_step(ctx.h, P(p), P(m), P(v), P(grad), p.numel(),
+                                        self.learning_rate, 0.9, 0.999, 1e-8, self._step))
+        self._packed_dirty = True
+        return float(self._cost.item())
+
+    # -- persistence ----------------------------------------------------------------------------------
+    def get_params(self):
+        """sess.run(model.d_params): [enc_W, dec_W (enc_W again when tied), enc_b, dec_b]."""
+        return [p.detach().cpu().numpy() for p in self.d_params]
+
+    def save_model(self, sess=None):
+        """DAEs.py:107-111: pickle of the four float32 arrays in d_params order."""
+        with open(self.save_dir, "wb") as f:
+            pickle.dump(self.get_params(), f)
+
+
+class DAE(DAE_tied):
+    """Untied DAE, optionally initialised from a pretrain pickle (reference DAEs.py:114-150)."""
+
+    tied = False
+
+    def __init__(self, conf):
+        DAE_tied.__init__(self, conf)
+        self.initval_dir = conf.initval               # DAEs.py:117
+
+    def _host_init(self):
+        if str(self.initval_dir).endswith("NULL"):    # DAEs.py:120 (Conf joins the dir in front)
+            rng = np.random.default_rng(self.init_seed)
+            return [self._xavier(rng, (self.n_input, self.n_hidden)),
+                    self._xavier(rng, (self.n_input, self.n_hidden)),
+                    np.zeros(self.n_hidden, np.float32), np.zeros(self.n_input, np.float32)]
+        with open(self.initval_dir, "rb") as f:       # DAEs.py:130-135
+            emb = pickle.load(f)
+        return [np.array(emb[0], np.float32), np.array(emb[1], np.float32),
+                np.array(emb[2], np.float32), np.array(emb[3], np.float32)]
+
+
+class Session:
+    """Minimal stand-in for tf.Session so that reference-style driver code runs unchanged:
+    `sess.run(model.y_pred, feed_dict=...)`, `sess.run([model.optimizer, model.cost], ...)`,
+    `sess.run(model.init_op)`, `sess.run(model.d_params)`."""
+
+    def __init__(self, model=None):
+        self.model = model
+
+    def run(self, fetches, feed_dict=None):
+        m = self.model
+        if m is None:
+            raise ValueError("Session needs the model: Session(model)")
+        feed = feed_dict or {}
+
+        def g(ph, default=None):
+            return feed.get(ph, default)
+
+        if fetches is m.init_op:
+            return None
+        if fetches is m.d_params or (isinstance(fetches, list) and fetches and fetches == m.d_params):
+            return m.get_params()
+        if fetches is m.y_pred:
+            return m.predict(g(m.x_positions), g(m.x_ones), g(m.keep_prob, 1.0),
+                             g(m.input_keep_prob, 1.0))
+        if isinstance(fetches, (list, tuple)) and len(fetches) == 2 and fetches[0] is m.optimizer \
+                and fetches[1] is m.cost:
+            cost = m.train_step(g(m.x_positions), g(m.x_ones), g(m.y_positions), g(m.y_ones),
+                                g(m.keep_prob, 1.0), g(m.input_keep_prob, 1.0))
+            return None, cost
+        raise ValueError("unsupported fetches %r" % (fetches,))

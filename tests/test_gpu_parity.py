@@ -1,0 +1,219 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  fp32 path: BIT-EXACT hidden activations, logits, top-k indices and scores
+(tolerance 0).  See DESIGN.md "canonical order"."""
+import numpy as np
+import pytest
+
+import oracle
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _problem(V, n_tracks, H, B, seed=0, dist="zipf", bias="zeros"):
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=seed, bias=bias, n_tracks=n_tracks)
+    b_enc = (np.random.default_rng(seed + 7).standard_normal(H) * 0.1).astype(np.float32)
+    pos, ones, seeds = make_playlists(B, n_tracks, V - n_tracks, seed=seed + 1, dist=dist)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, n_tracks)
+    return dict(W_enc=W_enc, b_enc=b_enc, W_dec=W_dec, b_dec=b_dec, rp=rp, col=col, val=val,
+                srp=srp, sc=sc, seeds=seeds, V=V, H=H, B=B, n_tracks=n_tracks)
+
+
+def _gpu_encode(ctx, p, ikp=1.0, kp=1.0, seed=0):
+    import torch
+    h = torch.empty((p["B"], p["H"]), dtype=torch.float32, device="cuda")
+    ctx.encode(_dev(p["rp"]), _dev(p["col"] if p["col"].size else np.zeros(1, np.int32)),
+               _dev(p["val"] if p["val"].size else np.zeros(1, np.float32)),
+               _dev(p["W_enc"]), _dev(p["b_enc"]), h, ikp=ikp, kp=kp, seed=seed)
+    return h
+
+
+@pytest.mark.parametrize("V,nt,H,B", [(2000, 1500, 32, 8), (3000, 2500, 256, 37), (1111, 1000, 64, 130),
+                                      (5000, 4000, 128, 200), (2048, 2048, 288, 5)])
+def test_encode_bit_exact(ctx, V, nt, H, B):
+    p = _problem(V, nt, H, B)
+    h_gpu = _gpu_encode(ctx, p).cpu().numpy()
+    h_ref = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    assert np.array_equal(h_gpu.view(np.uint32), h_ref.view(np.uint32))
+
+
+def test_encode_dropout_bit_exact(ctx):
+    p = _problem(3000, 2500, 64, 50)
+    h_gpu = _gpu_encode(ctx, p, ikp=0.75, kp=0.8, seed=1234).cpu().numpy()
+    h_ref = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], ikp=0.75, kp=0.8,
+                          seed=1234)
+    assert np.array_equal(h_gpu.view(np.uint32), h_ref.view(np.uint32))
+    assert (h_gpu == 0).mean() > 0.1          # hidden dropout really dropped units
+
+
+def test_encode_empty_rows(ctx):
+    """Short final batches leave all-zero rows: h = sigmoid(b_enc)."""
+    p = _problem(1000, 800, 32, 6)
+    p["rp"][3:] = p["rp"][3]                   # rows 3.. empty
+    h_gpu = _gpu_encode(ctx, p).cpu().numpy()
+    h_ref = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    assert np.array_equal(h_gpu.view(np.uint32), h_ref.view(np.uint32))
+    assert np.array_equal(h_gpu[4], h_gpu[5])
+
+
+@pytest.mark.parametrize("V,nt,H,B", [(2000, 1500, 32, 8), (3000, 2500, 256, 37), (1111, 1000, 64, 130),
+                                      (4100, 4100, 256, 256), (2048, 2048, 288, 5), (700, 650, 96, 300)])
+def test_decode_dense_bit_exact(ctx, V, nt, H, B):
+    import torch
+    p = _problem(V, nt, H, B)
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    out = torch.full((B, V + 3), 7.0, dtype=torch.float32, device="cuda")   # odd ld: scalar stores
+    ctx.decode_dense(_dev(h), out, apply_sigmoid=False)
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"])
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, :V].view(np.uint32), z_ref.view(np.uint32))
+    assert (o[:, V:] == 7.0).all()             # nothing written past the columns
+    out4 = torch.empty((B, (V + 3) // 4 * 4), dtype=torch.float32, device="cuda")
+    ctx.decode_dense(_dev(h), out4, apply_sigmoid=True)
+    y_ref = oracle.decode(h, p["W_dec"], p["b_dec"], apply_sigmoid=True)
+    assert np.array_equal(out4.cpu().numpy()[:, :V].view(np.uint32), y_ref.view(np.uint32))
+
+
+def test_decode_dense_column_shard(ctx):
+    import torch
+    p = _problem(3000, 2500, 64, 40)
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), 777, 2222)
+    out = torch.empty((40, 2222 - 777), dtype=torch.float32, device="cuda")
+    ctx.decode_dense(_dev(h), out, apply_sigmoid=False)
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"], 777, 2222)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), z_ref.view(np.uint32))
+
+
+def _check_topk(idx_g, sc_g, idx_r, sc_r):
+    assert np.array_equal(idx_g, idx_r)
+    assert np.array_equal(sc_g.view(np.uint32), sc_r.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,k,B", [(1500, 500, 9), (140, 500, 4), (5000, 10, 33), (40000, 500, 6),
+                                   (513, 512, 3), (3000, 1024, 2)])
+def test_topk_dense_bit_exact(ctx, n, k, B):
+    import torch
+    rng = np.random.default_rng(n + k)
+    z = rng.standard_normal((B, n + 5)).astype(np.float32)
+    z[:, ::7] = z[:, 1:2]                       # heavy ties, some across the cut
+    seeds = [list(rng.integers(0, n, size=rng.integers(0, 120))) for _ in range(B)]
+    srp, sc = seeds_to_csr(seeds, B, n)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.topk_dense(_dev(z), n, 100, _dev(srp), _dev(sc + 100 if sc.size else np.zeros(1, np.int32)),
+                   k, score, idx)
+    sc_r, idx_r = oracle.topk(z, k, srp, sc + 100, col_base=100, ncols=n)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+
+
+def test_topk_all_equal_and_saturated(ctx):
+    """All logits equal (tie order = ascending column) and sigmoid-saturated logits."""
+    import torch
+    B, n, k = 3, 2000, 500
+    z = np.zeros((B, n), np.float32)
+    z[1] = 40.0                                  # sigmoid == 1.0f for the whole row
+    z[2, :] = np.linspace(30, 31, n, dtype=np.float32)
+    srp, sc = seeds_to_csr([[0, 1, 2], [5], []], B, n)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.topk_dense(_dev(z), n, 0, _dev(srp), _dev(sc), k, score, idx)
+    sc_r, idx_r = oracle.topk(z, k, srp, sc)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+    assert idx.cpu().numpy()[0, 0] == 3
+
+
+@pytest.mark.parametrize("V,nt,H,B,k,dist,bias", [
+    (2000, 1500, 32, 8, 500, "zipf", "zeros"),          # small: unfused inside the library
+    (70000, 60000, 64, 40, 500, "zipf", "zipf"),        # fused: sample + filter + select
+    (50000, 41000, 256, 130, 500, "uniform", "zeros"),  # hidden=256 unrolled body, 2 row groups
+    (40000, 40000, 96, 300, 100, "zipf", "zipf"),
+    (33000, 30000, 256, 256, 500, "zipf", "zipf"),
+])
+def test_decode_topk_fused_bit_exact(ctx, V, nt, H, B, k, dist, bias):
+    import torch
+    p = _problem(V, nt, H, B, dist=dist, bias=bias)
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(sc), k, score, idx)
+    plan = ctx.last_plan()
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"], 0, nt)
+    sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+    if V >= 30000:
+        assert plan["fused"] == 1, plan
+    # no seed may be recommended (main_challenge.py:31-35)
+    ig = idx.cpu().numpy()
+    for r in range(B):
+        assert not (set(p["seeds"][r]) & set(ig[r].tolist()))
+
+
+def test_decode_topk_equals_unfused(ctx):
+    """dae_decode_dense + dae_topk_dense == dae_decode_topk (include/dae_hip.h contract)."""
+    import torch
+    V, nt, H, B, k = 60000, 52000, 128, 64, 500
+    p = _problem(V, nt, H, B, bias="zipf")
+    h = _gpu_encode(ctx, p)
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    s1 = torch.empty((B, k), dtype=torch.float32, device="cuda"); i1 = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    s2 = torch.empty_like(s1); i2 = torch.empty_like(i1)
+    ctx.decode_topk(h, nt, _dev(p["srp"]), _dev(p["sc"]), k, s1, i1)
+    z = torch.empty((B, V), dtype=torch.float32, device="cuda")
+    ctx.decode_dense(h, z, apply_sigmoid=False)
+    ctx.topk_dense(z, nt, 0, _dev(p["srp"]), _dev(p["sc"]), k, s2, i2)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
+
+
+def test_shard_merge_bit_exact(ctx):
+    """Column-sharded decode + K4 merge == unsharded, run on one GPU."""
+    import torch
+    V, nt, H, B, k, G = 64000, 50000, 64, 48, 500, 4
+    p = _problem(V, nt, H, B, bias="zipf")
+    h = _gpu_encode(ctx, p)
+    srp, sc = _dev(p["srp"]), _dev(p["sc"])
+    bounds = np.linspace(0, nt, G + 1).astype(int)
+    cl = torch.empty((G, B, k), dtype=torch.float32, device="cuda")
+    ci = torch.empty((G, B, k), dtype=torch.int32, device="cuda")
+    for g in range(G):
+        ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), int(bounds[g]), int(bounds[g + 1]))
+        ctx.decode_topk(h, nt, srp, sc, k, cl[g], ci[g], out_kind=_lib.DAE_OUT_LOGIT)
+    s = torch.empty((B, k), dtype=torch.float32, device="cuda"); i = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.topk_merge(cl, ci, s, i)
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    s0 = torch.empty_like(s); i0 = torch.empty_like(i)
+    ctx.decode_topk(h, nt, srp, sc, k, s0, i0)
+    assert torch.equal(i, i0) and torch.equal(s, s0)
+    sm, im = oracle.topk_merge(cl.cpu().numpy(), ci.cpu().numpy())
+    _check_topk(i.cpu().numpy(), s.cpu().numpy(), im, sm)
+
+
+def test_errors_are_loud(ctx):
+    import torch
+    h = torch.zeros((4, 30), dtype=torch.float32, device="cuda")
+    with pytest.raises(_lib.DaeError):
+        ctx.encode(_dev(np.zeros(5, np.int32)), _dev(np.zeros(1, np.int32)), _dev(np.zeros(1, np.float32)),
+                   torch.zeros((10, 30), device="cuda"), torch.zeros(30, device="cuda"), h)   # H % 4
+    c2 = _lib.Context(0)
+    with pytest.raises(_lib.DaeError):
+        c2.decode_dense(torch.zeros((4, 32), device="cuda"), torch.zeros((4, 8), device="cuda"))  # no prepack
+    c2.close()
