@@ -3,46 +3,72 @@
 //     cand = argsort(-scores); for s in seed: cand.remove(s); cand = cand[:500]
 // numpy's argsort leaves tie order unspecified, so the canonical rule is
 //     (fp32 logit descending, column index ascending)
-// implemented as an exact MSB radix select on the order-preserving key of the logit (3 passes of
-// 11/11/10 bits), an index radix select only when the k-th logit is tied across the cut, a
-// collect pass, and a bitonic sort of the <= 1024 survivors on the 64-bit composite key.
-// Seed tracks are removed through a per-row LDS bitmap over the ranked column range (the
-// reference's O(n) list.remove per seed becomes one LDS bit test per candidate).
+// i.e. descending order of the UNIQUE 64-bit composite key  (okey(logit) << 32) | ~column.
 //
-// Two element sources share the code:
+// Algorithm per row (one 1024-thread workgroup, everything after the first read stays in LDS):
+//   1. seed tracks -> per-row LDS bitmap over the ranked column range (the reference's O(n)
+//      list.remove per seed becomes one LDS bit test per element);
+//   2. every valid element's composite key is appended to an LDS key buffer (wave-aggregated
+//      append), with the running min / max key;
+//   3. range-adaptive MSB radix narrowing: histogram (key - lo) >> shift over 2048 bins with shift
+//      chosen from the live range [lo, hi], parallel suffix scan to find the bin holding the
+//      k-th key, shrink [lo, hi] to that bin; stop as soon as the keys >= lo fit the sort buffer
+//      (keys are unique, so no tie handling exists anywhere);
+//   4. collect those keys, bitonic-sort them descending, emit the first k.
+// Rows whose elements do not fit the LDS key buffer (dae_topk_dense over a whole vocabulary row)
+// run the same steps with step 3 re-reading the source instead of LDS.
+//
+// Element sources:
 //   dense : a row of logits (phase-A sample buffer of the fused path, dae_topk_dense)
-//   pairs : segments of (logit, column) pairs (phase-B candidate lists, shard merge K4)
+//   pairs : segments of (logit, column) pairs (phase-B candidate lists)
+//   soa   : [G, B, k] shard lists gathered by RCCL (K4 merge)
 #include "dae_internal.h"
 
 namespace {
 
-constexpr int TK_THREADS = 256;
+constexpr int TK_THREADS = 1024;
+constexpr int TK_WAVES = TK_THREADS / 64;
 constexpr int TK_BINS = 2048;
 constexpr int TK_MAX_SEG = 1024;
+constexpr int TK_SORT_MAX = 2048;
+typedef unsigned long long u64;
 
 struct DenseSrc {
     dae_dense_src s;
+    __device__ __forceinline__ void prepare(int, int, int*) const {}
+    __device__ __forceinline__ int count(int, const int*) const { return s.n; }
     template <typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, int* /*seg_prefix*/, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
         const float* rp = s.logits + (size_t)row * s.ld;
         const int step = 32 * s.tile_stride;
-        for (int p = tid; p < s.n; p += TK_THREADS) {
-            const int colv = s.col_base + (p >> 5) * step + (p & 31);
-            f(rp[p], colv);
+        int base = 0;                                  // block-uniform loop bounds
+        for (; base + 4 * TK_THREADS <= s.n; base += 4 * TK_THREADS) {
+            float z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) z[u] = rp[base + u * TK_THREADS + tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + u * TK_THREADS + tid;
+                f(z[u], s.col_base + (q >> 5) * step + (q & 31), true);
+            }
+        }
+        for (; base < s.n; base += TK_THREADS) {
+            const int q = base + tid;
+            const bool in = q < s.n;
+            const float z = in ? rp[q] : 0.f;
+            f(z, s.col_base + (q >> 5) * step + (q & 31), in);
         }
     }
-    __device__ __forceinline__ void prepare(int, int, int*) const {}
 };
 
 struct PairSrc {
     dae_pair_group g0, g1;
-
     __device__ __forceinline__ int seg_count(const dae_pair_group& g, int seg, int row) const
     {
         return g.cnt ? g.cnt[(size_t)seg * g.cnt_seg_stride + row] : g.fixed_cnt;
     }
-    // exclusive prefix of segment sizes in LDS: seg_prefix[0..nseg], nseg = g0.nseg + g1.nseg
+    // exclusive prefix of segment sizes in LDS: seg_prefix[0..nseg]
     __device__ __forceinline__ void prepare(int row, int tid, int* seg_prefix) const
     {
         const int nseg = g0.nseg + g1.nseg;
@@ -50,261 +76,284 @@ struct PairSrc {
             seg_prefix[s + 1] = s < g0.nseg ? seg_count(g0, s, row) : seg_count(g1, s - g0.nseg, row);
         if (tid == 0) seg_prefix[0] = 0;
         __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int s = 1; s <= nseg; ++s) { run += seg_prefix[s]; seg_prefix[s] = run; }
+        if (tid < 64) {           // one wave scans (nseg <= 1024: 16 chunks of 64)
+            int carry = 0;
+            for (int base = 0; base < nseg; base += 64) {
+                const int i = base + tid;
+                int v = i < nseg ? seg_prefix[i + 1] : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(v, d);
+                    if (tid >= d) v += o;
+                }
+                if (i < nseg) seg_prefix[i + 1] = v + carry;
+                carry += __shfl(v, 63);
+            }
         }
         __syncthreads();
     }
+    __device__ __forceinline__ int count(int, const int* seg_prefix) const
+    {
+        return seg_prefix[g0.nseg + g1.nseg];
+    }
     template <typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, int* seg_prefix, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, F f) const
     {
         const int nseg = g0.nseg + g1.nseg;
         const int total = seg_prefix[nseg];
-        for (int e = tid; e < total; e += TK_THREADS) {
-            int lo = 0, hiq = nseg;                 // largest s with seg_prefix[s] <= e
-            while (hiq - lo > 1) {
-                const int mid = (lo + hiq) >> 1;
-                if (seg_prefix[mid] <= e) lo = mid; else hiq = mid;
+        for (int e0 = 0; e0 < total; e0 += 2 * TK_THREADS) {
+            uint2 pr[2];
+            bool in[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = e0 + u * TK_THREADS + tid;
+                in[u] = e < total;
+                pr[u] = make_uint2(0u, 0xFFFFFFFFu);
+                if (in[u]) {
+                    int lo = 0, hiq = nseg;             // largest s with seg_prefix[s] <= e
+                    while (hiq - lo > 1) {
+                        const int mid = (lo + hiq) >> 1;
+                        if (seg_prefix[mid] <= e) lo = mid; else hiq = mid;
+                    }
+                    const int i = e - seg_prefix[lo];
+                    const bool first = lo < g0.nseg;
+                    const dae_pair_group& g = first ? g0 : g1;
+                    const int seg = first ? lo : lo - g0.nseg;
+                    pr[u] = g.base[(size_t)seg * g.seg_stride + (size_t)row * g.row_stride + i];
+                }
             }
-            const int i = e - seg_prefix[lo];
-            const dae_pair_group& g = lo < g0.nseg ? g0 : g1;
-            const int seg = lo < g0.nseg ? lo : lo - g0.nseg;
-            const uint2 pr = g.base[(size_t)seg * g.seg_stride + (size_t)row * g.row_stride + i];
-            const int colv = (int)pr.y;
-            f(colv < 0 ? -__builtin_inff() : __uint_as_float(pr.x), colv);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (e0 + u * TK_THREADS < total)        // wave-uniform: whole waves enter together
+                    f(__uint_as_float(pr[u].x), (int)pr[u].y, in[u]);
+            }
         }
     }
 };
 
-// shard lists gathered by RCCL: logit[(g*B + row)*k + i], idx[...]  (K4 merge)
 struct SoaSrc {
     const float* logit; const int32_t* idx; int G, B, k;
     __device__ __forceinline__ void prepare(int, int, int*) const {}
+    __device__ __forceinline__ int count(int, const int*) const { return G * k; }
     template <typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, int*, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
         const int total = G * k;
-        for (int e = tid; e < total; e += TK_THREADS) {
-            const int g = e / k, i = e - g * k;
-            const size_t o = ((size_t)g * B + row) * k + i;
-            const int colv = idx[o];
-            f(colv < 0 ? -__builtin_inff() : logit[o], colv);
+        for (int e0 = 0; e0 < total; e0 += TK_THREADS) {
+            const int e = e0 + tid;
+            const bool in = e < total;
+            float z = 0.f; int colv = -1;
+            if (in) {
+                const int g = e / k, i = e - g * k;
+                const size_t o = ((size_t)g * B + row) * k + i;
+                colv = idx[o]; z = logit[o];
+            }
+            f(z, colv, in);
         }
     }
 };
 
-// Find, scanning bins from the top, the bin where the running count reaches `need`.
-// hist[TK_BINS] in LDS; returns bin, count strictly above it (via LDS scalars).
-__device__ __forceinline__ void find_bin(const unsigned* hist, unsigned* part, int tid,
+// Block-wide: which bin (scanning from the top) holds the `need`-th element, and how many
+// elements sit in bins above it.  Thread t owns bins 2047-2t and 2046-2t.
+__device__ __forceinline__ void find_bin(const unsigned* hist, unsigned* wave_tot, int tid,
                                          unsigned need, int* s_bin, unsigned* s_above)
 {
-    // part[t] = sum of the 8 bins owned by thread t (bins 8t .. 8t+7)
-    unsigned s = 0;
+    const int b1 = TK_BINS - 1 - 2 * tid, b0 = b1 - 1;
+    const unsigned c1 = hist[b1], c0 = hist[b0];
+    unsigned v = c1 + c0;
+    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) s += hist[tid * 8 + b];
-    part[tid] = s;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) wave_tot[wv] = v;
     __syncthreads();
-    if (tid == 0) {
-        unsigned run = 0;
-        int t = TK_THREADS - 1;
-        for (; t > 0; --t) {
-            if (run + part[t] >= need) break;
-            run += part[t];
-        }
-        int b = t * 8 + 7;
-        for (; b > t * 8; --b) {
-            if (run + hist[b] >= need) break;
-            run += hist[b];
-        }
-        *s_bin = b;
-        *s_above = run;
+    unsigned pre = 0;
+    for (int w = 0; w < wv; ++w) pre += wave_tot[w];
+    const unsigned incl = pre + v, excl = incl - (c1 + c0);
+    if (excl < need && need <= incl) {
+        if (excl + c1 >= need) { *s_bin = b1; *s_above = excl; }
+        else                   { *s_bin = b0; *s_above = excl + c1; }
     }
     __syncthreads();
 }
 
 template <typename Src>
-__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const dae_topk_args a)
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const dae_topk_args a,
+                                                          const int key_cap)
 {
-    extern __shared__ unsigned dyn_bitmap[];             // ceil(bitmap_n/32) words
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ unsigned hist[TK_BINS];
-    __shared__ unsigned part[TK_THREADS];
-    __shared__ unsigned long long skey[DAE_MAX_K];
+    __shared__ u64 skey[TK_SORT_MAX];
     __shared__ int seg_prefix[TK_MAX_SEG + 2];
+    __shared__ unsigned wave_tot[TK_WAVES];
     __shared__ int s_bin;
     __shared__ unsigned s_above;
     __shared__ unsigned s_cnt;
+    __shared__ u64 s_min, s_max;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int row = blockIdx.x;
     const int k = a.k;
-
-    // ---- seed bitmap ---------------------------------------------------------------------------
     const int bm_words = (a.bitmap_n + 31) >> 5;
-    for (int w = tid; w < bm_words; w += TK_THREADS) dyn_bitmap[w] = 0;
+    unsigned* bitmap = reinterpret_cast<unsigned*>(dyn);
+    u64* keys = reinterpret_cast<u64*>(dyn + (((size_t)bm_words * 4 + 15) & ~(size_t)15));
+
+    // ---- 1. seed bitmap ---------------------------------------------------------------------------
+    for (int w = tid; w < bm_words; w += TK_THREADS) bitmap[w] = 0;
+    if (tid == 0) { s_cnt = 0; s_min = ~0ull; s_max = 0ull; }
     __syncthreads();
     if (a.seed_col && bm_words > 0) {
         const int sb = a.seed_row_ptr[row], se = a.seed_row_ptr[row + 1];
         for (int i = sb + tid; i < se; i += TK_THREADS) {
             const int pcol = a.seed_col[i] - a.bitmap_base;
-            if (pcol >= 0 && pcol < a.bitmap_n) atomicOr(&dyn_bitmap[pcol >> 5], 1u << (pcol & 31));
+            if (pcol >= 0 && pcol < a.bitmap_n) atomicOr(&bitmap[pcol >> 5], 1u << (pcol & 31));
         }
     }
     src.prepare(row, tid, seg_prefix);
     __syncthreads();
 
-    auto key_of = [&](float z, int colv) -> unsigned {
-        // 0 = absent (masked seed, -inf padding, missing entry); valid keys are > DAE_KEY_NEG_INF
-        if (colv < 0) return 0u;
+    // composite key of one element; 0 = absent (masked seed, -inf padding, missing entry)
+    auto ckey = [&](float z, int colv, bool in) -> u64 {
+        if (!in || colv < 0) return 0ull;
         const unsigned key = dae_okey(z);
-        if (key <= DAE_KEY_NEG_INF) return 0u;
+        if (key <= DAE_KEY_NEG_INF) return 0ull;
         const int pcol = colv - a.bitmap_base;
-        if (pcol >= 0 && pcol < a.bitmap_n && ((dyn_bitmap[pcol >> 5] >> (pcol & 31)) & 1u))
-            return 0u;
-        return key;
+        if (pcol >= 0 && pcol < a.bitmap_n && ((bitmap[pcol >> 5] >> (pcol & 31)) & 1u)) return 0ull;
+        return ((u64)key << 32) | (u64)(~(unsigned)colv);
     };
 
-    // ---- radix select on the logit key: 11 + 11 + 10 bits ---------------------------------------
-    unsigned prefix = 0;          // decided high bits of the k-th key
-    unsigned need = 0;            // how many still to take from the current bucket
-    unsigned k_eff = 0;
+    // ---- 2. first read: keys -> LDS (if they fit), count, min, max ---------------------------------
     {
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned key = key_of(z, colv);
-            if (key) atomicAdd(&hist[key >> 21], 1u);
+        u64 mn = ~0ull, mx = 0ull;
+        src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            const u64 ck = ckey(z, colv, in);
+            const bool v = ck != 0ull;
+            const u64 bal = __ballot(v);
+            if (bal) {
+                const int leader = __ffsll((long long)__ballot(1)) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                base = __shfl(base, leader);
+                if (v) {
+                    const unsigned slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (slot < (unsigned)key_cap) keys[slot] = ck;
+                    mn = ck < mn ? ck : mn;
+                    mx = ck > mx ? ck : mx;
+                }
+            }
         });
-        __syncthreads();
-        // total valid
-        unsigned s = 0;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) s += hist[tid * 8 + b];
-        part[tid] = s;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned tot = 0;
-            for (int t = 0; t < TK_THREADS; ++t) tot += part[t];
-            s_cnt = tot;
+        for (int d = 32; d > 0; d >>= 1) {
+            const u64 omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+            mn = omn < mn ? omn : mn;
+            mx = omx > mx ? omx : mx;
         }
-        __syncthreads();
-        const unsigned total_valid = s_cnt;
-        k_eff = total_valid < (unsigned)k ? total_valid : (unsigned)k;
-        __syncthreads();
+        if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    }
+    __syncthreads();
+    const unsigned m = s_cnt;                                   // valid elements
+    const bool in_lds = m <= (unsigned)key_cap;                 // all of them were kept in LDS
+    const unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;
+    int sort_n = 1;
+    while (sort_n < k) sort_n <<= 1;
+    if (sort_n < 1024) sort_n = 1024;                            // always <= TK_SORT_MAX (k <= 1024)
+    if (k > 512) sort_n = TK_SORT_MAX;
+
+    // every valid key, from LDS or (big rows) from the source again
+    auto for_keys = [&](auto f) {
+        if (in_lds) {
+            for (unsigned i = tid; i < m; i += TK_THREADS) f(keys[i]);
+        } else {
+            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+                const u64 ck = ckey(z, colv, in);
+                if (ck) f(ck);
+            });
+        }
+    };
+
+    // ---- 3. narrow [lo, hi] until the keys >= lo fit the sort buffer ---------------------------------
+    u64 lo = s_min, hi = s_max;
+    unsigned above = 0;                                          // keys > hi
+    if (m > (unsigned)sort_n) {
+        for (int it = 0; it < 8; ++it) {
+            const u64 range = hi - lo;
+            int shift = 64 - 11 - __clzll(range | 1ull);
+            if (shift < 0) shift = 0;
+            for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
+            __syncthreads();
+            for_keys([&](u64 ck) {
+                if (ck >= lo && ck <= hi) atomicAdd(&hist[(unsigned)((ck - lo) >> shift)], 1u);
+            });
+            __syncthreads();
+            find_bin(hist, wave_tot, tid, k_eff - above, &s_bin, &s_above);
+            const unsigned b = (unsigned)s_bin;
+            const unsigned cnt_b = hist[b];
+            const unsigned new_above = above + s_above;
+            const u64 nlo = lo + ((u64)b << shift);
+            u64 nhi = nlo + ((1ull << shift) - 1ull);
+            if (nhi > hi) nhi = hi;
+            __syncthreads();                                     // hist / s_bin consumed
+            lo = nlo;
+            if (new_above + cnt_b <= (unsigned)sort_n) break;    // keys >= lo fit
+            hi = nhi;
+            above = new_above;
+        }
     }
 
-    unsigned T = 0;               // k-th key
-    unsigned n_eq = 0;            // elements with key == T
-    if (k_eff > 0) {
-        find_bin(hist, part, tid, k_eff, &s_bin, &s_above);
-        prefix = (unsigned)s_bin << 21;
-        need = k_eff - s_above;
-        __syncthreads();
-
-        // pass B: bits 20..10 among keys with the same top 11 bits
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned key = key_of(z, colv);
-            if (key && (key >> 21) == (prefix >> 21)) atomicAdd(&hist[(key >> 10) & 0x7FFu], 1u);
-        });
-        __syncthreads();
-        find_bin(hist, part, tid, need, &s_bin, &s_above);
-        prefix |= (unsigned)s_bin << 10;
-        need -= s_above;
-        __syncthreads();
-
-        // pass C: bits 9..0 among keys with the same top 22 bits
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned key = key_of(z, colv);
-            if (key && (key >> 10) == (prefix >> 10)) atomicAdd(&hist[key & 0x3FFu], 1u);
-        });
-        __syncthreads();
-        find_bin(hist, part, tid, need, &s_bin, &s_above);
-        T = prefix | (unsigned)s_bin;
-        need -= s_above;
-        n_eq = hist[s_bin];
-        __syncthreads();
-    }
-
-    // ---- tie at the cut: take the `need` smallest column ids among key == T ----------------------
-    unsigned idx_cut = 0xFFFFFFFFu;     // take key == T elements with (unsigned)col <= idx_cut
-    if (k_eff > 0 && need < n_eq) {
-        // radix select the need-th SMALLEST column: work on inverted ids so "largest" logic applies
-        unsigned ipre = 0;
-        unsigned ineed = need;
-        // pass 1: bits 31..21
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            if (key_of(z, colv) == T) atomicAdd(&hist[(~(unsigned)colv) >> 21], 1u);
-        });
-        __syncthreads();
-        find_bin(hist, part, tid, ineed, &s_bin, &s_above);
-        ipre = (unsigned)s_bin << 21; ineed -= s_above;
-        __syncthreads();
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned ik = ~(unsigned)colv;
-            if (key_of(z, colv) == T && (ik >> 21) == (ipre >> 21))
-                atomicAdd(&hist[(ik >> 10) & 0x7FFu], 1u);
-        });
-        __syncthreads();
-        find_bin(hist, part, tid, ineed, &s_bin, &s_above);
-        ipre |= (unsigned)s_bin << 10; ineed -= s_above;
-        __syncthreads();
-        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned ik = ~(unsigned)colv;
-            if (key_of(z, colv) == T && (ik >> 10) == (ipre >> 10))
-                atomicAdd(&hist[ik & 0x3FFu], 1u);
-        });
-        __syncthreads();
-        find_bin(hist, part, tid, ineed, &s_bin, &s_above);
-        ipre |= (unsigned)s_bin;
-        idx_cut = ~ipre;                 // column ids are unique, so exactly `need` are <= idx_cut
-        __syncthreads();
-    }
-
-    // ---- collect the k_eff winners, sort them ----------------------------------------------------
-    int npow2 = 1;
-    while (npow2 < k) npow2 <<= 1;
-    for (int i = tid; i < npow2; i += TK_THREADS) skey[i] = 0ull;
+    // ---- 4. collect keys >= lo, sort descending, emit -------------------------------------------------
+    for (int i = tid; i < sort_n; i += TK_THREADS) skey[i] = 0ull;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    if (k_eff > 0) {
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv) {
-            const unsigned key = key_of(z, colv);
-            if (key > T || (key == T && (unsigned)colv <= idx_cut)) {
-                const unsigned slot = atomicAdd(&s_cnt, 1u);
-                if (slot < (unsigned)npow2)
-                    skey[slot] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)colv);
+    if (in_lds) {
+        for (unsigned i0 = 0; i0 < m; i0 += TK_THREADS) {
+            const unsigned i = i0 + tid;
+            const u64 ck = i < m ? keys[i] : 0ull;
+            const bool v = ck != 0ull && ck >= lo;
+            const u64 bal = __ballot(v);
+            if (bal) {
+                const int leader = __ffsll((long long)__ballot(1)) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                base = __shfl(base, leader);
+                const unsigned slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (v && slot < (unsigned)sort_n) skey[slot] = ck;
+            }
+        }
+    } else {
+        src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            const u64 ck = ckey(z, colv, in);
+            const bool v = ck != 0ull && ck >= lo;
+            const u64 bal = __ballot(v);
+            if (bal) {
+                const int leader = __ffsll((long long)__ballot(1)) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                base = __shfl(base, leader);
+                const unsigned slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (v && slot < (unsigned)sort_n) skey[slot] = ck;
             }
         });
     }
     __syncthreads();
 
-    // bitonic sort, descending
-    for (int size = 2; size <= npow2; size <<= 1) {
+    for (int size = 2; size <= sort_n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (npow2 >> 1); i += TK_THREADS) {
-                const int lo = (i / stride) * (stride << 1) + (i % stride);
-                const int hi2 = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long x = skey[lo], y = skey[hi2];
-                if ((x < y) == desc) { skey[lo] = y; skey[hi2] = x; }
+            for (int i = tid; i < (sort_n >> 1); i += TK_THREADS) {
+                const int l = (i / stride) * (stride << 1) + (i % stride);
+                const int h2 = l + stride;
+                const bool desc = ((l & size) == 0);
+                const u64 x = skey[l], y = skey[h2];
+                if ((x < y) == desc) { skey[l] = y; skey[h2] = x; }
             }
             __syncthreads();
         }
     }
 
-    // ---- write ----------------------------------------------------------------------------------
     for (int i = tid; i < k; i += TK_THREADS) {
-        const unsigned long long ck = skey[i];
+        const u64 ck = skey[i];
         const bool present = (unsigned)i < k_eff && ck != 0ull;
         const float z = present ? dae_okey_inv((unsigned)(ck >> 32)) : -__builtin_inff();
         const int colv = present ? (int)(~(unsigned)(ck & 0xFFFFFFFFull)) : -1;
@@ -315,26 +364,33 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(z), (unsigned)colv);
     }
     if (a.out_tau && tid == 0)
-        a.out_tau[row] = (k_eff == (unsigned)k) ? dae_okey_inv(T) : -__builtin_inff();
+        a.out_tau[row] = (k_eff == (unsigned)k) ? dae_okey_inv((unsigned)(skey[k - 1] >> 32))
+                                                : -__builtin_inff();
 }
 
 template <typename Src>
 int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
 {
-    if (a.k < 1 || a.k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", a.k, DAE_MAX_K);
+    if (a.k < 1 || a.k > DAE_MAX_K)
+        return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", a.k, DAE_MAX_K);
     if (a.B <= 0) return DAE_OK;
-    const size_t dyn = (size_t)((a.bitmap_n + 31) / 32) * sizeof(unsigned);
-    if (dyn > 128 * 1024)
+    const size_t bm_bytes = (((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) & ~(size_t)15;
+    // static LDS of the kernel: hist 8K + skey 16K + seg_prefix ~4K + scalars
+    const size_t lds_total = 160 * 1024, lds_static = 30 * 1024;
+    if (bm_bytes + lds_static + 8 * 1024 > lds_total)
         return dae_fail(ctx, DAE_ERR_ARG, "ranked column range %d too wide for the LDS seed bitmap",
                         a.bitmap_n);
+    const size_t dyn = lds_total - lds_static;                  // bitmap + key buffer
+    const int key_cap = (int)((dyn - bm_bytes) / 8);
     static bool attr_set = false;
     if (!attr_set) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               128 * 1024));
+                                               (int)dyn));
         attr_set = true;
     }
-    hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, a);
+    hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, a,
+                       key_cap);
     DAE_CHECK_LAUNCH(ctx, "topk_kernel");
     return DAE_OK;
 }
