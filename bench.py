@@ -112,11 +112,11 @@ def main():
         l_idx = torch.empty((B, k), dtype=torch.int32, device=dev)
 
     def step():
-        ctx.encode(d_rp, d_col, d_val, d_We, d_be, h)
         if world == 1:
-            ctx.decode_topk(h, n_tracks, d_srp, d_sc, k, score, idx)
+            ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, score, idx)
         else:
-            ctx.decode_topk(h, n_tracks, d_srp, d_sc, k, l_logit, l_idx, out_kind=_lib.DAE_OUT_LOGIT)
+            ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_logit, l_idx,
+                           out_kind=_lib.DAE_OUT_LOGIT)
             dist.all_gather_into_tensor(g_logit, l_logit)
             dist.all_gather_into_tensor(g_idx, l_idx)
             ctx.topk_merge(g_logit, g_idx, score, idx)

@@ -129,6 +129,18 @@ int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype,
                     int k, int out_kind,
                     float* out_score, int32_t* out_idx);
 
+/* The whole scoring path in one call: dae_encode (inference keep-probs) -> dae_decode_topk,
+ * with the hidden activations kept inside the ctx in the decode kernels' operand order (no
+ * [B,H] round trip, no re-pack pass).  Results are identical to calling the two separately.
+ * This is what main_challenge.py:80-90 / main_train.py:66-89 do per batch. */
+int dae_score_topk(dae_ctx* ctx,
+                   const int32_t* row_ptr, const int32_t* col, const float* val,
+                   const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                   int n_tracks,
+                   const int32_t* seed_row_ptr, const int32_t* seed_col,
+                   int k, int out_kind,
+                   float* out_score, int32_t* out_idx);
+
 /* Unfused ranking of caller-provided dense logits/scores [B, ld] whose column 0 is global
  * column `col_base`; ranks columns [0, ncols).  Same order/seed rules as dae_decode_topk.
  * (parity path: dae_decode_dense + dae_topk_dense must equal dae_decode_topk.) */

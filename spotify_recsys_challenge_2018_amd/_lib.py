@@ -16,7 +16,7 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
     "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
-    "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward", "dae_adam_step",
+    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward", "dae_adam_step",
 ]
 
 _lib = None
@@ -57,6 +57,8 @@ def load():
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
+    lib.dae_score_topk.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp,
+                                   c_int, c_int, vp, vp]
     lib.dae_topk_dense.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_topk_merge.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]
     lib.dae_train_forward_backward.argtypes = (
@@ -141,6 +143,15 @@ class Context:
         self.check(self.lib.dae_decode_topk(self.h, _ptr(h), B, H, int(dtype), int(n_tracks),
                                             _ptr(seed_row_ptr), _ptr(seed_col), int(k),
                                             int(out_kind), _ptr(out_score), _ptr(out_idx)))
+
+    def score_topk(self, row_ptr, col, val, W_enc, b_enc, n_tracks, seed_row_ptr, seed_col, k,
+                   out_score, out_idx, out_kind=DAE_OUT_SCORE, dtype=DAE_DTYPE_F32):
+        V, H = W_enc.shape
+        B = row_ptr.numel() - 1
+        self.check(self.lib.dae_score_topk(self.h, _ptr(row_ptr), _ptr(col), _ptr(val),
+                                           _ptr(W_enc), _ptr(b_enc), V, H, B, int(dtype),
+                                           int(n_tracks), _ptr(seed_row_ptr), _ptr(seed_col),
+                                           int(k), int(out_kind), _ptr(out_score), _ptr(out_idx)))
 
     def topk_dense(self, logits, ncols, col_base, seed_row_ptr, seed_col, k, out_score, out_idx,
                    out_kind=DAE_OUT_SCORE):

@@ -184,7 +184,8 @@ int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const f
     if ((reinterpret_cast<uintptr_t>(W_enc) | reinterpret_cast<uintptr_t>(b_enc) |
          reinterpret_cast<uintptr_t>(h_out)) % 16)
         return dae_fail(ctx, DAE_ERR_ARG, "W_enc, b_enc, h_out must be 16-byte aligned");
-    return dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, ikp, kp, seed, h_out);
+    return dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, ikp, kp, seed, h_out,
+                             nullptr, 0, 0);
 }
 
 int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, int V, int H,
@@ -219,24 +220,17 @@ int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int 
     return prof_end(ctx);
 }
 
-int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
-                    const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
-                    float* out_score, int32_t* out_idx)
+static long long geom_key(int B, int H, int R_TILE)
 {
-    if (!ctx) return DAE_ERR_ARG;
-    if (!h || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
-    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
-    if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
-    if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
-        return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
-    const dae_packed* pk = packed_for(ctx, dtype, H);
-    if (!pk) return DAE_ERR_STATE;
-    if (B <= 0) return DAE_OK;
+    return ((long long)B << 32) | ((long long)H << 12) | (long long)R_TILE;
+}
 
-    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
-    int rc = dae_launch_pack_h(ctx, h, B, H, g);
-    if (rc) return rc;
-
+// decode + rank with the hidden tile already packed in ctx->h_packed for geometry g
+static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B,
+                            int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                            int k, int out_kind, float* out_score, int32_t* out_idx)
+{
+    int rc;
     const int ntiles = pk->ntiles;
     const int n_valid_col = n_tracks < pk->col_hi ? n_tracks : pk->col_hi;       // global bound
     int nrank = n_valid_col - pk->col_lo;                                         // ranked columns
@@ -307,6 +301,71 @@ int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n
     ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
     ta.out_score = out_score; ta.out_idx = out_idx;
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
+}
+
+static int check_topk_args(dae_ctx* ctx, int dtype, int k, const int32_t* seed_row_ptr,
+                           const int32_t* seed_col, const void* out_score, const void* out_idx)
+{
+    if (!out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
+    if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
+        return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
+    return DAE_OK;
+}
+
+int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
+                    const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
+                    float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!h) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    int rc = check_topk_args(ctx, dtype, k, seed_row_ptr, seed_col, out_score, out_idx);
+    if (rc) return rc;
+    const dae_packed* pk = packed_for(ctx, dtype, H);
+    if (!pk) return DAE_ERR_STATE;
+    if (B <= 0) return DAE_OK;
+    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
+    rc = dae_launch_pack_h(ctx, h, B, H, g);          // rewrites the whole image incl. zero pads
+    if (rc) return rc;
+    ctx->h_geom_key = geom_key(B, H, g.R_TILE);
+    ctx->h_geom_ptr = ctx->h_packed.p;
+    return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
+                            out_score, out_idx);
+}
+
+int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                   const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                   int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                   int k, int out_kind, float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !W_enc || !b_enc) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (H <= 0 || (H % 4) != 0) return dae_fail(ctx, DAE_ERR_ARG, "H=%d must be a positive multiple of 4", H);
+    if ((reinterpret_cast<uintptr_t>(W_enc) | reinterpret_cast<uintptr_t>(b_enc)) % 16)
+        return dae_fail(ctx, DAE_ERR_ARG, "W_enc, b_enc must be 16-byte aligned");
+    int rc = check_topk_args(ctx, dtype, k, seed_row_ptr, seed_col, out_score, out_idx);
+    if (rc) return rc;
+    const dae_packed* pk = packed_for(ctx, dtype, H);
+    if (!pk) return DAE_ERR_STATE;
+    if (B <= 0) return DAE_OK;
+    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
+    const int G = pk->Hp / DAE_KG, RB = g.R_TILE / 32;
+    const size_t bytes = (size_t)g.n_rg * G * RB * 64 * sizeof(float4);
+    rc = dae_reserve(ctx, ctx->h_packed, bytes);
+    if (rc) return rc;
+    const long long key = geom_key(B, H, g.R_TILE);
+    if (ctx->h_geom_key != key || ctx->h_geom_ptr != ctx->h_packed.p) {
+        // pad rows / pad k of the image are never written by the encode kernel: zero them once
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, bytes, ctx->stream));
+        ctx->h_geom_key = key;
+        ctx->h_geom_ptr = ctx->h_packed.p;
+    }
+    rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, nullptr,
+                           static_cast<float*>(ctx->h_packed.p), G, RB);
+    if (rc) return rc;
+    return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
+                            out_score, out_idx);
 }
 
 int dae_topk_dense(dae_ctx* ctx, const float* logits, int64_t ld, int B, int ncols, int col_base,

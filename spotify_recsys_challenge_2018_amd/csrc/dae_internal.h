@@ -45,6 +45,8 @@ struct dae_ctx {
 
     // scratch (grown lazily, never shrunk)
     dae_buf h_packed;          // [n_rg][Hp/8][RB][64][4] fp32 (or bf16 image)
+    long long h_geom_key = -1; // (B, H, R_TILE) whose pad region of h_packed is known to be zero
+    void* h_geom_ptr = nullptr;
     dae_buf sample;            // phase-A dense logits [Bpad][n_sample_cols]
     dae_buf tau;               // [Bpad] fp32
     dae_buf sample_top;        // [Bpad][k] (logit, idx) pairs
@@ -154,7 +156,8 @@ dae_rowgeom dae_row_geometry(int B, int Hp);
 // encode.hip
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
                       const float* W_enc, const float* b_enc, int V, int H, int B,
-                      float ikp, float kp, uint32_t seed, float* h_out);
+                      float ikp, float kp, uint32_t seed, float* h_out,
+                      float* h_packed, int G, int RB);
 
 // decode_f32.hip
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,

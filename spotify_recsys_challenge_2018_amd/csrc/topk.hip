@@ -14,7 +14,7 @@
 //      chosen from the live range [lo, hi], parallel suffix scan to find the bin holding the
 //      k-th key, shrink [lo, hi] to that bin; stop as soon as the keys >= lo fit the sort buffer
 //      (keys are unique, so no tie handling exists anywhere);
-//   4. collect those keys, bitonic-sort them descending, emit the first k.
+//   4. collect those keys, sort them descending (bitonic: wave shuffles + 10 LDS stages), emit k.
 // Rows whose elements do not fit the LDS key buffer (dae_topk_dense over a whole vocabulary row)
 // run the same steps with step 3 re-reading the source instead of LDS.
 //
@@ -181,7 +181,7 @@ __device__ __forceinline__ void find_bin(const unsigned* hist, unsigned* wave_to
 
 template <typename Src>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const dae_topk_args a,
-                                                          const int key_cap)
+                                                          const int key_cap, const int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ unsigned hist[TK_BINS];
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     }
     src.prepare(row, tid, seg_prefix);
     __syncthreads();
+    if (dbg_stop == 1) return;
 
     // composite key of one element; 0 = absent (masked seed, -inf padding, missing entry)
     auto ckey = [&](float z, int colv, bool in) -> u64 {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     }
     __syncthreads();
+    if (dbg_stop == 2) return;
     const unsigned m = s_cnt;                                   // valid elements
     const bool in_lds = m <= (unsigned)key_cap;                 // all of them were kept in LDS
     const unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;
@@ -262,16 +264,34 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     if (sort_n < 1024) sort_n = 1024;                            // always <= TK_SORT_MAX (k <= 1024)
     if (k > 512) sort_n = TK_SORT_MAX;
 
-    // every valid key, from LDS or (big rows) from the source again
+    // every valid key, from LDS or (big rows) from the source again.  f(key) is called by WHOLE
+    // waves (key == 0 for lanes without an element) so it may use wave-level aggregation.
     auto for_keys = [&](auto f) {
         if (in_lds) {
-            for (unsigned i = tid; i < m; i += TK_THREADS) f(keys[i]);
+            for (unsigned i0 = 0; i0 < m; i0 += TK_THREADS) {
+                const unsigned i = i0 + tid;
+                f(i < m ? keys[i] : 0ull);
+            }
         } else {
             src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
-                const u64 ck = ckey(z, colv, in);
-                if (ck) f(ck);
+                f(ckey(z, colv, in));
             });
         }
+    };
+    // histogram update with wave-level aggregation: the bulk of a row's logits falls into a
+    // handful of bins, and same-address LDS atomics serialise; up to 6 rounds of "leader's bin:
+    // one atomic for all lanes that share it", the (few, scattered) rest as plain atomics.
+    auto hist_add = [&](unsigned bin, bool valid) {
+        u64 todo = __ballot(valid);
+        for (int it = 0; it < 6 && todo; ++it) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+            const u64 same = __ballot(valid && bin == lb);
+            if (lane == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+            if (bin == lb) valid = false;
+            todo &= ~same;
+        }
+        if (valid) atomicAdd(&hist[bin], 1u);
     };
 
     // ---- 3. narrow [lo, hi] until the keys >= lo fit the sort buffer ---------------------------------
@@ -285,7 +305,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
             __syncthreads();
             for_keys([&](u64 ck) {
-                if (ck >= lo && ck <= hi) atomicAdd(&hist[(unsigned)((ck - lo) >> shift)], 1u);
+                const bool v = ck != 0ull && ck >= lo && ck <= hi;
+                hist_add(v ? (unsigned)((ck - lo) >> shift) : 0u, v);
             });
             __syncthreads();
             find_bin(hist, wave_tot, tid, k_eff - above, &s_bin, &s_above);
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         }
     }
 
+    if (dbg_stop == 3) return;
     // ---- 4. collect keys >= lo, sort descending, emit -------------------------------------------------
     for (int i = tid; i < sort_n; i += TK_THREADS) skey[i] = 0ull;
     if (tid == 0) s_cnt = 0;
@@ -339,33 +361,79 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     }
     __syncthreads();
 
-    for (int size = 2; size <= sort_n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (sort_n >> 1); i += TK_THREADS) {
-                const int l = (i / stride) * (stride << 1) + (i % stride);
-                const int h2 = l + stride;
-                const bool desc = ((l & size) == 0);
-                const u64 x = skey[l], y = skey[h2];
-                if ((x < y) == desc) { skey[l] = y; skey[h2] = x; }
+    if (dbg_stop == 4) return;
+    // Hybrid bitonic sort, descending.  Thread t holds elements t and t + 1024 (the second only
+    // when sort_n = 2048).  Strides < 64 exchange through wave shuffles, strides 64..512 through
+    // LDS, stride 1024 inside the thread.
+    {
+        const int E = sort_n > TK_THREADS ? 2 : 1;
+        u64 kr[2];
+        kr[0] = tid < sort_n ? skey[tid] : 0ull;
+        kr[1] = E == 2 ? skey[tid + TK_THREADS] : 0ull;
+        for (int size = 2; size <= sort_n; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                if (stride >= TK_THREADS) {                      // 1024: the thread's own pair
+                    const bool desc = (((unsigned)tid & (unsigned)size) == 0);   // i = tid
+                    const u64 a0 = kr[0], a1 = kr[1];
+                    const bool sw = (a0 < a1) == desc;
+                    kr[0] = sw ? a1 : a0; kr[1] = sw ? a0 : a1;
+                } else if (stride >= 64) {
+                    __syncthreads();
+                    skey[tid] = kr[0];
+                    if (E == 2) skey[tid + TK_THREADS] = kr[1];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e < E) {
+                            const int i = e * TK_THREADS + tid;
+                            const u64 other = skey[i ^ stride];
+                            const bool desc = ((i & size) == 0);
+                            const bool lower = ((i & stride) == 0);
+                            const u64 mx = kr[e] > other ? kr[e] : other;
+                            const u64 mn = kr[e] > other ? other : kr[e];
+                            kr[e] = (lower == desc) ? mx : mn;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (e < E) {
+                            const int i = e * TK_THREADS + tid;
+                            const u64 other = __shfl_xor(kr[e], stride);
+                            const bool desc = ((i & size) == 0);
+                            const bool lower = ((i & stride) == 0);
+                            const u64 mx = kr[e] > other ? kr[e] : other;
+                            const u64 mn = kr[e] > other ? other : kr[e];
+                            kr[e] = (lower == desc) ? mx : mn;
+                        }
+                    }
+                }
             }
-            __syncthreads();
+        }
+        if (dbg_stop == 5) return;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned i = (unsigned)(e * TK_THREADS + tid);
+            if (e < E && i < k_eff) {
+                const u64 mine = kr[e];
+                const float z = dae_okey_inv((unsigned)(mine >> 32));
+                const int colv = (int)(~(unsigned)(mine & 0xFFFFFFFFull));
+                const size_t o = (size_t)row * k + i;
+                if (a.out_idx) a.out_idx[o] = colv;
+                if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
+                if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(z), (unsigned)colv);
+                if (a.out_tau && i == (unsigned)k - 1) a.out_tau[row] = z;
+            }
         }
     }
-
-    for (int i = tid; i < k; i += TK_THREADS) {
-        const u64 ck = skey[i];
-        const bool present = (unsigned)i < k_eff && ck != 0ull;
-        const float z = present ? dae_okey_inv((unsigned)(ck >> 32)) : -__builtin_inff();
-        const int colv = present ? (int)(~(unsigned)(ck & 0xFFFFFFFFull)) : -1;
+    // fewer than k valid elements: pad like the reference's cand[:500] of a short list
+    for (unsigned i = k_eff + tid; i < (unsigned)k; i += TK_THREADS) {
         const size_t o = (size_t)row * k + i;
-        if (a.out_idx) a.out_idx[o] = colv;
-        if (a.out_score)
-            a.out_score[o] = (present && a.out_kind == DAE_OUT_SCORE) ? dae_sigmoidf(z) : z;
-        if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(z), (unsigned)colv);
+        if (a.out_idx) a.out_idx[o] = -1;
+        if (a.out_score) a.out_score[o] = -__builtin_inff();
+        if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(-__builtin_inff()), 0xFFFFFFFFu);
     }
-    if (a.out_tau && tid == 0)
-        a.out_tau[row] = (k_eff == (unsigned)k) ? dae_okey_inv((unsigned)(skey[k - 1] >> 32))
-                                                : -__builtin_inff();
+    if (a.out_tau && tid == 0 && k_eff < (unsigned)k) a.out_tau[row] = -__builtin_inff();
 }
 
 template <typename Src>
@@ -389,8 +457,12 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
                                                (int)dyn));
         attr_set = true;
     }
+    // debug: DAE_TOPK_STOP=n stops the phase-A (tau-producing) kernel after stage n,
+    // DAE_TOPK_STOP=-n the other launches (bisecting stage costs under rocprofv3)
+    static const int dbg_env = getenv("DAE_TOPK_STOP") ? atoi(getenv("DAE_TOPK_STOP")) : 0;
+    const int dbg_stop = dbg_env > 0 ? (a.out_tau ? dbg_env : 0) : (a.out_tau ? 0 : -dbg_env);
     hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, a,
-                       key_cap);
+                       key_cap, dbg_stop);
     DAE_CHECK_LAUNCH(ctx, "topk_kernel");
     return DAE_OK;
 }

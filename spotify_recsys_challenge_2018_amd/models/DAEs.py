@@ -213,14 +213,17 @@ class DAE_tied:
         Returns (idx [n_rows,k] int32 with -1 padding, score [n_rows,k] float32)."""
         import torch
         self._ensure_packed()
-        h = self.encode(x_positions, x_ones)
+        self.ctx.bind_stream()
+        dev = self.weights["encoder_h"].device
+        rp, c, v = self._upload_csr(x_positions, x_ones)
         srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
         d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
-        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=h.device)
-        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=h.device)
-        self.ctx.decode_topk(h, self.n_tracks, d_srp, d_sc, k, score, idx)
+        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
+        self.ctx.score_topk(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"],
+                            self.n_tracks, d_srp, d_sc, k, score, idx)
         n_rows = self.n_batch if n_rows is None else n_rows
         return idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
 

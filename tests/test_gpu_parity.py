@@ -217,3 +217,21 @@ def test_errors_are_loud(ctx):
     with pytest.raises(_lib.DaeError):
         c2.decode_dense(torch.zeros((4, 32), device="cuda"), torch.zeros((4, 8), device="cuda"))  # no prepack
     c2.close()
+
+
+@pytest.mark.parametrize("V,nt,H,B,k", [(50000, 41000, 256, 130, 500), (33000, 30000, 72, 77, 500),
+                                        (2000, 1500, 32, 8, 100)])
+def test_score_topk_fused_call_bit_exact(ctx, V, nt, H, B, k):
+    """dae_score_topk == oracle (and == dae_encode + dae_decode_topk); H=72 exercises k padding."""
+    import torch
+    p = _problem(V, nt, H, B, bias="zipf")
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+    for _ in range(2):       # second call reuses the zero-padded image
+        ctx.score_topk(_dev(p["rp"]), _dev(p["col"]), _dev(p["val"]), _dev(p["W_enc"]), _dev(p["b_enc"]),
+                       nt, _dev(p["srp"]), _dev(sc), k, score, idx)
+    s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"],
+                                      p["b_dec"], nt, nt, p["srp"], p["sc"], k)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
