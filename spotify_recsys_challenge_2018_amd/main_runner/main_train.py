@@ -1,0 +1,119 @@
+"""--pretrain / --dae driver (reference main_runner/main_train.py, INTENDED behaviour: the
+snapshot does not run; citations relative to /root/reference).
+
+Loop (main_train.py:193-253): next_batch -> input keep-prob ~ U(input_kp range) -> fair coin:
+feed tracks-only or artists-only as x, tracks+artists as y -> one Adam step.  When the reader
+wraps, evaluate r-precision on every test split (seed tracks in, top-500 out, main_train.py:48-100)
+and save the parameters if the summed r-precision over `update_seed` did not get worse.
+"""
+import datetime
+import os
+import random
+
+import numpy as np
+
+from ..models.DAEs import DAE, DAE_tied
+from ..utils import metrics as met
+from ..utils.data_reader import data_reader, data_reader_firstN, data_reader_test
+
+
+def log_write(conf, log):
+    with open(os.path.join(conf.dir, 'log.txt'), "a") as f:
+        f.write(log)
+        f.write('\n')
+    if getattr(conf, 'verbose', True):
+        print(log)
+
+
+def eval(reader_test, conf, model):
+    """Mean r-precision over one test split (main_train.py:48-100): seed tracks only, both
+    keep-probs 1.0, rank the track columns, drop the seeds, top 500."""
+    total, count = 0.0, len(reader_test.playlists)
+    while True:
+        x_positions, test_seed, test_answer, _titles, x_ones = reader_test.next_batch_test()
+        idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))
+        for i in range(len(test_seed)):
+            total += met.eval_topk(idx[i], test_answer[i])
+        if reader_test.test_idx == 0:
+            break
+    return total / max(count, 1)
+
+
+def run(conf, only_testmode):
+    if -1 in conf.firstN:                                           # main_train.py:129-133
+        reader = data_reader(data_dir=conf.data_dir, filename='train', batch_size=conf.batch)
+    else:
+        reader = data_reader_firstN(data_dir=conf.data_dir, filename='train',
+                                    batch_size=conf.batch, from_to=conf.firstN)
+    conf.class_divpnt = reader.class_divpnt
+    conf.n_tracks = reader.num_tracks
+    conf.n_input = reader.num_items
+    conf.n_output = reader.num_items
+    conf.charsize = reader.num_char
+    conf.strmaxlen = reader.max_title_len
+    kp_range = conf.input_kp
+
+    readers_test = {}
+    for seed in conf.test_seed:
+        path = os.path.join(conf.data_dir, seed)
+        if not os.path.exists(path):
+            log_write(conf, "test split %s not found, skipped" % path)
+            continue
+        readers_test[seed] = data_reader_test(data_dir=conf.data_dir, filename=seed,
+                                              batch_size=conf.batch, test_num=conf.testsize)
+    print(conf.n_input)
+
+    if conf.mode == 'pretrain':                                     # main_train.py:154-161
+        info, model = '[pretrain mode]', DAE_tied(conf)
+    elif conf.mode == 'dae':
+        if only_testmode:
+            conf.initval = conf.save
+        info, model = '[dae mode]', DAE(conf)
+    else:
+        raise ValueError("mode %r is outside the DAE scoring path" % conf.mode)
+    log_write(conf, '*' * 10)
+    log_write(conf, info + ' start at ' + str(datetime.datetime.now()))
+    model.fit()
+
+    if only_testmode:                                               # main_train.py:181-191
+        log_write(conf, '<<only test mode>>')
+        out = {}
+        for seed_num, reader_test in readers_test.items():
+            out[seed_num] = eval(reader_test, conf, model)
+            log_write(conf, "seed num: %s rprecision: %f" % (seed_num, out[seed_num]))
+        return out
+
+    epoch, it, loss, max_eval = 0, 0, 0.0, 0.0
+    history = []
+    while True:
+        start_idx = reader.train_idx
+        trk_positions, art_positions, y_positions, _titles, trk_val, art_val = reader.next_batch()
+        end_idx = reader.train_idx
+        input_kp = random.uniform(kp_range[0], kp_range[-1])        # main_train.py:199
+        if np.random.randint(2) == 0:                               # :202 fair coin
+            x_pos, x_val = trk_positions, trk_val
+        else:
+            x_pos, x_val = art_positions, art_val
+        l = model.train_step(x_pos, x_val, y_positions, np.ones(len(y_positions), np.float32),
+                             conf.kp, input_kp)
+        loss += l
+        it += 1
+        if start_idx > end_idx or end_idx == 0:                     # :227 reader wrapped
+            epoch += 1
+            log_write(conf, "epoch " + str(epoch))
+            log_write(conf, "training loss: " + str(loss / it))
+            cur_eval = 0.0
+            for seed_num, reader_test in readers_test.items():
+                rprec = eval(reader_test, conf, model)
+                log_write(conf, "seed num: %s rprecision: %f" % (seed_num, rprec))
+                if seed_num in conf.update_seed:
+                    cur_eval += rprec
+            history.append((epoch, loss / it, cur_eval))
+            if cur_eval >= max_eval:                                # :243-249
+                model.save_model()
+                max_eval = cur_eval
+                log_write(conf, "The highest score is updated. Parameters are saved")
+            loss, it = 0.0, 0
+            if epoch == conf.epochs:
+                break
+    return history

@@ -29,19 +29,20 @@ def all_shard_bounds(n_cols, world, align=TILE):
     return [shard_bounds(n_cols, world, g, align) for g in range(world)]
 
 
-def gather_shard_topk(local_logit, local_idx, group=None):
+def gather_shard_topk(local_logit, local_idx, group=None, out=None):
     """All-gather the per-shard candidate lists: [B,k] -> [G,B,k] (logit fp32, column int32).
     One collective per tensor; with RCCL over xGMI each rank sends its 2 x B x k x 4 bytes once."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    g_logit = torch.empty((world,) + tuple(local_logit.shape), dtype=local_logit.dtype,
-                          device=local_logit.device)
-    g_idx = torch.empty((world,) + tuple(local_idx.shape), dtype=local_idx.dtype,
-                        device=local_idx.device)
+    B, k = local_logit.shape
+    if out is None:
+        out = (torch.empty((world * B, k), dtype=local_logit.dtype, device=local_logit.device),
+               torch.empty((world * B, k), dtype=local_idx.dtype, device=local_idx.device))
+    g_logit, g_idx = out                       # rank-major concatenation along dim 0
     dist.all_gather_into_tensor(g_logit, local_logit.contiguous(), group=group)
     dist.all_gather_into_tensor(g_idx, local_idx.contiguous(), group=group)
-    return g_logit, g_idx
+    return g_logit.view(world, B, k), g_idx.view(world, B, k)
 
 
 class ShardedRanker:

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Generates the golden fixtures under tests/golden/ by RUNNING THE REAL REFERENCE where it can be
+imported (pure-Python parts only: TensorFlow is unavailable).  Run in the build
+container (needs /root/reference); the fixtures it writes are data (inputs + expected outputs) and
+are what travels to the GPU box -- nothing under tests/ reads /root/reference at test time.
+
+    python tests/golden/make_golden.py
+
+Writes
+  data/train, data/challenge_inorder_5to100     <- reference Spotify_train / Spotify_challenge
+  data/test-5                                   <- hand-built (the reference's Spotify_test raises)
+  expected_readers.json.gz                      <- reference utils/data_reader.py outputs
+  expected_metrics.json                         <- reference utils/metrics.py outputs
+  forward_small.npz                             <- forward/top-k vectors of THIS repo's restatement
+                                                   (oracle/: labelled as such, parity unpinned)
+"""
+import io
+import json
+import os
+import random
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+DATA = os.path.join(HERE, "data")
+
+
+def synth_mpd(path, n_playlists, rng, first_pid, n_tracks=150, n_artists=45):
+    """A tiny MPD-shaped slice with Zipf track popularity and repeated artists."""
+    playlists = []
+    for p in range(n_playlists):
+        n = int(rng.integers(3, 70))
+        tr = np.minimum(n_tracks - 1, np.floor(np.exp(rng.random(n) * np.log(n_tracks))).astype(int) - 1)
+        tracks = []
+        for pos, t in enumerate(tr):
+            t = int(max(t, 0))
+            tracks.append({"pos": pos, "track_uri": "spotify:track:T%04d" % t,
+                           "artist_uri": "spotify:artist:A%03d" % (t % n_artists),
+                           "track_name": "t%d" % t, "artist_name": "a%d" % (t % n_artists)})
+        if p == 1:      # one track / artist seen exactly once: spotify_reader.py:140 needs a count
+            tracks.append({"pos": len(tracks), "track_uri": "spotify:track:T9999%d" % first_pid,
+                           "artist_uri": "spotify:artist:A999%d" % first_pid,
+                           "track_name": "rare", "artist_name": "rare"})   # == min_count - 1
+        playlists.append({"name": "Chill #%d vibes!" % p if p % 3 else "ROCK & roll_%d" % p,
+                          "pid": first_pid + p, "tracks": tracks, "num_tracks": n})
+    with open(path, "w") as f:
+        json.dump({"info": {}, "playlists": playlists}, f)
+
+
+def synth_challenge(path, rng, n_tracks=150, n_artists=45):
+    playlists = []
+    pid = 900000
+    for num_samples in [5, 10, 25, 100, 100, 5, 25, 10, 100, 5, 10, 25, 100]:
+        tr = np.minimum(n_tracks - 1, np.floor(np.exp(rng.random(num_samples) * np.log(n_tracks))).astype(int) - 1)
+        tracks = [{"pos": pos, "track_uri": "spotify:track:T%04d" % int(max(t, 0)),
+                   "artist_uri": "spotify:artist:A%03d" % (int(max(t, 0)) % n_artists)}
+                  for pos, t in enumerate(tr)]
+        pl = {"pid": pid, "num_samples": num_samples, "tracks": tracks, "num_holdouts": 10,
+              "num_tracks": num_samples + 10}
+        if pid % 4:
+            pl["name"] = "Summer Mix %d" % pid
+        playlists.append(pl)
+        pid += 1
+    with open(path, "w") as f:
+        json.dump({"playlists": playlists}, f)
+
+
+def tolist(a):
+    return np.asarray(a).astype(np.int64).tolist()
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("needs %s (build container only)" % REF)
+    sys.path.insert(0, REF)
+    if not hasattr(np, "int"):
+        np.int = int                       # numpy 2.x removed the alias the reference uses
+    os.makedirs(DATA, exist_ok=True)
+    tmp = "/tmp/_golden_mpd"
+    os.makedirs(tmp, exist_ok=True)
+    rng = np.random.default_rng(20180630)
+
+    # ---- reference preprocessing (spotify_reader.py) -------------------------------------------
+    from utils import spotify_reader as sr
+    synth_mpd(os.path.join(tmp, "mpd.slice.0-59.json"), 60, rng, 0)
+    synth_mpd(os.path.join(tmp, "mpd.slice.60-99.json"), 40, rng, 60)
+    synth_challenge(os.path.join(tmp, "challenge_set.json"), rng)
+    with redirect_stdout(io.StringIO()):
+        sr.Spotify_train([os.path.join(tmp, "mpd.slice.0-59.json"), os.path.join(tmp, "mpd.slice.60-99.json")],
+                         2, 2, True, DATA)
+        sr.Spotify_challenge([os.path.join(tmp, "challenge_set.json")], os.path.join(DATA, "train"),
+                             DATA, [5, 10, 25, 100], True)
+    train = json.load(open(os.path.join(DATA, "train")))
+    n_tracks = len(train["track_uri2id"])
+
+    # test split in the layout the reference's READER unpacks (data_reader.py:158):
+    # [seed, seed_art, answer, seed_cls, answer_cls]
+    test_pl = []
+    for p in train["playlists"][:23]:
+        trk = p[0]
+        if len(trk) < 8:
+            continue
+        seed, answer = trk[:5], [t for t in dict.fromkeys(trk[5:]) if t not in trk[:5]]
+        answer = answer + [-1] if len(answer) % 2 else answer      # out-of-vocabulary answers
+        test_pl.append([seed, p[1][:5], answer, [0] * len(seed), [0] * len(answer)])
+    with open(os.path.join(DATA, "test-5"), "w") as f:
+        json.dump({"playlists": test_pl}, f)
+
+    # ---- reference readers (utils/data_reader.py) ----------------------------------------------
+    from utils import data_reader as dr
+    exp = {"n_tracks": n_tracks}
+    with redirect_stdout(io.StringIO()):
+        random.seed(1234)
+        r = dr.data_reader(DATA, "train", 16)
+        out = []
+        for _ in range(9):                                           # crosses the epoch wrap
+            tp, ap, yp, titles, tv, av = r.next_batch()
+            out.append({"trk": tolist(tp), "art": tolist(ap), "y": tolist(yp), "titles": titles,
+                        "trk_val": list(map(float, tv)), "art_val": list(map(float, av)),
+                        "train_idx": r.train_idx})
+        exp["data_reader"] = out
+
+        for key, ft in (("firstN_frac", [0.0, 0.3]), ("firstN_count", [1.0, 5.0])):
+            random.seed(4321)
+            r = dr.data_reader_firstN(DATA, "train", 16, ft)
+            out = []
+            for _ in range(8):
+                tp, ap, yp, titles, tv, av = r.next_batch()
+                out.append({"trk": tolist(tp), "art": tolist(ap), "y": tolist(yp),
+                            "trk_val": list(map(float, tv)), "art_val": list(map(float, av)),
+                            "train_idx": r.train_idx})
+            exp[key] = out
+
+        r = dr.data_reader_challenge(DATA, "challenge_inorder_5to100", 5)
+        out = []
+        while True:
+            xp, seed, titles, texist, pid, xo = r.next_batch()
+            out.append({"x": tolist(xp), "seed": seed, "titles": titles, "titles_exist": texist,
+                        "pid": pid, "x_ones": list(map(float, xo))})
+            if r.ch_idx == 0:
+                break
+        exp["challenge"] = out
+        exp["challenge_meta"] = {"num_tracks": r.num_tracks, "num_items": r.num_items,
+                                 "in_order": r.is_in_order}
+
+        r = dr.data_reader_test(DATA, "test-5", 6, 1000)
+        out = []
+        while True:
+            tp, seed, answer, _cls, _afg = r.next_batch_test()
+            out.append({"x": tolist(tp), "seed": seed, "answer": answer})
+            if r.test_idx == 0:
+                break
+        exp["test"] = out
+    import gzip
+    with gzip.open(os.path.join(HERE, "expected_readers.json.gz"), "wt") as f:
+        json.dump(exp, f)
+
+    # ---- reference metrics (utils/metrics.py) ---------------------------------------------------
+    from utils import metrics as rm
+    cases = []
+    mrng = np.random.default_rng(7)
+    for i in range(40):
+        n_ans = int(mrng.integers(1, 60))
+        answer = [int(x) for x in mrng.choice(400, size=n_ans, replace=False)]
+        if i % 5 == 0:
+            answer += [-1, -1]
+        cand = [int(x) for x in mrng.permutation(400)[:int(mrng.integers(max(n_ans, 5), 300))]]
+        cases.append({"answer": answer, "cand": cand,
+                      "r_precision": rm.get_r_precision(answer, cand, [0] * len(answer), [10, 20, 30]),
+                      "ndcg": rm.get_ndcg(answer, cand), "rsc": rm.get_rsc(answer, cand)})
+    with open(os.path.join(HERE, "expected_metrics.json"), "w") as f:
+        json.dump(cases, f)
+
+    # ---- forward / top-k vectors of this repo's own restatement (NOT reference outputs) ----------
+    sys.path.insert(0, ROOT)
+    import oracle
+    from oracle import dae_numpy as dn
+    from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
+    from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+    V, nt, H, B, k = 2000, 1500, 32, 8, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    h = oracle.encode(rp, col, val, W_enc, b_enc)
+    z = oracle.decode(h, W_dec, b_dec, 0, nt)
+    s, i = oracle.topk(z, k, srp, sc)
+    x = dn.sparse_to_dense(pos, ones, B, V)
+    _, h_np, z_np = dn.forward(x, W_enc, b_enc, W_dec, b_dec)
+    np.savez_compressed(os.path.join(HERE, "forward_small.npz"),
+                        note="generated by oracle/ (this repo's CPU restatement), not by TensorFlow",
+                        shape=np.array([V, nt, H, B, k]), pos=pos, ones=ones,
+                        seeds_row_ptr=srp, seeds_col=sc,
+                        h=h, logits_tracks_row0=z[0], topk_idx=i, topk_score=s,
+                        h_numpy_dense=h_np, w_checksum=np.array([W_enc.sum(dtype=np.float64),
+                                                                 W_dec.sum(dtype=np.float64)]))
+    print("golden fixtures written under", HERE)
+    for f in sorted(os.listdir(HERE)) + ["data/" + x for x in sorted(os.listdir(DATA))]:
+        p = os.path.join(HERE, f)
+        if os.path.isfile(p):
+            print("  %-40s %8d B" % (f, os.path.getsize(p)))
+
+
+if __name__ == "__main__":
+    main()

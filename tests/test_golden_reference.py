@@ -1,0 +1,95 @@
+"""CPU tests against fixtures produced by the REAL reference (tests/golden/make_golden.py):
+utils/data_reader.py layouts and utils/metrics.py values.  No reference code is read here."""
+import gzip
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from spotify_recsys_challenge_2018_amd.utils import data_reader as dr
+from spotify_recsys_challenge_2018_amd.utils import metrics as met
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DATA = os.path.join(G, "data")
+
+
+@pytest.fixture(scope="module")
+def exp():
+    with gzip.open(os.path.join(G, "expected_readers.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def _pos(a):
+    return np.asarray(a, dtype=np.int64).reshape(-1, 2)
+
+
+def test_data_reader_matches_reference_across_epoch_wrap(exp, capsys):
+    random.seed(1234)
+    r = dr.data_reader(DATA, "train", 16)
+    assert r.num_tracks == exp["n_tracks"]
+    for want in exp["data_reader"]:
+        tp, ap, yp, titles, tv, av = r.next_batch()
+        assert np.array_equal(tp, _pos(want["trk"]))
+        assert np.array_equal(ap, _pos(want["art"]))
+        assert np.array_equal(yp, _pos(want["y"]))
+        assert titles == want["titles"]
+        assert np.array_equal(tv, np.asarray(want["trk_val"], np.float32))
+        assert np.array_equal(av, np.asarray(want["art_val"], np.float32))
+        assert r.train_idx == want["train_idx"]
+
+
+@pytest.mark.parametrize("key,ft", [("firstN_frac", [0.0, 0.3]), ("firstN_count", [1.0, 5.0])])
+def test_data_reader_firstN_matches_reference(exp, key, ft):
+    random.seed(4321)
+    r = dr.data_reader_firstN(DATA, "train", 16, ft)
+    for want in exp[key]:
+        tp, ap, yp, _titles, tv, av = r.next_batch()
+        assert np.array_equal(tp, _pos(want["trk"]))
+        assert np.array_equal(ap, _pos(want["art"]))
+        assert np.array_equal(yp, _pos(want["y"]))
+        assert np.array_equal(tv, np.asarray(want["trk_val"], np.float32))
+        assert np.array_equal(av, np.asarray(want["art_val"], np.float32))
+        assert r.train_idx == want["train_idx"]
+
+
+def test_data_reader_challenge_matches_reference(exp, capsys):
+    r = dr.data_reader_challenge(DATA, "challenge_inorder_5to100", 5)
+    assert (r.num_tracks, r.num_items, r.is_in_order) == (
+        exp["challenge_meta"]["num_tracks"], exp["challenge_meta"]["num_items"],
+        exp["challenge_meta"]["in_order"])
+    saw_015 = False
+    for want in exp["challenge"]:
+        xp, seed, titles, texist, pid, xo = r.next_batch()
+        assert np.array_equal(xp, _pos(want["x"]))
+        assert seed == want["seed"] and titles == want["titles"]
+        assert texist == want["titles_exist"] and pid == want["pid"]
+        assert np.array_equal(xo, np.asarray(want["x_ones"], np.float32))
+        saw_015 |= bool(np.any(xo == np.float32(0.15)))
+    assert r.ch_idx == 0
+    assert saw_015, "fixture must exercise the >50-seed 0.15 weighting (data_reader.py:288-289)"
+
+
+def test_data_reader_test_matches_reference(exp, capsys):
+    r = dr.data_reader_test(DATA, "test-5", 6, 1000)
+    for want in exp["test"]:
+        xp, seed, answer, _titles, x_ones = r.next_batch_test()
+        assert np.array_equal(xp, _pos(want["x"]))
+        assert seed == want["seed"] and answer == want["answer"]
+        assert np.array_equal(x_ones, np.ones(len(xp), np.float32))
+    assert r.test_idx == 0
+
+
+def test_metrics_match_reference():
+    cases = json.load(open(os.path.join(G, "expected_metrics.json")))
+    assert len(cases) >= 40
+    for c in cases:
+        assert met.get_r_precision(c["answer"], c["cand"], None, None) == c["r_precision"]
+        assert met.get_ndcg(c["answer"], c["cand"]) == pytest.approx(c["ndcg"], rel=0, abs=1e-15)
+        assert met.get_rsc(c["answer"], c["cand"]) == c["rsc"]
+        assert met.eval_topk(np.asarray(c["cand"] + [-1, -1]), c["answer"]) == c["r_precision"]
+
+
+def test_r_precision_counts_oov_answers_in_denominator():
+    assert met.get_r_precision([1, 2, -1, -1], [1, 2, 3, 4]) == 0.5
