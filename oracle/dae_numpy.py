@@ -106,14 +106,21 @@ def grads(x, y, W_enc, b_enc, W_dec, b_dec, n_batch, tied, reg_lambda=0.0,
 
 
 def adam_tf(p, m, v, g, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer (DAEs.py:102), TF formulation: epsilon OUTSIDE the
-    bias correction.  Dense.  Returns new (p, m, v) in fp32."""
+    """tf.train.AdamOptimizer (DAEs.py:102) as TF1's ApplyAdam functor computes it, all in fp32
+    (epsilon OUTSIDE the bias correction, dense update):
+        alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)      (beta powers = fp32 running products)
+        m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2);  p -= (m * alpha) / (sqrt(v) + eps)
+    Returns new (p, m, v)."""
     p = p.astype(F); m = m.astype(F); v = v.astype(F); g = g.astype(F)
-    lr_t = F(lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t))
-    m = F(beta1) * m + F(1.0 - beta1) * g
-    v = F(beta2) * v + F(1.0 - beta2) * g * g
-    p = p - lr_t * m / (np.sqrt(v) + F(eps))
-    return p.astype(F), m.astype(F), v.astype(F)
+    b1, b2 = F(beta1), F(beta2)
+    b1p, b2p = F(1.0), F(1.0)
+    for _ in range(int(t)):
+        b1p = F(b1p * b1); b2p = F(b2p * b2)
+    alpha = F(F(lr) * np.sqrt(F(1.0) - b2p, dtype=F) / (F(1.0) - b1p))
+    m = (m + (g - m) * (F(1.0) - b1)).astype(F)
+    v = (v + (g * g - v) * (F(1.0) - b2)).astype(F)
+    p = (p - (m * alpha) / (np.sqrt(v, dtype=F) + F(eps))).astype(F)
+    return p, m, v
 
 
 def cand_generate(scores, seed, k=500):

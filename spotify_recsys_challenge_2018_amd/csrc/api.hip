@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 #include <climits>
+#include <cmath>
 
 #include "dae_internal.h"
 
@@ -401,18 +402,40 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k, const float* cand_logit,
 }
 
 int dae_train_forward_backward(dae_ctx* ctx,
-        const int32_t*, const int32_t*, const float*, const int32_t*, const int32_t*, const float*,
-        const float*, const float*, const float*, const float*,
-        int, int, int, int, int, float, float, uint32_t, float,
-        float*, float*, float*, float*, float*)
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+        int V, int H, int B, int n_batch, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out)
 {
-    return dae_fail(ctx, DAE_ERR_STATE, "training kernels are not in this build yet");
+    if (!ctx) return DAE_ERR_ARG;
+    if (!x_row_ptr || !y_row_ptr || !W_enc || !b_enc || !b_dec || !gW_enc || !gb_enc || !gb_dec || !cost_out)
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (!tied && (!W_dec || !gW_dec)) return dae_fail(ctx, DAE_ERR_ARG, "untied model needs W_dec and gW_dec");
+    if (V <= 0 || H <= 0 || B <= 0 || n_batch <= 0) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
+    if (!(ikp > 0.f && ikp <= 1.f) || !(kp > 0.f && kp <= 1.f))
+        return dae_fail(ctx, DAE_ERR_ARG, "keep probabilities must be in (0,1]");
+    return dae_train_step_f32(ctx, x_row_ptr, x_col, x_val, y_row_ptr, y_col, y_val, W_enc, b_enc,
+                              W_dec, b_dec, V, H, B, n_batch, tied, ikp, kp, seed, reg_lambda,
+                              gW_enc, gb_enc, gW_dec, gb_dec, cost_out);
 }
 
-int dae_adam_step(dae_ctx* ctx, float*, float*, float*, const float*, int64_t, float, float, float,
-                  float, int)
+int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int t)
 {
-    return dae_fail(ctx, DAE_ERR_STATE, "training kernels are not in this build yet");
+    if (!ctx) return DAE_ERR_ARG;
+    if (!param || !m || !v || !grad) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (t < 1) return dae_fail(ctx, DAE_ERR_ARG, "t is the 1-based step count");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(grad)) % 16)
+        return dae_fail(ctx, DAE_ERR_ARG, "param, m, v, grad must be 16-byte aligned");
+    // alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t) with the beta powers kept as fp32 running
+    // products, as TF's beta1_power / beta2_power variables are
+    float b1p = 1.0f, b2p = 1.0f;
+    for (int i = 0; i < t; ++i) { b1p *= beta1; b2p *= beta2; }
+    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    return dae_launch_adam(ctx, param, m, v, grad, n, alpha, beta1, beta2, eps);
 }
 
 }  // extern "C"

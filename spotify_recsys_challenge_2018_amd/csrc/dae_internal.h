@@ -157,7 +157,8 @@ dae_rowgeom dae_row_geometry(int B, int Hp);
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
                       const float* W_enc, const float* b_enc, int V, int H, int B,
                       float ikp, float kp, uint32_t seed, float* h_out,
-                      float* h_packed, int G, int RB);
+                      float* h_packed, int G, int RB, float* sg_out = nullptr,
+                      float* xhat_out = nullptr);
 
 // decode_f32.hip
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
@@ -177,6 +178,23 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
                                  int cap);
+
+// training forward: all tiles, epilogue turns logits into dL/dz in place over the dense targets
+// already scattered into `dz` ([B, ld] row-major), also writes dz transposed ([ncols, ldT]) and one
+// loss partial per workgroup (DAEs.py:98-100).
+int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
+                               float* dz, int64_t ld, float* dzT, int64_t ldT, float* loss_part);
+
+// train.hip
+int dae_train_step_f32(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+        int V, int H, int B, int n_batch, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out);
+int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps);
 
 // topk.hip
 struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)

@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int EPI_DENSE = 0;
 constexpr int EPI_FILTER = 1;
+constexpr int EPI_LOSS = 2;        // training: logits -> loss + dL/dz (DAEs.py:98-100)
 
 struct DecP {
     const float4* Wp;      // [ntiles][G][64] float4
@@ -44,6 +45,8 @@ struct DecP {
     float* out; int64_t ld; int apply_sigmoid; int mask_from_col; int fill_pad; int vec_ok;
     // filter epilogue
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
+    // loss epilogue
+    float inv_nb; float* dzT; int64_t ldT; float* loss_part;
 };
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         }
     }
 
+    float loss_acc = 0.0f;
     const int n_ws = p.nb_rg * NW;
     const int item0 = bir * NW + wave;
 
@@ -203,6 +207,33 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                     }
                 }
             }
+        } else if (EPI == EPI_LOSS) {
+            // out holds the dense targets y; it is overwritten with dL/dz (mean over n_batch
+            // folded in).  L = -[y log(p+1e-10) + 0.55 (1-y) log(1-p+1e-10)], p = sigmoid(z).
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                if (row >= p.B) continue;
+                float* orow = p.out + (size_t)row * p.ld + (size_t)t * 32 + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int lc = tcol0 + 8 * qd;
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (lc + e < p.ncols) {
+                            const float y = orow[8 * qd + e];
+                            const float pr = dae_sigmoidf(acc[rb][4 * qd + e] + zb[e]);
+                            const float a1 = pr + 1e-10f, a0 = 1.0f - pr + 1e-10f;
+                            loss_acc -= y * __logf(a1) + 0.55f * (1.0f - y) * __logf(a0);
+                            const float dz = -(y / a1 - 0.55f * (1.0f - y) / a0) * pr * (1.0f - pr) *
+                                             p.inv_nb;
+                            orow[8 * qd + e] = dz;
+                            p.dzT[(size_t)(lc + e) * p.ldT + row] = dz;
+                        }
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -244,6 +275,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     if (EPI == EPI_FILTER) {
         __syncthreads();
         if (tid < R_TILE) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + tid] = lcnt[tid];
+    }
+    if (EPI == EPI_LOSS) {
+        // deterministic: lanes -> wave (shuffle tree), waves -> block (fixed order), one slot/block
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
+        float* wsum = reinterpret_cast<float*>(lcnt);
+        __syncthreads();
+        if (lane == 0) wsum[wave] = loss_acc;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.0f;
+            for (int w = 0; w < NW; ++w) s += wsum[w];
+            p.loss_part[blockIdx.x] = s * p.inv_nb;          // reduce_mean over the fixed n_batch
+        }
     }
 }
 
@@ -437,6 +482,17 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
     return launch_decode_rb<EPI_DENSE>(ctx, g, p);
+}
+
+int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
+                               float* dz, int64_t ld, float* dzT, int64_t ldT, float* loss_part)
+{
+    DecP p;
+    dae_tileset ts{ctx->pk_f32.ntiles, 1, 0};
+    int rc = fill_common(ctx, g, B, ts, p);
+    if (rc) return rc;
+    p.out = dz; p.ld = ld; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
+    return launch_decode_rb<EPI_LOSS>(ctx, g, p);
 }
 
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,

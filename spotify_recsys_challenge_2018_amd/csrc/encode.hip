@@ -32,6 +32,8 @@ struct EncP {
     float* h_out;        // [B,H] row-major or null
     float* hp;           // packed [n_rg][G][RB][2][32][4] or null
     int G, RB;           // packed geometry (G = Hp/8, RB = R_TILE/32)
+    float* sg_out;       // [B,H] sigmoid BEFORE hidden dropout (training backward) or null
+    float* xhat_out;     // [nnz] normalised, dropped-out input weights (training backward) or null
 };
 
 // issue the loads of one group of 16 non-zeros (indices base..base+15 of the current 64-chunk);
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
                         x = (x / p.ikp) * floorf(p.ikp + u);
                     }
                     w_l = x / denom;
+                    if (p.xhat_out && hbase == 0) p.xhat_out[base + lane] = w_l;
                 }
                 float4 xa[ENC_GRP], xb[ENC_GRP];
                 float wa[ENC_GRP], wb[ENC_GRP];
@@ -120,6 +123,9 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
                 const float4 be = *reinterpret_cast<const float4*>(p.b_enc + hoff);
                 float hv[4] = {dae_sigmoidf(acc.x + be.x), dae_sigmoidf(acc.y + be.y),
                                dae_sigmoidf(acc.z + be.z), dae_sigmoidf(acc.w + be.w)};
+                if (p.sg_out)
+                    *reinterpret_cast<float4*>(p.sg_out + (size_t)row * H + hoff) =
+                        make_float4(hv[0], hv[1], hv[2], hv[3]);
                 if (p.kp < 1.0f) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
                       const float* W_enc, const float* b_enc, int V, int H, int B,
                       float ikp, float kp, uint32_t seed, float* h_out,
-                      float* h_packed, int G, int RB)
+                      float* h_packed, int G, int RB, float* sg_out, float* xhat_out)
 {
     (void)V;
     if (B <= 0) return DAE_OK;
@@ -161,6 +167,7 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
     p.row_ptr = row_ptr; p.col = col; p.val = val; p.W = W_enc; p.b_enc = b_enc;
     p.H = H; p.B = B; p.ikp = ikp; p.kp = kp; p.seed = seed;
     p.h_out = h_out; p.hp = h_packed; p.G = G; p.RB = RB;
+    p.sg_out = sg_out; p.xhat_out = xhat_out;
     if (B <= 2048) {
         // few rows: one wave per workgroup spreads the rows over all CUs (latency bound)
         hipLaunchKernelGGL(encode_kernel<1>, dim3(B), dim3(64), 0, ctx->stream, p);

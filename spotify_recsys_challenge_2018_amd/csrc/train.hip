@@ -1,0 +1,504 @@
+// train.hip -- the training step of the reference graph (models/DAEs.py:98-102; SURVEY.md 8a
+// rows a8-a10, App. B.5), fp32 on the CDNA4 matrix cores:
+//
+//   forward   K1 encode with dropout (encode.hip) -> K5 decode GEMM whose epilogue turns logits
+//             into the weighted-BCE loss and dL/dz in place over the dense targets
+//             (decode_f32.hip EPI_LOSS), writing dz [B,V] and dz^T [V,B]
+//   K6        gW_dec[v,:] = sum_r dz[r,v] h[r,:]   (+ gb_dec = column sums)      contraction B
+//   K7        dh[r,:]     = sum_v dz[r,v] W_dec[v,:]  split over V, partials reduced   contraction V
+//   K8        dpre = dh * dropout-mask/kp * s(1-s); gb_enc; gW_enc[c,:] += xhat[r,c] dpre[r,:]
+//   K9        TF1 Adam, dense (moments decay on zero-gradient rows too)
+//
+// Both backward GEMMs use v_mfma_f32_32x32x2_f32 with D[i = hidden unit][j = v or r]; operands are
+// read in their natural row-major layouts because the contraction index is the slow dimension of
+// both, and the 4 (2) tiles a wave owns along i (j) are interleaved (hidden = hc0 + 4 i + a) so
+// that one float4 (float2) per lane feeds 4 (2) MFMAs.  Summation orders differ from the oracle's
+// float64 reference: parity is by tolerance (tests/test_gpu_train.py), not bitwise.
+#include "dae_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- dense targets: dz[r, c] = y value (buffer pre-zeroed) -------------------------------------
+__global__ __launch_bounds__(256) void scatter_y_kernel(const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ col,
+                                                        const float* __restrict__ val, int B,
+                                                        float* __restrict__ dz, int64_t ld)
+{
+    const int row = blockIdx.x;
+    if (row >= B) return;
+    for (int i = row_ptr[row] + threadIdx.x; i < row_ptr[row + 1]; i += 256)
+        dz[(size_t)row * ld + col[i]] = val[i];
+}
+
+// ---- K6: gW[v, hc] (+)= sum_r dz[r, v] * h[r, hc];  gb[v] = sum_r dz[r, v] ----------------------
+// block = 4 waves sharing the LDS image of h[:, hc0 : hc0+128] (K = B <= 256 rows); a wave owns
+// tiles of 64 vocabulary columns (2 MFMA tiles, v = v0 + 2 j + b) x 128 hidden units (4 tiles).
+struct GwP {
+    const float* dz; int64_t ld;      // [B, ld]
+    const float* h; int H, B, V;
+    float* gW;                        // [V, H]
+    float* gb;                        // [V] (written by the hc0 == 0 blocks) or null
+    int accumulate;                   // gW += instead of =
+    int n_half, nb_half;              // H / 128 hidden halves, blocks per half
+};
+
+// NA = hidden tiles per wave (4, 2 or 1): a "half" is 32*NA hidden units, hidden = hc0 + NA*i + a
+template <int NA>
+__global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [Bp][32*NA] floats
+    constexpr int HW = 32 * NA;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gs = DAE_NUM_XCD * p.n_half;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int half = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int hc0 = half * HW;
+    const int Bp = (p.B + 1) & ~1;                                   // k-steps come in pairs of rows
+
+    for (int i = tid; i < Bp * HW; i += 256) {
+        const int r = i / HW, c = i - r * HW;
+        lds[i] = r < p.B ? p.h[(size_t)r * p.H + hc0 + c] : 0.0f;
+    }
+    __syncthreads();
+
+    const int n_tiles = (p.V + 63) / 64;
+    const int n_ws = p.nb_half * 4;
+    for (int t = bir * 4 + wave; t < n_tiles; t += n_ws) {
+        const int v0 = t * 64;
+        const int vcol = v0 + 2 * j;                                 // this lane's 2 columns
+        const bool ok0 = vcol < p.V, ok1 = vcol + 1 < p.V;
+        const bool vec = ok1 && ((p.ld & 1) == 0);
+        f32x16 acc[NA][2];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+        float cs0 = 0.f, cs1 = 0.f;
+
+        for (int r0 = 0; r0 < Bp; r0 += 16) {                        // 8 k-steps of 2 rows
+            float2 d[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int r = r0 + 2 * s + hi;
+                d[s] = make_float2(0.f, 0.f);
+                if (r < p.B) {
+                    const float* src = p.dz + (size_t)r * p.ld + vcol;
+                    if (vec) d[s] = *reinterpret_cast<const float2*>(src);
+                    else { if (ok0) d[s].x = src[0]; if (ok1) d[s].y = src[1]; }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int r = r0 + 2 * s + hi;
+                if (r0 + 2 * s < Bp) {
+                    const float* ap = lds + (size_t)(r < Bp ? r : Bp - 1) * HW + NA * j;
+                    float av[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) av[a] = ap[a];
+                    cs0 += d[s].x; cs1 += d[s].y;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+                        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], d[s].x, acc[a][0], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+                        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], d[s].y, acc[a][1], 0, 0, 0);
+                }
+            }
+        }
+        // D[i][j]: hidden unit hc0 + NA * i_idx + a, i_idx = (reg & 3) + 8 (reg >> 2) + 4 hi; column
+        // v0 + 2 j + b.  The NA `a` accumulators of one reg are NA consecutive hidden units.
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int v = vcol + b;
+            if (v >= p.V) continue;
+            float* orow = p.gW + (size_t)v * p.H + hc0;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i_idx = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    float* dst = orow + NA * i_idx + a;
+                    *dst = p.accumulate ? *dst + acc[a][b][reg] : acc[a][b][reg];
+                }
+            }
+        }
+        if (p.gb && half == 0) {
+            cs0 += __shfl_xor(cs0, 32);
+            cs1 += __shfl_xor(cs1, 32);
+            if (hi == 0) {
+                if (ok0) p.gb[vcol] = cs0;
+                if (ok1) p.gb[vcol + 1] = cs1;
+            }
+        }
+    }
+}
+
+// ---- K7: dh partial [chunk][r][hc] = sum_{v in chunk} dzT[v, r] * W[v, hc] -----------------------
+// a wave owns one (hidden half of 128, 64 playlists) output tile for one chunk of V: 8 accumulators;
+// A = W rows (float4 per lane: hc0 + 4 i + a), B = dz^T rows (float2 per lane: r0 + 2 j + b); no LDS.
+struct DhP {
+    const float* dzT; int64_t ldT;     // [V, ldT]  (ldT >= Bpad64)
+    const float* W; int H, V;
+    float* part;                       // [n_chunk][Bpad64][H]
+    int n_chunk, chunk, Bpad64, n_half, n_rblk;
+};
+
+template <int NA>
+__global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
+{
+    constexpr int HW = 32 * NA;
+    const int lane = threadIdx.x & 63, hi = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_out = p.n_half * p.n_rblk;
+    const int total = n_out * p.n_chunk;
+    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
+        const int ot = w % n_out, ch = w / n_out;      // neighbours share the W chunk (L2)
+        const int half = ot % p.n_half, rblk = ot / p.n_half;
+        const int hc0 = half * HW, r0 = rblk * 64;
+        const int v_beg = ch * p.chunk;
+        int v_end = v_beg + p.chunk;
+        if (v_end > p.V) v_end = p.V;
+        f32x16 acc[NA][2];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+        const float* Wl = p.W + hc0 + NA * j;
+        const float* Dl = p.dzT + r0 + 2 * j;
+        for (int v0 = v_beg; v0 < v_end; v0 += 16) {
+            float av[8][NA];
+            float2 d[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int v = v0 + 2 * s + hi;
+                const bool in = v < v_end;
+                const int vc = in ? v : v_beg;
+                const float* wr = Wl + (size_t)vc * p.H;
+                if (NA == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(wr);
+                    av[s][0] = t4.x; av[s][1 % NA] = t4.y; av[s][2 % NA] = t4.z; av[s][3 % NA] = t4.w;
+                } else if (NA == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(wr);
+                    av[s][0] = t2.x; av[s][1 % NA] = t2.y;
+                } else {
+                    av[s][0] = wr[0];
+                }
+                d[s] = in ? *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT)
+                          : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], d[s].x, acc[a][0], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], d[s].y, acc[a][1], 0, 0, 0);
+            }
+        }
+        float* prow = p.part + ((size_t)ch * p.Bpad64) * p.H + hc0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = r0 + 2 * j + b;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i_idx = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) prow[(size_t)r * p.H + NA * i_idx + a] = acc[a][b][reg];
+            }
+        }
+    }
+}
+
+// ---- K8a: dpre[r, k] = (sum_chunks part) * (h > 0 ? 1/kp : 0) * s (1 - s)  (DAEs.py:67-68) ------
+__global__ __launch_bounds__(256) void hidden_backward_kernel(const float* __restrict__ part,
+                                                              int n_chunk, int Bpad64, int H, int B,
+                                                              const float* __restrict__ h,
+                                                              const float* __restrict__ sg, float kp,
+                                                              float* __restrict__ dpre)
+{
+    const size_t n = (size_t)B * H;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunk; ++c) s += part[(size_t)c * Bpad64 * H + o];   // fixed order
+        const float sv = sg[o];
+        const float keep = h[o] != 0.0f ? 1.0f / kp : 0.0f;
+        dpre[o] = s * keep * sv * (1.0f - sv);
+    }
+}
+
+// column sums over rows: out[k] = sum_r a[r, k] (+ lambda * base[k])
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int B, int H,
+                                                     float lambda, const float* __restrict__ base,
+                                                     float* __restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= H) return;
+    float s = 0.f;
+    for (int r = 0; r < B; ++r) s += a[(size_t)r * H + k];
+    out[k] = s + (lambda != 0.f ? lambda * base[k] : 0.f);
+}
+
+// ---- K8b: gW_enc[c, :] += xhat[r, c] * dpre[r, :]  (row-sparse; several rows may share c) ---------
+// xhat is recomputed exactly as the encode kernel does (same dropout draws, same order).
+__global__ __launch_bounds__(256) void scatter_gwenc_kernel(const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val, int B,
+                                                            int H, float ikp, uint32_t seed,
+                                                            const float* __restrict__ dpre,
+                                                            float* __restrict__ gW)
+{
+    const int row = blockIdx.x;
+    if (row >= B) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    float s = 0.0f;
+    for (int i = beg; i < end; ++i) {
+        float x = val[i];
+        if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[i]));
+        s += x;
+    }
+    const float denom = s + 1e-10f;
+    for (int k = threadIdx.x; k < H; k += 256) {
+        const float dv = dpre[(size_t)row * H + k];
+        for (int i = beg; i < end; ++i) {
+            float x = val[i];
+            if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[i]));
+            const float w = x / denom;
+            if (w != 0.0f) atomicAdd(&gW[(size_t)col[i] * H + k], w * dv);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                   float a, size_t n)
+{
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256)
+        y[o] += a * x[o];
+}
+
+// sum of squares / 2 of a tensor, one partial per block (tf.nn.l2_loss, DAEs.py:79-82)
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ x, size_t n,
+                                                         double* __restrict__ part)
+{
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256)
+        s += (double)x[o] * (double)x[o];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = 0.5 * (ws[0] + ws[1] + ws[2] + ws[3]);
+}
+
+// cost = sum(loss partials) + lambda * sum(l2 partials), fixed order, in double
+__global__ void finish_cost_kernel(const float* __restrict__ loss_part, int n_loss,
+                                   const double* __restrict__ l2_part, int n_l2, float lambda,
+                                   float* __restrict__ cost)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n_loss; ++i) s += (double)loss_part[i];
+    double l2 = 0.0;
+    for (int i = 0; i < n_l2; ++i) l2 += l2_part[i];
+    *cost = (float)(s + (double)lambda * l2);
+}
+
+// ---- K9: TF1 AdamOptimizer, dense ------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                   float* __restrict__ v,
+                                                   const float* __restrict__ g, size_t n,
+                                                   float lr_t, float b1, float b2, float eps)
+{
+    const size_t n4 = n / 4;
+    float4* p4 = reinterpret_cast<float4*>(p); float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v); const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n4; o += (size_t)gridDim.x * 256) {
+        float4 pp = p4[o], mm = m4[o], vv = v4[o];
+        const float4 gg = g4[o];
+// TF1 ApplyAdam functor: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= (m alpha)/(sqrt(v)+eps)
+#define ADAM1(c)                                                     \
+        mm.c = mm.c + (gg.c - mm.c) * (1.0f - b1);                   \
+        vv.c = vv.c + (gg.c * gg.c - vv.c) * (1.0f - b2);            \
+        pp.c = pp.c - (mm.c * lr_t) / (sqrtf(vv.c) + eps);
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        p4[o] = pp; m4[o] = mm; v4[o] = vv;
+    }
+    for (size_t o = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; o < n;
+         o += (size_t)gridDim.x * 256) {
+        const float gg = g[o];
+        const float mm = m[o] + (gg - m[o]) * (1.0f - b1);
+        const float vv = v[o] + (gg * gg - v[o]) * (1.0f - b2);
+        m[o] = mm; v[o] = vv;
+        p[o] = p[o] - (mm * lr_t) / (sqrtf(vv) + eps);
+    }
+}
+
+int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+}  // namespace
+
+int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps)
+{
+    if (n <= 0) return DAE_OK;
+    size_t work = (size_t)n / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(work ? work : 1)), dim3(256), 0, ctx->stream, param, m, v,
+                       grad, (size_t)n, lr_t, beta1, beta2, eps);
+    DAE_CHECK_LAUNCH(ctx, "adam_kernel");
+    return DAE_OK;
+}
+
+int dae_train_step_f32(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+        int V, int H, int B, int n_batch, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out)
+{
+    if ((H % 32) != 0) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H %% 32 == 0 (H=%d)", H);
+    const int NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
+    if (B > 256) return dae_fail(ctx, DAE_ERR_ARG, "training batch %d > 256 not supported yet", B);
+    hipStream_t st = ctx->stream;
+    int rc;
+
+    // decoder weights change every step: re-tile them for the forward GEMM
+    rc = dae_launch_prepack_f32(ctx, tied ? W_enc : W_dec, b_dec, V, H, 0, V);
+    if (rc) return rc;
+    const dae_packed& pk = ctx->pk_f32;
+    const dae_rowgeom g = dae_row_geometry(B, pk.Hp);
+    const int G = pk.Hp / DAE_KG, RB = g.R_TILE / 32;
+    const int Bpad64 = (B + 63) / 64 * 64;
+
+    // ---- scratch --------------------------------------------------------------------------------
+    // train_a: dz [B][V] | train_b: dzT [V][Bpad64] | train_c: h, sg, dpre [B][H] x3, xhat, partials
+    const size_t hp_bytes = (size_t)g.n_rg * G * RB * 64 * sizeof(float4);
+    if ((rc = dae_reserve(ctx, ctx->h_packed, hp_bytes))) return rc;
+    if ((rc = dae_reserve(ctx, ctx->train_a, (size_t)B * V * sizeof(float)))) return rc;
+    if ((rc = dae_reserve(ctx, ctx->train_b, (size_t)V * Bpad64 * sizeof(float)))) return rc;
+    // split of the V contraction of K7: about one (output tile, chunk) work item per wave slot
+    const int NA_ = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
+    const int n_out_tiles = (H / (32 * NA_)) * (Bpad64 / 64);
+    int want_chunks = (DAE_NUM_CU * 4) / n_out_tiles;
+    if (want_chunks < 1) want_chunks = 1;
+    int chunk = ((V + want_chunks - 1) / want_chunks + 15) / 16 * 16;
+    if (chunk < 16) chunk = 16;
+    const int n_chunk = (V + chunk - 1) / chunk;
+    const size_t bh = (size_t)B * H;
+    const size_t c_floats = 3 * bh + (size_t)n_chunk * Bpad64 * H + (size_t)g.grid + 64;
+    if ((rc = dae_reserve(ctx, ctx->train_c, c_floats * sizeof(float) + 4096 * sizeof(double)))) return rc;
+    float* dz = static_cast<float*>(ctx->train_a.p);
+    float* dzT = static_cast<float*>(ctx->train_b.p);
+    float* hbuf = static_cast<float*>(ctx->train_c.p);
+    float* sg = hbuf + bh;
+    float* dpre = sg + bh;
+    float* part = dpre + bh;
+    float* loss_part = part + (size_t)n_chunk * Bpad64 * H;
+    double* l2_part = reinterpret_cast<double*>(
+        (reinterpret_cast<uintptr_t>(loss_part + g.grid) + 63) & ~(uintptr_t)63);
+
+    // ---- forward ----------------------------------------------------------------------------------
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, hp_bytes, st));
+    ctx->h_geom_key = -1;
+    rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, hbuf,
+                           static_cast<float*>(ctx->h_packed.p), G, RB, sg, nullptr);
+    if (rc) return rc;
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(dz, 0, (size_t)B * V * sizeof(float), st));
+    if (Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(dzT, 0, (size_t)V * Bpad64 * sizeof(float), st));
+    hipLaunchKernelGGL(scatter_y_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, dz,
+                       (int64_t)V);
+    DAE_CHECK_LAUNCH(ctx, "scatter_y_kernel");
+    rc = dae_launch_decode_loss_f32(ctx, g, B, 1.0f / (float)n_batch, dz, V, dzT, Bpad64, loss_part);
+    if (rc) return rc;
+
+    // ---- cost (+ lambda * l2) ----------------------------------------------------------------------
+    int n_l2 = 0;
+    if (reg_lambda != 0.0f) {
+        const float* ts[4] = {W_enc, b_dec, b_enc, tied ? nullptr : W_dec};
+        const size_t ns[4] = {(size_t)V * H, (size_t)V, (size_t)H, (size_t)V * H};
+        for (int i = 0; i < 4; ++i) {
+            if (!ts[i]) continue;
+            const int nb = grid_for(ns[i]) > 1024 ? 1024 : grid_for(ns[i]);
+            hipLaunchKernelGGL(l2_partial_kernel, dim3(nb), dim3(256), 0, st, ts[i], ns[i], l2_part + n_l2);
+            DAE_CHECK_LAUNCH(ctx, "l2_partial_kernel");
+            n_l2 += nb;
+        }
+    }
+    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(64), 0, st, loss_part, g.grid, l2_part, n_l2,
+                       reg_lambda, cost_out);
+    DAE_CHECK_LAUNCH(ctx, "finish_cost_kernel");
+
+    // ---- K6: decoder gradient ------------------------------------------------------------------------
+    float* gWd = tied ? gW_enc : gW_dec;
+    {
+        GwP p;
+        p.dz = dz; p.ld = V; p.h = hbuf; p.H = H; p.B = B; p.V = V; p.gW = gWd; p.gb = gb_dec;
+        p.accumulate = 0;
+        p.n_half = H / (32 * NA);
+        int nb = (DAE_NUM_CU / p.n_half) / DAE_NUM_XCD * DAE_NUM_XCD;
+        if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
+        p.nb_half = nb;
+        const size_t lds = (size_t)((B + 1) & ~1) * 32 * NA * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        const dim3 grid(p.n_half * nb), blk(256);
+        if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, st, p);
+        else if (NA == 2) hipLaunchKernelGGL(grad_wdec_kernel<2>, grid, blk, lds, st, p);
+        else hipLaunchKernelGGL(grad_wdec_kernel<1>, grid, blk, lds, st, p);
+        DAE_CHECK_LAUNCH(ctx, "grad_wdec_kernel");
+    }
+
+    // ---- K7: dh, split over V ------------------------------------------------------------------------
+    {
+        DhP p;
+        p.dzT = dzT; p.ldT = Bpad64; p.W = tied ? W_enc : W_dec; p.H = H; p.V = V; p.part = part;
+        p.n_chunk = n_chunk; p.chunk = chunk; p.Bpad64 = Bpad64; p.n_half = H / (32 * NA);
+        p.n_rblk = Bpad64 / 64;
+        const int total = p.n_half * p.n_rblk * n_chunk;
+        int blocks = (total + 3) / 4;
+        if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
+        if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+        else if (NA == 2) hipLaunchKernelGGL(grad_hidden_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(grad_hidden_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+        DAE_CHECK_LAUNCH(ctx, "grad_hidden_kernel");
+    }
+    hipLaunchKernelGGL(hidden_backward_kernel, dim3(grid_for(bh)), dim3(256), 0, st, part, n_chunk,
+                       Bpad64, H, B, hbuf, sg, kp, dpre);
+    DAE_CHECK_LAUNCH(ctx, "hidden_backward_kernel");
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 255) / 256), dim3(256), 0, st, dpre, B, H, reg_lambda,
+                       b_enc, gb_enc);
+    DAE_CHECK_LAUNCH(ctx, "colsum_kernel");
+
+    // ---- K8: encoder gradient (row-sparse) -----------------------------------------------------------
+    if (!tied) DAE_HIP_CHECK(ctx, hipMemsetAsync(gW_enc, 0, (size_t)V * H * sizeof(float), st));
+    hipLaunchKernelGGL(scatter_gwenc_kernel, dim3(B), dim3(256), 0, st, x_row_ptr, x_col, x_val, B, H,
+                       ikp, seed, dpre, gW_enc);
+    DAE_CHECK_LAUNCH(ctx, "scatter_gwenc_kernel");
+
+    if (reg_lambda != 0.0f) {
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V * H)), dim3(256), 0, st, gW_enc, W_enc,
+                           reg_lambda, (size_t)V * H);
+        if (!tied)
+            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V * H)), dim3(256), 0, st, gW_dec, W_dec,
+                               reg_lambda, (size_t)V * H);
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V)), dim3(256), 0, st, gb_dec, b_dec,
+                           reg_lambda, (size_t)V);
+        DAE_CHECK_LAUNCH(ctx, "axpy_kernel");
+    }
+    ctx->pk_f32.valid = true;
+    return DAE_OK;
+}
