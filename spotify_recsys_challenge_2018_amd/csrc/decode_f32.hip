@@ -81,8 +81,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     // ---- hidden tile of this row group -> LDS, once ------------------------------------------
     const int n_h4 = RB * 64 * G;
     {
+        // 8 independent 16 B loads in flight per thread (a load->wait->ds_write chain per element
+        // costs one L2 round trip each: ~25k cycles for the 128 KiB tile, measured with SQ_WAIT_ANY)
         const float4* src = p.hp + (size_t)rg * n_h4;
-        for (int i = tid; i < n_h4; i += NW * 64) lds4[i] = src[i];
+        constexpr int NT = NW * 64;
+        int i = tid;
+        for (; i + 7 * NT < n_h4; i += 8 * NT) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i + u * NT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lds4[i + u * NT] = v[u];
+        }
+        for (; i < n_h4; i += NT) lds4[i] = src[i];
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     if (EPI == EPI_FILTER) {
@@ -419,9 +430,9 @@ dae_rowgeom dae_row_geometry(int B, int Hp)
     if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
     g.nb_rg = nb;
     g.grid = g.n_rg * nb;
-    // waves per workgroup: 8 (two per SIMD, one covers the other's epilogue) on the unrolled
-    // hidden=256 body, else 4.  DAE_DECODE_WAVES=4|8 overrides (A/B on hardware).
-    g.waves = (rt == 128 && Hp == 256) ? 8 : 4;
+    // waves per workgroup: 4 = one per SIMD (measured 505k vs 465k playlists/s against 8 = two per
+    // SIMD on the hidden=256 body, profiles/r01_notes.md).  DAE_DECODE_WAVES=8 re-enables the A/B.
+    g.waves = 4;
     if (const char* e = getenv("DAE_DECODE_WAVES")) {
         const int w = atoi(e);
         if ((w == 4 || w == 8) && rt == 128 && Hp == 256) g.waves = w;
