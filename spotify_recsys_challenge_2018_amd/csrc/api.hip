@@ -272,11 +272,14 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
 
     rc = dae_reserve(ctx, ctx->tau, (size_t)g.Bpad * sizeof(float));
     if (rc) return rc;
-    rc = dae_reserve(ctx, ctx->sample_top, (size_t)g.Bpad * k * sizeof(uint2));
+    const int pstride = DAE_MAX_K;                         // room for k or the <= 512 unsorted survivors
+    rc = dae_reserve(ctx, ctx->sample_top, ((size_t)g.Bpad * pstride) * sizeof(uint2) + (size_t)g.Bpad * sizeof(int));
     if (rc) return rc;
+    int* sample_cnt = reinterpret_cast<int*>(static_cast<uint2*>(ctx->sample_top.p) + (size_t)g.Bpad * pstride);
     ta.out_kind = DAE_OUT_LOGIT;
     ta.out_pairs = static_cast<uint2*>(ctx->sample_top.p);
     ta.out_tau = static_cast<float*>(ctx->tau.p);
+    ta.out_cnt = sample_cnt; ta.pairs_stride = pstride;
     rc = dae_launch_topk_dense(ctx, ds, ta);
     if (rc) return rc;
 
@@ -296,10 +299,10 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = prof_end(ctx); if (rc) return rc;
 
     // final: exact top-k of (sample winners) U (filter survivors), seeds removed
-    dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), nullptr, 0, k, 0, 1, k};
+    dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), sample_cnt, 0, pstride, 0, 1, 0};
     dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
-    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
+    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr; ta.out_cnt = nullptr;
     ta.out_score = out_score; ta.out_idx = out_idx;
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
 }

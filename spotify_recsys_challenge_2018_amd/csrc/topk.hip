@@ -99,33 +99,43 @@ struct PairSrc {
     template <typename F>
     __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, F f) const
     {
-        const int nseg = g0.nseg + g1.nseg;
-        const int total = seg_prefix[nseg];
-        for (int e0 = 0; e0 < total; e0 += 2 * TK_THREADS) {
-            uint2 pr[2];
-            bool in[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int e = e0 + u * TK_THREADS + tid;
-                in[u] = e < total;
-                pr[u] = make_uint2(0u, 0xFFFFFFFFu);
-                if (in[u]) {
-                    int lo = 0, hiq = nseg;             // largest s with seg_prefix[s] <= e
-                    while (hiq - lo > 1) {
-                        const int mid = (lo + hiq) >> 1;
-                        if (seg_prefix[mid] <= e) lo = mid; else hiq = mid;
-                    }
-                    const int i = e - seg_prefix[lo];
-                    const bool first = lo < g0.nseg;
-                    const dae_pair_group& g = first ? g0 : g1;
-                    const int seg = first ? lo : lo - g0.nseg;
-                    pr[u] = g.base[(size_t)seg * g.seg_stride + (size_t)row * g.row_stride + i];
-                }
+        // group 0 (few, long segments: the sample winners): flat over the whole workgroup
+        for (int sg = 0; sg < g0.nseg; ++sg) {
+            const int cnt = seg_prefix[sg + 1] - seg_prefix[sg];
+            const uint2* base = g0.base + (size_t)sg * g0.seg_stride + (size_t)row * g0.row_stride;
+            for (int i0 = 0; i0 < cnt; i0 += TK_THREADS) {
+                const int i = i0 + tid;
+                const bool in = i < cnt;
+                const uint2 pr = in ? base[i] : make_uint2(0u, 0xFFFFFFFFu);
+                f(__uint_as_float(pr.x), (int)pr.y, in);
             }
+        }
+        // group 1 (many short segments: one candidate list per decode workgroup): a wave per
+        // segment, 4 segments in flight, no per-element search
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int s0 = wave; s0 < g1.nseg; s0 += 4 * TK_WAVES) {
+            int cnt[4];
+            const uint2* base[4];
+            int mx = 0;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (e0 + u * TK_THREADS < total)        // wave-uniform: whole waves enter together
-                    f(__uint_as_float(pr[u].x), (int)pr[u].y, in[u]);
+            for (int u = 0; u < 4; ++u) {
+                const int sg = s0 + u * TK_WAVES;
+                const bool ok = sg < g1.nseg;
+                cnt[u] = ok ? seg_prefix[g0.nseg + sg + 1] - seg_prefix[g0.nseg + sg] : 0;
+                base[u] = g1.base + (size_t)(ok ? sg : 0) * g1.seg_stride + (size_t)row * g1.row_stride;
+                mx = cnt[u] > mx ? cnt[u] : mx;
+            }
+            for (int i0 = 0; i0 < mx; i0 += 64) {
+                uint2 pr[4];
+                bool in[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    in[u] = i0 + lane < cnt[u];
+                    pr[u] = in[u] ? base[u][i0 + lane] : make_uint2(0u, 0xFFFFFFFFu);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 < cnt[u]) f(__uint_as_float(pr[u].x), (int)pr[u].y, in[u]);
             }
         }
     }
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __shared__ unsigned wave_tot[TK_WAVES];
     __shared__ int s_bin;
     __shared__ unsigned s_above;
-    __shared__ unsigned s_cnt;
-    __shared__ u64 s_min, s_max;
+    __shared__ unsigned s_cnt, s_cnt2;
+    __shared__ u64 s_min, s_max, s_min2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     };
 
     // ---- 2. first read: keys -> LDS (if they fit), count, min, max ---------------------------------
+    u64 tmax = 0ull;                                             // this thread's largest key
     {
         u64 mn = ~0ull, mx = 0ull;
         src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 }
             }
         });
+        tmax = mx;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             const u64 omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
@@ -294,10 +306,56 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         if (valid) atomicAdd(&hist[bin], 1u);
     };
 
-    // ---- 3. narrow [lo, hi] until the keys >= lo fit the sort buffer ---------------------------------
+    // ---- 3a. cheap lower bound from ONE value per thread --------------------------------------------
+    // The per-thread maxima are distinct elements of the row, so their k-th largest is <= the row's
+    // k-th largest key: a valid cut.  With the row spread over 1024 threads it is also tight
+    // (~1.4 k keys survive for k = 500), and it costs one histogram over <= 1024 values instead of
+    // one over the whole row.
     u64 lo = s_min, hi = s_max;
     unsigned above = 0;                                          // keys > hi
+    bool narrowed = false;
     if (m > (unsigned)sort_n) {
+        if (tid == 0) { s_cnt2 = 0; s_min2 = ~0ull; }
+        __syncthreads();
+        {
+            const bool has = tmax != 0ull;
+            const u64 bal = __ballot(has);
+            u64 wmn = has ? tmax : ~0ull;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_xor(wmn, d); wmn = o < wmn ? o : wmn; }
+            if (lane == 0 && bal) { atomicAdd(&s_cnt2, (unsigned)__popcll(bal)); atomicMin(&s_min2, wmn); }
+        }
+        __syncthreads();
+        const unsigned n_max = s_cnt2;
+        if (n_max >= k_eff) {
+            const u64 mlo = s_min2, mhi = s_max;                 // the row maximum is a thread maximum
+            const u64 range = mhi - mlo;
+            int shift = 64 - 11 - __clzll(range | 1ull);
+            if (shift < 0) shift = 0;
+            for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
+            __syncthreads();
+            if (tmax != 0ull) atomicAdd(&hist[(unsigned)((tmax - mlo) >> shift)], 1u);
+            __syncthreads();
+            find_bin(hist, wave_tot, tid, k_eff, &s_bin, &s_above);
+            const u64 cut = mlo + ((u64)(unsigned)s_bin << shift);   // <= k-th largest thread maximum
+            __syncthreads();
+            // count the row's keys >= cut
+            unsigned cnt = 0;
+            for_keys([&](u64 ck) { cnt += (ck != 0ull && ck >= cut) ? 1u : 0u; });
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (tid == 0) s_cnt2 = 0;
+            __syncthreads();
+            if (lane == 0) atomicAdd(&s_cnt2, cnt);
+            __syncthreads();
+            if (s_cnt2 <= (unsigned)sort_n) { lo = cut; narrowed = true; }
+            else { lo = cut; }                                   // still a valid cut: narrow inside it
+            __syncthreads();
+        }
+    }
+
+    // ---- 3b. general narrowing of [lo, hi] until the keys >= lo fit the sort buffer ----------------
+    if (m > (unsigned)sort_n && !narrowed) {
         for (int it = 0; it < 8; ++it) {
             const u64 range = hi - lo;
             int shift = 64 - 11 - __clzll(range | 1ull);
@@ -362,6 +420,119 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __syncthreads();
 
     if (dbg_stop == 4) return;
+    // ---- 4b. k <= 512: get down to <= 512 keys so that the cheap ordering stage applies.  If more
+    // than 512 were collected, cut at the k-th key with one more histogram over the collected keys
+    // (one per thread).
+    u64 cut_final = lo;
+    if (sort_n == 1024 && k_eff > 0) {
+        if (s_cnt <= 512u) {
+            sort_n = 512;
+        } else {
+            const unsigned c = s_cnt < 1024u ? s_cnt : 1024u;
+            const u64 mine = (unsigned)tid < c ? skey[tid] : 0ull;
+            // float keys are log-spaced, so one linear histogram over [cut, max] can leave the k-th
+            // key in a fat bin: re-bin inside that bin until what is kept fits (one key per thread,
+            // so every pass is a handful of barriers)
+            u64 rlo = lo, rhi = s_max, cut2 = lo;
+            unsigned rabove = 0, keep = c;
+            for (int it = 0; it < 6 && keep > 512u; ++it) {
+                const u64 range = rhi - rlo;
+                int shift = 64 - 11 - __clzll(range | 1ull);
+                if (shift < 0) shift = 0;
+                for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
+                __syncthreads();
+                if (mine != 0ull && mine >= rlo && mine <= rhi)
+                    atomicAdd(&hist[(unsigned)((mine - rlo) >> shift)], 1u);
+                __syncthreads();
+                find_bin(hist, wave_tot, tid, k_eff - rabove, &s_bin, &s_above);
+                const unsigned bcnt = hist[s_bin];
+                cut2 = rlo + ((u64)(unsigned)s_bin << shift);
+                keep = rabove + s_above + bcnt;                  // keys >= cut2
+                u64 nhi = cut2 + ((1ull << shift) - 1ull);
+                if (nhi > rhi) nhi = rhi;
+                rabove += s_above;
+                rlo = cut2; rhi = nhi;
+                __syncthreads();
+            }
+            if (keep <= 512u) {
+                if (tid == 0) s_cnt = 0;
+                __syncthreads();
+                const bool v = mine != 0ull && mine >= cut2;
+                const u64 bal = __ballot(v);
+                unsigned base = 0;
+                if (bal) {
+                    const int leader = __ffsll((long long)bal) - 1;
+                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                    base = __shfl(base, leader);
+                }
+                __syncthreads();                                 // all old skey reads are done
+                if (tid < 512) skey[tid] = 0ull;
+                __syncthreads();
+                if (v) skey[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine;
+                __syncthreads();
+                sort_n = 512;
+                cut_final = cut2;
+            }
+        }
+        if (sort_n == 512 && a.out_cnt && k_eff == (unsigned)k) {
+            // threshold mode (phase A): >= k keys are >= cut_final, so its logit is a valid lower
+            // bound of the k-th largest logit -- all phase B needs; survivors go out unsorted.
+            const unsigned c2 = s_cnt;
+            if ((unsigned)tid < c2) {
+                const u64 ck = skey[tid];
+                a.out_pairs[(size_t)row * a.pairs_stride + tid] =
+                    make_uint2(__float_as_uint(dae_okey_inv((unsigned)(ck >> 32))),
+                               ~(unsigned)(ck & 0xFFFFFFFFull));
+            }
+            if (tid == 0) {
+                a.out_cnt[row] = (int)c2;
+                a.out_tau[row] = dae_okey_inv((unsigned)(cut_final >> 32));
+            }
+            return;
+        }
+    }
+
+    if (dbg_stop == 99 && tid == 0)
+        printf("SLOWPATH row %d m %u k_eff %u s_cnt %u sort_n %d narrowed %d tau_mode %d\n", row, m, k_eff,
+               s_cnt, sort_n, (int)narrowed, a.out_cnt ? 1 : 0);
+    if (dbg_stop == 5) return;
+    if (sort_n == 512) {
+        // <= 512 unique keys: bitonic network over the 8 waves that hold them (one key per thread);
+        // strides < 64 through wave shuffles, 64..256 through LDS.  The other 8 waves only join
+        // the barriers, so the network is not slowed by their instruction issue.
+        const bool act = tid < 512;
+        u64 kr = act ? skey[tid] : 0ull;
+        for (int size = 2; size <= 512; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                if (stride >= 64) {
+                    __syncthreads();
+                    if (act) skey[tid] = kr;
+                    __syncthreads();
+                    if (act) {
+                        const u64 other = skey[tid ^ stride];
+                        const bool desc = ((tid & size) == 0), lower = ((tid & stride) == 0);
+                        const u64 mx = kr > other ? kr : other, mn = kr > other ? other : kr;
+                        kr = (lower == desc) ? mx : mn;
+                    }
+                } else if (act) {
+                    const u64 other = __shfl_xor(kr, stride);
+                    const bool desc = ((tid & size) == 0), lower = ((tid & stride) == 0);
+                    const u64 mx = kr > other ? kr : other, mn = kr > other ? other : kr;
+                    kr = (lower == desc) ? mx : mn;
+                }
+            }
+        }
+        if (act && (unsigned)tid < k_eff) {
+            const float z = dae_okey_inv((unsigned)(kr >> 32));
+            const int colv = (int)(~(unsigned)(kr & 0xFFFFFFFFull));
+            const size_t o = (size_t)row * k + tid;
+            if (a.out_idx) a.out_idx[o] = colv;
+            if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
+            if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + tid] =
+                make_uint2(__float_as_uint(z), (unsigned)colv);
+            if (a.out_tau && tid == k - 1) a.out_tau[row] = z;
+        }
+    } else
     // Hybrid bitonic sort, descending.  Thread t holds elements t and t + 1024 (the second only
     // when sort_n = 2048).  Strides < 64 exchange through wave shuffles, strides 64..512 through
     // LDS, stride 1024 inside the thread.
@@ -410,7 +581,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 }
             }
         }
-        if (dbg_stop == 5) return;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const unsigned i = (unsigned)(e * TK_THREADS + tid);
@@ -421,7 +591,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 const size_t o = (size_t)row * k + i;
                 if (a.out_idx) a.out_idx[o] = colv;
                 if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
-                if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(z), (unsigned)colv);
+                if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + (o - (size_t)row * k)] = make_uint2(__float_as_uint(z), (unsigned)colv);
                 if (a.out_tau && i == (unsigned)k - 1) a.out_tau[row] = z;
             }
         }
@@ -431,9 +601,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         const size_t o = (size_t)row * k + i;
         if (a.out_idx) a.out_idx[o] = -1;
         if (a.out_score) a.out_score[o] = -__builtin_inff();
-        if (a.out_pairs) a.out_pairs[o] = make_uint2(__float_as_uint(-__builtin_inff()), 0xFFFFFFFFu);
+        if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + i] = make_uint2(__float_as_uint(-__builtin_inff()), 0xFFFFFFFFu);
     }
     if (a.out_tau && tid == 0 && k_eff < (unsigned)k) a.out_tau[row] = -__builtin_inff();
+    if (a.out_cnt && tid == 0) a.out_cnt[row] = k;
 }
 
 template <typename Src>
