@@ -33,6 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec
 
 
@@ -48,6 +49,11 @@ def parse():
     ap.add_argument("--k", type=int, default=500)
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--bias", default="zipf", choices=["zipf", "zeros"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="decode arithmetic: f32 = bit-exact headline path, bf16 = BASELINE configs[4]")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight: each has its own library context and HIP stream, so the "
+                         "latency-bound kernels of one batch overlap the MFMA-bound decode of the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
@@ -94,40 +100,58 @@ def main():
     d_rp, d_col, d_val = up(rp, torch.int32), up(col, torch.int32), up(val, torch.float32)
     d_srp, d_sc = up(srp, torch.int32), up(sc if sc.size else np.zeros(1, np.int32), torch.int32)
     col_lo, col_hi = shard_bounds(V, world, rank)
-    ctx = _lib.Context(local_rank)
+    n_str = max(1, args.streams)
+    ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
+    ctx = ctxs[0]
     d_Wd, d_bd = up(W_dec, torch.float32), up(b_dec, torch.float32)
+    DT = _lib.DAE_DTYPE_BF16 if args.dtype == "bf16" else _lib.DAE_DTYPE_F32
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.prepack_decoder(d_Wd, d_bd, col_lo, col_hi)
+    ctx.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
     torch.cuda.synchronize()
     prepack_ms = (time.perf_counter() - t0) * 1e3
+    for c in ctxs[1:]:
+        c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
+    torch.cuda.synchronize()
     if world > 1:
         del d_Wd            # a shard owner only keeps its packed slice
     h = torch.empty((B, H), dtype=torch.float32, device=dev)
-    score = torch.empty((B, k), dtype=torch.float32, device=dev)
-    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    outs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+    score, idx = outs[0]
     if world > 1:
-        g_bufs = (torch.empty((world * B, k), dtype=torch.float32, device=dev),
-                  torch.empty((world * B, k), dtype=torch.int32, device=dev))
-        l_logit = torch.empty((B, k), dtype=torch.float32, device=dev)
-        l_idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+        g_bufs = [(torch.empty((world * B, k), dtype=torch.float32, device=dev),
+                   torch.empty((world * B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+        l_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
+                   torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+    for c, st in zip(ctxs, streams):
+        with torch.cuda.stream(st):
+            c.bind_stream()
+    step_no = [0]
 
     def step():
-        if world == 1:
-            ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, score, idx)
-        else:
-            ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_logit, l_idx,
-                           out_kind=_lib.DAE_OUT_LOGIT)
-            g_logit, g_idx = gather_shard_topk(l_logit, l_idx, out=g_bufs)
-            ctx.topk_merge(g_logit, g_idx, score, idx)
+        s = step_no[0] % n_str
+        step_no[0] += 1
+        c = ctxs[s]
+        with torch.cuda.stream(streams[s]):
+            if world == 1:
+                c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[s][0], outs[s][1],
+                             dtype=DT)
+            else:
+                c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[s][0],
+                             l_bufs[s][1], out_kind=_lib.DAE_OUT_LOGIT, dtype=DT)
+                g_logit, g_idx = gather_shard_topk(l_bufs[s][0], l_bufs[s][1], out=g_bufs[s])
+                c.topk_merge(g_logit, g_idx, outs[s][0], outs[s][1])
 
-    ctx.bind_stream()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile_enable(True)
+    for c in ctxs:
+        c.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -136,8 +160,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.profile_read()
-    ctx.profile_enable(False)
+    kern_ms, kern_n = 0.0, 0
+    for c in ctxs:
+        ms_, n_ = c.profile_read()
+        kern_ms += ms_; kern_n += n_
+        c.profile_enable(False)
     plan = ctx.last_plan()
 
     if world > 1:
@@ -160,16 +187,39 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     roofline = {"kernel": "decode_f32_kernel<filter>" if plan["fused"] else "decode_f32_kernel<dense>",
-                "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": PEAK_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved_tflops / PEAK_F32_TFLOPS, 4),
+                "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": round(achieved_tflops / peak_tf, 4),
                 "traffic": traffic, "flop_per_launch": flop_per_launch,
                 "avg_launch_ms": round(kern_avg_ms, 4), "launches": kern_n}
+
+    # the same kernel alone on the GPU (one stream, nothing overlapping it), after the timed region
+    if n_str > 1:
+        torch.cuda.synchronize()
+        ctx.bind_stream()
+        ctx.profile_enable(True)
+        for _ in range(10):
+            if world == 1:
+                ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[0][0], outs[0][1], dtype=DT)
+            else:
+                ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[0][0], l_bufs[0][1],
+                               out_kind=_lib.DAE_OUT_LOGIT, dtype=DT)
+        torch.cuda.synchronize()
+        iso_ms, iso_n = ctx.profile_read()
+        ctx.profile_enable(False)
+        iso_avg = iso_ms / max(iso_n, 1)
+        iso_tf = flop_per_launch / (iso_avg * 1e-3) / 1e12 if iso_avg > 0 else 0.0
+        roofline["isolated"] = {"avg_launch_ms": round(iso_avg, 4), "achieved": round(iso_tf, 2),
+                                "frac": round(iso_tf / peak_tf, 4),
+                                "note": "same launch with no second batch in flight; the timed region overlaps "
+                                        "%d batches, which stretches each launch but raises throughput" % n_str}
 
     # ---- K1 encode against the HBM roofline (separate loop, same inputs) --------------------------
     enc_iters = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
+    ctx.bind_stream()
     e0.record()
     for _ in range(enc_iters):
         ctx.encode(d_rp, d_col, d_val, d_We, d_be, h)
@@ -188,20 +238,27 @@ def main():
         "metric": "playlists scored/sec (encode+decode+top-500) at |vocab|~170k",
         "value": round(value, 1), "unit": "playlists/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "untied DAE scoring: encode+decode(all %d cols)+top-%d over %d track cols, "
                                "hidden=%d, batch=%d/GPU (global %d), ids=%s, b_dec=%s, "
                                "BASELINE.json configs[%d]" % (V, k, n_tracks, H, args.batch_per_gpu, B,
                                                                args.dist, args.bias, 1 if world == 1 else 2),
                    "vocab": V, "n_tracks": n_tracks, "hidden": H, "global_batch": B, "k": k,
                    "parallelism": "1 GPU" if world == 1 else "vocab column shard x%d + RCCL all-gather" % world,
-                   "plan": plan, "prepack_ms": round(prepack_ms, 2),
+                   "plan": plan, "streams": n_str, "prepack_ms": round(prepack_ms, 2),
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,
     }
 
     # ---- CPU baseline: the C oracle ("port"), one thread, bounded sample --------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if args.dtype == "bf16":
+        # W_dec bf16 is 87 MB: at batch 256 the decode is bounded by streaming it (2*B/2 = 256 FLOP/B
+        # < the 400 FLOP/B machine balance); report the HBM view next to the MFMA one
+        w_bytes = dom_tiles * 32 * H * 2
+        out["roofline_hbm_view"] = {"kernel": roofline["kernel"], "bound": "hbm",
+                                    "achieved": round(w_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0,
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_launch": w_bytes}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         import oracle
         ns = min(args.cpu_sample, B)
         rows = slice(0, ns)

@@ -70,6 +70,23 @@ int prof_end(dae_ctx* ctx)
     return DAE_OK;
 }
 
+dae_rowgeom geom_for(int dtype, int B, int Hp)
+{
+    return dtype == DAE_DTYPE_F32 ? dae_row_geometry(B, Hp) : dae_row_geometry_bf16(B, Hp);
+}
+
+int pack_hidden(dae_ctx* ctx, int dtype, const float* h, int B, int H, const dae_rowgeom& g)
+{
+    if (dtype == DAE_DTYPE_F32) {
+        int rc = dae_launch_pack_h(ctx, h, B, H, g);          // rewrites the whole image incl. zero pads
+        if (rc) return rc;
+        ctx->h_geom_key = ((long long)B << 32) | ((long long)H << 12) | (long long)g.R_TILE;
+        ctx->h_geom_ptr = ctx->h_packed.p;
+        return DAE_OK;
+    }
+    return dae_launch_pack_h_bf16(ctx, h, B, H, g);
+}
+
 const dae_packed* packed_for(dae_ctx* ctx, int dtype, int H)
 {
     const dae_packed* pk = dtype == DAE_DTYPE_F32 ? &ctx->pk_f32 : &ctx->pk_bf16;
@@ -114,7 +131,7 @@ int dae_destroy(dae_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
-                       &ctx->cand_cnt, &ctx->dense_tmp, &ctx->train_a, &ctx->train_b,
+                       &ctx->cand_cnt, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -197,7 +214,8 @@ int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, in
     if (H <= 0 || V <= 0 || col_lo < 0 || col_hi > V || col_lo >= col_hi)
         return dae_fail(ctx, DAE_ERR_ARG, "bad shape V=%d H=%d cols=[%d,%d)", V, H, col_lo, col_hi);
     if (dtype == DAE_DTYPE_F32) return dae_launch_prepack_f32(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
-    return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    if (dtype == DAE_DTYPE_BF16) return dae_launch_prepack_bf16(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
+    return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
 }
 
 int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int apply_sigmoid,
@@ -205,18 +223,18 @@ int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int 
 {
     if (!ctx) return DAE_ERR_ARG;
     if (!h || !out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
-    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
     const dae_packed* pk = packed_for(ctx, dtype, H);
     if (!pk) return DAE_ERR_STATE;
     const int ncols = pk->col_hi - pk->col_lo;
     if (ld_out < ncols) return dae_fail(ctx, DAE_ERR_ARG, "ld_out=%lld < %d columns", (long long)ld_out, ncols);
     if (B <= 0) return DAE_OK;
-    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
-    int rc = dae_launch_pack_h(ctx, h, B, H, g);
+    const dae_rowgeom g = geom_for(dtype, B, pk->Hp);
+    int rc = pack_hidden(ctx, dtype, h, B, H, g);
     if (rc) return rc;
     dae_tileset ts{pk->ntiles, 1, 0};
     rc = prof_begin(ctx); if (rc) return rc;
-    rc = dae_launch_decode_dense_f32(ctx, g, B, ts, apply_sigmoid, INT_MAX, out, ld_out, 0);
+    rc = dae_launch_decode_dense_f32(ctx, g, B, ts, apply_sigmoid, INT_MAX, out, ld_out, 0, dtype);
     if (rc) return rc;
     return prof_end(ctx);
 }
@@ -229,7 +247,7 @@ static long long geom_key(int B, int H, int R_TILE)
 // decode + rank with the hidden tile already packed in ctx->h_packed for geometry g
 static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B,
                             int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                            int k, int out_kind, float* out_score, int32_t* out_idx)
+                            int k, int out_kind, float* out_score, int32_t* out_idx, int dtype)
 {
     int rc;
     const int ntiles = pk->ntiles;
@@ -260,7 +278,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     float* sample = static_cast<float*>(ctx->sample.p);
     dae_tileset tsA{n_samp, fused ? S : 1, fused ? 1 : 0};
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
-    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1);
+    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
@@ -294,7 +312,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = prof_begin(ctx); if (rc) return rc;
     rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
                                       n_valid_col, static_cast<uint2*>(ctx->cand.p),
-                                      static_cast<int*>(ctx->cand_cnt.p), cap);
+                                      static_cast<int*>(ctx->cand_cnt.p), cap, dtype);
     if (rc) return rc;
     rc = prof_end(ctx); if (rc) return rc;
 
@@ -311,7 +329,7 @@ static int check_topk_args(dae_ctx* ctx, int dtype, int k, const int32_t* seed_r
                            const int32_t* seed_col, const void* out_score, const void* out_idx)
 {
     if (!out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
-    if (dtype != DAE_DTYPE_F32) return dae_fail(ctx, DAE_ERR_ARG, "dtype %d not available in this build", dtype);
+    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
     if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
     if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
         return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
@@ -329,13 +347,11 @@ int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n
     const dae_packed* pk = packed_for(ctx, dtype, H);
     if (!pk) return DAE_ERR_STATE;
     if (B <= 0) return DAE_OK;
-    const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
-    rc = dae_launch_pack_h(ctx, h, B, H, g);          // rewrites the whole image incl. zero pads
+    const dae_rowgeom g = geom_for(dtype, B, pk->Hp);
+    rc = pack_hidden(ctx, dtype, h, B, H, g);
     if (rc) return rc;
-    ctx->h_geom_key = geom_key(B, H, g.R_TILE);
-    ctx->h_geom_ptr = ctx->h_packed.p;
     return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                            out_score, out_idx);
+                            out_score, out_idx, dtype);
 }
 
 int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
@@ -353,6 +369,20 @@ int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, con
     const dae_packed* pk = packed_for(ctx, dtype, H);
     if (!pk) return DAE_ERR_STATE;
     if (B <= 0) return DAE_OK;
+    if (dtype == DAE_DTYPE_BF16) {
+        // encode stays fp32 (north_star: bf16 decode GEMM + fp32 encode / top-k); the hidden rows are
+        // rounded to bf16 while being re-tiled for the MFMA
+        const dae_rowgeom g16 = dae_row_geometry_bf16(B, pk->Hp);
+        rc = dae_reserve(ctx, ctx->h_scratch, (size_t)B * H * sizeof(float));
+        if (rc) return rc;
+        float* hs = static_cast<float*>(ctx->h_scratch.p);
+        rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, hs, nullptr, 0, 0);
+        if (rc) return rc;
+        rc = dae_launch_pack_h_bf16(ctx, hs, B, H, g16);
+        if (rc) return rc;
+        return decode_topk_core(ctx, pk, g16, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
+                                out_score, out_idx, dtype);
+    }
     const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
     const int G = pk->Hp / DAE_KG, RB = g.R_TILE / 32;
     const size_t bytes = (size_t)g.n_rg * G * RB * 64 * sizeof(float4);
@@ -369,7 +399,7 @@ int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, con
                            static_cast<float*>(ctx->h_packed.p), G, RB);
     if (rc) return rc;
     return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                            out_score, out_idx);
+                            out_score, out_idx, dtype);
 }
 
 int dae_topk_dense(dae_ctx* ctx, const float* logits, int64_t ld, int B, int ncols, int col_base,

@@ -45,6 +45,8 @@ struct dae_ctx {
 
     // scratch (grown lazily, never shrunk)
     dae_buf h_packed;          // [n_rg][Hp/8][RB][64][4] fp32 (or bf16 image)
+    dae_buf h_packed16;        // bf16 image of the hidden tile [n_rg][Hp/16][RB][64][8 bf16]
+    dae_buf h_scratch;         // [B,H] fp32 hidden activations when the caller does not keep them
     long long h_geom_key = -1; // (B, H, R_TILE) whose pad region of h_packed is known to be zero
     void* h_geom_ptr = nullptr;
     dae_buf sample;            // phase-A dense logits [Bpad][n_sample_cols]
@@ -152,6 +154,10 @@ struct dae_rowgeom {        // how B rows are cut into row groups for the decode
     int waves;              // waves per workgroup (4 or 8)
 };
 dae_rowgeom dae_row_geometry(int B, int Hp);
+dae_rowgeom dae_row_geometry_bf16(int B, int Hp);
+int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,
+                            int col_lo, int col_hi);
+int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
 
 // encode.hip
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
@@ -173,11 +179,11 @@ struct dae_tileset {        // which wave tiles a decode launch walks
 // dense epilogue: out[row*ld + item*32 + vl] (item = position of the tile in the set)
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad);
+                                int fill_pad, int dtype = DAE_DTYPE_F32);
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
-                                 int cap);
+                                 int cap, int dtype = DAE_DTYPE_F32);
 
 // training forward: all tiles, epilogue turns logits into dL/dz in place over the dense targets
 // already scattered into `dz` ([B, ld] row-major), also writes dz transposed ([ncols, ldT]) and one

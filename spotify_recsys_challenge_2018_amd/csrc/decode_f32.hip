@@ -27,16 +27,22 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int DT_F32 = 0;          // v_mfma_f32_32x32x2_f32, exact fp32 (bit-equal to the oracle)
+constexpr int DT_BF16 = 1;         // v_mfma_f32_32x32x16_bf16, fp32 accumulate (BASELINE configs[4])
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 
 constexpr int EPI_DENSE = 0;
 constexpr int EPI_FILTER = 1;
 constexpr int EPI_LOSS = 2;        // training: logits -> loss + dL/dz (DAEs.py:98-100)
 
 struct DecP {
-    const float4* Wp;      // [ntiles][G][64] float4
+    const float4* Wp;      // f32: [ntiles][G][64] float4   bf16: [ntiles][G][64] uint4 (8 bf16)
     const float* bias;     // [ntiles*32]
-    const float4* hp;      // [n_rg][G][RB][64] float4
-    int G;                 // Hp / 8
+    const float4* hp;      // f32: [n_rg][G][RB][64] float4  bf16: [n_rg][G][RB][64] uint4
+    int G;                 // k groups per tile: Hp / 8 (f32, 4 MFMA each) or Hp / 16 (bf16, 1 MFMA)
     int ncols;             // col_hi - col_lo of the prepacked image
     int col_lo;
     int B, n_rg, nb_rg, Bpad;
@@ -60,7 +66,7 @@ __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
 // GT > 0: hidden size known at compile time (G = GT groups of 8 k) -> the k loop is fully
 // unrolled, so no loop header sits between the register-ring loads and their use (hipcc drains
 // vmcnt to 0 at every loop header; with the loop gone the waits are exact counted vmcnt(3)).
-template <int RB, int EPI, int GT, int NW>
+template <int RB, int EPI, int GT, int NW, int DT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
@@ -118,11 +124,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     // of that stream, so the prefetch runs across tile boundaries (and under the epilogue).
     float4 wb0, wb1, wb2, wb3;
     float4 bA[RB], bB[RB];
+    // bf16: one 16-byte load = the A operand of ONE MFMA (K = 16); ring of 8 steps (4 KiB ahead)
+    constexpr int QR = 8;
+    uint4 wq[QR];
+    uint4 cb[2][RB];
+    const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
     if (item0 < p.ts.n_items) {
         const float4* w0 = p.Wp + (size_t)tile_of_item(p.ts, item0) * G * 64 + lane;
-        wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
+        if (DT == DT_F32) {
+            wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+            for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+        } else {
+            const uint4* q0 = reinterpret_cast<const uint4*>(w0);
+#pragma unroll
+            for (int u = 0; u < QR; ++u) wq[u] = q0[(size_t)(u < G ? u : G - 1) * 64];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
+        }
     }
 
     for (int item = item0; item < p.ts.n_items; item += n_ws) {
@@ -165,6 +184,42 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         __builtin_amdgcn_sched_barrier(0);                                                     \
     }
 
+        if (DT == DT_BF16) {
+            const uint4* wq_cur = reinterpret_cast<const uint4*>(wp);
+            const uint4* wq_nxt = reinterpret_cast<const uint4*>(wn);
+            if (GT > 0) {
+                // hidden size known: fully unrolled, ring slot and fragment buffer are static
+#pragma unroll
+                for (int s = 0; s < (GT > 0 ? GT : 1); ++s) {
+                    const uint4 a = wq[s % QR];
+                    wq[s % QR] = (s + QR < GT) ? wq_cur[(size_t)(s + QR) * 64]
+                                               : wq_nxt[(size_t)(s + QR - GT) * 64];
+                    const int sn = (s + 1) % (GT > 0 ? GT : 1);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) cb[(s + 1) & 1][rb] = ldsq[(size_t)(sn * RB + rb) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(cb[s & 1][rb]),
+                                                                          acc[rb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // generic hidden size (G even): two steps per iteration, no deep ring
+                for (int s = 0; s < G; s += 2) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const uint4 a = wq_cur[(size_t)(s + h2) * 64];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            const uint4 b = ldsq[(size_t)((s + h2) * RB + rb) * 64 + lane];
+                            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b),
+                                                                              acc[rb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
         int g = 0;
 #pragma unroll
         for (; g < G - 4; g += 4) {
@@ -179,6 +234,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         DAE_STEP(wb1, wn + 64,  bB, bA, g + 2)
         DAE_STEP(wb2, wn + 128, bA, bB, g + 3)
         DAE_STEP(wb3, wn + 192, bB, bA, 0)
+        }
 #undef DAE_STEP
 
         // ---- epilogue -----------------------------------------------------------------------
@@ -363,18 +419,78 @@ __global__ __launch_bounds__(256) void pack_h_kernel(const float* __restrict__ h
     }
 }
 
-template <int RB, int EPI, int GT, int NW>
+__device__ __forceinline__ unsigned bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
+    return u >> 16;
+}
+
+// out uint4 index = (t*NS + s)*64 + lane, lane = hi*32 + i: bf16 of W[col_lo+32t+i][16s+8hi+0..7]
+__global__ __launch_bounds__(256) void prepack_bf16_kernel(const float* __restrict__ W,
+                                                           const float* __restrict__ b, int H, int NS,
+                                                           int col_lo, int col_hi, int ntiles,
+                                                           uint4* __restrict__ Wp,
+                                                           float* __restrict__ bias)
+{
+    const size_t total = (size_t)ntiles * NS * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = (int)(o & 63);
+        const size_t ts = o >> 6;
+        const int s = (int)(ts % NS), t = (int)(ts / NS);
+        const int hi = lane >> 5, i = lane & 31;
+        const int v = col_lo + t * 32 + i;
+        unsigned e[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int k = 16 * s + 8 * hi + x;
+            e[x] = (v < col_hi && k < H) ? bf16_rne(W[(size_t)v * H + k]) : 0u;
+        }
+        Wp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+    const int nb = ntiles * 32;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
+        const int v = col_lo + o;
+        bias[o] = v < col_hi ? b[v] : 0.0f;
+    }
+}
+
+// out uint4 index = ((rg*NS + s)*RB + rb)*64 + lane: bf16 of h[(rg*RB+rb)*32+j][16s+8hi+0..7]
+__global__ __launch_bounds__(256) void pack_h_bf16_kernel(const float* __restrict__ h, int B, int H,
+                                                          int NS, int RB, int n_rg,
+                                                          uint4* __restrict__ hp)
+{
+    const size_t total = (size_t)n_rg * NS * RB * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = (int)(o & 63);
+        size_t x = o >> 6;
+        const int rb = (int)(x % RB); x /= RB;
+        const int s = (int)(x % NS);
+        const int rg = (int)(x / NS);
+        const int hi = lane >> 5, jj = lane & 31;
+        const int r = (rg * RB + rb) * 32 + jj;
+        unsigned e[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 16 * s + 8 * hi + c;
+            e[c] = (r < B && k < H) ? bf16_rne(h[(size_t)r * H + k]) : 0u;
+        }
+        hp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+}
+
+template <int RB, int EPI, int GT, int NW, int DT>
 int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
     const size_t lds = (size_t)RB * 64 * p.G * sizeof(float4) + (size_t)RB * 32 * sizeof(int);
     static bool attr_set = false;     // per template instantiation
     if (!attr_set) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(
-                               reinterpret_cast<const void*>(&decode_f32_kernel<RB, EPI, GT, NW>),
+                               reinterpret_cast<const void*>(&decode_f32_kernel<RB, EPI, GT, NW, DT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW>), dim3(g.grid), dim3(NW * 64), lds,
+    hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
                        ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "decode_f32_kernel");
     return DAE_OK;
@@ -385,28 +501,53 @@ int launch_decode_rb(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
     // the shipped configs all use hidden = 256 (config.ini:12): G = 32 gets the unrolled body
     if (g.R_TILE == 128 && p.G == 32) {
-        if (g.waves == 8) return launch_decode<4, EPI, 32, 8>(ctx, g, p);
-        return launch_decode<4, EPI, 32, 4>(ctx, g, p);
+        if (g.waves == 8) return launch_decode<4, EPI, 32, 8, DT_F32>(ctx, g, p);
+        return launch_decode<4, EPI, 32, 4, DT_F32>(ctx, g, p);
     }
     if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "bad wave count %d", g.waves);
     switch (g.R_TILE) {
-        case 128: return launch_decode<4, EPI, 0, 4>(ctx, g, p);
-        case 64:  return launch_decode<2, EPI, 0, 4>(ctx, g, p);
-        case 32:  return launch_decode<1, EPI, 0, 4>(ctx, g, p);
+        case 128: return launch_decode<4, EPI, 0, 4, DT_F32>(ctx, g, p);
+        case 64:  return launch_decode<2, EPI, 0, 4, DT_F32>(ctx, g, p);
+        case 32:  return launch_decode<1, EPI, 0, 4, DT_F32>(ctx, g, p);
     }
     return dae_fail(ctx, DAE_ERR_ARG, "bad R_TILE %d", g.R_TILE);
 }
 
-int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p)
+template <int EPI>
+int launch_decode_rb_bf16(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
-    const dae_packed& pk = ctx->pk_f32;
-    if (!pk.valid) return dae_fail(ctx, DAE_ERR_STATE, "decoder not prepacked (fp32)");
-    if (!ctx->h_packed.p) return dae_fail(ctx, DAE_ERR_STATE, "hidden tile not packed");
+    // hidden = 256 -> 16 steps of K = 16: unrolled body with the 8-deep register ring
+    // two waves per SIMD here: with 16x faster MFMAs the VALU epilogue of a tile is comparable to
+    // its matrix time, and the second wave's MFMAs cover it (DAE_DECODE_WAVES_BF16=4 for the A/B)
+    if (g.R_TILE == 256 && p.G == 16) {
+        if (g.waves == 8) return launch_decode<8, EPI, 16, 8, DT_BF16>(ctx, g, p);
+        return launch_decode<8, EPI, 16, 4, DT_BF16>(ctx, g, p);
+    }
+    if (g.R_TILE == 128 && p.G == 16) {
+        if (g.waves == 8) return launch_decode<4, EPI, 16, 8, DT_BF16>(ctx, g, p);
+        return launch_decode<4, EPI, 16, 4, DT_BF16>(ctx, g, p);
+    }
+    switch (g.R_TILE) {
+        case 256: return launch_decode<8, EPI, 0, 4, DT_BF16>(ctx, g, p);
+        case 128: return launch_decode<4, EPI, 0, 4, DT_BF16>(ctx, g, p);
+        case 64:  return launch_decode<2, EPI, 0, 4, DT_BF16>(ctx, g, p);
+        case 32:  return launch_decode<1, EPI, 0, 4, DT_BF16>(ctx, g, p);
+    }
+    return dae_fail(ctx, DAE_ERR_ARG, "bad R_TILE %d", g.R_TILE);
+}
+
+int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p,
+                int dtype = DAE_DTYPE_F32)
+{
+    const dae_packed& pk = dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16;
+    const dae_buf& hb = dtype == DAE_DTYPE_F32 ? ctx->h_packed : ctx->h_packed16;
+    if (!pk.valid) return dae_fail(ctx, DAE_ERR_STATE, "decoder not prepacked (dtype %d)", dtype);
+    if (!hb.p) return dae_fail(ctx, DAE_ERR_STATE, "hidden tile not packed");
     memset(&p, 0, sizeof(p));
     p.Wp = static_cast<const float4*>(pk.W.p);
     p.bias = static_cast<const float*>(pk.bias.p);
-    p.hp = static_cast<const float4*>(ctx->h_packed.p);
-    p.G = pk.Hp / DAE_KG;
+    p.hp = static_cast<const float4*>(hb.p);
+    p.G = dtype == DAE_DTYPE_F32 ? pk.Hp / DAE_KG : pk.Hp / 16;
     p.ncols = pk.col_hi - pk.col_lo;
     p.col_lo = pk.col_lo;
     p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg; p.Bpad = g.Bpad;
@@ -438,6 +579,69 @@ dae_rowgeom dae_row_geometry(int B, int Hp)
         if ((w == 4 || w == 8) && rt == 128 && Hp == 256) g.waves = w;
     }
     return g;
+}
+
+// bf16: 128-playlist tiles (64 KiB of LDS at H = 256).  256-playlist tiles fit LDS too but need
+// 394 registers per wave, which rules out the second wave per SIMD that hides the epilogue.
+dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
+{
+    dae_rowgeom g;
+    int rt = 128;
+    while (rt > 32 && (size_t)rt * Hp * 2 > 128 * 1024) rt >>= 1;
+    while (rt > 32 && B <= rt / 2) rt >>= 1;
+    g.R_TILE = rt;
+    g.n_rg = (B + rt - 1) / rt;
+    g.Bpad = g.n_rg * rt;
+    int nb = (DAE_NUM_CU / g.n_rg) / DAE_NUM_XCD * DAE_NUM_XCD;
+    if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
+    g.nb_rg = nb;
+    g.grid = g.n_rg * nb;
+    g.waves = 4;      // measured: 1.94 M playlists/s vs 1.65 M with 8 (B = 256; profiles/r01_notes.md)
+    if (const char* e = getenv("DAE_DECODE_WAVES_BF16")) {
+        const int w = atoi(e);
+        if ((w == 4 || w == 8) && Hp == 256 && rt >= 128) g.waves = w;
+    }
+    return g;
+}
+
+int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,
+                            int col_lo, int col_hi)
+{
+    dae_packed& pk = ctx->pk_bf16;
+    pk.valid = false;
+    const int Hp = dae_round_up(H, DAE_HPAD);
+    if ((size_t)32 * Hp * 2 > 128 * 1024)
+        return dae_fail(ctx, DAE_ERR_ARG, "hidden size %d too large", H);
+    const int ntiles = (col_hi - col_lo + DAE_VT - 1) / DAE_VT;
+    const int NS = Hp / 16;
+    int rc = dae_reserve(ctx, pk.W, (size_t)ntiles * NS * 64 * sizeof(uint4));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, pk.bias, (size_t)ntiles * 32 * sizeof(float));
+    if (rc) return rc;
+    const size_t total = (size_t)ntiles * NS * 64;
+    int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(prepack_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, NS,
+                       col_lo, col_hi, ntiles, static_cast<uint4*>(pk.W.p), static_cast<float*>(pk.bias.p));
+    DAE_CHECK_LAUNCH(ctx, "prepack_bf16_kernel");
+    pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
+    pk.valid = true;
+    return DAE_OK;
+}
+
+int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g)
+{
+    const int Hp = dae_round_up(H, DAE_HPAD);
+    const int NS = Hp / 16, RB = g.R_TILE / 32;
+    const size_t total = (size_t)g.n_rg * NS * RB * 64;
+    int rc = dae_reserve(ctx, ctx->h_packed16, total * sizeof(uint4));
+    if (rc) return rc;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_h_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, h, B, H, NS, RB,
+                       g.n_rg, static_cast<uint4*>(ctx->h_packed16.p));
+    DAE_CHECK_LAUNCH(ctx, "pack_h_bf16_kernel");
+    return DAE_OK;
 }
 
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
@@ -483,16 +687,17 @@ int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowg
 
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad)
+                                int fill_pad, int dtype)
 {
     DecP p;
-    int rc = fill_common(ctx, g, B, ts, p);
+    int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
-    return launch_decode_rb<EPI_DENSE>(ctx, g, p);
+    return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_DENSE>(ctx, g, p)
+                                  : launch_decode_rb_bf16<EPI_DENSE>(ctx, g, p);
 }
 
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
@@ -508,11 +713,12 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
 
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
-                                 int cap)
+                                 int cap, int dtype)
 {
     DecP p;
-    int rc = fill_common(ctx, g, B, ts, p);
+    int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
-    return launch_decode_rb<EPI_FILTER>(ctx, g, p);
+    return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_FILTER>(ctx, g, p)
+                                  : launch_decode_rb_bf16<EPI_FILTER>(ctx, g, p);
 }

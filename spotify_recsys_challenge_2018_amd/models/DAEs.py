@@ -123,7 +123,10 @@ class DAE_tied:
         self.ctx = None
         self._adam = None
         self._step = 0
-        self._packed_dirty = True
+        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+        # decode arithmetic of recommend(): "f32" (bit-exact path) or "bf16" (BASELINE configs[4])
+        self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
+            else _lib.DAE_DTYPE_F32
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
 
     # -- parameters ---------------------------------------------------------------------------------
@@ -155,7 +158,7 @@ class DAE_tied:
         self.biases["decoder_b"] = torch.from_numpy(np.ascontiguousarray(dec_b, np.float32)).to(dev)
         self.d_params = [self.weights["encoder_h"], self.weights["decoder_h"],
                          self.biases["encoder_b"], self.biases["decoder_b"]]
-        self._packed_dirty = True
+        self._mark_dirty()
 
     def fit(self):
         """DAEs.py:84-105.  Creates the device context, the parameters and the fetch handles."""
@@ -180,12 +183,15 @@ class DAE_tied:
             c = np.zeros(1, np.int32); v = np.zeros(1, np.float32)
         return self._to_dev(rp, torch.int32), self._to_dev(c, torch.int32), self._to_dev(v, torch.float32)
 
+    def _mark_dirty(self):
+        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+
     def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
-        if self._packed_dirty:
+        if self._packed_dirty[dtype]:
             self.ctx.bind_stream()
             self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0,
                                      self.n_input, dtype)
-            self._packed_dirty = False
+            self._packed_dirty[dtype] = False
 
     def encode(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
         """DAEs.py:40-42 + :64-70 -> hidden [n_batch, n_hidden] (torch CUDA tensor)."""
@@ -207,12 +213,14 @@ class DAE_tied:
         self.ctx.decode_dense(h, out, apply_sigmoid=True)
         return out.cpu().numpy()
 
-    def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None):
+    def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None):
         """Fused scoring path: encode -> decode -> top-k (track columns, seeds removed).
         Equivalent of main_challenge.py:80-90 / main_train.py:66-89 without the dense matrix.
         Returns (idx [n_rows,k] int32 with -1 padding, score [n_rows,k] float32)."""
         import torch
-        self._ensure_packed()
+        dtype = self.decode_dtype if dtype is None else (
+            _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
+        self._ensure_packed(dtype)
         self.ctx.bind_stream()
         dev = self.weights["encoder_h"].device
         rp, c, v = self._upload_csr(x_positions, x_ones)
@@ -223,7 +231,7 @@ class DAE_tied:
         score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
         idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
         self.ctx.score_topk(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"],
-                            self.n_tracks, d_srp, d_sc, k, score, idx)
+                            self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
         n_rows = self.n_batch if n_rows is None else n_rows
         return idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
 
@@ -262,7 +270,7 @@ class DAE_tied:
             m, v = self._adam[n]
             ctx.check(lib.dae_adam_step(ctx.h, P(p), P(m), P(v), P(grad), p.numel(),
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
-        self._packed_dirty = True
+        self._mark_dirty()
         return float(self._cost.item())
 
     # -- persistence ----------------------------------------------------------------------------------

@@ -1,0 +1,112 @@
+"""GPU (-m gpu): the bf16 decode path (BASELINE.json configs[4]: bf16 MFMA decode + fp32 encode and
+top-k).  The MFMA sums 16 exact bf16 products per instruction in an unspecified order, so parity
+with the bf16 oracle (operands rounded to bf16, fp32 accumulation) is by tolerance: |dz| <= 3e-5
+absolute on logits of magnitude <= 10.  Rankings are compared with the fp32 path through
+r-precision (tolerance 0.02) as configs[4] asks."""
+import os
+import pickle
+import shutil
+
+import numpy as np
+import pytest
+
+import oracle
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import DAE, coo_to_csr, seeds_to_csr
+from spotify_recsys_challenge_2018_amd.utils import metrics as met
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BF = _lib.DAE_DTYPE_BF16
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("V,H,B", [(3000, 256, 300), (2000, 32, 8), (5000, 128, 130), (1111, 96, 70), (4096, 256, 64)])
+def test_bf16_decode_dense_vs_bf16_oracle(ctx, V, H, B):
+    import torch
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=3, bias="zipf")
+    h = np.random.default_rng(0).random((B, H)).astype(np.float32)
+    dW, db, dh = _dev(W_dec), _dev(b_dec), _dev(h)
+    ctx.prepack_decoder(dW, db, dtype=BF)
+    out = torch.empty((B, V), dtype=torch.float32, device="cuda")
+    ctx.decode_dense(dh, out, apply_sigmoid=False, dtype=BF)
+    z_ref = oracle.decode(h, W_dec, b_dec, bf16=True)
+    z = out.cpu().numpy()
+    assert np.max(np.abs(z - z_ref)) <= 3e-5
+    z32 = oracle.decode(h, W_dec, b_dec)
+    assert np.max(np.abs(z - z32)) < 0.05 and np.max(np.abs(z - z32)) > 1e-6      # it really is bf16
+
+
+def test_bf16_fused_topk_equals_unfused_and_tracks_fp32(ctx):
+    import torch
+    V, nt, H, B, k = 60000, 50000, 256, 300, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=1, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=2)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+    ctx.prepack_decoder(d[5], d[6], dtype=BF)
+    ctx.prepack_decoder(d[5], d[6], dtype=_lib.DAE_DTYPE_F32)
+    s16 = torch.empty((B, k), device="cuda"); i16 = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    s32 = torch.empty_like(s16); i32 = torch.empty_like(i16)
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s16, i16, dtype=BF)
+    assert ctx.last_plan()["fused"] == 1 and ctx.last_plan()["R_TILE"] == 128
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s32, i32)
+    # unfused bf16: same logits, same ranking rule -> identical
+    h = torch.empty((B, H), device="cuda")
+    ctx.encode(d[0], d[1], d[2], d[3], d[4], h)
+    z = torch.empty((B, V), device="cuda")
+    ctx.decode_dense(h, z, apply_sigmoid=False, dtype=BF)
+    s_u = torch.empty_like(s16); i_u = torch.empty_like(i16)
+    ctx.topk_dense(z, nt, 0, d[7], d[8], k, s_u, i_u)
+    assert torch.equal(i16, i_u) and torch.equal(s16, s_u)
+    # against fp32: r-precision of the bf16 list w.r.t. the fp32 top-R as "answers"
+    a16, a32 = i16.cpu().numpy(), i32.cpu().numpy()
+    for R in (10, 100, 500):
+        rp_ = np.mean([met.get_r_precision(a32[r, :R].tolist(), a16[r].tolist()) for r in range(B)])
+        assert rp_ >= 0.97, (R, rp_)
+    assert np.max(np.abs(s16.cpu().numpy()[:, 0] - s32.cpu().numpy()[:, 0])) < 5e-3
+
+
+def test_bf16_vs_fp32_r_precision_on_trained_model(tmp_path, capsys):
+    """configs[4]: r-precision@500 of bf16 decode within 0.02 of fp32 on a trained model (golden
+    mini dataset, 3 epochs of --pretrain on the GPU)."""
+    import random
+    from spotify_recsys_challenge_2018_amd import main as cli
+    from spotify_recsys_challenge_2018_amd.main_runner import main_train
+    from spotify_recsys_challenge_2018_amd.utils.data_reader import data_reader_test
+    work = tmp_path / "run"; work.mkdir()
+    cfg = open(os.path.join(G, "config.ini")).read().replace("epochs = 2", "epochs = 3")
+    open(work / "config.ini", "w").write(cfg)
+    shutil.copytree(os.path.join(G, "data"), tmp_path / "data")
+    cwd = os.getcwd(); os.chdir(tmp_path)
+    try:
+        random.seed(1); np.random.seed(1)
+        assert cli.main(["--dir", "run", "--pretrain"]) == 0
+        conf = cli.load_conf("./run"); conf.set_dae_conf(); conf.initval = conf.save = str(work / "w_pretrain")
+        conf.n_tracks, conf.n_input = None, None
+        rd = data_reader_test("./data", "test-5", conf.batch, 1000)
+        import json
+        tr = json.load(open("./data/train"))
+        conf.n_tracks = len(tr["track_uri2id"]); conf.n_input = conf.n_tracks + len(tr["artist_uri2id"])
+        res = {}
+        for name in ("f32", "bf16"):
+            conf.decode_dtype = name
+            m = DAE(conf); m.fit()
+            res[name] = main_train.eval(rd, conf, m)
+        assert res["f32"] > 0.05                       # the model learnt something
+        assert abs(res["f32"] - res["bf16"]) <= 0.02, res
+    finally:
+        os.chdir(cwd)
