@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="batches in flight: each has its own library context and HIP stream, so the "
                          "latency-bound kernels of one batch overlap the MFMA-bound decode of the other")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the sharded code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=96, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
@@ -74,9 +76,11 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from spotify_recsys_challenge_2018_amd import _lib
     from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
@@ -114,13 +118,13 @@ def main():
     for c in ctxs[1:]:
         c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         del d_Wd            # a shard owner only keeps its packed slice
     h = torch.empty((B, H), dtype=torch.float32, device=dev)
     outs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
              torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
     score, idx = outs[0]
-    if world > 1:
+    if sharded:
         g_bufs = [(torch.empty((world * B, k), dtype=torch.float32, device=dev),
                    torch.empty((world * B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
         l_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
@@ -135,7 +139,7 @@ def main():
         step_no[0] += 1
         c = ctxs[s]
         with torch.cuda.stream(streams[s]):
-            if world == 1:
+            if not sharded:
                 c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[s][0], outs[s][1],
                              dtype=DT)
             else:
@@ -147,7 +151,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     for c in ctxs:
@@ -156,7 +160,7 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -167,7 +171,7 @@ def main():
         c.profile_enable(False)
     plan = ctx.last_plan()
 
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +204,7 @@ def main():
         ctx.bind_stream()
         ctx.profile_enable(True)
         for _ in range(10):
-            if world == 1:
+            if not sharded:
                 ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[0][0], outs[0][1], dtype=DT)
             else:
                 ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[0][0], l_bufs[0][1],
@@ -284,7 +288,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,40 @@
+"""Training-step timing at BASELINE.json configs[3] shape (V=170 000, H=256, B=256, fp32 MFMA):
+forward with dropout + loss + backward (dae_train_forward_backward) + dense Adam on all variables."""
+import json, sys, time
+import numpy as np, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+tied = "--tied" in sys.argv
+V, nt, H, B = 170000, 140000, 256, 256
+W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zeros", n_tracks=nt, tied=tied)
+pos, ones, _ = make_playlists(B, nt, V - nt, seed=1, seed_counts=(20, 40, 66, 100))
+m = pos[:, 1] < nt
+xr, xc, xv = coo_to_csr(pos[m], ones[m], B, V)
+yr, yc, yv = coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+ctx = _lib.Context(0)
+P = _lib._ptr
+t = {k: dev(v) for k, v in dict(xr=xr, xc=xc, xv=xv, yr=yr, yc=yc, yv=yv, We=W_enc, be=b_enc, Wd=W_dec, bd=b_dec).items()}
+names = ["We", "be", "bd"] + ([] if tied else ["Wd"])
+g = {n: torch.zeros_like(t[n]) for n in names}
+mom = {n: (torch.zeros_like(t[n]), torch.zeros_like(t[n])) for n in names}
+cost = torch.zeros(1, device="cuda")
+def step(i):
+    ctx.check(ctx.lib.dae_train_forward_backward(ctx.h, P(t["xr"]), P(t["xc"]), P(t["xv"]), P(t["yr"]), P(t["yc"]), P(t["yv"]),
+        P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]), V, H, B, B, 1 if tied else 0, 0.75, 0.8, 100 + i, 0.0,
+        P(g["We"]), P(g["be"]), None if tied else P(g["Wd"]), P(g["bd"]), P(cost)))
+    for n in names:
+        ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(), 0.005, 0.9, 0.999, 1e-8, i + 1))
+for i in range(3): step(i)
+torch.cuda.synchronize(); costs = []
+t0 = time.perf_counter(); K = 20
+for i in range(K):
+    step(3 + i)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / K * 1e3
+flop = 3 * 2.0 * B * V * H
+print(json.dumps({"what": "training step (%s), fwd+loss+bwd+Adam" % ("tied" if tied else "untied"), "ms_per_step": round(ms, 3),
+                  "playlists_per_s": round(B / ms * 1e3, 1), "gemm_tflops_incl_everything": round(flop / ms / 1e9, 1),
+                  "cost_first_last": [float(cost.item())]}))
