@@ -238,6 +238,30 @@ def main():
                        "avg_launch_ms": round(enc_ms, 4), "mean_nnz": round(mean_nnz, 1),
                        "note": "W_enc (174 MB) is Infinity-Cache resident after warm-up"}
 
+    # K1 again at a batch where it is bandwidth- rather than latency-bound (same kernel family)
+    Bl = 8192
+    posL, onesL, _ = make_playlists(Bl, n_tracks, args.n_artists, seed=5, dist=args.dist)
+    rpL, colL, valL = coo_to_csr(posL, onesL, Bl, V)
+    dL = (up(rpL, torch.int32), up(colL, torch.int32), up(valL, torch.float32))
+    hL = torch.empty((Bl, H), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        ctx.encode(dL[0], dL[1], dL[2], d_We, d_be, hL)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        ctx.encode(dL[0], dL[1], dL[2], d_We, d_be, hL)
+    e1.record()
+    torch.cuda.synchronize()
+    encL_ms = e0.elapsed_time(e1) / 5
+    encL_bytes = colL.size * (4 * H + 8) + Bl * 4 * H
+    roofline_encode["large_batch"] = {"batch": Bl, "bytes_per_launch": encL_bytes,
+                                      "avg_launch_ms": round(encL_ms, 4),
+                                      "achieved": round(encL_bytes / (encL_ms * 1e-3) / 1e9, 1),
+                                      "frac": round(encL_bytes / (encL_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                      "note": "at batch %d the step's encode launch is latency-bound (a chain of small "
+                                              "dependent loads per row); this is the same gather where bandwidth matters" % B}
+    del hL, dL
+
     out = {
         "metric": "playlists scored/sec (encode+decode+top-500) at |vocab|~170k",
         "value": round(value, 1), "unit": "playlists/s", "n_gpus": world, "steps": args.steps,

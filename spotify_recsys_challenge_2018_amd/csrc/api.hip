@@ -257,9 +257,12 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
 
     // ---- plan: how many tiles form the threshold sample (phase A) ---------------------------------
     const int n_ws = g.nb_rg * g.waves;                 // wave slots per row group
-    int rounds = (int)(((double)ntiles / 8.0) / n_ws + 0.5);
+    // phase A decodes one tile per SIMD of the row group's workgroups (a full, short round on the
+    // matrix pipes whatever the wave count), i.e. every S-th tile; at least ntiles/8 for a tight tau
+    const int n_simd = g.nb_rg * 4;
+    int rounds = (int)(((double)ntiles / 8.0) / n_simd + 0.5);
     if (rounds < 1) rounds = 1;
-    int S = (ntiles + rounds * n_ws - 1) / (rounds * n_ws);
+    int S = (ntiles + rounds * n_simd - 1) / (rounds * n_simd);
     const bool fused = S >= 2 && nrank > 0;
     const int n_samp = fused ? (ntiles + S - 1) / S : ntiles;
     const int n_other = ntiles - n_samp;

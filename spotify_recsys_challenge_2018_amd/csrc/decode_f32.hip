@@ -53,6 +53,7 @@ struct DecP {
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
     // loss epilogue
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
+    int dbg_noepi;
 };
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
@@ -117,8 +118,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     }
 
     float loss_acc = 0.0f;
+    // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
+    // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
     const int n_ws = p.nb_rg * NW;
-    const int item0 = bir * NW + wave;
+    const int item0 = wave * p.nb_rg + bir;
 
     // W stream: the wave's tiles back to back; the register ring always holds the next 4 groups
     // of that stream, so the prefetch runs across tile boundaries (and under the epilogue).
@@ -242,7 +245,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
         const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
 
-        if (EPI == EPI_DENSE) {
+        if (p.dbg_noepi) {
+            // experiment: upper bound of what hiding the epilogue could buy (results are garbage)
+            float keep = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keep += acc[rb][e];
+            if (keep == 12345.678f) p.loss_part[0] = keep;      // never true: keeps the MFMAs alive
+        } else if (EPI == EPI_DENSE) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
@@ -519,16 +530,12 @@ int launch_decode_rb_bf16(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
     // hidden = 256 -> 16 steps of K = 16: unrolled body with the 8-deep register ring
     // two waves per SIMD here: with 16x faster MFMAs the VALU epilogue of a tile is comparable to
     // its matrix time, and the second wave's MFMAs cover it (DAE_DECODE_WAVES_BF16=4 for the A/B)
-    if (g.R_TILE == 256 && p.G == 16) {
-        if (g.waves == 8) return launch_decode<8, EPI, 16, 8, DT_BF16>(ctx, g, p);
-        return launch_decode<8, EPI, 16, 4, DT_BF16>(ctx, g, p);
-    }
     if (g.R_TILE == 128 && p.G == 16) {
         if (g.waves == 8) return launch_decode<4, EPI, 16, 8, DT_BF16>(ctx, g, p);
         return launch_decode<4, EPI, 16, 4, DT_BF16>(ctx, g, p);
     }
+    if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "bad wave count %d", g.waves);
     switch (g.R_TILE) {
-        case 256: return launch_decode<8, EPI, 0, 4, DT_BF16>(ctx, g, p);
         case 128: return launch_decode<4, EPI, 0, 4, DT_BF16>(ctx, g, p);
         case 64:  return launch_decode<2, EPI, 0, 4, DT_BF16>(ctx, g, p);
         case 32:  return launch_decode<1, EPI, 0, 4, DT_BF16>(ctx, g, p);
@@ -552,6 +559,8 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     p.col_lo = pk.col_lo;
     p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg; p.Bpad = g.Bpad;
     p.ts = ts;
+    static const int noepi = getenv("DAE_DBG_NOEPI") ? atoi(getenv("DAE_DBG_NOEPI")) : 0;
+    p.dbg_noepi = noepi;
     return DAE_OK;
 }
 
@@ -596,7 +605,9 @@ dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
     if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
     g.nb_rg = nb;
     g.grid = g.n_rg * nb;
-    g.waves = 4;      // measured: 1.94 M playlists/s vs 1.65 M with 8 (B = 256; profiles/r01_notes.md)
+    // two waves per SIMD: with 16x faster MFMAs a tile's VALU epilogue is comparable to its matrix
+    // time and the partner wave covers it (B=256: 2.13 vs 2.00 M playlists/s, B=1024: 2.80 vs 2.53 M)
+    g.waves = (Hp == 256 && rt >= 128) ? 8 : 4;
     if (const char* e = getenv("DAE_DECODE_WAVES_BF16")) {
         const int w = atoi(e);
         if ((w == 4 || w == 8) && Hp == 256 && rt >= 128) g.waves = w;

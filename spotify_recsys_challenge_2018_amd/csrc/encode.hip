@@ -24,6 +24,25 @@ __device__ __forceinline__ float rl_f(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// W_enc through a buffer descriptor: row offset (wave-uniform, from v_readlane) in the SCALAR offset
+// operand, lane offset constant in the vector offset -- v_readlane + s_mul + buffer_load per
+// non-zero instead of a 64-bit scalar multiply/add chain per global_load (measured: the gather
+// was instruction-bound, 17 of 24 us at batch 256, with every read redirected to row 0 as slow).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(const float* W, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct EncP {
     const int32_t* row_ptr; const int32_t* col; const float* val;
     const float* W; const float* b_enc;
@@ -34,18 +53,19 @@ struct EncP {
     int G, RB;           // packed geometry (G = Hp/8, RB = R_TILE/32)
     float* sg_out;       // [B,H] sigmoid BEFORE hidden dropout (training backward) or null
     float* xhat_out;     // [nnz] normalised, dropped-out input weights (training backward) or null
+    unsigned w_bytes;    // V * H * 4 (< 4 GiB: buffer descriptor range)
+    int dbg_row0;        // experiment: read row 0 instead of the real rows
+    int dbg_stop;        // experiment: leave the kernel after stage n
 };
 
 // issue the loads of one group of 16 non-zeros (indices base..base+15 of the current 64-chunk);
 // indices past n re-read the chunk's last row (cache hit) and get weight 0: fmaf(0, w, acc) == acc.
 #define ENC_LOAD(X, WS, BASE)                                                                  \
     _Pragma("unroll") for (int u = 0; u < ENC_GRP; ++u) {                                      \
-        const int ii = (BASE) + u;                                                             \
-        const int ic = ii < n ? ii : n - 1;                                                    \
-        const int c = __builtin_amdgcn_readlane(c_l, ic);                                      \
-        const float w = rl_f(w_l, ic);                                                         \
-        WS[u] = ii < n ? w : 0.0f;                                                             \
-        X[u] = *reinterpret_cast<const float4*>(Wl + (size_t)c * H);                           \
+        const int ii = (BASE) + u;             /* lanes >= n hold column 0 / weight 0 */       \
+        const int c = __builtin_amdgcn_readlane(c_l, ii);                                      \
+        WS[u] = rl_f(w_l, ii);                                                                 \
+        X[u] = ld4(rs, voff, c * hbytes);                                                      \
     }
 #define ENC_FMA(X, WS)                                                                         \
     _Pragma("unroll") for (int u = 0; u < ENC_GRP; ++u) {                                      \
@@ -62,6 +82,8 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_total = gridDim.x * NW;
     const int H = p.H;
+    const int hbytes = H * 4;
+    const __amdgpu_buffer_rsrc_t rs = w_rsrc(p.W, p.w_bytes);
 
     for (int row = blockIdx.x * NW + wave; row < p.B; row += waves_total) {
         const int beg = p.row_ptr[row], end = p.row_ptr[row + 1];
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
         for (int hbase = 0; hbase < H; hbase += 256) {
             const int hoff = hbase + lane * 4;
             const bool active = hoff < H;
-            const float* Wl = p.W + (active ? hoff : 0);     // idle lanes read column 0 (unused)
+            const int voff = (active ? hoff : 0) * 4;        // idle lanes read column 0 (unused)
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
             for (int base = beg; base < end; base += 64) {
@@ -154,6 +176,143 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
     }
 }
 
+// Latency mode for small batches: a row is split over HS waves by hidden units (wave q owns units
+// [q*H/HS, (q+1)*H/HS), one or more floats per lane), so HS times more row reads are in flight per
+// playlist.  The per-unit fmaf chain over the non-zeros is unchanged -> same bits as encode_kernel.
+template <int HS>
+__global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
+{
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x / HS;
+    const int q = blockIdx.x % HS;
+    const int H = p.H;
+    const int hq = H / HS;                       // hidden units of this wave (multiple of 4)
+    const int hbytes = H * 4;
+    const __amdgpu_buffer_rsrc_t rs = w_rsrc(p.W, p.w_bytes);
+    if (p.dbg_stop == 1) return;
+    const int beg = p.row_ptr[row], end = p.row_ptr[row + 1];
+    const int nnz = end - beg;
+    if (p.dbg_stop == 2) { if (nnz == -7) p.h_out[0] = 0.f; return; }
+
+    // Typical rows (<= 256 non-zeros: a playlist holds <= 250 items, spotify_reader.py:84) keep
+    // their (column, value) entries in 4 registers per lane, fetched by 8 INDEPENDENT loads; the
+    // chunk-by-chunk version paid one dependent round trip per 64 entries, twice.
+    int cl[4];
+    float xl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = beg + 64 * c + lane;
+        const bool in = 64 * c + lane < nnz;
+        cl[c] = in ? p.col[i] : 0;
+        xl[c] = in ? p.val[i] : 0.0f;
+    }
+    if (p.ikp < 1.0f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (64 * c + lane < nnz)
+                xl[c] = (xl[c] / p.ikp) * floorf(p.ikp + dae_uniform(p.seed, 0U, (uint32_t)row, (uint32_t)cl[c]));
+    }
+    if (p.dbg_stop == 3) { if (xl[0] + xl[1] + xl[2] + xl[3] + cl[0] == -7.f) p.h_out[0] = 0.f; return; }
+    // s = sum of the weights in column order (sequential: canonical order)
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = min(64, nnz - 64 * c);
+        for (int i = 0; i < n; ++i) s += rl_f(xl[c], i);
+    }
+    for (int base = beg + 256; base < end; base += 64) {         // rows beyond 256 entries (rare)
+        const int n = min(64, end - base);
+        float x = 0.0f;
+        if (lane < n) {
+            x = p.val[base + lane];
+            if (p.ikp < 1.0f)
+                x = (x / p.ikp) * floorf(p.ikp + dae_uniform(p.seed, 0U, (uint32_t)row, (uint32_t)p.col[base + lane]));
+        }
+        for (int i = 0; i < n; ++i) s += rl_f(x, i);
+    }
+    const float denom = s + 1e-10f;
+    if (p.dbg_stop == 4) { if (denom == -7.f) p.h_out[0] = 0.f; return; }
+    float wl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        wl[c] = (64 * c + lane < nnz) ? xl[c] / denom : 0.0f;
+        if (p.xhat_out && q == 0 && 64 * c + lane < nnz) p.xhat_out[beg + 64 * c + lane] = wl[c];
+    }
+
+// lanes past the row's end hold column 0 / weight 0, so no clamps or selects are needed; 16 slots
+// at a time so that short rows do not pay for 64
+#define ENC_ISSUE(X, CL, N)                                                                    \
+        _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                    \
+            if (16 * k16 < (N)) {                                                              \
+                _Pragma("unroll") for (int u = 16 * k16; u < 16 * k16 + 16; ++u)               \
+                    X[u] = ld1(rs, voff, __builtin_amdgcn_readlane(CL, u) * hbytes);           \
+            }
+#define ENC_CHAIN(X, WL, N)                                                                    \
+        _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                    \
+            if (16 * k16 < (N)) {                                                              \
+                _Pragma("unroll") for (int u = 16 * k16; u < 16 * k16 + 16; ++u)               \
+                    acc = fmaf(rl_f(WL, u), X[u], acc);                                        \
+            }
+
+    for (int hb = 0; hb < hq; hb += 64) {
+        const int hu = q * hq + hb + lane;       // this lane's hidden unit
+        const bool active = hb + lane < hq;
+        const int voff = (active ? hu : 0) * 4;
+        float acc = 0.0f;
+        float xa[64], xb[64];
+        // chunks 0..3 from registers, double buffered: chunk c+1's 64 row reads are issued before
+        // chunk c's ordered fmaf chain runs
+        const int n0 = min(64, nnz), n1 = min(64, nnz - 64), n2 = min(64, nnz - 128), n3 = min(64, nnz - 192);
+        if (n0 > 0) {
+            ENC_ISSUE(xa, cl[0], n0)
+            if (n1 > 0) { ENC_ISSUE(xb, cl[1], n1) }
+            ENC_CHAIN(xa, wl[0], n0)
+            if (n1 > 0) {
+                if (n2 > 0) { ENC_ISSUE(xa, cl[2], n2) }
+                ENC_CHAIN(xb, wl[1], n1)
+                if (n2 > 0) {
+                    if (n3 > 0) { ENC_ISSUE(xb, cl[3], n3) }
+                    ENC_CHAIN(xa, wl[2], n2)
+                    if (n3 > 0) { ENC_CHAIN(xb, wl[3], n3) }
+                }
+            }
+        }
+        for (int base = beg + 256; base < end; base += 64) {     // rare long tail, chunk by chunk
+            const int n = min(64, end - base);
+            int c_l = 0; float w_l = 0.0f;
+            if (lane < n) {
+                c_l = p.col[base + lane];
+                float x = p.val[base + lane];
+                if (p.ikp < 1.0f)
+                    x = (x / p.ikp) * floorf(p.ikp + dae_uniform(p.seed, 0U, (uint32_t)row, (uint32_t)c_l));
+                w_l = x / denom;
+                if (p.xhat_out && q == 0 && hb == 0) p.xhat_out[base + lane] = w_l;
+            }
+            ENC_ISSUE(xa, c_l, n)
+            ENC_CHAIN(xa, w_l, n)
+        }
+        if (p.dbg_stop == 5) { if (acc == -7.f) p.h_out[0] = 0.f; return; }
+        if (active) {
+            float hv = dae_sigmoidf(acc + p.b_enc[hu]);
+            if (p.sg_out) p.sg_out[(size_t)row * H + hu] = hv;
+            if (p.kp < 1.0f) {
+                const float u = dae_uniform(p.seed, 1U, (uint32_t)row, (uint32_t)hu);
+                hv = (hv / p.kp) * floorf(p.kp + u);
+            }
+            if (p.h_out) p.h_out[(size_t)row * H + hu] = hv;
+            if (p.hp) {
+                const int R_TILE = p.RB * 32;
+                const int rg = row / R_TILE, rl = row - rg * R_TILE;
+                const int rb = rl >> 5, j = rl & 31;
+                const int g = hu >> 3, e2 = (hu & 7) >> 1, hi2 = hu & 1;
+                p.hp[((((size_t)rg * p.G + g) * p.RB + rb) * 64 + hi2 * 32 + j) * 4 + e2] = hv;
+            }
+        }
+    }
+#undef ENC_ISSUE
+#undef ENC_CHAIN
+}
+
 }  // namespace
 
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
@@ -161,15 +320,24 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
                       float ikp, float kp, uint32_t seed, float* h_out,
                       float* h_packed, int G, int RB, float* sg_out, float* xhat_out)
 {
-    (void)V;
     if (B <= 0) return DAE_OK;
     EncP p;
     p.row_ptr = row_ptr; p.col = col; p.val = val; p.W = W_enc; p.b_enc = b_enc;
     p.H = H; p.B = B; p.ikp = ikp; p.kp = kp; p.seed = seed;
     p.h_out = h_out; p.hp = h_packed; p.G = G; p.RB = RB;
     p.sg_out = sg_out; p.xhat_out = xhat_out;
-    if (B <= 2048) {
-        // few rows: one wave per workgroup spreads the rows over all CUs (latency bound)
+    if ((size_t)V * H * 4 >= 0xFFFFFFFFull)
+        return dae_fail(ctx, DAE_ERR_ARG, "W_enc of %d x %d exceeds the 4 GiB buffer range", V, H);
+    p.w_bytes = (unsigned)((size_t)V * H * 4);
+    static const int dbg_row0 = getenv("DAE_DBG_ENC_ROW0") ? atoi(getenv("DAE_DBG_ENC_ROW0")) : 0;
+    p.dbg_row0 = dbg_row0;
+    static const int dbg_stop = getenv("DAE_DBG_ENC_STOP") ? atoi(getenv("DAE_DBG_ENC_STOP")) : 0;
+    p.dbg_stop = dbg_stop;
+    if (B <= 1024 && (H % 16) == 0 && H >= 64) {
+        // small batch: latency bound -> 4 waves per row (by hidden units), 4x the bytes in flight
+        hipLaunchKernelGGL(encode_split_kernel<4>, dim3(B * 4), dim3(64), 0, ctx->stream, p);
+    } else if (B <= 2048) {
+        // few rows: one wave per workgroup spreads the rows over all CUs
         hipLaunchKernelGGL(encode_kernel<1>, dim3(B), dim3(64), 0, ctx->stream, p);
     } else {
         int blocks = (B + 3) / 4;
