@@ -278,6 +278,33 @@ def main():
         "roofline": roofline, "roofline_encode": roofline_encode,
     }
 
+    # ---- own row: decode ONLY the track columns --------------------------------
+    # The reference computes all n_input columns and slices to tracks afterwards
+    # (main_challenge.py:87); the ranking never needs the artist columns, results are identical.
+    if not sharded and n_tracks < V:
+        for c in ctxs:
+            c.prepack_decoder(d_Wd, d_bd, 0, n_tracks, dtype=DT)
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        out["tracks_only"] = {"value": round(B * args.steps / el2, 1), "unit": "playlists/s",
+                              "ms_per_step": round(el2 / args.steps * 1e3, 4), "decoded_columns": n_tracks,
+                              "note": "NOT the headline: decodes the %d track columns only (the %d artist "
+                                      "columns are sliced away by the reference after computing them); "
+                                      "top-500 output identical" % (n_tracks, V - n_tracks)}
+        s2, i2 = outs[0][0].clone(), outs[0][1].clone()
+        for c in ctxs:
+            c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
+        step(); step()
+        torch.cuda.synchronize()
+        out["tracks_only"]["identical_to_all_columns"] = bool(torch.equal(i2, outs[0][1]) and torch.equal(s2, outs[0][0]))
+
     # ---- CPU baseline: the C oracle ("port"), one thread, bounded sample --------------------------
     if args.dtype == "bf16":
         # W_dec bf16 is 87 MB: at batch 256 the decode is bounded by streaming it (2*B/2 = 256 FLOP/B

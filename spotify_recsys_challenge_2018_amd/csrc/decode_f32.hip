@@ -54,6 +54,7 @@ struct DecP {
     // loss epilogue
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
     int dbg_noepi;
+    int dbg_stagger;       // second wave group start delay, in units of 1024 cycles
 };
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         }
     }
 
+    // Two waves per SIMD do the same work per tile and would stay in lockstep (both multiplying, then
+    // both in the per-tile scalar/VALU work with the matrix pipe idle): hold the second group back by
+    // about half a tile so that one wave's overhead falls under the other's MFMAs.
+    if (NW == 8 && wave >= 4) {
+        const int st = p.dbg_stagger;
+        for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(16);       // 16 * 64 cycles each
+    }
     float loss_acc = 0.0f;
     // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
     // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
@@ -127,10 +135,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     // of that stream, so the prefetch runs across tile boundaries (and under the epilogue).
     float4 wb0, wb1, wb2, wb3;
     float4 bA[RB], bB[RB];
-    // bf16: one 16-byte load = the A operand of ONE MFMA (K = 16); ring of 8 steps (4 KiB ahead)
-    constexpr int QR = 8;
+    // bf16: one 16-byte load = the A operand of ONE MFMA (K = 16); the ring holds a whole tile
+    // (16 steps at hidden = 256): the next tile streams in while this one is multiplied
+    constexpr int QR = 16;
     uint4 wq[QR];
-    uint4 cb[2][RB];
+    uint4 cb[2][RB];              // hidden fragments: in use / next step
     const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
     if (item0 < p.ts.n_items) {
         const float4* w0 = p.Wp + (size_t)tile_of_item(p.ts, item0) * G * 64 + lane;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
         const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
 
-        if (p.dbg_noepi) {
+        if (p.dbg_noepi & 1) {
             // experiment: upper bound of what hiding the epilogue could buy (results are garbage)
             float keep = 0.f;
 #pragma unroll
@@ -561,6 +570,8 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     p.ts = ts;
     static const int noepi = getenv("DAE_DBG_NOEPI") ? atoi(getenv("DAE_DBG_NOEPI")) : 0;
     p.dbg_noepi = noepi;
+    static const int stg = getenv("DAE_STAGGER") ? atoi(getenv("DAE_STAGGER")) : 0;   // no effect measured
+    p.dbg_stagger = stg;
     return DAE_OK;
 }
 

@@ -235,3 +235,46 @@ def test_score_topk_fused_call_bit_exact(ctx, V, nt, H, B, k):
     s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"],
                                       p["b_dec"], nt, nt, p["srp"], p["sc"], k)
     _check_topk(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
+
+
+@pytest.mark.parametrize("V,nt,H,B,k", [(40, 20, 32, 1, 1), (31, 31, 32, 3, 500), (64, 64, 64, 2, 64),
+                                        (5000, 5000, 512, 40, 500), (3000, 2000, 1024, 9, 1024)])
+def test_edge_shapes_bit_exact(ctx, V, nt, H, B, k):
+    """Tiny vocabularies (< one tile), k larger than the vocabulary, batch 1, hidden 512 / 1024."""
+    import torch
+    p = _problem(V, nt, H, B, bias="zipf")
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+    keep = [_dev(a) for a in (p["rp"], p["col"] if p["col"].size else np.zeros(1, np.int32),
+                              p["val"] if p["val"].size else np.zeros(1, np.float32), p["W_enc"], p["b_enc"],
+                              p["srp"], sc)]
+    ctx.score_topk(keep[0], keep[1], keep[2], keep[3], keep[4], nt, keep[5], keep[6], k, score, idx)
+    s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"],
+                                      p["b_dec"], nt, nt, p["srp"], p["sc"], k)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
+
+
+def test_all_tracks_are_seeds_and_no_seeds(ctx):
+    """Every track of the vocabulary is a seed -> nothing to recommend (all -1); and NULL seeds."""
+    import torch
+    V, nt, H, B, k = 300, 200, 32, 4, 50
+    p = _problem(V, nt, H, B)
+    seeds = [list(range(nt))] * 2 + [[], [5]]
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]))
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    keep = [_dev(a) for a in (p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], srp, sc)]
+    ctx.score_topk(keep[0], keep[1], keep[2], keep[3], keep[4], nt, keep[5], keep[6], k, score, idx)
+    s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"],
+                                      p["b_dec"], nt, nt, srp, sc, k)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
+    assert (idx.cpu().numpy()[:2] == -1).all() and np.isneginf(score.cpu().numpy()[:2]).all()
+    h = torch.empty((B, H), device="cuda")
+    ctx.encode(keep[0], keep[1], keep[2], keep[3], keep[4], h)
+    ctx.decode_topk(h, nt, None, None, k, score, idx)                     # no seed lists at all
+    z = oracle.decode(h.cpu().numpy(), p["W_dec"], p["b_dec"], 0, nt)
+    s0, i0 = oracle.topk(z, k)
+    _check_topk(idx.cpu().numpy(), score.cpu().numpy(), i0, s0)
