@@ -36,11 +36,12 @@ __global__ __launch_bounds__(256) void scatter_y_kernel(const int32_t* __restric
 // block = 4 waves sharing the LDS image of h[:, hc0 : hc0+128] (K = B <= 256 rows); a wave owns
 // tiles of 64 vocabulary columns (2 MFMA tiles, v = v0 + 2 j + b) x 128 hidden units (4 tiles).
 struct GwP {
-    const float* dz; int64_t ld;      // [B, ld]
+    const float* dzT; int64_t ldT;    // [V, ldT] (dz transposed, rows zero padded to ldT)
     const float* h; int H, B, V;
     float* gW;                        // [V, H]
     float* gb;                        // [V] (written by the hc0 == 0 blocks) or null
     int accumulate;                   // gW += instead of =
+    int dbg;                          // experiments: 1 = no stores, 2 = no dz^T loads
     int n_half, nb_half;              // H / 128 hidden halves, blocks per half
 };
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
     const int half = rem / DAE_NUM_XCD;
     const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
     const int hc0 = half * HW;
-    const int Bp = (p.B + 1) & ~1;                                   // k-steps come in pairs of rows
+    const int Bp = (p.B + 31) & ~31;           // rows padded to whole 32-row groups (zero rows)
 
     for (int i = tid; i < Bp * HW; i += 256) {
         const int r = i / HW, c = i - r * HW;
@@ -71,7 +72,6 @@ __global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
         const int v0 = t * 64;
         const int vcol = v0 + 2 * j;                                 // this lane's 2 columns
         const bool ok0 = vcol < p.V, ok1 = vcol + 1 < p.V;
-        const bool vec = ok1 && ((p.ld & 1) == 0);
         f32x16 acc[NA][2];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -81,38 +81,79 @@ __global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
         float cs0 = 0.f, cs1 = 0.f;
 
-        for (int r0 = 0; r0 < Bp; r0 += 16) {                        // 8 k-steps of 2 rows
-            float2 d[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int r = r0 + 2 * s + hi;
-                d[s] = make_float2(0.f, 0.f);
-                if (r < p.B) {
-                    const float* src = p.dz + (size_t)r * p.ld + vcol;
-                    if (vec) d[s] = *reinterpret_cast<const float2*>(src);
-                    else { if (ok0) d[s].x = src[0]; if (ok1) d[s].y = src[1]; }
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int r = r0 + 2 * s + hi;
-                if (r0 + 2 * s < Bp) {
-                    const float* ap = lds + (size_t)(r < Bp ? r : Bp - 1) * HW + NA * j;
-                    float av[NA];
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) av[a] = ap[a];
-                    cs0 += d[s].x; cs1 += d[s].y;
-#pragma unroll
-                    for (int a = 0; a < NA; ++a)
-                        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], d[s].x, acc[a][0], 0, 0, 0);
-#pragma unroll
-                    for (int a = 0; a < NA; ++a)
-                        acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], d[s].y, acc[a][1], 0, 0, 0);
-                }
-            }
+        // B operand from dz^T [V][ldT]: the tile's 64 columns x B rows are ONE contiguous 64 KiB
+        // block there (a strip of row-major dz is 256-byte pieces at a 4*V-byte stride: every piece
+        // another DRAM page and TLB entry -- 584 us measured).  A lane owns columns vcol, vcol+1 =
+        // two rows of dz^T; one float4 per row carries 4 consecutive playlists = 2 k-steps
+        // (playlist 4q + 2*step + hi).
+        const float* t0p = p.dzT + (size_t)(ok0 ? vcol : 0) * p.ldT;
+        const float* t1p = p.dzT + (size_t)(ok1 ? vcol + 1 : 0) * p.ldT;
+// unconditional loads (conditional writes to these arrays sent them to scratch memory): columns
+// past V read row 0 and accumulate values that are never stored; the prefetch issued in the last
+// iteration re-reads the last group
+#define GW_LOAD(T0, T1, R0)                                                                    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                     \
+            const int r4 = min((R0) + 4 * q_, Bp4 - 4);                                        \
+            T0[q_] = *reinterpret_cast<const float4*>(t0p + r4);                               \
+            T1[q_] = *reinterpret_cast<const float4*>(t1p + r4);                               \
         }
+#define GW_STEP(DX, DY, R)                                                                     \
+        {                                                                                      \
+            const float* ap = lds + (size_t)((R) + hi) * HW + NA * j;                          \
+            float av[NA];                                                                      \
+            if (NA == 4) {                                                                     \
+                const float4 t4 = *reinterpret_cast<const float4*>(ap);                        \
+                av[0] = t4.x; av[1 % NA] = t4.y; av[2 % NA] = t4.z; av[3 % NA] = t4.w;         \
+            } else if (NA == 2) {                                                              \
+                const float2 t2 = *reinterpret_cast<const float2*>(ap);                        \
+                av[0] = t2.x; av[1 % NA] = t2.y;                                               \
+            } else {                                                                           \
+                av[0] = ap[0];                                                                 \
+            }                                                                                  \
+            cs0 += (DX); cs1 += (DY);                                                          \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DX), acc[a][0], 0, 0, 0); \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DY), acc[a][1], 0, 0, 0); \
+        }
+// the upper half-wave takes the odd playlist.  A bit blend (v_bfi), NOT `hi ? t.y : t.x`: the
+// optimizer turns that into a dynamically indexed vector extract, which lives in scratch memory.
+#define GW_SEL(A, Bv) __uint_as_float((__float_as_uint(Bv) & himask) | (__float_as_uint(A) & ~himask))
+#define GW_MMA(T0, T1, R0)                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                     \
+            const int r4 = (R0) + 4 * q_;                                                      \
+            GW_STEP(GW_SEL(T0[q_].x, T0[q_].y), GW_SEL(T1[q_].x, T1[q_].y), r4)                \
+            GW_STEP(GW_SEL(T0[q_].z, T0[q_].w), GW_SEL(T1[q_].z, T1[q_].w), r4 + 2)            \
+        }
+        const int Bp4 = Bp;                          // dz^T rows are zero padded to a multiple of 64
+        const unsigned himask = hi ? 0xFFFFFFFFu : 0u;
+        float4 ta0[4], ta1[4], tb0[4], tb1[4];
+        GW_LOAD(ta0, ta1, 0)
+        for (int r0 = 0; r0 < Bp; r0 += 32) {        // straight-line 16 k-steps per iteration
+            GW_LOAD(tb0, tb1, r0 + 16)
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch AHEAD of the 64 MFMAs below
+            GW_MMA(ta0, ta1, r0)                     // (hipcc sinks loads next to their first use)
+            __builtin_amdgcn_sched_barrier(0);
+            GW_LOAD(ta0, ta1, r0 + 32)               // past the end: re-reads the last group
+            __builtin_amdgcn_sched_barrier(0);
+            GW_MMA(tb0, tb1, r0 + 16)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef GW_LOAD
+#undef GW_STEP
+#undef GW_SEL
+#undef GW_MMA
         // D[i][j]: hidden unit hc0 + NA * i_idx + a, i_idx = (reg & 3) + 8 (reg >> 2) + 4 hi; column
         // v0 + 2 j + b.  The NA `a` accumulators of one reg are NA consecutive hidden units.
+        if (p.dbg & 1) {
+            float keep = cs0 + cs1;
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keep += acc[a][0][e] + acc[a][1][e];
+            if (keep == 12345.678f) p.gW[0] = keep;
+            continue;
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int v = vcol + b;
@@ -121,10 +162,17 @@ __global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int i_idx = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                if (NA == 4) {
+                    float4* dst = reinterpret_cast<float4*>(orow + 4 * i_idx);
+                    float4 o = make_float4(acc[0][b][reg], acc[1 % NA][b][reg], acc[2 % NA][b][reg], acc[3 % NA][b][reg]);
+                    if (p.accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    *dst = o;
+                } else {
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    float* dst = orow + NA * i_idx + a;
-                    *dst = p.accumulate ? *dst + acc[a][b][reg] : acc[a][b][reg];
+                    for (int a = 0; a < NA; ++a) {
+                        float* dst = orow + NA * i_idx + a;
+                        *dst = p.accumulate ? *dst + acc[a][b][reg] : acc[a][b][reg];
+                    }
                 }
             }
         }
@@ -211,8 +259,13 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int i_idx = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                if (NA == 4) {
+                    *reinterpret_cast<float4*>(prow + (size_t)r * p.H + 4 * i_idx) =
+                        make_float4(acc[0][b][reg], acc[1 % NA][b][reg], acc[2 % NA][b][reg], acc[3 % NA][b][reg]);
+                } else {
 #pragma unroll
-                for (int a = 0; a < NA; ++a) prow[(size_t)r * p.H + NA * i_idx + a] = acc[a][b][reg];
+                    for (int a = 0; a < NA; ++a) prow[(size_t)r * p.H + NA * i_idx + a] = acc[a][b][reg];
+                }
             }
         }
     }
@@ -236,15 +289,21 @@ __global__ __launch_bounds__(256) void hidden_backward_kernel(const float* __res
 }
 
 // column sums over rows: out[k] = sum_r a[r, k] (+ lambda * base[k])
+// one block per 64 columns; 4 row lanes per column, combined in fixed order (deterministic)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int B, int H,
                                                      float lambda, const float* __restrict__ base,
                                                      float* __restrict__ out)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= H) return;
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int r = 0; r < B; ++r) s += a[(size_t)r * H + k];
-    out[k] = s + (lambda != 0.f ? lambda * base[k] : 0.f);
+    if (k < H)
+        for (int r = rl; r < B; r += 4) s += a[(size_t)r * H + k];
+    part[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && k < H)
+        out[k] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + (lambda != 0.f ? lambda * base[k] : 0.f);
 }
 
 // ---- K8b: gW_enc[c, :] += xhat[r, c] * dpre[r, :]  (row-sparse; several rows may share c) ---------
@@ -442,13 +501,15 @@ int dae_train_step_f32(dae_ctx* ctx,
     float* gWd = tied ? gW_enc : gW_dec;
     {
         GwP p;
-        p.dz = dz; p.ld = V; p.h = hbuf; p.H = H; p.B = B; p.V = V; p.gW = gWd; p.gb = gb_dec;
+        p.dzT = dzT; p.ldT = Bpad64; p.h = hbuf; p.H = H; p.B = B; p.V = V; p.gW = gWd; p.gb = gb_dec;
         p.accumulate = 0;
+        static const int k6dbg = getenv("DAE_DBG_K6") ? atoi(getenv("DAE_DBG_K6")) : 0;
+        p.dbg = k6dbg;
         p.n_half = H / (32 * NA);
         int nb = (DAE_NUM_CU / p.n_half) / DAE_NUM_XCD * DAE_NUM_XCD;
         if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
         p.nb_half = nb;
-        const size_t lds = (size_t)((B + 1) & ~1) * 32 * NA * sizeof(float);
+        const size_t lds = (size_t)((B + 31) & ~31) * 32 * NA * sizeof(float);
         static bool attr = false;
         if (!attr) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4>),
@@ -479,7 +540,7 @@ int dae_train_step_f32(dae_ctx* ctx,
     hipLaunchKernelGGL(hidden_backward_kernel, dim3(grid_for(bh)), dim3(256), 0, st, part, n_chunk,
                        Bpad64, H, B, hbuf, sg, kp, dpre);
     DAE_CHECK_LAUNCH(ctx, "hidden_backward_kernel");
-    hipLaunchKernelGGL(colsum_kernel, dim3((H + 255) / 256), dim3(256), 0, st, dpre, B, H, reg_lambda,
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64), dim3(256), 0, st, dpre, B, H, reg_lambda,
                        b_enc, gb_enc);
     DAE_CHECK_LAUNCH(ctx, "colsum_kernel");
 
