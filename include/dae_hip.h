@@ -172,6 +172,45 @@ int dae_train_forward_backward(dae_ctx* ctx,
         float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec,
         float* cost_out);
 
+/* ---- the same step with the vocabulary ROW-SHARDED over ranks (training) ------
+ * Rank g owns rows [col_lo, col_hi) of W_enc, W_dec and b_dec (pointers *_loc address the shard's
+ * own [col_hi-col_lo, H] / [col_hi-col_lo] arrays); b_enc is replicated.  Every rank receives the
+ * whole batch CSR with GLOBAL column ids.  One step = three stages around the two exchanges the
+ * path really has (the caller issues them: RCCL all-reduce(sum) over [B,H] fp32):
+ *
+ *   dae_train_shard_encode   pre_partial[B,H] = sum over own columns of xhat * W_enc_loc rows
+ *                            (xhat normalised by the row's global sum, DAEs.py:40-42, :66)
+ *        -- all-reduce pre_partial --
+ *   dae_train_shard_decode   h = dropout(sigmoid(pre + b_enc)) (:67-68); decode + loss + dz over own
+ *                            columns (:75/:143, :98-100); gW_dec_loc, gb_dec_loc; dh_partial[B,H];
+ *                            cost_partial (device scalar: own columns' loss / n_batch + lambda * l2
+ *                            of the tensors this rank owns; b_enc counted by the col_lo == 0 rank)
+ *        -- all-reduce dh_partial and cost_partial --
+ *   dae_train_shard_finish   dpre, gb_enc (replicated, identical on all ranks), row-sparse gW_enc_loc
+ *
+ * tied != 0: W_dec_loc is ignored (W_enc_loc is the decoder), stage "decode" writes the decoder
+ * gradient into gW_out = gW_enc_loc and stage "finish" accumulates the encoder part on top.
+ * untied: gW_out = gW_dec_loc.  Adam is local: dae_adam_step on the owned rows.
+ * The stages keep h / sigmoid in ctx scratch between calls: run them in order on one ctx.
+ * With a single shard [0, V) the result equals dae_train_forward_backward up to fp32
+ * re-association in the encoder sum. */
+int dae_train_shard_encode(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const float* W_enc_loc, int col_lo, int col_hi, int H, int B,
+        float ikp, uint32_t seed, float* pre_partial);
+int dae_train_shard_decode(dae_ctx* ctx, const float* pre, const float* b_enc,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc_loc, const float* W_dec_loc, const float* b_dec_loc,
+        int col_lo, int col_hi, int H, int B, int n_batch, int tied,
+        float kp, uint32_t seed, float reg_lambda,
+        float* gW_out, float* gb_dec_loc, float* dh_partial, float* cost_partial);
+int dae_train_shard_finish(dae_ctx* ctx, const float* dh,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const float* W_enc_loc, const float* b_enc, const float* W_dec_loc, const float* b_dec_loc,
+        int col_lo, int col_hi, int H, int B, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc);
+
 /* TF1 AdamOptimizer update (DAEs.py:102): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr_t*m/(sqrt(v)+eps).  Dense over n elements.
  * t = 1-based step count. */

@@ -154,3 +154,75 @@ def topk_valid_under_reference_rule(scores_row, seed, picked, k=500):
     lo_picked = scores_row[picked].min() if picked else np.inf
     hi_rest = scores_row[mask].max() if mask.any() else -np.inf
     return bool(lo_picked >= hi_rest), bool(lo_picked == hi_rest)
+
+
+class NumpyTrainStages:
+    """TEST INFRASTRUCTURE: float64 restatement of the three stages of the vocabulary-sharded
+    training step (include/dae_hip.h dae_train_shard_*), dense formulation, keep
+    probabilities 1.0 only.  Stands in for the device kernels in the gloo tests of
+    sharding.ShardedTrainer and is the yardstick of the GPU stage tests.  Tensors are torch CPU
+    tensors (written in place), matching HipTrainStages' call signature."""
+
+    def __init__(self, V):
+        self.V = V
+
+    def _xhat(self, x, B):
+        rp, col, val = (np.asarray(t) for t in x)
+        xd = np.zeros((B, self.V), np.float64)
+        for r in range(B):
+            xd[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+        return xd / (xd.sum(axis=1, keepdims=True) + 1e-10)                   # DAEs.py:41-42
+
+    def encode(self, x, W_enc, lo, hi, ikp, seed, pre):
+        assert ikp == 1.0
+        xh = self._xhat(x, pre.shape[0])
+        pre.copy_(_t(xh[:, lo:hi] @ W_enc.numpy().astype(np.float64)))        # DAEs.py:66
+
+    def decode(self, pre, b_enc, y, W_enc, W_dec, b_dec, lo, hi, n_batch, tied, kp, seed, lam,
+               gW_out, gb_dec, dh, cost):
+        assert kp == 1.0
+        D = np.float64
+        B = pre.shape[0]
+        Wd = (W_enc if tied else W_dec).numpy().astype(D)
+        sg = 1.0 / (1.0 + np.exp(-(pre.numpy().astype(D) + b_enc.numpy().astype(D))))   # :67
+        rp, col, val = (np.asarray(t) for t in y)
+        yd = np.zeros((B, self.V), D)
+        for r in range(B):
+            yd[r, col[rp[r]:rp[r + 1]]] = val[rp[r]:rp[r + 1]]
+        yd = yd[:, lo:hi]
+        p = 1.0 / (1.0 + np.exp(-(sg @ Wd.T + b_dec.numpy().astype(D))))               # :75 / :143
+        L = -np.sum(yd * np.log(p + 1e-10) + 0.55 * (1 - yd) * np.log(1 - p + 1e-10))   # :98-99
+        dz = -(yd / (p + 1e-10) - 0.55 * (1 - yd) / (1 - p + 1e-10)) * p * (1 - p) / n_batch
+        l2 = 0.5 * ((W_enc.numpy().astype(D) ** 2).sum() + (b_dec.numpy().astype(D) ** 2).sum())
+        if lo == 0:
+            l2 += 0.5 * (b_enc.numpy().astype(D) ** 2).sum()
+        if not tied:
+            l2 += 0.5 * (Wd ** 2).sum()
+        cost.copy_(_t(np.array([L / n_batch + lam * l2])))
+        gW_out.copy_(_t(dz.T @ sg))
+        gb_dec.copy_(_t(dz.sum(axis=0)))
+        dh.copy_(_t(dz @ Wd))
+        self._sg = sg
+
+    def finish(self, dh, x, W_enc, b_enc, W_dec, b_dec, lo, hi, tied, ikp, kp, seed, lam,
+               gW_enc, gb_enc, gW_dec, gb_dec):
+        D = np.float64
+        sg = self._sg
+        dpre = dh.numpy().astype(D) * sg * (1 - sg)
+        gb_enc.copy_(_t(dpre.sum(axis=0) + lam * b_enc.numpy().astype(D)))
+        ge = self._xhat(x, dh.shape[0])[:, lo:hi].T @ dpre
+        if tied:
+            ge = ge + gW_enc.numpy().astype(D)
+        gW_enc.copy_(_t(ge + lam * W_enc.numpy().astype(D)))
+        if not tied:
+            gW_dec.copy_(_t(gW_dec.numpy().astype(D) + lam * W_dec.numpy().astype(D)))
+        gb_dec.copy_(_t(gb_dec.numpy().astype(D) + lam * b_dec.numpy().astype(D)))
+
+    def adam(self, p, m, v, g, lr, t):
+        p2, m2, v2 = adam_tf(p.numpy(), m.numpy(), v.numpy(), g.numpy(), lr, t)
+        p.copy_(_t(p2)); m.copy_(_t(m2)); v.copy_(_t(v2))
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))

@@ -16,7 +16,8 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
     "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
-    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward", "dae_adam_step",
+    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward",
+    "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_adam_step",
 ]
 
 _lib = None
@@ -63,6 +64,11 @@ def load():
     lib.dae_topk_merge.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]
     lib.dae_train_forward_backward.argtypes = (
         [vp] + [vp] * 6 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 5)
+    lib.dae_train_shard_encode.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_f, c_u32, vp]
+    lib.dae_train_shard_decode.argtypes = (
+        [vp, vp, vp] + [vp] * 3 + [vp] * 3 + [c_int] * 6 + [c_f, c_u32, c_f] + [vp] * 4)
+    lib.dae_train_shard_finish.argtypes = (
+        [vp, vp] + [vp] * 3 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 4)
     lib.dae_adam_step.argtypes = [vp, vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_int]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes"):

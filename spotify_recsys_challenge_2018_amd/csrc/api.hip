@@ -457,6 +457,66 @@ int dae_train_forward_backward(dae_ctx* ctx,
                               gW_enc, gb_enc, gW_dec, gb_dec, cost_out);
 }
 
+static int check_shard(dae_ctx* ctx, int col_lo, int col_hi, int H, int B, float ikp, float kp)
+{
+    if (col_lo < 0 || col_hi <= col_lo) return dae_fail(ctx, DAE_ERR_ARG, "bad shard [%d,%d)", col_lo, col_hi);
+    if (H <= 0 || B <= 0) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
+    if (!(ikp > 0.f && ikp <= 1.f) || !(kp > 0.f && kp <= 1.f))
+        return dae_fail(ctx, DAE_ERR_ARG, "keep probabilities must be in (0,1]");
+    return DAE_OK;
+}
+
+int dae_train_shard_encode(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const float* W_enc_loc, int col_lo, int col_hi, int H, int B,
+        float ikp, uint32_t seed, float* pre_partial)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!x_row_ptr || !W_enc_loc || !pre_partial) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    int rc = check_shard(ctx, col_lo, col_hi, H, B, ikp, 1.0f);
+    if (rc) return rc;
+    return dae_train_shard_encode_f32(ctx, x_row_ptr, x_col, x_val, W_enc_loc, col_lo, col_hi, H, B,
+                                      ikp, seed, pre_partial);
+}
+
+int dae_train_shard_decode(dae_ctx* ctx, const float* pre, const float* b_enc,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc_loc, const float* W_dec_loc, const float* b_dec_loc,
+        int col_lo, int col_hi, int H, int B, int n_batch, int tied,
+        float kp, uint32_t seed, float reg_lambda,
+        float* gW_out, float* gb_dec_loc, float* dh_partial, float* cost_partial)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!pre || !b_enc || !y_row_ptr || !W_enc_loc || !b_dec_loc || !gW_out || !gb_dec_loc || !dh_partial ||
+        !cost_partial)
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (!tied && !W_dec_loc) return dae_fail(ctx, DAE_ERR_ARG, "untied model needs W_dec_loc");
+    if (n_batch <= 0) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
+    int rc = check_shard(ctx, col_lo, col_hi, H, B, 1.0f, kp);
+    if (rc) return rc;
+    return dae_train_shard_decode_f32(ctx, pre, b_enc, y_row_ptr, y_col, y_val, W_enc_loc, W_dec_loc,
+                                      b_dec_loc, col_lo, col_hi, H, B, n_batch, tied, kp, seed,
+                                      reg_lambda, gW_out, gb_dec_loc, dh_partial, cost_partial);
+}
+
+int dae_train_shard_finish(dae_ctx* ctx, const float* dh,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const float* W_enc_loc, const float* b_enc, const float* W_dec_loc, const float* b_dec_loc,
+        int col_lo, int col_hi, int H, int B, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!dh || !x_row_ptr || !W_enc_loc || !b_enc || !b_dec_loc || !gW_enc_loc || !gb_enc || !gb_dec_loc)
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (!tied && (!W_dec_loc || !gW_dec_loc)) return dae_fail(ctx, DAE_ERR_ARG, "untied model needs W_dec_loc and gW_dec_loc");
+    int rc = check_shard(ctx, col_lo, col_hi, H, B, ikp, kp);
+    if (rc) return rc;
+    return dae_train_shard_finish_f32(ctx, dh, x_row_ptr, x_col, x_val, W_enc_loc, b_enc, W_dec_loc,
+                                      b_dec_loc, col_lo, col_hi, H, B, tied, ikp, kp, seed, reg_lambda,
+                                      gW_enc_loc, gb_enc, gW_dec_loc, gb_dec_loc);
+}
+
 int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                   float lr, float beta1, float beta2, float eps, int t)
 {

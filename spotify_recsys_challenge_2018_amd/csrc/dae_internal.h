@@ -199,6 +199,21 @@ int dae_train_step_f32(dae_ctx* ctx,
         int V, int H, int B, int n_batch, int tied,
         float ikp, float kp, uint32_t seed, float reg_lambda,
         float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out);
+int dae_train_shard_encode_f32(dae_ctx* ctx, const int32_t* x_row_ptr, const int32_t* x_col,
+                               const float* x_val, const float* W_enc_loc, int col_lo, int col_hi,
+                               int H, int B, float ikp, uint32_t seed, float* pre_partial);
+int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_enc,
+                               const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                               const float* W_enc_loc, const float* W_dec_loc, const float* b_dec_loc,
+                               int col_lo, int col_hi, int H, int B, int n_batch, int tied,
+                               float kp, uint32_t seed, float reg_lambda,
+                               float* gW_out, float* gb_dec_loc, float* dh_partial, float* cost_partial);
+int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_row_ptr,
+                               const int32_t* x_col, const float* x_val,
+                               const float* W_enc_loc, const float* b_enc, const float* W_dec_loc,
+                               const float* b_dec_loc, int col_lo, int col_hi, int H, int B, int tied,
+                               float ikp, float kp, uint32_t seed, float reg_lambda,
+                               float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc);
 int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                     float lr_t, float beta1, float beta2, float eps);
 

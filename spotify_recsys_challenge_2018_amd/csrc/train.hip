@@ -21,15 +21,19 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- dense targets: dz[r, c] = y value (buffer pre-zeroed) -------------------------------------
+// only columns of this shard [col_lo, col_hi) are kept, re-based to the shard's local index
 __global__ __launch_bounds__(256) void scatter_y_kernel(const int32_t* __restrict__ row_ptr,
                                                         const int32_t* __restrict__ col,
                                                         const float* __restrict__ val, int B,
+                                                        int col_lo, int col_hi,
                                                         float* __restrict__ dz, int64_t ld)
 {
     const int row = blockIdx.x;
     if (row >= B) return;
-    for (int i = row_ptr[row] + threadIdx.x; i < row_ptr[row + 1]; i += 256)
-        dz[(size_t)row * ld + col[i]] = val[i];
+    for (int i = row_ptr[row] + threadIdx.x; i < row_ptr[row + 1]; i += 256) {
+        const int c = col[i];
+        if (c >= col_lo && c < col_hi) dz[(size_t)row * ld + (c - col_lo)] = val[i];
+    }
 }
 
 // ---- K6: gW[v, hc] (+)= sum_r dz[r, v] * h[r, hc];  gb[v] = sum_r dz[r, v] ----------------------
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(256) void scatter_gwenc_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val, int B,
                                                             int H, float ikp, uint32_t seed,
+                                                            int col_lo, int col_hi,
                                                             const float* __restrict__ dpre,
                                                             float* __restrict__ gW)
 {
@@ -331,8 +336,71 @@ __global__ __launch_bounds__(256) void scatter_gwenc_kernel(const int32_t* __res
             float x = val[i];
             if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[i]));
             const float w = x / denom;
-            if (w != 0.0f) atomicAdd(&gW[(size_t)col[i] * H + k], w * dv);
+            const int c = col[i];
+            if (w != 0.0f && c >= col_lo && c < col_hi) atomicAdd(&gW[(size_t)(c - col_lo) * H + k], w * dv);
         }
+    }
+}
+
+// ---- vocabulary-sharded training: partial pre-activation of the encoder -------------
+// pre[r, k] = sum over this shard's columns of xhat[r, c] * W_loc[c - col_lo, k]; xhat is normalised
+// by the row's GLOBAL sum (the CSR carries the whole row on every rank), no bias, no sigmoid.
+__global__ __launch_bounds__(256) void encode_partial_kernel(const int32_t* __restrict__ row_ptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const float* __restrict__ val, int B,
+                                                             int H, float ikp, uint32_t seed,
+                                                             int col_lo, int col_hi,
+                                                             const float* __restrict__ W,
+                                                             float* __restrict__ pre)
+{
+    const int row = blockIdx.x;
+    if (row >= B) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    float s = 0.0f;
+    for (int i = beg; i < end; ++i) {
+        float x = val[i];
+        if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[i]));
+        s += x;
+    }
+    const float denom = s + 1e-10f;
+    for (int k = threadIdx.x; k < H; k += 256) {
+        float acc = 0.0f;
+        for (int i = beg; i < end; ++i) {
+            const int c = col[i];
+            if (c < col_lo || c >= col_hi) continue;
+            float x = val[i];
+            if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)c));
+            acc = fmaf(x / denom, W[(size_t)(c - col_lo) * H + k], acc);
+        }
+        pre[(size_t)row * H + k] = acc;
+    }
+}
+
+// sg = sigmoid(pre + b_enc); h = dropout(sg, kp) with the encode kernel's draws (DAEs.py:66-68)
+__global__ __launch_bounds__(256) void activate_kernel(const float* __restrict__ pre,
+                                                       const float* __restrict__ b_enc, int B, int H,
+                                                       float kp, uint32_t seed,
+                                                       float* __restrict__ h, float* __restrict__ sg)
+{
+    const size_t n = (size_t)B * H;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
+        const int row = (int)(o / H), hu = (int)(o - (size_t)row * H);
+        float hv = dae_sigmoidf(pre[o] + b_enc[hu]);
+        sg[o] = hv;
+        if (kp < 1.0f) hv = (hv / kp) * floorf(kp + dae_uniform(seed, 1U, (uint32_t)row, (uint32_t)hu));
+        h[o] = hv;
+    }
+}
+
+// dh[o] = sum over the K7 chunks, fixed order
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const float* __restrict__ part, int n_chunk,
+                                                         size_t chunk_stride, size_t n,
+                                                         float* __restrict__ out)
+{
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunk; ++c) s += part[(size_t)c * chunk_stride + o];
+        out[o] = s;
     }
 }
 
@@ -417,91 +485,76 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
     return DAE_OK;
 }
 
-int dae_train_step_f32(dae_ctx* ctx,
-        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
-        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
-        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
-        int V, int H, int B, int n_batch, int tied,
-        float ikp, float kp, uint32_t seed, float reg_lambda,
-        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out)
+namespace {
+
+// scratch carved for one training step over a [Vl, H] weight (shard) and B rows; stable for a given
+// (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
+struct TrainPlan {
+    int NA, G, RB, Bpad64, n_chunk, chunk;
+    dae_rowgeom g;
+    size_t bh, hp_bytes;
+    float *dz, *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
+    double* l2_part;
+};
+
+int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
 {
     if ((H % 32) != 0) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H %% 32 == 0 (H=%d)", H);
-    const int NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
-    if (B > 256) return dae_fail(ctx, DAE_ERR_ARG, "training batch %d > 256 not supported yet", B);
-    hipStream_t st = ctx->stream;
+    if (B < 1 || B > 256) return dae_fail(ctx, DAE_ERR_ARG, "training batch %d outside [1, 256]", B);
+    if (Vl < 1) return dae_fail(ctx, DAE_ERR_ARG, "empty vocabulary shard");
     int rc;
-
-    // decoder weights change every step: re-tile them for the forward GEMM
-    rc = dae_launch_prepack_f32(ctx, tied ? W_enc : W_dec, b_dec, V, H, 0, V);
-    if (rc) return rc;
-    const dae_packed& pk = ctx->pk_f32;
-    const dae_rowgeom g = dae_row_geometry(B, pk.Hp);
-    const int G = pk.Hp / DAE_KG, RB = g.R_TILE / 32;
-    const int Bpad64 = (B + 63) / 64 * 64;
-
-    // ---- scratch --------------------------------------------------------------------------------
-    // train_a: dz [B][V] | train_b: dzT [V][Bpad64] | train_c: h, sg, dpre [B][H] x3, xhat, partials
-    const size_t hp_bytes = (size_t)g.n_rg * G * RB * 64 * sizeof(float4);
-    if ((rc = dae_reserve(ctx, ctx->h_packed, hp_bytes))) return rc;
-    if ((rc = dae_reserve(ctx, ctx->train_a, (size_t)B * V * sizeof(float)))) return rc;
-    if ((rc = dae_reserve(ctx, ctx->train_b, (size_t)V * Bpad64 * sizeof(float)))) return rc;
+    t.NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
+    const int Hp = dae_round_up(H, DAE_HPAD);
+    t.g = dae_row_geometry(B, Hp);
+    t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
+    t.Bpad64 = (B + 63) / 64 * 64;
+    t.hp_bytes = (size_t)t.g.n_rg * t.G * t.RB * 64 * sizeof(float4);
+    if ((rc = dae_reserve(ctx, ctx->h_packed, t.hp_bytes))) return rc;
+    if ((rc = dae_reserve(ctx, ctx->train_a, (size_t)B * Vl * sizeof(float)))) return rc;
+    if ((rc = dae_reserve(ctx, ctx->train_b, (size_t)Vl * t.Bpad64 * sizeof(float)))) return rc;
     // split of the V contraction of K7: about one (output tile, chunk) work item per wave slot
-    const int NA_ = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
-    const int n_out_tiles = (H / (32 * NA_)) * (Bpad64 / 64);
+    const int n_out_tiles = (H / (32 * t.NA)) * (t.Bpad64 / 64);
     int want_chunks = (DAE_NUM_CU * 4) / n_out_tiles;
     if (want_chunks < 1) want_chunks = 1;
-    int chunk = ((V + want_chunks - 1) / want_chunks + 15) / 16 * 16;
-    if (chunk < 16) chunk = 16;
-    const int n_chunk = (V + chunk - 1) / chunk;
-    const size_t bh = (size_t)B * H;
-    const size_t c_floats = 3 * bh + (size_t)n_chunk * Bpad64 * H + (size_t)g.grid + 64;
+    t.chunk = ((Vl + want_chunks - 1) / want_chunks + 15) / 16 * 16;
+    if (t.chunk < 16) t.chunk = 16;
+    t.n_chunk = (Vl + t.chunk - 1) / t.chunk;
+    t.bh = (size_t)B * H;
+    const size_t c_floats = 3 * t.bh + (size_t)t.n_chunk * t.Bpad64 * H + (size_t)t.g.grid + 64;
     if ((rc = dae_reserve(ctx, ctx->train_c, c_floats * sizeof(float) + 4096 * sizeof(double)))) return rc;
-    float* dz = static_cast<float*>(ctx->train_a.p);
-    float* dzT = static_cast<float*>(ctx->train_b.p);
-    float* hbuf = static_cast<float*>(ctx->train_c.p);
-    float* sg = hbuf + bh;
-    float* dpre = sg + bh;
-    float* part = dpre + bh;
-    float* loss_part = part + (size_t)n_chunk * Bpad64 * H;
-    double* l2_part = reinterpret_cast<double*>(
-        (reinterpret_cast<uintptr_t>(loss_part + g.grid) + 63) & ~(uintptr_t)63);
+    t.dz = static_cast<float*>(ctx->train_a.p);
+    t.dzT = static_cast<float*>(ctx->train_b.p);
+    t.hbuf = static_cast<float*>(ctx->train_c.p);
+    t.sg = t.hbuf + t.bh;
+    t.dpre = t.sg + t.bh;
+    t.part = t.dpre + t.bh;
+    t.loss_part = t.part + (size_t)t.n_chunk * t.Bpad64 * H;
+    t.l2_part = reinterpret_cast<double*>(
+        (reinterpret_cast<uintptr_t>(t.loss_part + t.g.grid) + 63) & ~(uintptr_t)63);
+    return DAE_OK;
+}
 
-    // ---- forward ----------------------------------------------------------------------------------
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, hp_bytes, st));
-    ctx->h_geom_key = -1;
-    rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, hbuf,
-                           static_cast<float*>(ctx->h_packed.p), G, RB, sg, nullptr);
-    if (rc) return rc;
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(dz, 0, (size_t)B * V * sizeof(float), st));
-    if (Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(dzT, 0, (size_t)V * Bpad64 * sizeof(float), st));
-    hipLaunchKernelGGL(scatter_y_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, dz,
-                       (int64_t)V);
+// dense targets -> K5 loss/dz over the prepacked decoder image -> K6 (gW, gb) -> K7 partials of dh.
+// h (row-major in t.hbuf and tiled in ctx->h_packed) and ctx->pk_f32 must be current.
+int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B, int n_batch,
+                          const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                          int col_lo, int col_hi, const float* Wd, float* gWd, float* gb_dec)
+{
+    hipStream_t st = ctx->stream;
+    const int NA = t.NA;
+    int rc;
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dz, 0, (size_t)B * Vl * sizeof(float), st));
+    if (t.Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * sizeof(float), st));
+    hipLaunchKernelGGL(scatter_y_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B,
+                       col_lo, col_hi, t.dz, (int64_t)Vl);
     DAE_CHECK_LAUNCH(ctx, "scatter_y_kernel");
-    rc = dae_launch_decode_loss_f32(ctx, g, B, 1.0f / (float)n_batch, dz, V, dzT, Bpad64, loss_part);
+    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dz, Vl, t.dzT, t.Bpad64, t.loss_part);
     if (rc) return rc;
-
-    // ---- cost (+ lambda * l2) ----------------------------------------------------------------------
-    int n_l2 = 0;
-    if (reg_lambda != 0.0f) {
-        const float* ts[4] = {W_enc, b_dec, b_enc, tied ? nullptr : W_dec};
-        const size_t ns[4] = {(size_t)V * H, (size_t)V, (size_t)H, (size_t)V * H};
-        for (int i = 0; i < 4; ++i) {
-            if (!ts[i]) continue;
-            const int nb = grid_for(ns[i]) > 1024 ? 1024 : grid_for(ns[i]);
-            hipLaunchKernelGGL(l2_partial_kernel, dim3(nb), dim3(256), 0, st, ts[i], ns[i], l2_part + n_l2);
-            DAE_CHECK_LAUNCH(ctx, "l2_partial_kernel");
-            n_l2 += nb;
-        }
-    }
-    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(64), 0, st, loss_part, g.grid, l2_part, n_l2,
-                       reg_lambda, cost_out);
-    DAE_CHECK_LAUNCH(ctx, "finish_cost_kernel");
 
     // ---- K6: decoder gradient ------------------------------------------------------------------------
-    float* gWd = tied ? gW_enc : gW_dec;
     {
         GwP p;
-        p.dzT = dzT; p.ldT = Bpad64; p.h = hbuf; p.H = H; p.B = B; p.V = V; p.gW = gWd; p.gb = gb_dec;
+        p.dzT = t.dzT; p.ldT = t.Bpad64; p.h = t.hbuf; p.H = H; p.B = B; p.V = Vl; p.gW = gWd; p.gb = gb_dec;
         p.accumulate = 0;
         static const int k6dbg = getenv("DAE_DBG_K6") ? atoi(getenv("DAE_DBG_K6")) : 0;
         p.dbg = k6dbg;
@@ -526,10 +579,10 @@ int dae_train_step_f32(dae_ctx* ctx,
     // ---- K7: dh, split over V ------------------------------------------------------------------------
     {
         DhP p;
-        p.dzT = dzT; p.ldT = Bpad64; p.W = tied ? W_enc : W_dec; p.H = H; p.V = V; p.part = part;
-        p.n_chunk = n_chunk; p.chunk = chunk; p.Bpad64 = Bpad64; p.n_half = H / (32 * NA);
-        p.n_rblk = Bpad64 / 64;
-        const int total = p.n_half * p.n_rblk * n_chunk;
+        p.dzT = t.dzT; p.ldT = t.Bpad64; p.W = Wd; p.H = H; p.V = Vl; p.part = t.part;
+        p.n_chunk = t.n_chunk; p.chunk = t.chunk; p.Bpad64 = t.Bpad64; p.n_half = H / (32 * NA);
+        p.n_rblk = t.Bpad64 / 64;
+        const int total = p.n_half * p.n_rblk * t.n_chunk;
         int blocks = (total + 3) / 4;
         if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
         if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
@@ -537,29 +590,166 @@ int dae_train_step_f32(dae_ctx* ctx,
         else hipLaunchKernelGGL(grad_hidden_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
         DAE_CHECK_LAUNCH(ctx, "grad_hidden_kernel");
     }
-    hipLaunchKernelGGL(hidden_backward_kernel, dim3(grid_for(bh)), dim3(256), 0, st, part, n_chunk,
-                       Bpad64, H, B, hbuf, sg, kp, dpre);
+    return DAE_OK;
+}
+
+// cost = sum of the loss partials + lambda * (l2 of the listed tensors)
+int train_cost(dae_ctx* ctx, const TrainPlan& t, float reg_lambda, const float* const* ts,
+               const size_t* ns, int n_t, float* cost_out)
+{
+    hipStream_t st = ctx->stream;
+    int n_l2 = 0;
+    if (reg_lambda != 0.0f) {
+        for (int i = 0; i < n_t; ++i) {
+            if (!ts[i] || ns[i] == 0) continue;
+            const int nb = grid_for(ns[i]) > 1024 ? 1024 : grid_for(ns[i]);
+            hipLaunchKernelGGL(l2_partial_kernel, dim3(nb), dim3(256), 0, st, ts[i], ns[i], t.l2_part + n_l2);
+            DAE_CHECK_LAUNCH(ctx, "l2_partial_kernel");
+            n_l2 += nb;
+        }
+    }
+    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(64), 0, st, t.loss_part, t.g.grid, t.l2_part, n_l2,
+                       reg_lambda, cost_out);
+    DAE_CHECK_LAUNCH(ctx, "finish_cost_kernel");
+    return DAE_OK;
+}
+
+// dpre from dh (n_chunk partials at `part`), gb_enc, the row-sparse gW_enc of this column range,
+// and the lambda terms of the weight gradients
+int train_encoder_backward(dae_ctx* ctx, const TrainPlan& t, const float* part, int n_chunk,
+                           const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+                           int col_lo, int col_hi, int H, int B, int tied, float ikp, float kp,
+                           uint32_t seed, float reg_lambda, const float* W_enc, const float* b_enc,
+                           const float* W_dec, const float* b_dec,
+                           float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nW = (size_t)(col_hi - col_lo) * H;
+    hipLaunchKernelGGL(hidden_backward_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, part, n_chunk,
+                       t.Bpad64, H, B, t.hbuf, t.sg, kp, t.dpre);
     DAE_CHECK_LAUNCH(ctx, "hidden_backward_kernel");
-    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64), dim3(256), 0, st, dpre, B, H, reg_lambda,
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64), dim3(256), 0, st, t.dpre, B, H, reg_lambda,
                        b_enc, gb_enc);
     DAE_CHECK_LAUNCH(ctx, "colsum_kernel");
 
     // ---- K8: encoder gradient (row-sparse) -----------------------------------------------------------
-    if (!tied) DAE_HIP_CHECK(ctx, hipMemsetAsync(gW_enc, 0, (size_t)V * H * sizeof(float), st));
+    if (!tied) DAE_HIP_CHECK(ctx, hipMemsetAsync(gW_enc, 0, nW * sizeof(float), st));
     hipLaunchKernelGGL(scatter_gwenc_kernel, dim3(B), dim3(256), 0, st, x_row_ptr, x_col, x_val, B, H,
-                       ikp, seed, dpre, gW_enc);
+                       ikp, seed, col_lo, col_hi, t.dpre, gW_enc);
     DAE_CHECK_LAUNCH(ctx, "scatter_gwenc_kernel");
 
     if (reg_lambda != 0.0f) {
-        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V * H)), dim3(256), 0, st, gW_enc, W_enc,
-                           reg_lambda, (size_t)V * H);
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(nW)), dim3(256), 0, st, gW_enc, W_enc, reg_lambda, nW);
         if (!tied)
-            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V * H)), dim3(256), 0, st, gW_dec, W_dec,
-                               reg_lambda, (size_t)V * H);
-        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)V)), dim3(256), 0, st, gb_dec, b_dec,
-                           reg_lambda, (size_t)V);
+            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(nW)), dim3(256), 0, st, gW_dec, W_dec, reg_lambda, nW);
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)(col_hi - col_lo))), dim3(256), 0, st, gb_dec,
+                           b_dec, reg_lambda, (size_t)(col_hi - col_lo));
         DAE_CHECK_LAUNCH(ctx, "axpy_kernel");
     }
+    return DAE_OK;
+}
+
+}  // namespace
+
+int dae_train_step_f32(dae_ctx* ctx,
+        const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
+        const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+        const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+        int V, int H, int B, int n_batch, int tied,
+        float ikp, float kp, uint32_t seed, float reg_lambda,
+        float* gW_enc, float* gb_enc, float* gW_dec, float* gb_dec, float* cost_out)
+{
+    hipStream_t st = ctx->stream;
+    TrainPlan t;
+    int rc = train_plan(ctx, V, H, B, t);
+    if (rc) return rc;
+    const float* Wd = tied ? W_enc : W_dec;
+    // decoder weights change every step: re-tile them for the forward GEMM
+    rc = dae_launch_prepack_f32(ctx, Wd, b_dec, V, H, 0, V);
+    if (rc) return rc;
+
+    // ---- forward ----------------------------------------------------------------------------------
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
+    ctx->h_geom_key = -1;
+    rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
+                           static_cast<float*>(ctx->h_packed.p), t.G, t.RB, t.sg, nullptr);
+    if (rc) return rc;
+    rc = train_decode_backward(ctx, t, V, H, B, n_batch, y_row_ptr, y_col, y_val, 0, V, Wd,
+                               tied ? gW_enc : gW_dec, gb_dec);
+    if (rc) return rc;
+
+    // ---- cost (+ lambda * l2) ----------------------------------------------------------------------
+    const float* ts[4] = {W_enc, b_dec, b_enc, tied ? nullptr : W_dec};
+    const size_t ns[4] = {(size_t)V * H, (size_t)V, (size_t)H, (size_t)V * H};
+    rc = train_cost(ctx, t, reg_lambda, ts, ns, 4, cost_out);
+    if (rc) return rc;
+
+    rc = train_encoder_backward(ctx, t, t.part, t.n_chunk, x_row_ptr, x_col, x_val, 0, V, H, B, tied,
+                                ikp, kp, seed, reg_lambda, W_enc, b_enc, W_dec, b_dec,
+                                gW_enc, gb_enc, gW_dec, gb_dec);
+    if (rc) return rc;
     ctx->pk_f32.valid = true;
     return DAE_OK;
+}
+
+// ---- vocabulary-row sharded step: three stages around the caller's two all-reduces ------
+int dae_train_shard_encode_f32(dae_ctx* ctx, const int32_t* x_row_ptr, const int32_t* x_col,
+                               const float* x_val, const float* W_enc_loc, int col_lo, int col_hi,
+                               int H, int B, float ikp, uint32_t seed, float* pre_partial)
+{
+    hipLaunchKernelGGL(encode_partial_kernel, dim3(B), dim3(256), 0, ctx->stream, x_row_ptr, x_col, x_val,
+                       B, H, ikp, seed, col_lo, col_hi, W_enc_loc, pre_partial);
+    DAE_CHECK_LAUNCH(ctx, "encode_partial_kernel");
+    return DAE_OK;
+}
+
+int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_enc,
+                               const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                               const float* W_enc_loc, const float* W_dec_loc, const float* b_dec_loc,
+                               int col_lo, int col_hi, int H, int B, int n_batch, int tied,
+                               float kp, uint32_t seed, float reg_lambda,
+                               float* gW_out, float* gb_dec_loc, float* dh_partial, float* cost_partial)
+{
+    hipStream_t st = ctx->stream;
+    const int Vl = col_hi - col_lo;
+    TrainPlan t;
+    int rc = train_plan(ctx, Vl, H, B, t);
+    if (rc) return rc;
+    const float* Wd = tied ? W_enc_loc : W_dec_loc;
+    rc = dae_launch_prepack_f32(ctx, Wd, b_dec_loc, Vl, H, 0, Vl);
+    if (rc) return rc;
+    hipLaunchKernelGGL(activate_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, pre, b_enc, B, H, kp, seed,
+                       t.hbuf, t.sg);
+    DAE_CHECK_LAUNCH(ctx, "activate_kernel");
+    ctx->h_geom_key = -1;
+    rc = dae_launch_pack_h(ctx, t.hbuf, B, H, t.g);
+    if (rc) return rc;
+    rc = train_decode_backward(ctx, t, Vl, H, B, n_batch, y_row_ptr, y_col, y_val, col_lo, col_hi, Wd,
+                               gW_out, gb_dec_loc);
+    if (rc) return rc;
+    // b_enc is replicated: its l2 term is counted once, by the shard that owns column 0
+    const float* ts[4] = {W_enc_loc, b_dec_loc, col_lo == 0 ? b_enc : nullptr, tied ? nullptr : W_dec_loc};
+    const size_t ns[4] = {(size_t)Vl * H, (size_t)Vl, (size_t)H, (size_t)Vl * H};
+    rc = train_cost(ctx, t, reg_lambda, ts, ns, 4, cost_partial);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, t.part, t.n_chunk,
+                       (size_t)t.Bpad64 * H, t.bh, dh_partial);
+    DAE_CHECK_LAUNCH(ctx, "sum_chunks_kernel");
+    ctx->pk_f32.valid = true;
+    return DAE_OK;
+}
+
+int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_row_ptr,
+                               const int32_t* x_col, const float* x_val,
+                               const float* W_enc_loc, const float* b_enc, const float* W_dec_loc,
+                               const float* b_dec_loc, int col_lo, int col_hi, int H, int B, int tied,
+                               float ikp, float kp, uint32_t seed, float reg_lambda,
+                               float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc)
+{
+    TrainPlan t;
+    int rc = train_plan(ctx, col_hi - col_lo, H, B, t);       // same carving as the decode stage
+    if (rc) return rc;
+    return train_encoder_backward(ctx, t, dh, 1, x_row_ptr, x_col, x_val, col_lo, col_hi, H, B, tied,
+                                  ikp, kp, seed, reg_lambda, W_enc_loc, b_enc, W_dec_loc, b_dec_loc,
+                                  gW_enc_loc, gb_enc, gW_dec_loc, gb_dec_loc);
 }

@@ -18,6 +18,8 @@ from ..utils.data_reader import data_reader, data_reader_firstN, data_reader_tes
 
 
 def log_write(conf, log):
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
     with open(os.path.join(conf.dir, 'log.txt'), "a") as f:
         f.write(log)
         f.write('\n')
@@ -39,7 +41,29 @@ def eval(reader_test, conf, model):
     return total / max(count, 1)
 
 
+def _init_distributed(conf):
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the env):
+    RCCL process group, this rank's device, and the SAME host RNG streams on every rank so that all
+    ranks draw the same batches, coin flips and keep-probabilities (the batch is replicated, the
+    vocabulary rows are sharded).  Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    conf.device_index = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(conf.device_index)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    random.seed(int(getattr(conf, "seed", 0)))
+    np.random.seed(int(getattr(conf, "seed", 0)))
+    conf.verbose = getattr(conf, "verbose", True) and rank == 0
+    return rank, world
+
+
 def run(conf, only_testmode):
+    rank, world = _init_distributed(conf)
     if -1 in conf.firstN:                                           # main_train.py:129-133
         reader = data_reader(data_dir=conf.data_dir, filename='train', batch_size=conf.batch)
     else:
@@ -74,6 +98,8 @@ def run(conf, only_testmode):
     log_write(conf, '*' * 10)
     log_write(conf, info + ' start at ' + str(datetime.datetime.now()))
     model.fit()
+    if world > 1 and not only_testmode:
+        model.shard_training(rank, world)
 
     if only_testmode:                                               # main_train.py:181-191
         log_write(conf, '<<only test mode>>')
@@ -109,8 +135,10 @@ def run(conf, only_testmode):
                 if seed_num in conf.update_seed:
                     cur_eval += rprec
             history.append((epoch, loss / it, cur_eval))
+            model.sync_params()            # collective when sharded: every rank, before rank 0 saves
             if cur_eval >= max_eval:                                # :243-249
-                model.save_model()
+                if rank == 0:
+                    model.save_model()
                 max_eval = cur_eval
                 log_write(conf, "The highest score is updated. Parameters are saved")
             loss, it = 0.0, 0

@@ -128,6 +128,8 @@ class DAE_tied:
         self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
             else _lib.DAE_DTYPE_F32
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
+        self._sharded = None          # sharding.ShardedTrainer when training is row-sharded over ranks
+        self._params_stale = False
 
     # -- parameters ---------------------------------------------------------------------------------
     def _xavier(self, rng, shape):
@@ -186,7 +188,34 @@ class DAE_tied:
     def _mark_dirty(self):
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
 
+    # -- multi-GPU training: rows of W_enc / W_dec / b_dec sharded over the ranks ---------
+    def shard_training(self, rank, world, group=None):
+        """Train through sharding.ShardedTrainer: this rank updates only its vocabulary rows (two
+        [batch, hidden] all-reduces per step over RCCL).  Inference keeps a full replica per rank
+        (W_enc replicated); it is refreshed from the shards by `sync_params`, which the
+        scoring / persistence entry points call when training has run since the last refresh."""
+        from ..sharding import HipTrainStages, ShardedTrainer
+        self._sharded = ShardedTrainer(self.get_params(), self.n_batch, self.learning_rate,
+                                       self.reg_lambda, self.tied, HipTrainStages(self.ctx),
+                                       device=self.weights["encoder_h"].device, rank=rank, world=world,
+                                       group=group, seed=int(self._rng.randint(0, 2 ** 31 - 1)))
+
+    def sync_params(self):
+        """Collective when sharded (every rank must call it at the same point)."""
+        if self._sharded is None or not self._params_stale:
+            return
+        import torch
+        enc_W, dec_W, enc_b, dec_b = self._sharded.gather_params()
+        self.weights["encoder_h"].copy_(torch.from_numpy(enc_W))
+        if not self.tied:
+            self.weights["decoder_h"].copy_(torch.from_numpy(dec_W))
+        self.biases["encoder_b"].copy_(torch.from_numpy(enc_b))
+        self.biases["decoder_b"].copy_(torch.from_numpy(dec_b))
+        self._params_stale = False
+        self._mark_dirty()
+
     def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
+        self.sync_params()
         if self._packed_dirty[dtype]:
             self.ctx.bind_stream()
             self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0,
@@ -196,6 +225,7 @@ class DAE_tied:
     def encode(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
         """DAEs.py:40-42 + :64-70 -> hidden [n_batch, n_hidden] (torch CUDA tensor)."""
         import torch
+        self.sync_params()
         self.ctx.bind_stream()
         rp, c, v = self._upload_csr(x_positions, x_ones)
         h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32,
@@ -240,6 +270,11 @@ class DAE_tied:
         """sess.run([model.optimizer, model.cost], ...) (main_train.py:204-213) -> cost (float)."""
         import torch
         self.ctx.bind_stream()
+        if self._sharded is not None:
+            x = self._upload_csr(x_positions, x_ones)
+            y = self._upload_csr(y_positions, y_ones)
+            self._params_stale = True
+            return self._sharded.train_step(x, y, keep_prob, input_keep_prob)
         dev = self.weights["encoder_h"].device
         if self._adam is None:
             self._grads = {}
@@ -276,6 +311,7 @@ class DAE_tied:
     # -- persistence ----------------------------------------------------------------------------------
     def get_params(self):
         """sess.run(model.d_params): [enc_W, dec_W (enc_W again when tied), enc_b, dec_b]."""
+        self.sync_params()
         return [p.detach().cpu().numpy() for p in self.d_params]
 
     def save_model(self, sess=None):

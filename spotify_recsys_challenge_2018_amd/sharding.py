@@ -61,3 +61,141 @@ class ShardedRanker:
         l_logit, l_idx = self.local_topk(h, k)
         g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group)
         return self.merge(g_logit, g_idx)
+
+
+# ---- training: vocabulary rows sharded, two all-reduces per step ------------------
+
+class HipTrainStages:
+    """The three device stages of a sharded training step + local Adam, through the C ABI
+    (include/dae_hip.h: dae_train_shard_encode / _decode / _finish, dae_adam_step)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def encode(self, x, W_enc, lo, hi, ikp, seed, pre):
+        from ._lib import _ptr as P
+        c = self.ctx
+        B, H = pre.shape
+        c.check(c.lib.dae_train_shard_encode(c.h, P(x[0]), P(x[1]), P(x[2]), P(W_enc), lo, hi, H, B,
+                                             float(ikp), int(seed), P(pre)))
+
+    def decode(self, pre, b_enc, y, W_enc, W_dec, b_dec, lo, hi, n_batch, tied, kp, seed, lam,
+               gW_out, gb_dec, dh, cost):
+        from ._lib import _ptr as P
+        c = self.ctx
+        B, H = pre.shape
+        c.check(c.lib.dae_train_shard_decode(
+            c.h, P(pre), P(b_enc), P(y[0]), P(y[1]), P(y[2]), P(W_enc), P(W_dec), P(b_dec),
+            lo, hi, H, B, int(n_batch), 1 if tied else 0, float(kp), int(seed), float(lam),
+            P(gW_out), P(gb_dec), P(dh), P(cost)))
+
+    def finish(self, dh, x, W_enc, b_enc, W_dec, b_dec, lo, hi, tied, ikp, kp, seed, lam,
+               gW_enc, gb_enc, gW_dec, gb_dec):
+        from ._lib import _ptr as P
+        c = self.ctx
+        B, H = dh.shape
+        c.check(c.lib.dae_train_shard_finish(
+            c.h, P(dh), P(x[0]), P(x[1]), P(x[2]), P(W_enc), P(b_enc), P(W_dec), P(b_dec),
+            lo, hi, H, B, 1 if tied else 0, float(ikp), float(kp), int(seed), float(lam),
+            P(gW_enc), P(gb_enc), P(gW_dec), P(gb_dec)))
+
+    def adam(self, p, m, v, g, lr, t):
+        from ._lib import _ptr as P
+        c = self.ctx
+        c.check(c.lib.dae_adam_step(c.h, P(p), P(m), P(v), P(g), p.numel(), float(lr), 0.9, 0.999,
+                                    1e-8, int(t)))
+
+
+class ShardedTrainer:
+    """One training step of DAE_tied / DAE (models/DAEs.py:98-102 of the reference) with the [V, H]
+    matrices row-sharded over the ranks of `group`.
+
+    Rank g owns rows [lo_g, hi_g) of W_enc, W_dec (untied) and b_dec together with their Adam
+    moments; b_enc and its moments are replicated (its gradient is identical on all ranks after the
+    dh all-reduce, so the replicas stay in lock-step without a broadcast).  Per step the path
+    exchanges exactly two [B, H] fp32 tensors (pre-activation partials, dh partials) plus the
+    scalar cost: all-reduce(sum) over RCCL.  `stages` carries the device work (HipTrainStages);
+    it is injected so the exchange / bookkeeping logic runs under gloo on CPU in the tests.
+
+    full_params: [W_enc, W_dec, b_enc, b_dec] host arrays (d_params order, DAEs.py:61/:138) that
+    every rank slices identically -- a sharded run starts from the same point as an unsharded one.
+    """
+
+    def __init__(self, full_params, n_batch, lr, reg_lambda, tied, stages, device="cpu",
+                 rank=0, world=1, group=None, seed=0):
+        import torch
+        W_enc, W_dec, b_enc, b_dec = full_params
+        self.V, self.H = W_enc.shape
+        self.n_batch, self.lr, self.lam, self.tied = int(n_batch), float(lr), float(reg_lambda), bool(tied)
+        self.rank, self.world, self.group, self.stages = rank, world, group, stages
+        self.lo, self.hi = shard_bounds(self.V, world, rank)
+        self.device = device
+        sl = slice(self.lo, self.hi)
+
+        def dev(a):
+            return torch.from_numpy(np.array(a, dtype=np.float32, order="C", copy=True)).to(device)   # own copy
+        self.W_enc = dev(W_enc[sl])
+        self.W_dec = self.W_enc if self.tied else dev(W_dec[sl])
+        self.b_dec = dev(b_dec[sl])
+        self.b_enc = dev(b_enc)
+        names = ["W_enc", "b_enc", "b_dec"] + ([] if self.tied else ["W_dec"])
+        self.params = {n: getattr(self, n) for n in names}
+        self.grads = {n: torch.zeros_like(p) for n, p in self.params.items()}
+        self.moments = {n: (torch.zeros_like(p), torch.zeros_like(p)) for n, p in self.params.items()}
+        self.pre = torch.zeros((self.n_batch, self.H), dtype=torch.float32, device=device)
+        self.dh = torch.zeros_like(self.pre)
+        self.cost = torch.zeros(1, dtype=torch.float32, device=device)
+        self.step = 0
+        self._rng = np.random.RandomState(seed)        # same stream on every rank: same dropout draws
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.group)
+
+    def train_step(self, x_csr, y_csr, keep_prob, input_keep_prob):
+        """x_csr / y_csr: (row_ptr, col, val) device tensors of the WHOLE batch with global column
+        ids (models.DAEs.coo_to_csr).  Returns the global cost (float)."""
+        st, g = self.stages, self.grads
+        seed = int(self._rng.randint(0, 2 ** 31 - 1))
+        st.encode(x_csr, self.W_enc, self.lo, self.hi, input_keep_prob, seed, self.pre)
+        self._allreduce(self.pre)
+        gW_out = g["W_enc"] if self.tied else g["W_dec"]
+        st.decode(self.pre, self.b_enc, y_csr, self.W_enc, None if self.tied else self.W_dec, self.b_dec,
+                  self.lo, self.hi, self.n_batch, self.tied, keep_prob, seed, self.lam,
+                  gW_out, g["b_dec"], self.dh, self.cost)
+        self._allreduce(self.dh)
+        self._allreduce(self.cost)
+        st.finish(self.dh, x_csr, self.W_enc, self.b_enc, None if self.tied else self.W_dec, self.b_dec,
+                  self.lo, self.hi, self.tied, input_keep_prob, keep_prob, seed, self.lam,
+                  g["W_enc"], g["b_enc"], None if self.tied else g["W_dec"], g["b_dec"])
+        self.step += 1
+        for n, p in self.params.items():
+            m, v = self.moments[n]
+            st.adam(p, m, v, g[n], self.lr, self.step)
+        return float(self.cost.item())
+
+    def gather_params(self):
+        """The full d_params list [W_enc, W_dec, b_enc, b_dec] (DAEs.py:61/:138) on every rank:
+        all-gather of the row shards (padded to the largest shard, then trimmed)."""
+        import torch
+        if self.world == 1:
+            full = {n: p for n, p in self.params.items()}
+        else:
+            import torch.distributed as dist
+            bounds = all_shard_bounds(self.V, self.world)
+            rows = max(hi - lo for lo, hi in bounds)
+            full = {"b_enc": self.b_enc}
+            for n in self.params:
+                if n == "b_enc":
+                    continue
+                p = self.params[n]
+                pad = torch.zeros((rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+                pad[:p.shape[0]] = p
+                out = torch.empty((self.world * rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+                dist.all_gather_into_tensor(out, pad, group=self.group)
+                out = out.view((self.world, rows) + tuple(p.shape[1:]))
+                full[n] = torch.cat([out[r, :hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
+        W_enc = full["W_enc"].cpu().numpy()
+        W_dec = W_enc if self.tied else full["W_dec"].cpu().numpy()
+        return [W_enc, W_dec, full["b_enc"].cpu().numpy(), full["b_dec"].cpu().numpy()]
