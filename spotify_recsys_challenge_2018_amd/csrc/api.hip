@@ -129,7 +129,7 @@ int dae_destroy(dae_ctx* ctx)
     if (!ctx) return DAE_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias,
+    dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d};
@@ -232,7 +232,7 @@ int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int 
     const dae_rowgeom g = geom_for(dtype, B, pk->Hp);
     int rc = pack_hidden(ctx, dtype, h, B, H, g);
     if (rc) return rc;
-    dae_tileset ts{pk->ntiles, 1, 0};
+    dae_tileset ts{pk->ntiles, 1, 0, static_cast<const int*>(pk->ident.p)};
     rc = prof_begin(ctx); if (rc) return rc;
     rc = dae_launch_decode_dense_f32(ctx, g, B, ts, apply_sigmoid, INT_MAX, out, ld_out, 0, dtype);
     if (rc) return rc;
@@ -256,7 +256,6 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     if (nrank < 0) nrank = 0;
 
     // ---- plan: how many tiles form the threshold sample (phase A) ---------------------------------
-    const int n_ws = g.nb_rg * g.waves;                 // wave slots per row group
     // phase A decodes one tile per SIMD of the row group's workgroups (a full, short round on the
     // matrix pipes whatever the wave count), i.e. every S-th tile; at least ntiles/8 for a tight tau
     const int n_simd = g.nb_rg * 4;
@@ -279,13 +278,20 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = dae_reserve(ctx, ctx->sample, (size_t)B * ld_s * sizeof(float));
     if (rc) return rc;
     float* sample = static_cast<float*>(ctx->sample.p);
-    dae_tileset tsA{n_samp, fused ? S : 1, fused ? 1 : 0};
+    const int* order = static_cast<const int*>(pk->ident.p);
+    if (fused) {
+        dae_packed& pkm = dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16;
+        rc = dae_launch_tile_order(ctx, pkm, nrank, n_samp, S);
+        if (rc) return rc;
+        order = static_cast<const int*>(pkm.order.p);
+    }
+    dae_tileset tsA{n_samp, fused ? S : 1, fused ? 3 : 0, order};
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
     rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
-    dae_dense_src ds{sample, ld_s, (int)ld_s, pk->col_lo, fused ? S : 1};
+    dae_dense_src ds{sample, ld_s, (int)ld_s, pk->col_lo, 1, fused ? order : nullptr};
     if (!fused) {
         ta.out_kind = out_kind; ta.out_score = out_score; ta.out_idx = out_idx;
         return dae_launch_topk_dense(ctx, ds, ta);
@@ -305,13 +311,12 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     if (rc) return rc;
 
     // phase B: everything else through the threshold filter
-    const int items_per_wave = (n_other + n_ws - 1) / n_ws;
-    const int cap = items_per_wave * g.waves * 32;
+    const int cap = dae_filter_block_tiles(g, n_other, dtype, pk->Hp) * 32;     // worst case: everything passes
     rc = dae_reserve(ctx, ctx->cand, (size_t)g.nb_rg * g.Bpad * cap * sizeof(uint2));
     if (rc) return rc;
     rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
     if (rc) return rc;
-    dae_tileset tsB{n_other, S, 2};
+    dae_tileset tsB{n_other, S, 3, order + n_samp};
     rc = prof_begin(ctx); if (rc) return rc;
     rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
                                       n_valid_col, static_cast<uint2*>(ctx->cand.p),

@@ -33,6 +33,14 @@ struct dae_packed {            // one prepacked decoder image
     int ntiles = 0;            // ceil((col_hi-col_lo)/32)
     dae_buf W;                 // fp32: [ntiles][Hp/8][64 lanes][4]   bf16: see decode_bf16.hip
     dae_buf bias;              // [ntiles*32] fp32, zero padded
+    dae_buf bias16;            // bf16 image: [ntiles][64] uint4 bias fragments (decode_f32.hip)
+    // tiles ordered by the largest bias among their rankable columns, descending (the threshold
+    // sample of the fused path takes the head of this list); rebuilt when the image or the number
+    // of rankable columns changes
+    dae_buf order;             // [ntiles] int32
+    dae_buf ident;             // [ntiles] int32: 0, 1, 2, ... (the tile list of "all tiles")
+    int order_nrank = -1;      // rankable columns the order was built for (-1: none)
+    int order_nsamp = -1;
 };
 
 struct dae_ctx {
@@ -170,11 +178,15 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
                            int col_lo, int col_hi);
 int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
+// (re)build pk.order for `nrank` rankable columns; the first n_samp entries are the threshold sample
+int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp);
+int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, int S);
 
 struct dae_tileset {        // which wave tiles a decode launch walks
     int n_items;            // number of tiles in the set
     int stride;             // S
-    int mode;               // 0: all tiles t=i; 1: sampled t=i*S; 2: the others
+    int mode;               // informational: 0 = all tiles (identity list), 3 = ordered list
+    const int* list;        // tile of item i; never null
 };
 // dense epilogue: out[row*ld + item*32 + vl] (item = position of the tile in the set)
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
@@ -222,6 +234,7 @@ struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)
     const float* logits; int64_t ld; int n;
     int col_base;           // global column of tile 0
     int tile_stride;        // column = col_base + (p/32)*32*tile_stride + p%32
+    const int* tile_list;   // non-null: column = col_base + tile_list[p/32]*32 + p%32
 };
 struct dae_pair_group {     // element (seg, r, i) = base[seg*seg_stride + r*row_stride + i]
     const uint2* base; const int* cnt; int64_t seg_stride; int64_t row_stride;

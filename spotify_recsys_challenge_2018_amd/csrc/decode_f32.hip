@@ -34,6 +34,15 @@ constexpr int DT_BF16 = 1;         // v_mfma_f32_32x32x16_bf16, fp32 accumulate 
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 
+// bf16 kernels take the bias through the matrix pipe: b = e0 + e1 + e2 (three bf16 terms, exact to
+// 2^-25 |b|) sits in k-slots 0..2 of an extra A fragment per tile and is multiplied by this B fragment
+// of ones, so the accumulators START at the bias: no bias loads or adds in any epilogue, and every
+// bf16 kernel produces the same logits for the same (row, column).
+__device__ __forceinline__ uint4 bf16_ones_fragment(int hi)
+{
+    return hi == 0 ? make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+}
+
 constexpr int EPI_DENSE = 0;
 constexpr int EPI_FILTER = 1;
 constexpr int EPI_LOSS = 2;        // training: logits -> loss + dL/dz (DAEs.py:98-100)
@@ -41,6 +50,7 @@ constexpr int EPI_LOSS = 2;        // training: logits -> loss + dL/dz (DAEs.py:
 struct DecP {
     const float4* Wp;      // f32: [ntiles][G][64] float4   bf16: [ntiles][G][64] uint4 (8 bf16)
     const float* bias;     // [ntiles*32]
+    const uint4* bias16;   // bf16 image only: [ntiles][64] A-operand fragments holding b as 3 bf16 terms
     const float4* hp;      // f32: [n_rg][G][RB][64] float4  bf16: [n_rg][G][RB][64] uint4
     int G;                 // k groups per tile: Hp / 8 (f32, 4 MFMA each) or Hp / 16 (bf16, 1 MFMA)
     int ncols;             // col_hi - col_lo of the prepacked image
@@ -59,10 +69,7 @@ struct DecP {
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
 {
-    if (ts.mode == 0) return i;
-    if (ts.mode == 1) return i * ts.stride;
-    const int s1 = ts.stride - 1;                  // mode 2: i-th tile with t % S != 0
-    return (i / s1) * ts.stride + (i % s1) + 1;
+    return ts.list[i];          // always a list (the identity for "all tiles"): no branch around a load
 }
 
 // GT > 0: hidden size known at compile time (G = GT groups of 8 k) -> the k loop is fully
@@ -140,9 +147,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     constexpr int QR = 16;
     uint4 wq[QR];
     uint4 cb[2][RB];              // hidden fragments: in use / next step
+    uint4 bfrag = make_uint4(0u, 0u, 0u, 0u);                     // bias fragment of the wave's next tile
+    const uint4 ones = bf16_ones_fragment(hi);
     const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
+    // Tile indices come from a list in global memory.  A vector load that the code then waits for
+    // drains the WHOLE in-order load queue (s_waitcnt vmcnt(0)), i.e. the W prefetch ring; so the
+    // index of a tile is fetched two tiles ahead, before that tile's predecessor issues its W loads.
+    int t_cur = 0, t_nxt = 0;
     if (item0 < p.ts.n_items) {
-        const float4* w0 = p.Wp + (size_t)tile_of_item(p.ts, item0) * G * 64 + lane;
+        t_cur = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item0));
+        t_nxt = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item0 + n_ws < p.ts.n_items ? item0 + n_ws : item0));
+    }
+    if (DT == DT_BF16 && item0 < p.ts.n_items) bfrag = p.bias16[(size_t)t_cur * 64 + lane];
+    if (item0 < p.ts.n_items) {
+        const float4* w0 = p.Wp + (size_t)t_cur * G * 64 + lane;
         if (DT == DT_F32) {
             wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
 #pragma unroll
@@ -157,24 +175,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     }
 
     for (int item = item0; item < p.ts.n_items; item += n_ws) {
-        const int t = tile_of_item(p.ts, item);
+        const int t = t_cur;
         const float4* wp = p.Wp + (size_t)t * G * 64 + lane;
         // next tile of this wave (or this one again at the end: in-bounds, values unused)
         const int item_n = item + n_ws < p.ts.n_items ? item + n_ws : item;
-        const float4* wn = p.Wp + (size_t)tile_of_item(p.ts, item_n) * G * 64 + lane;
+        const float4* wn = p.Wp + (size_t)t_nxt * G * 64 + lane;
+        const int item_nn = item_n + n_ws < p.ts.n_items ? item_n + n_ws : item_n;
+        const int t_nn_v = tile_of_item(p.ts, item_nn);            // consumed at the end of this tile
 
         // bias of the tile's 32 columns, fetched now so the epilogue never waits on memory:
         // lane holds columns v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi, reg = 0..15
         const float* bp = p.bias + (size_t)t * 32 + 4 * hi;
         float4 bq[4];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const float4*>(bp + 8 * qd);
+        for (int qd = 0; qd < 4; ++qd)
+            bq[qd] = DT == DT_BF16 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bp + 8 * qd);
 
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rb][e] = 0.0f;
+        if (DT == DT_BF16) {
+            const uint4 bcur = bfrag;
+            bfrag = p.bias16[(size_t)t_nxt * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bcur), as_bf16x8(ones), acc[rb], 0, 0, 0);
+        }
 
 // one k-group (8 k = 4 MFMA steps per accumulator): consume ring slot WB with hidden fragments
 // BC, refill the slot from PF, and fetch the NEXT group's hidden fragments into BN.
@@ -370,6 +398,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                 }
             }
         }
+        t_cur = t_nxt;
+        t_nxt = __builtin_amdgcn_readfirstlane(t_nn_v);
     }
 
     if (EPI == EPI_FILTER) {
@@ -390,6 +420,203 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
             p.loss_part[blockIdx.x] = s * p.inv_nb;          // reduce_mean over the fixed n_batch
         }
     }
+}
+
+// ---- bf16, hidden = 256, filter epilogue (phase B of the fused path) --------------------------------
+// One wave per SIMD owns NT column tiles x RB row blocks (8 accumulators = 128 registers):
+//   <NT = 1, RB = 8>  256-playlist row groups: every W fragment (1 KiB from L2 / HBM) feeds 8 MFMAs.
+//                     At batch 256 W is then read exactly once; at batch 1024 the L2 -> CU traffic
+//                     (the measured limit of the 128-row kernels: 790 MB per launch, 11 TB/s) halves.
+//   <NT = 2, RB = 4>  128-playlist row groups (batches <= 128): two column tiles share each hidden
+//                     fragment read from LDS.
+// The W ring is 16 steps deep per tile (the whole next tile group streams in while this one is
+// multiplied); tile indices are fetched two groups ahead; the accumulators start at the bias; the
+// epilogue is a max-reduction and one compare per row block unless some lane really passes.
+template <int NT, int RB, int QR, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(const DecP p)
+{
+    constexpr int NS = 16, R_TILE = RB * 32;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+
+    constexpr int n_h4 = RB * 64 * NS;
+    {
+        const float4* src = p.hp + (size_t)rg * n_h4;
+        constexpr int NTH = NW * 64;
+#pragma unroll
+        for (int i0 = 0; i0 < n_h4; i0 += 8 * NTH) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * NTH + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lds4[i0 + u * NTH + tid] = v[u];
+        }
+    }
+    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    for (int i = tid; i < R_TILE; i += NW * 64) lcnt[i] = 0;
+    __syncthreads();
+
+    float tau_r[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rg * R_TILE + rb * 32 + j;
+        tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
+    }
+
+    const int n_items = p.ts.n_items;
+    const int n_grp = (n_items + NT - 1) / NT;                   // groups of NT tiles
+    const int n_ws = p.nb_rg * NW;
+    const int grp0 = wave * p.nb_rg + bir;
+    const uint4* Wq = reinterpret_cast<const uint4*>(p.Wp);      // uniform base; the lane is the index
+    const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
+    const uint4 ones = bf16_ones_fragment(hi);
+    // item of (group, nt), clamped to the group's first item when the last group is ragged
+    auto item_of = [&](int grp, int nt) { const int i = NT * grp + nt; return i < n_items ? i : NT * grp; };
+
+    uint4 wq[NT][QR];
+    uint4 cb[2][RB];
+    uint4 bfr[NT];                                               // bias fragments of the NEXT group
+    int t[NT], u[NT];                                            // tiles of this / the next group (uniform)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { t[nt] = 0; u[nt] = 0; bfr[nt] = make_uint4(0u, 0u, 0u, 0u); }
+    if (grp0 < n_grp) {
+        const int gn = grp0 + n_ws < n_grp ? grp0 + n_ws : grp0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            t[nt] = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_of(grp0, nt)));
+            u[nt] = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_of(gn, nt)));
+            bfr[nt] = p.bias16[(size_t)t[nt] * 64 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < QR; ++k)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wq[nt][k] = Wq[(size_t)t[nt] * (NS * 64) + k * 64 + lane];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
+    }
+
+    for (int grp = grp0; grp < n_grp; grp += n_ws) {
+        const int gn = grp + n_ws < n_grp ? grp + n_ws : grp;
+        const int gnn = gn + n_ws < n_grp ? gn + n_ws : gn;
+        int wv[NT];
+        const uint4 *cur[NT], *nxt[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            wv[nt] = tile_of_item(p.ts, item_of(gnn, nt));        // consumed at the end of this group
+            cur[nt] = Wq + (size_t)t[nt] * (NS * 64);
+            nxt[nt] = Wq + (size_t)u[nt] * (NS * 64);
+        }
+
+        // the accumulators start at the bias (see bf16_ones_fragment)
+        f32x16 acc[NT][RB];
+        {
+            f32x16 zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint4 bc = bfr[nt];
+                bfr[nt] = p.bias16[(size_t)u[nt] * 64 + lane];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[nt][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bc), as_bf16x8(ones), zero, 0, 0, 0);
+            }
+        }
+
+        // One wave per SIMD issues in order: a burst of loads in front of the MFMAs would leave the
+        // matrix pipe idle while the burst issues.  So every MFMA (32 cycles in the pipe) is followed
+        // by ONE memory instruction of the prefetch -- the next step's hidden fragments from LDS, then
+        // the W fragments of step s + QR -- and sched_barrier pins that order.
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sn = (s + 1) % NS;
+            uint4 a[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) a[nt] = wq[nt][s % QR];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[nt][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[nt]), as_bf16x8(cb[s & 1][rb]),
+                                                                          acc[nt][rb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int mi = nt * RB + rb;                      // MFMA index within the step
+                    if (mi < RB) {                                    // next step's fragment rb = mi
+                        cb[(s + 1) & 1][mi] = ldsq[(sn * RB + mi) * 64 + lane];
+                    } else if (mi - RB < NT && (mi - RB) <= nt - 1) { // W of step s+QR for a tile already consumed
+                        const int w = mi - RB;
+                        wq[w][s % QR] = (s + QR < NS) ? cur[w][(s + QR) * 64 + lane] : nxt[w][(s + QR - NS) * 64 + lane];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // W fragments not yet refilled (their tile's MFMAs of this step had to finish first)
+#pragma unroll
+            for (int w = 0; w < NT; ++w) {
+                const bool done_inline = (NT * RB > RB + w) && (w <= ((RB + w) / RB) - 1);
+                if (!done_inline)
+                    wq[w][s % QR] = (s + QR < NS) ? cur[w][(s + QR) * 64 + lane] : nxt[w][(s + QR - NS) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: lane = playlist j of row block rb; register reg of tile t is column
+        // 32 t + (reg & 3) + 8 (reg >> 2) + 4 hi.  The tiles of this launch are the LOW-bias ones:
+        // most hold no value above tau at all, so the common case is a max-reduction and one compare
+        // per row block; masks, list slots (LDS atomic) and stores only where a lane really passes.
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float tv = tau_r[rb];
+            float mx = acc[0][rb][0];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) mx = fmaxf(mx, acc[nt][rb][reg]);
+            if (mx >= tv) {
+                unsigned m[NT];
+                int cnt = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    m[nt] = 0;
+                    const bool live = NT * grp + nt < n_items;            // ragged last group
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int lc = t[nt] * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
+                        if (live && acc[nt][rb][reg] >= tv && lc < p.ncols && p.col_lo + lc < p.n_valid_col)
+                            m[nt] |= 1u << reg;
+                    }
+                    cnt += __popc(m[nt]);
+                }
+                if (cnt) {
+                    int at = atomicAdd(&lcnt[rb * 32 + j], cnt);
+                    uint2* dst = p.cand + ((size_t)bir * p.Bpad + rg * R_TILE + rb * 32 + j) * (size_t)p.cap;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int cg = p.col_lo + t[nt] * 32 + 4 * hi;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (m[nt] & (1u << reg))
+                                dst[at++] = make_uint2(__float_as_uint(acc[nt][rb][reg]),
+                                                       (unsigned)(cg + (reg & 3) + 8 * (reg >> 2)));
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { t[nt] = u[nt]; u[nt] = __builtin_amdgcn_readfirstlane(wv[nt]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < R_TILE; i += NW * 64) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + i] = lcnt[i];
 }
 
 // ---- prepack: W_dec rows -> MFMA A-operand order ----------------------------------------------
@@ -422,6 +649,66 @@ __global__ __launch_bounds__(256) void prepack_f32_kernel(const float* __restric
     for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
         const int v = col_lo + o;
         bias[o] = v < col_hi ? b[v] : 0.0f;
+    }
+}
+
+// ---- tile order for the fused path's threshold sample -------------------------------------------
+// The sample only has to be SOME subset of the rankable columns (its k-th largest logit is a lower
+// bound of the row's k-th largest whatever the subset), but the tighter that bound, the fewer
+// candidates phase B has to keep.  Vocabulary ids are popularity ranks and the trained b_dec is the
+// popularity prior, so the tiles with the largest bias hold most of every row's winners: sample
+// those.  One workgroup: key = (ordered max bias over the tile's rankable columns, ~tile) sorted
+// descending by a bitonic network in LDS.
+constexpr int ORDER_MAX_TILES = 8192;
+__global__ __launch_bounds__(1024) void tile_order_kernel(const float* __restrict__ bias, int ntiles,
+                                                          int nrank, int* __restrict__ order)
+{
+    __shared__ unsigned long long keys[ORDER_MAX_TILES];
+    int n2 = 1024;
+    while (n2 < ntiles) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 1024) {
+        unsigned long long k = 0ULL;                       // padding sorts last
+        if (i < ntiles) {
+            float m = -__builtin_inff();
+            for (int c = 0; c < 32; ++c) {
+                const int col = i * 32 + c;
+                if (col < nrank) m = fmaxf(m, bias[col]);
+            }
+            k = ((unsigned long long)dae_okey(m) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += 1024) {
+                const int jx = i ^ stride;
+                if (jx > i) {
+                    const unsigned long long a = keys[i], b = keys[jx];
+                    const bool desc = (i & size) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[jx] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < ntiles; i += 1024)
+        order[i] = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFULL));
+}
+
+__global__ __launch_bounds__(256) void tile_iota_kernel(int n, int* __restrict__ out)
+{
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) out[t] = t;
+}
+
+// fallback for images of more than ORDER_MAX_TILES tiles (and the DAE_SAMPLE=strided experiment):
+// every S-th tile first, then the others
+__global__ __launch_bounds__(256) void tile_order_strided_kernel(int ntiles, int n_samp, int S,
+                                                                 int* __restrict__ order)
+{
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+        if (t % S == 0) order[t / S] = t;
+        else order[n_samp + (t / S) * (S - 1) + (t % S) - 1] = t;
     }
 }
 
@@ -464,7 +751,8 @@ __global__ __launch_bounds__(256) void prepack_bf16_kernel(const float* __restri
                                                            const float* __restrict__ b, int H, int NS,
                                                            int col_lo, int col_hi, int ntiles,
                                                            uint4* __restrict__ Wp,
-                                                           float* __restrict__ bias)
+                                                           float* __restrict__ bias,
+                                                           uint4* __restrict__ bias16)
 {
     const size_t total = (size_t)ntiles * NS * 64;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
@@ -485,6 +773,22 @@ __global__ __launch_bounds__(256) void prepack_bf16_kernel(const float* __restri
     for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
         const int v = col_lo + o;
         bias[o] = v < col_hi ? b[v] : 0.0f;
+    }
+    // bias fragments: lane (hi = 0, i) of tile t carries b[col_lo + 32 t + i] = e0 + e1 + e2 in k-slots 0..2
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < ntiles * 64; o += gridDim.x * 256) {
+        const int lane = o & 63, t = o >> 6;
+        const int v = col_lo + t * 32 + (lane & 31);
+        uint4 f = make_uint4(0u, 0u, 0u, 0u);
+        if ((lane >> 5) == 0 && v < col_hi) {
+            const float bv = b[v];
+            const unsigned e0 = bf16_rne(bv);
+            const float r1 = bv - __uint_as_float(e0 << 16);
+            const unsigned e1 = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(e1 << 16);
+            const unsigned e2 = bf16_rne(r2);
+            f.x = e0 | (e1 << 16); f.y = e2;
+        }
+        bias16[o] = f;
     }
 }
 
@@ -552,17 +856,22 @@ int launch_decode_rb_bf16(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
     // hidden = 256 -> 16 steps of K = 16: unrolled body with the 8-deep register ring
     // two waves per SIMD here: with 16x faster MFMAs the VALU epilogue of a tile is comparable to
     // its matrix time, and the second wave's MFMAs cover it (DAE_DECODE_WAVES_BF16=4 for the A/B)
-    if (g.R_TILE == 128 && p.G == 16) {
-        if (g.waves == 8) return launch_decode<4, EPI, 16, 8, DT_BF16>(ctx, g, p);
-        return launch_decode<4, EPI, 16, 4, DT_BF16>(ctx, g, p);
-    }
     if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "bad wave count %d", g.waves);
+    if (g.R_TILE == 256 && p.G == 16) return launch_decode<8, EPI, 16, 4, DT_BF16>(ctx, g, p);
+    if (g.R_TILE == 128 && p.G == 16) return launch_decode<4, EPI, 16, 4, DT_BF16>(ctx, g, p);
     switch (g.R_TILE) {
         case 128: return launch_decode<4, EPI, 0, 4, DT_BF16>(ctx, g, p);
         case 64:  return launch_decode<2, EPI, 0, 4, DT_BF16>(ctx, g, p);
         case 32:  return launch_decode<1, EPI, 0, 4, DT_BF16>(ctx, g, p);
     }
     return dae_fail(ctx, DAE_ERR_ARG, "bad R_TILE %d", g.R_TILE);
+}
+
+// the dedicated phase-B kernel: hidden = 256 (16 steps), one wave per SIMD, 128- or 256-row groups
+bool bf16_fast_filter(const dae_rowgeom& g, int dtype, int G)
+{
+    static const bool off = getenv("DAE_BF16_GENERIC") != nullptr;                // A/B against the generic body
+    return dtype == DAE_DTYPE_BF16 && G == 16 && g.waves == 4 && (g.R_TILE == 128 || g.R_TILE == 256) && !off;
 }
 
 int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p,
@@ -575,6 +884,7 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     memset(&p, 0, sizeof(p));
     p.Wp = static_cast<const float4*>(pk.W.p);
     p.bias = static_cast<const float*>(pk.bias.p);
+    p.bias16 = static_cast<const uint4*>(pk.bias16.p);
     p.hp = static_cast<const float4*>(hb.p);
     p.G = dtype == DAE_DTYPE_F32 ? pk.Hp / DAE_KG : pk.Hp / 16;
     p.ncols = pk.col_hi - pk.col_lo;
@@ -589,6 +899,18 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
 }
 
 }  // namespace
+
+// most tiles one workgroup of the filter launch can walk (sizes its private candidate lists)
+int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp)
+{
+    const int n_ws = g.nb_rg * g.waves;
+    if (bf16_fast_filter(g, dtype, Hp / 16)) {
+        const int nt = g.R_TILE == 256 ? 1 : 2;
+        const int n_grp = (n_items + nt - 1) / nt;
+        return nt * g.waves * ((n_grp + n_ws - 1) / n_ws);
+    }
+    return g.waves * ((n_items + n_ws - 1) / n_ws);
+}
 
 // Rows are cut into groups of R_TILE playlists whose hidden tile (R_TILE x Hp fp32) stays in LDS.
 dae_rowgeom dae_row_geometry(int B, int Hp)
@@ -619,9 +941,14 @@ dae_rowgeom dae_row_geometry(int B, int Hp)
 dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
 {
     dae_rowgeom g;
-    int rt = 128;
+    // hidden = 256: 256-playlist row groups (128 KiB of LDS) for batches > 128 -- each W fragment then
+    // feeds 8 MFMAs and a batch of 256 reads W exactly once; one wave per SIMD with 512 registers
+    int rt = (Hp == 256 && B > 128) ? 256 : 128;
     while (rt > 32 && (size_t)rt * Hp * 2 > 128 * 1024) rt >>= 1;
     while (rt > 32 && B <= rt / 2) rt >>= 1;
+    if (const char* e = getenv("DAE_BF16_RTILE")) {                  // A/B: force 128-row groups
+        if (atoi(e) == 128 && rt == 256) rt = 128;
+    }
     g.R_TILE = rt;
     g.n_rg = (B + rt - 1) / rt;
     g.Bpad = g.n_rg * rt;
@@ -629,13 +956,7 @@ dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
     if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
     g.nb_rg = nb;
     g.grid = g.n_rg * nb;
-    // two waves per SIMD: with 16x faster MFMAs a tile's VALU epilogue is comparable to its matrix
-    // time and the partner wave covers it (B=256: 2.13 vs 2.00 M playlists/s, B=1024: 2.80 vs 2.53 M)
-    g.waves = (Hp == 256 && rt >= 128) ? 8 : 4;
-    if (const char* e = getenv("DAE_DECODE_WAVES_BF16")) {
-        const int w = atoi(e);
-        if ((w == 4 || w == 8) && Hp == 256 && rt >= 128) g.waves = w;
-    }
+    g.waves = 4;
     return g;
 }
 
@@ -643,7 +964,7 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
                             int col_lo, int col_hi)
 {
     dae_packed& pk = ctx->pk_bf16;
-    pk.valid = false;
+    pk.valid = false; pk.order_nrank = -1;
     const int Hp = dae_round_up(H, DAE_HPAD);
     if ((size_t)32 * Hp * 2 > 128 * 1024)
         return dae_fail(ctx, DAE_ERR_ARG, "hidden size %d too large", H);
@@ -653,13 +974,21 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
     if (rc) return rc;
     rc = dae_reserve(ctx, pk.bias, (size_t)ntiles * 32 * sizeof(float));
     if (rc) return rc;
+    rc = dae_reserve(ctx, pk.bias16, (size_t)ntiles * 64 * sizeof(uint4));
+    if (rc) return rc;
     const size_t total = (size_t)ntiles * NS * 64;
     int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(prepack_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, NS,
-                       col_lo, col_hi, ntiles, static_cast<uint4*>(pk.W.p), static_cast<float*>(pk.bias.p));
+                       col_lo, col_hi, ntiles, static_cast<uint4*>(pk.W.p), static_cast<float*>(pk.bias.p),
+                       static_cast<uint4*>(pk.bias16.p));
     DAE_CHECK_LAUNCH(ctx, "prepack_bf16_kernel");
     pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
+    rc = dae_reserve(ctx, pk.ident, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int));
+    if (rc) return rc;
+    hipLaunchKernelGGL(tile_iota_kernel, dim3((ntiles + 255) / 256 > 0 ? (ntiles + 255) / 256 : 1), dim3(256), 0,
+                       ctx->stream, ntiles, static_cast<int*>(pk.ident.p));
+    DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
     pk.valid = true;
     return DAE_OK;
 }
@@ -683,7 +1012,7 @@ int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, 
                            int col_lo, int col_hi)
 {
     dae_packed& pk = ctx->pk_f32;
-    pk.valid = false;
+    pk.valid = false; pk.order_nrank = -1;
     const int Hp = dae_round_up(H, DAE_HPAD);
     if ((size_t)32 * Hp * 4 > 128 * 1024)
         return dae_fail(ctx, DAE_ERR_ARG, "hidden size %d too large (max 1024)", H);
@@ -701,7 +1030,30 @@ int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, 
                        static_cast<float*>(pk.bias.p));
     DAE_CHECK_LAUNCH(ctx, "prepack_f32_kernel");
     pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
+    rc = dae_reserve(ctx, pk.ident, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int));
+    if (rc) return rc;
+    hipLaunchKernelGGL(tile_iota_kernel, dim3((ntiles + 255) / 256 > 0 ? (ntiles + 255) / 256 : 1), dim3(256), 0,
+                       ctx->stream, ntiles, static_cast<int*>(pk.ident.p));
+    DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
     pk.valid = true;
+    return DAE_OK;
+}
+
+int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, int S)
+{
+    if (pk.order_nrank == nrank && pk.order_nsamp == n_samp && pk.order.p) return DAE_OK;
+    int rc = dae_reserve(ctx, pk.order, (size_t)pk.ntiles * sizeof(int));
+    if (rc) return rc;
+    static const bool strided = getenv("DAE_SAMPLE") && !strcmp(getenv("DAE_SAMPLE"), "strided");
+    if (pk.ntiles > ORDER_MAX_TILES || strided) {
+        hipLaunchKernelGGL(tile_order_strided_kernel, dim3((pk.ntiles + 255) / 256), dim3(256), 0, ctx->stream,
+                           pk.ntiles, n_samp, S, static_cast<int*>(pk.order.p));
+    } else {
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           static_cast<const float*>(pk.bias.p), pk.ntiles, nrank, static_cast<int*>(pk.order.p));
+    }
+    DAE_CHECK_LAUNCH(ctx, "tile_order_kernel");
+    pk.order_nrank = nrank; pk.order_nsamp = n_samp;
     return DAE_OK;
 }
 
@@ -739,7 +1091,7 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
                                float* dz, int64_t ld, float* dzT, int64_t ldT, float* loss_part)
 {
     DecP p;
-    dae_tileset ts{ctx->pk_f32.ntiles, 1, 0};
+    dae_tileset ts{ctx->pk_f32.ntiles, 1, 0, static_cast<const int*>(ctx->pk_f32.ident.p)};
     int rc = fill_common(ctx, g, B, ts, p);
     if (rc) return rc;
     p.out = dz; p.ld = ld; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
@@ -755,6 +1107,23 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
+    if (bf16_fast_filter(g, dtype, p.G)) {
+        const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<2, 4, 16, 4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 8, 16, 4>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (g.R_TILE == 256)
+            hipLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 8, 16, 4>), dim3(g.grid), dim3(256), lds, ctx->stream, p);
+        else
+            hipLaunchKernelGGL((decode_bf16_h256_filter_kernel<2, 4, 16, 4>), dim3(g.grid), dim3(256), lds, ctx->stream, p);
+        DAE_CHECK_LAUNCH(ctx, "decode_bf16_h256_filter_kernel");
+        return DAE_OK;
+    }
     return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_FILTER>(ctx, g, p)
                                   : launch_decode_rb_bf16<EPI_FILTER>(ctx, g, p);
 }

@@ -50,14 +50,16 @@ struct DenseSrc {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = base + u * TK_THREADS + tid;
-                f(z[u], s.col_base + (q >> 5) * step + (q & 31), true);
+                const int tb = s.tile_list ? s.tile_list[q >> 5] * 32 : (q >> 5) * step;
+                f(z[u], s.col_base + tb + (q & 31), true);
             }
         }
         for (; base < s.n; base += TK_THREADS) {
             const int q = base + tid;
             const bool in = q < s.n;
             const float z = in ? rp[q] : 0.f;
-            f(z, s.col_base + (q >> 5) * step + (q & 31), in);
+            const int tb = s.tile_list ? s.tile_list[in ? (q >> 5) : 0] * 32 : (q >> 5) * step;
+            f(z, s.col_base + tb + (q & 31), in);
         }
     }
 };
