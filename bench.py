@@ -188,11 +188,13 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
     if os.path.exists(tpath) and world == 1:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("bf16" if args.dtype == "bf16" else "f32", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-    roofline = {"kernel": "decode_f32_kernel<filter>" if plan["fused"] else "decode_f32_kernel<dense>",
+    roofline = {"kernel": ("decode_bf16_h256_filter_kernel" if args.dtype == "bf16" and H == 256 else
+                           "decode_f32_kernel<filter>") if plan["fused"] else "decode_f32_kernel<dense>",
                 "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tflops / peak_tf, 4),
                 "traffic": traffic, "flop_per_launch": flop_per_launch,

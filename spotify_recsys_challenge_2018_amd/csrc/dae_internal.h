@@ -251,6 +251,7 @@ struct dae_topk_args {
     // the sort and emit the <= 512 surviving pairs UNSORTED at out_pairs[row*pairs_stride + i],
     // their number in out_cnt[row], and any valid lower bound of the k-th logit in out_tau.
     int* out_cnt; int pairs_stride;
+    int lean, sort_cap;           // set by the launcher (topk.hip): LDS mode, sort buffer keys
 };
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);
 int dae_launch_topk_pairs(dae_ctx* ctx, const dae_pair_group& g0, const dae_pair_group& g1,

@@ -362,37 +362,43 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                     }
                 }
             }
-        } else {
+        } else if ((t * 32 < p.ncols) && (p.col_lo + t * 32 < p.n_valid_col)) {
+            // filter: tiles without a rankable column (the artist columns) need no epilogue at all; in
+            // the others the common case -- this launch walks the LOW-bias tiles -- is "no value of
+            // the row block reaches tau": 16 adds, a max-reduction and one compare.  Masks, the LDS
+            // atomic for the list slots and the stores only where a lane really passes.
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const float tv = tau_r[rb];
                 float z[16];
-                unsigned m = 0;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     z[4 * qd + 0] = acc[rb][4 * qd + 0] + bq[qd].x;
                     z[4 * qd + 1] = acc[rb][4 * qd + 1] + bq[qd].y;
                     z[4 * qd + 2] = acc[rb][4 * qd + 2] + bq[qd].z;
                     z[4 * qd + 3] = acc[rb][4 * qd + 3] + bq[qd].w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int lc = tcol0 + 8 * qd + e;
-                        const bool ok = (z[4 * qd + e] >= tv) && (lc < p.ncols) &&
-                                        (p.col_lo + lc < p.n_valid_col);
-                        m |= (ok ? 1u : 0u) << (4 * qd + e);
-                    }
                 }
-                if (m) {
-                    const int rloc = rb * 32 + j;
-                    const int row = rg * R_TILE + rloc;
-                    int base = atomicAdd(&lcnt[rloc], __popc(m));
-                    uint2* dst = p.cand + ((size_t)bir * p.Bpad + row) * (size_t)p.cap;
+                float mx = z[0];
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        if (m & (1u << reg)) {
-                            const int lc = tcol0 + (reg & 3) + 8 * (reg >> 2);
-                            dst[base++] = make_uint2(__float_as_uint(z[reg]),
-                                                     (unsigned)(p.col_lo + lc));
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, z[e]);
+                if (mx >= tv) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lc = tcol0 + (e & 3) + 8 * (e >> 2);
+                        if (z[e] >= tv && lc < p.ncols && p.col_lo + lc < p.n_valid_col) m |= 1u << e;
+                    }
+                    if (m) {
+                        const int rloc = rb * 32 + j;
+                        const int row = rg * R_TILE + rloc;
+                        int base = atomicAdd(&lcnt[rloc], __popc(m));
+                        uint2* dst = p.cand + ((size_t)bir * p.Bpad + row) * (size_t)p.cap;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (m & (1u << reg)) {
+                                const int lc = tcol0 + (reg & 3) + 8 * (reg >> 2);
+                                dst[base++] = make_uint2(__float_as_uint(z[reg]), (unsigned)(p.col_lo + lc));
+                            }
                         }
                     }
                 }
@@ -941,14 +947,12 @@ dae_rowgeom dae_row_geometry(int B, int Hp)
 dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
 {
     dae_rowgeom g;
-    // hidden = 256: 256-playlist row groups (128 KiB of LDS) for batches > 128 -- each W fragment then
-    // feeds 8 MFMAs and a batch of 256 reads W exactly once; one wave per SIMD with 512 registers
-    int rt = (Hp == 256 && B > 128) ? 256 : 128;
+    // 128-playlist row groups.  256-row groups (every W fragment feeds 8 MFMAs, a batch of 256 reads W
+    // exactly once) measured the same kernel time but a slower phase A: DAE_BF16_RTILE=256 for the A/B.
+    int rt = 128;
+    if (const char* e = getenv("DAE_BF16_RTILE")) { if (atoi(e) == 256 && Hp == 256 && B > 128) rt = 256; }
     while (rt > 32 && (size_t)rt * Hp * 2 > 128 * 1024) rt >>= 1;
     while (rt > 32 && B <= rt / 2) rt >>= 1;
-    if (const char* e = getenv("DAE_BF16_RTILE")) {                  // A/B: force 128-row groups
-        if (atoi(e) == 128 && rt == 256) rt = 128;
-    }
     g.R_TILE = rt;
     g.n_rg = (B + rt - 1) / rt;
     g.Bpad = g.n_rg * rt;

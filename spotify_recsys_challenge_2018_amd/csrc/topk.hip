@@ -34,6 +34,7 @@ constexpr int TK_SORT_MAX = 2048;
 typedef unsigned long long u64;
 
 struct DenseSrc {
+    static constexpr int kSegs = 0;
     dae_dense_src s;
     __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return s.n; }
@@ -45,13 +46,17 @@ struct DenseSrc {
         int base = 0;                                  // block-uniform loop bounds
         for (; base + 4 * TK_THREADS <= s.n; base += 4 * TK_THREADS) {
             float z[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) z[u] = rp[base + u * TK_THREADS + tid];
+            int tb[4];                                 // tile bases: loaded with the logits, not after
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = base + u * TK_THREADS + tid;
-                const int tb = s.tile_list ? s.tile_list[q >> 5] * 32 : (q >> 5) * step;
-                f(z[u], s.col_base + tb + (q & 31), true);
+                z[u] = rp[q];
+                tb[u] = s.tile_list ? s.tile_list[q >> 5] * 32 : (q >> 5) * step;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + u * TK_THREADS + tid;
+                f(z[u], s.col_base + tb[u] + (q & 31), true);
             }
         }
         for (; base < s.n; base += TK_THREADS) {
@@ -65,6 +70,7 @@ struct DenseSrc {
 };
 
 struct PairSrc {
+    static constexpr int kSegs = TK_MAX_SEG;
     dae_pair_group g0, g1;
     __device__ __forceinline__ int seg_count(const dae_pair_group& g, int seg, int row) const
     {
@@ -144,6 +150,7 @@ struct PairSrc {
 };
 
 struct SoaSrc {
+    static constexpr int kSegs = 0;
     const float* logit; const int32_t* idx; int G, B, k;
     __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return G * k; }
@@ -197,8 +204,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ unsigned hist[TK_BINS];
-    __shared__ u64 skey[TK_SORT_MAX];
-    __shared__ int seg_prefix[TK_MAX_SEG + 2];
+    __shared__ int seg_prefix[Src::kSegs + 2];
     __shared__ unsigned wave_tot[TK_WAVES];
     __shared__ int s_bin;
     __shared__ unsigned s_above;
@@ -209,17 +215,28 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     const int lane = tid & 63;
     const int row = blockIdx.x;
     const int k = a.k;
-    const int bm_words = (a.bitmap_n + 31) >> 5;
+    // dynamic LDS: [seed bitmap (bitmap mode only)] [skey: sort buffer, sort_cap keys] [key cache]
+    const bool lean = a.lean != 0;
+    const int bm_words = lean ? 0 : (a.bitmap_n + 31) >> 5;
     unsigned* bitmap = reinterpret_cast<unsigned*>(dyn);
-    u64* keys = reinterpret_cast<u64*>(dyn + (((size_t)bm_words * 4 + 15) & ~(size_t)15));
+    u64* skey = reinterpret_cast<u64*>(dyn + (((size_t)bm_words * 4 + 15) & ~(size_t)15));
+    u64* keys = skey + a.sort_cap;
 
-    // ---- 1. seed bitmap ---------------------------------------------------------------------------
+    // ---- 1. seeds -----------------------------------------------------------------------------------
+    // bitmap mode: per-row LDS bitmap over the ranked columns, tested for every element.
+    // lean mode (small LDS footprint, so that this kernel can share a CU with the decode workgroups
+    // of another batch): no bitmap.  With ns seeds in the row, the (k + ns)-th largest key over ALL
+    // elements is a valid cut for the k-th largest non-seed key, so the narrowing stages run seed-blind
+    // with rank k + ns, and the seeds are removed once, from the <= sort_n keys that were collected.
+    // Rows with k + ns above the sort buffer test every element against the seed list instead.
+    const int seed_b = a.seed_col ? a.seed_row_ptr[row] : 0;
+    const int seed_e = a.seed_col ? a.seed_row_ptr[row + 1] : 0;
+    const int ns = seed_e - seed_b;
     for (int w = tid; w < bm_words; w += TK_THREADS) bitmap[w] = 0;
     if (tid == 0) { s_cnt = 0; s_min = ~0ull; s_max = 0ull; }
     __syncthreads();
-    if (a.seed_col && bm_words > 0) {
-        const int sb = a.seed_row_ptr[row], se = a.seed_row_ptr[row + 1];
-        for (int i = sb + tid; i < se; i += TK_THREADS) {
+    if (!lean && a.seed_col && bm_words > 0) {
+        for (int i = seed_b + tid; i < seed_e; i += TK_THREADS) {
             const int pcol = a.seed_col[i] - a.bitmap_base;
             if (pcol >= 0 && pcol < a.bitmap_n) atomicOr(&bitmap[pcol >> 5], 1u << (pcol & 31));
         }
@@ -228,13 +245,29 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __syncthreads();
     if (dbg_stop == 1) return;
 
+    int sort_n = 1;
+    while (sort_n < k) sort_n <<= 1;
+    if (sort_n < 1024) sort_n = 1024;                            // always <= TK_SORT_MAX (k <= 1024)
+    if (k > 512) sort_n = TK_SORT_MAX;
+    const bool seed_blind = lean && ns > 0 && k + ns <= sort_n;  // remove the seeds after the collect
+    const bool seed_scan = lean && ns > 0 && !seed_blind;         // (rare) test every element
+    auto is_seed = [&](int colv) -> bool {
+        bool hit = false;
+        for (int i = seed_b; i < seed_e; ++i) hit = hit || (a.seed_col[i] == colv);   // uniform address
+        return hit;
+    };
+
     // composite key of one element; 0 = absent (masked seed, -inf padding, missing entry)
     auto ckey = [&](float z, int colv, bool in) -> u64 {
         if (!in || colv < 0) return 0ull;
         const unsigned key = dae_okey(z);
         if (key <= DAE_KEY_NEG_INF) return 0ull;
-        const int pcol = colv - a.bitmap_base;
-        if (pcol >= 0 && pcol < a.bitmap_n && ((bitmap[pcol >> 5] >> (pcol & 31)) & 1u)) return 0ull;
+        if (!lean) {
+            const int pcol = colv - a.bitmap_base;
+            if (pcol >= 0 && pcol < a.bitmap_n && ((bitmap[pcol >> 5] >> (pcol & 31)) & 1u)) return 0ull;
+        } else if (seed_scan) {
+            if (is_seed(colv)) return 0ull;
+        }
         return ((u64)key << 32) | (u64)(~(unsigned)colv);
     };
 
@@ -272,11 +305,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     if (dbg_stop == 2) return;
     const unsigned m = s_cnt;                                   // valid elements
     const bool in_lds = m <= (unsigned)key_cap;                 // all of them were kept in LDS
-    const unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;
-    int sort_n = 1;
-    while (sort_n < k) sort_n <<= 1;
-    if (sort_n < 1024) sort_n = 1024;                            // always <= TK_SORT_MAX (k <= 1024)
-    if (k > 512) sort_n = TK_SORT_MAX;
+    unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;        // outputs of the row (final after seed removal)
+    const unsigned k_sel = seed_blind ? (unsigned)(k + ns) : (unsigned)k;
+    const unsigned k_rank = m < k_sel ? m : k_sel;               // rank the narrowing stages cut at
 
     // every valid key, from LDS or (big rows) from the source again.  f(key) is called by WHOLE
     // waves (key == 0 for lanes without an element) so it may use wave-level aggregation.
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         }
         __syncthreads();
         const unsigned n_max = s_cnt2;
-        if (n_max >= k_eff) {
+        if (n_max >= k_rank) {
             const u64 mlo = s_min2, mhi = s_max;                 // the row maximum is a thread maximum
             const u64 range = mhi - mlo;
             int shift = 64 - 11 - __clzll(range | 1ull);
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             __syncthreads();
             if (tmax != 0ull) atomicAdd(&hist[(unsigned)((tmax - mlo) >> shift)], 1u);
             __syncthreads();
-            find_bin(hist, wave_tot, tid, k_eff, &s_bin, &s_above);
+            find_bin(hist, wave_tot, tid, k_rank, &s_bin, &s_above);
             const u64 cut = mlo + ((u64)(unsigned)s_bin << shift);   // <= k-th largest thread maximum
             __syncthreads();
             // count the row's keys >= cut
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 hist_add(v ? (unsigned)((ck - lo) >> shift) : 0u, v);
             });
             __syncthreads();
-            find_bin(hist, wave_tot, tid, k_eff - above, &s_bin, &s_above);
+            find_bin(hist, wave_tot, tid, k_rank - above, &s_bin, &s_above);
             const unsigned b = (unsigned)s_bin;
             const unsigned cnt_b = hist[b];
             const unsigned new_above = above + s_above;
@@ -420,6 +451,37 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         });
     }
     __syncthreads();
+
+    // ---- 4a. lean mode: drop the seeds among the collected keys (order is irrelevant here) ------------
+    if (seed_blind) {
+        u64 kk[2];
+        bool keep[2];
+        const unsigned c = s_cnt < (unsigned)sort_n ? s_cnt : (unsigned)sort_n;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned i = (unsigned)(e * TK_THREADS + tid);
+            kk[e] = i < c ? skey[i] : 0ull;
+            keep[e] = kk[e] != 0ull && !is_seed((int)(~(unsigned)(kk[e] & 0xFFFFFFFFull)));
+        }
+        __syncthreads();                                         // every skey read is done
+        if (tid == 0) s_cnt = 0;
+        for (int i = tid; i < sort_n; i += TK_THREADS) skey[i] = 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u64 bal = __ballot(keep[e]);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                base = __shfl(base, leader);
+                if (keep[e]) skey[base + __popcll(bal & ((1ull << lane) - 1ull))] = kk[e];
+            }
+        }
+        __syncthreads();
+        // >= k + ns keys were above the cut and <= ns of them were seeds; short rows were collected whole
+        k_eff = s_cnt < (unsigned)k ? s_cnt : (unsigned)k;
+    }
 
     if (dbg_stop == 4) return;
     // ---- 4b. k <= 512: get down to <= 512 keys so that the cheap ordering stage applies.  If more
@@ -615,26 +677,47 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     if (a.k < 1 || a.k > DAE_MAX_K)
         return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", a.k, DAE_MAX_K);
     if (a.B <= 0) return DAE_OK;
-    const size_t bm_bytes = (((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) & ~(size_t)15;
-    // static LDS of the kernel: hist 8K + skey 16K + seg_prefix ~4K + scalars
-    const size_t lds_total = 160 * 1024, lds_static = 30 * 1024;
-    if (bm_bytes + lds_static + 8 * 1024 > lds_total)
-        return dae_fail(ctx, DAE_ERR_ARG, "ranked column range %d too wide for the LDS seed bitmap",
-                        a.bitmap_n);
-    const size_t dyn = lds_total - lds_static;                  // bitmap + key buffer
-    const int key_cap = (int)((dyn - bm_bytes) / 8);
+    int sort_n = 1024;
+    if (a.k > 512) sort_n = TK_SORT_MAX;
+    dae_topk_args aa = a;
+    aa.sort_cap = sort_n;
+    // Two LDS modes, both covered by the parity tests:
+    //   bitmap (default): per-row seed bitmap + a key cache filling the CU's LDS -- fastest alone.
+    //   lean (DAE_TOPK_LEAN=1): no bitmap (seed-blind narrowing at rank k + n_seeds, seeds removed once
+    //     from the collected keys), sort buffer + small cache only: <= 30 KiB and <= 56 registers per
+    //     thread, so a workgroup fits on a CU NEXT to a decode workgroup of another batch.  Measured
+    //     (profiles/r01_notes.md): the co-resident decode launch slows down by about what the overlap
+    //     gains, and the kernel alone is slower (re-reads its source), so it is not the default.
+    static const bool want_lean = getenv("DAE_TOPK_LEAN") != nullptr;
+    aa.lean = want_lean ? 1 : 0;
+    const size_t lds_total = 160 * 1024, lds_static = 14 * 1024;    // hist 8K + seg_prefix 4K + scalars
+    size_t dyn;
+    int key_cap;
+    if (aa.lean) {
+        const size_t budget = 30 * 1024 - (sizeof(unsigned) * TK_BINS + (Src::kSegs ? (Src::kSegs + 2) * 4 : 8) + 256);
+        const size_t sk = (size_t)sort_n * 8;
+        key_cap = budget > sk ? (int)((budget - sk) / 8) : 0;
+        dyn = sk + (size_t)key_cap * 8;
+    } else {
+        const size_t bm_bytes = (((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) & ~(size_t)15;
+        if (bm_bytes + (size_t)sort_n * 8 + lds_static + 8 * 1024 > lds_total)
+            return dae_fail(ctx, DAE_ERR_ARG, "ranked column range %d too wide for the LDS seed bitmap",
+                            a.bitmap_n);
+        dyn = lds_total - lds_static;                               // bitmap + sort buffer + key cache
+        key_cap = (int)((dyn - bm_bytes - (size_t)sort_n * 8) / 8);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)dyn));
+                                               (int)(lds_total - lds_static)));
         attr_set = true;
     }
     // debug: DAE_TOPK_STOP=n stops the phase-A (tau-producing) kernel after stage n,
     // DAE_TOPK_STOP=-n the other launches (bisecting stage costs under rocprofv3)
     static const int dbg_env = getenv("DAE_TOPK_STOP") ? atoi(getenv("DAE_TOPK_STOP")) : 0;
     const int dbg_stop = dbg_env > 0 ? (a.out_tau ? dbg_env : 0) : (a.out_tau ? 0 : -dbg_env);
-    hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, a,
+    hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, aa,
                        key_cap, dbg_stop);
     DAE_CHECK_LAUNCH(ctx, "topk_kernel");
     return DAE_OK;

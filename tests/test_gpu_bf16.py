@@ -62,7 +62,7 @@ def test_bf16_fused_topk_equals_unfused_and_tracks_fp32(ctx):
     s16 = torch.empty((B, k), device="cuda"); i16 = torch.empty((B, k), dtype=torch.int32, device="cuda")
     s32 = torch.empty_like(s16); i32 = torch.empty_like(i16)
     ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s16, i16, dtype=BF)
-    assert ctx.last_plan()["fused"] == 1 and ctx.last_plan()["R_TILE"] == 256      # 256-row groups above 128 playlists
+    assert ctx.last_plan()["fused"] == 1 and ctx.last_plan()["R_TILE"] == 128
     ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s32, i32)
     # unfused bf16: same logits, same ranking rule -> identical
     h = torch.empty((B, H), device="cuda")
