@@ -36,6 +36,7 @@ typedef unsigned long long u64;
 struct DenseSrc {
     static constexpr int kSegs = 0;
     dae_dense_src s;
+    int max_keys() const { return s.n; }                  // host: most keys a row can hold
     __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return s.n; }
     template <typename F>
@@ -72,6 +73,7 @@ struct DenseSrc {
 struct PairSrc {
     static constexpr int kSegs = TK_MAX_SEG;
     dae_pair_group g0, g1;
+    int max_keys() const { return 8192; }                 // typical rows are far below; larger rows re-read
     __device__ __forceinline__ int seg_count(const dae_pair_group& g, int seg, int row) const
     {
         return g.cnt ? g.cnt[(size_t)seg * g.cnt_seg_stride + row] : g.fixed_cnt;
@@ -152,6 +154,7 @@ struct PairSrc {
 struct SoaSrc {
     static constexpr int kSegs = 0;
     const float* logit; const int32_t* idx; int G, B, k;
+    int max_keys() const { return G * k; }
     __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return G * k; }
     template <typename F>
@@ -703,8 +706,13 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
         if (bm_bytes + (size_t)sort_n * 8 + lds_static + 8 * 1024 > lds_total)
             return dae_fail(ctx, DAE_ERR_ARG, "ranked column range %d too wide for the LDS seed bitmap",
                             a.bitmap_n);
-        dyn = lds_total - lds_static;                               // bitmap + sort buffer + key cache
-        key_cap = (int)((dyn - bm_bytes - (size_t)sort_n * 8) / 8);
+        // bitmap + sort buffer + key cache.  The cache is sized to what a row can hold, not to the CU:
+        // with many rows of few keys (large batches, vocabulary shards) two workgroups then share a CU.
+        const size_t room = lds_total - lds_static - bm_bytes - (size_t)sort_n * 8;
+        size_t want = (size_t)(src.max_keys() > 0 ? src.max_keys() : 8192) * 8;
+        if (want > room) want = room;
+        key_cap = (int)(want / 8);
+        dyn = bm_bytes + (size_t)sort_n * 8 + want;
     }
     static bool attr_set = false;
     if (!attr_set) {
