@@ -86,6 +86,20 @@ int dae_last_plan(int32_t out[8]);
 
 /* ---- encode (DAEs.py:40-42 dropout+normalise, :64-70 encoder) ----------------------------- */
 
+/* The feed of the reference graph on the device (models/DAEs.py:23-35; utils/data_reader.py builds
+ * it row by row): COO entries (row, col) -> value in FEED ORDER, duplicates allowed;
+ * tf.sparse_tensor_to_dense(validate_indices=False) scatters them by assignment, so the LAST
+ * occurrence of a (row, col) wins.  Produces the CSR every other entry point takes: columns
+ * ascending per row, one entry per (row, col), explicit zeros dropped.
+ *   positions [nnz,2] int64 (row in batch, column), values [nnz] fp32 (or ONE value for all entries
+ *   when values_broadcast != 0: the reference feeds np.ones / a scalar).
+ *   row_ptr [n_rows+1], col / val with room for nnz entries (row_ptr[n_rows] of them are written).
+ *   status: device int32, 0 = ok, bit 0 = an entry had row/col out of range (it is skipped; the host
+ *   restatement raises ValueError for the same input). */
+int dae_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                   int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                   int32_t* status);
+
 /* h[r,:] = hidden_dropout( sigmoid( sum_c (x[r,c]/(s_r+1e-10)) * W_enc[c,:] + b_enc ) )
  *   x      = input_dropout(CSR row r), s_r = sum of surviving weights.
  *   ikp/kp = input / hidden keep probabilities (1.0 = identity, the inference setting);

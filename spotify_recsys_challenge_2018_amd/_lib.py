@@ -15,7 +15,7 @@ DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
-    "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
+    "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_adam_step",
 ]
@@ -54,6 +54,7 @@ def load():
     lib.dae_profile_enable.argtypes = [vp, c_int]
     lib.dae_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
     lib.dae_last_plan.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    lib.dae_coo_to_csr.argtypes = [vp, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
@@ -110,6 +111,22 @@ class Context:
         if rc != 0:
             raise DaeError("libdae_hip error %d: %s"
                            % (rc, self.lib.dae_last_error(self.h).decode()))
+
+    def coo_to_csr(self, positions, values, n_rows, n_cols):
+        """Device COO (feed order, duplicates: last wins) -> CSR.  positions: int64 [nnz,2] CUDA tensor,
+        values: float32 [nnz] or [1].  Returns (row_ptr, col, val, status) CUDA tensors; col / val have
+        room for nnz entries, row_ptr[n_rows] of them are valid.  status != 0: an index was out of range."""
+        import torch
+        nnz = int(positions.shape[0])
+        dev = positions.device
+        rp = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        val = torch.empty(max(nnz, 1), dtype=torch.float32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        bcast = 1 if (values.numel() == 1 and nnz != 1) else 0
+        self.check(self.lib.dae_coo_to_csr(self.h, _ptr(positions), _ptr(values), bcast, nnz, int(n_rows),
+                                           int(n_cols), _ptr(rp), _ptr(col), _ptr(val), _ptr(status)))
+        return rp, col, val, status
 
     def close(self):
         if getattr(self, "h", None):

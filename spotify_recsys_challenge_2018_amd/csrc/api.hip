@@ -132,7 +132,7 @@ int dae_destroy(dae_ctx* ctx)
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
-                       &ctx->train_c, &ctx->train_d};
+                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -187,6 +187,19 @@ int dae_last_plan(int32_t out[8])
     out[0] = g_plan.R_TILE; out[1] = g_plan.n_rg; out[2] = g_plan.nb_rg; out[3] = g_plan.S;
     out[4] = g_plan.n_samp; out[5] = g_plan.n_other; out[6] = g_plan.fused; out[7] = g_plan.ntiles;
     return DAE_OK;
+}
+
+int dae_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                   int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                   int32_t* status)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !status || (nnz > 0 && (!positions || !values || !col || !val)))
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (nnz < 0 || nnz >= (int64_t)1 << 31) return dae_fail(ctx, DAE_ERR_ARG, "nnz=%lld out of range", (long long)nnz);
+    if (n_rows < 1 || n_cols < 1) return dae_fail(ctx, DAE_ERR_ARG, "bad shape %d x %d", n_rows, n_cols);
+    return dae_launch_coo_to_csr(ctx, positions, values, values_broadcast, nnz, n_rows, n_cols, row_ptr, col, val,
+                                 status);
 }
 
 int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,

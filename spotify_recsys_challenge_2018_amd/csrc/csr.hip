@@ -1,0 +1,198 @@
+// csr.hip -- the feed of the reference graph on the device: COO (row, col) -> value entries in FEED
+// ORDER, duplicates allowed, scattered by ASSIGNMENT into a dense [n_batch, n_input] matrix
+// (models/DAEs.py:33-35, tf.sparse_tensor_to_dense(validate_indices=False): the LAST occurrence of a
+// (row, col) wins) -> the CSR the kernels consume: columns ascending per
+// row, one entry per (row, col), explicit zeros dropped.  Same result as the host restatement
+// models/DAEs.py:coo_to_csr of this repo, entry for entry (tests/test_gpu_csr.py).
+//
+// Integer / byte work, HBM- and latency-bound, a few tens of KB per batch: six small launches
+//   count rows -> scan -> scatter into row buckets -> per-row order + last-wins dedup -> scan -> compact
+// The per-row step ranks by counting inside LDS (rows of a playlist batch hold <= a few hundred
+// entries; the quadratic count is cheaper than a sorting network at that size and needs no padding);
+// rows longer than the LDS buffer take the same code over global memory.
+#include "dae_internal.h"
+
+namespace {
+
+constexpr int CSR_ROW_CAP = 4096;      // entries of one row held in LDS (16 B each)
+
+__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ pos, int64_t nnz,
+                                                        int n_rows, int n_cols, int* __restrict__ cnt,
+                                                        int* __restrict__ status)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = pos[2 * i], c = pos[2 * i + 1];
+        if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) { atomicOr(status, 1); continue; }
+        atomicAdd(&cnt[r], 1);
+    }
+}
+
+// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); one workgroup
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ in, int n,
+                                                        int* __restrict__ out)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? in[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const int c0 = carry;
+        if (i < n) out[i] = c0 + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry = c0 + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restrict__ pos,
+                                                          const float* __restrict__ val, int val_bcast,
+                                                          int64_t nnz, int n_rows, int n_cols,
+                                                          const int* __restrict__ bptr, int* __restrict__ cursor,
+                                                          int* __restrict__ t_col, int* __restrict__ t_feed,
+                                                          float* __restrict__ t_val)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = pos[2 * i], c = pos[2 * i + 1];
+        if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) continue;
+        const int slot = bptr[r] + atomicAdd(&cursor[r], 1);
+        t_col[slot] = (int)c;
+        t_feed[slot] = (int)i;                       // feed order (nnz < 2^31 checked by the caller)
+        t_val[slot] = val[val_bcast ? 0 : i];
+    }
+}
+
+// One workgroup per row.  Entry i is KEPT iff its value is non-zero and no entry of the row with the
+// same column comes later in the feed; a kept entry's output slot is the number of kept entries with
+// a smaller column.  Kept entries go to k_col / k_val at the row's bucket offset, their number to kcnt.
+__global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bptr,
+                                                      const int* __restrict__ t_col,
+                                                      const int* __restrict__ t_feed,
+                                                      const float* __restrict__ t_val,
+                                                      int* __restrict__ k_col, float* __restrict__ k_val,
+                                                      int* __restrict__ kcnt)
+{
+    __shared__ int s_col[CSR_ROW_CAP];
+    __shared__ int s_feed[CSR_ROW_CAP];
+    __shared__ unsigned char s_keep[CSR_ROW_CAP];
+    __shared__ int s_n;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int b = bptr[row], n = bptr[row + 1] - b;
+    if (tid == 0) s_n = 0;
+    const bool in_lds = n <= CSR_ROW_CAP;
+    if (in_lds)
+        for (int i = tid; i < n; i += 256) { s_col[i] = t_col[b + i]; s_feed[i] = t_feed[b + i]; }
+    __syncthreads();
+    const int* colp = in_lds ? s_col : t_col + b;
+    const int* feedp = in_lds ? s_feed : t_feed + b;
+    // pass 1: keep flags (rows beyond the LDS buffer keep them in the low bit of k_col's slot)
+    for (int i = tid; i < n; i += 256) {
+        const int c = colp[i], f = feedp[i];
+        bool later = false;
+        for (int j = 0; j < n; ++j) later = later || (colp[j] == c && feedp[j] > f);
+        const bool keep = !later && t_val[b + i] != 0.0f;
+        if (in_lds) s_keep[i] = keep ? 1 : 0;
+        else k_col[b + i] = keep ? 1 : 0;            // scratch use; rewritten below after a barrier
+    }
+    __syncthreads();
+    // pass 2: slot among the kept entries.  LDS rows write their output directly; long rows keep their
+    // flags in k_col until every reader is done, so they park the SOURCE INDEX of slot s in k_val[s].
+    for (int i = tid; i < n; i += 256) {
+        const bool keep = in_lds ? s_keep[i] != 0 : k_col[b + i] != 0;
+        if (!keep) continue;
+        const int c = colp[i];
+        int slot = 0;
+        for (int j = 0; j < n; ++j) {
+            const bool kj = in_lds ? s_keep[j] != 0 : k_col[b + j] != 0;
+            slot += (kj && colp[j] < c) ? 1 : 0;
+        }
+        atomicAdd(&s_n, 1);
+        if (in_lds) { k_col[b + slot] = c; k_val[b + slot] = t_val[b + i]; }
+        else k_val[b + slot] = __int_as_float(i);
+    }
+    __syncthreads();
+    if (!in_lds) {
+        const int m = s_n;
+        for (int s = tid; s < m; s += 256) {
+            const int i = __float_as_int(k_val[b + s]);
+            k_col[b + s] = -1 - i;                   // flags are dead now; mark as "source index"
+        }
+        __syncthreads();
+        for (int s = tid; s < m; s += 256) {
+            const int i = -1 - k_col[b + s];
+            k_col[b + s] = t_col[b + i];
+            k_val[b + s] = t_val[b + i];
+        }
+    }
+    if (tid == 0) kcnt[row] = s_n;
+}
+
+__global__ __launch_bounds__(256) void csr_compact_kernel(const int* __restrict__ bptr,
+                                                          const int* __restrict__ row_ptr,
+                                                          const int* __restrict__ k_col,
+                                                          const float* __restrict__ k_val,
+                                                          int32_t* __restrict__ col, float* __restrict__ val)
+{
+    const int row = blockIdx.x;
+    const int b = bptr[row], o = row_ptr[row], m = row_ptr[row + 1] - o;
+    for (int s = threadIdx.x; s < m; s += 256) { col[o + s] = k_col[b + s]; val[o + s] = k_val[b + s]; }
+}
+
+}  // namespace
+
+int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                          int32_t* status)
+{
+    hipStream_t st = ctx->stream;
+    int rc;
+    // scratch: cnt | cursor | bptr | kcnt  (n_rows + 1 each), then t_col | t_feed | t_val | k_col | k_val
+    const size_t nr = (size_t)n_rows + 1;
+    const size_t ints = 4 * nr + 5 * (size_t)(nnz > 0 ? nnz : 1);
+    if ((rc = dae_reserve(ctx, ctx->csr_tmp, ints * sizeof(int)))) return rc;
+    int* cnt = static_cast<int*>(ctx->csr_tmp.p);
+    int* cursor = cnt + nr;
+    int* bptr = cursor + nr;
+    int* kcnt = bptr + nr;
+    int* t_col = kcnt + nr;
+    int* t_feed = t_col + nnz;
+    float* t_val = reinterpret_cast<float*>(t_feed + nnz);
+    int* k_col = reinterpret_cast<int*>(t_val + nnz);
+    float* k_val = reinterpret_cast<float*>(k_col + nnz);
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, 2 * nr * sizeof(int), st));          // cnt and cursor
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    if (nnz > 0) {
+        int blocks = (int)((nnz + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(csr_count_kernel, dim3(blocks), dim3(256), 0, st, positions, nnz, n_rows, n_cols, cnt,
+                           status);
+        DAE_CHECK_LAUNCH(ctx, "csr_count_kernel");
+    }
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n_rows, bptr);
+    DAE_CHECK_LAUNCH(ctx, "csr_scan_kernel");
+    if (nnz > 0) {
+        int blocks = (int)((nnz + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(csr_scatter_kernel, dim3(blocks), dim3(256), 0, st, positions, values, values_broadcast,
+                           nnz, n_rows, n_cols, bptr, cursor, t_col, t_feed, t_val);
+        DAE_CHECK_LAUNCH(ctx, "csr_scatter_kernel");
+    }
+    hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
+                       kcnt);
+    DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, kcnt, n_rows, row_ptr);
+    DAE_CHECK_LAUNCH(ctx, "csr_scan_kernel");
+    hipLaunchKernelGGL(csr_compact_kernel, dim3(n_rows), dim3(256), 0, st, bptr, row_ptr, k_col, k_val, col, val);
+    DAE_CHECK_LAUNCH(ctx, "csr_compact_kernel");
+    return DAE_OK;
+}

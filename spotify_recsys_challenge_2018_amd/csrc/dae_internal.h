@@ -64,6 +64,7 @@ struct dae_ctx {
     dae_buf cand_cnt;          // [nb_rg][Bpad] int
     dae_buf dense_tmp;         // unfused fallback logits
     dae_buf train_a, train_b, train_c, train_d;
+    dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -228,6 +229,11 @@ int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_r
                                float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc);
 int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                     float lr_t, float beta1, float beta2, float eps);
+
+// csr.hip
+int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                          int32_t* status);
 
 // topk.hip
 struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)

@@ -76,17 +76,26 @@ def coo_to_csr(positions, values, n_rows, n_cols=None):
 
 def seeds_to_csr(seeds, n_rows, n_tracks):
     """Per-row seed track lists (main_challenge.py:31-35 `cand.remove(i)`) -> CSR of sorted unique
-    in-range track ids."""
-    row_ptr = np.zeros(n_rows + 1, dtype=np.int32)
-    cols = []
-    for i in range(n_rows):
-        s = seeds[i] if i < len(seeds) else []
-        u = np.unique(np.asarray(s, dtype=np.int64)) if len(s) else np.zeros(0, dtype=np.int64)
-        u = u[(u >= 0) & (u < n_tracks)]
-        cols.append(u.astype(np.int32))
-        row_ptr[i + 1] = row_ptr[i] + u.size
-    col = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int32)
-    return row_ptr, col.astype(np.int32)
+    in-range track ids.  One lexsort over all rows (the per-row np.unique loop was the largest host cost
+    of a scoring call)."""
+    lens = np.fromiter((len(seeds[i]) if i < len(seeds) else 0 for i in range(n_rows)), dtype=np.int64,
+                       count=n_rows)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(n_rows + 1, dtype=np.int32), np.zeros(0, dtype=np.int32)
+    flat = np.fromiter((int(t) for i in range(min(n_rows, len(seeds))) for t in seeds[i]), dtype=np.int64,
+                       count=total)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
+    ok = (flat >= 0) & (flat < n_tracks)
+    flat, rows = flat[ok], rows[ok]
+    order = np.lexsort((flat, rows))
+    flat, rows = flat[order], rows[order]
+    first = np.ones(flat.size, dtype=bool)
+    first[1:] = (rows[1:] != rows[:-1]) | (flat[1:] != flat[:-1])
+    flat, rows = flat[first], rows[first]
+    row_ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(row_ptr, rows + 1, 1)
+    return np.cumsum(row_ptr).astype(np.int32), flat.astype(np.int32)
 
 
 class DAE_tied:
@@ -128,6 +137,8 @@ class DAE_tied:
         self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
             else _lib.DAE_DTYPE_F32
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
+        self.device_csr = bool(getattr(conf, "device_csr", True))
+        self._csr_status = None
         self._sharded = None          # sharding.ShardedTrainer when training is row-sharded over ranks
         self._params_stale = False
 
@@ -179,11 +190,36 @@ class DAE_tied:
         return t.to(torch.device("cuda", self.device_index), dtype=dtype, non_blocking=False)
 
     def _upload_csr(self, positions, values):
+        """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
+        and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
+        restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
         import torch
+        if self.device_csr:
+            pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64).reshape(-1, 2))
+            vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+            if vals.size != 1 and vals.size != pos.shape[0]:
+                raise ValueError("positions (%d) and values (%d) differ in length" % (pos.shape[0], vals.size))
+            if pos.shape[0] == 0:
+                pos = np.zeros((0, 2), np.int64)
+            d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64)[:pos.shape[0]]
+            d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32)
+            rp, c, v, status = self.ctx.coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
+            self._csr_status = status            # checked lazily (no sync on the scoring path)
+            return rp, c, v
         rp, c, v = coo_to_csr(positions, values, self.n_batch, self.n_input)
         if c.size == 0:          # keep valid device pointers for empty batches
             c = np.zeros(1, np.int32); v = np.zeros(1, np.float32)
         return self._to_dev(rp, torch.int32), self._to_dev(c, torch.int32), self._to_dev(v, torch.float32)
+
+    def _check_feed(self):
+        """After the results of a call have been fetched (the stream is drained anyway): the device CSR
+        builder skips entries whose row / column is out of range and raises the flag checked here."""
+        if self._csr_status is not None:
+            bad = int(self._csr_status.item())
+            self._csr_status = None
+            if bad:
+                raise ValueError("feed holds a row or column index out of range [0,%d) x [0,%d)"
+                                 % (self.n_batch, self.n_input))
 
     def _mark_dirty(self):
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
@@ -241,7 +277,9 @@ class DAE_tied:
         h = self.encode(x_positions, x_ones, keep_prob, input_keep_prob, seed)
         out = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=h.device)
         self.ctx.decode_dense(h, out, apply_sigmoid=True)
-        return out.cpu().numpy()
+        res = out.cpu().numpy()
+        self._check_feed()
+        return res
 
     def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None):
         """Fused scoring path: encode -> decode -> top-k (track columns, seeds removed).
@@ -263,7 +301,9 @@ class DAE_tied:
         self.ctx.score_topk(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"],
                             self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
         n_rows = self.n_batch if n_rows is None else n_rows
-        return idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
+        res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
+        self._check_feed()
+        return res
 
     # -- training -----------------------------------------------------------------------------------
     def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob):
@@ -306,7 +346,9 @@ class DAE_tied:
             ctx.check(lib.dae_adam_step(ctx.h, P(p), P(m), P(v), P(grad), p.numel(),
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
         self._mark_dirty()
-        return float(self._cost.item())
+        cost = float(self._cost.item())
+        self._check_feed()
+        return cost
 
     # -- persistence ----------------------------------------------------------------------------------
     def get_params(self):

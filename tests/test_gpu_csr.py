@@ -1,0 +1,103 @@
+"""GPU (-m gpu): the device feed builder dae_coo_to_csr (csrc/csr.hip; reference DAEs.py:33-35 scatter
+semantics) against the numpy restatement models.DAEs.coo_to_csr -- integer work,
+so the bar is entry-for-entry equality."""
+import numpy as np
+import pytest
+
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dt=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+def _run(ctx, pos, vals, B, V):
+    import torch
+    pos = np.asarray(pos, np.int64).reshape(-1, 2)
+    vals = np.asarray(vals, np.float32).reshape(-1)
+    d_pos = _dev(pos if len(pos) else np.zeros((1, 2), np.int64))[:len(pos)]
+    rp, c, v, st = ctx.coo_to_csr(d_pos, _dev(vals if vals.size else np.zeros(1, np.float32)), B, V)
+    torch.cuda.synchronize()
+    rp = rp.cpu().numpy(); n = int(rp[-1])
+    return rp, c.cpu().numpy()[:n], v.cpu().numpy()[:n], int(st.item())
+
+
+@pytest.mark.parametrize("B,V,nnz,seed", [(256, 170000, 25000, 0), (7, 50, 400, 1), (1, 10, 1, 2), (64, 3000, 0, 3),
+                                          (300, 1000, 60000, 4)])
+def test_random_feeds_with_duplicates_zeros_and_any_order(B, V, nnz, seed):
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(0, B, nnz)
+    cols = np.minimum(V - 1, np.floor(np.exp(rng.random(nnz) * np.log(V))).astype(np.int64) - 1).clip(0)   # zipf: many dups
+    pos = np.stack([rows, cols], 1) if nnz else np.zeros((0, 2), np.int64)
+    vals = rng.choice(np.array([0.0, 0.5, 1.0, 0.15, -2.0], np.float32), nnz)
+    rp, c, v, st = _run(ctx, pos, vals, B, V)
+    rp0, c0, v0 = coo_to_csr(pos, vals, B, V)
+    assert st == 0
+    assert np.array_equal(rp, rp0) and np.array_equal(c, c0) and np.array_equal(v.view(np.uint32), v0.view(np.uint32))
+    ctx.close()
+
+
+def test_reader_shaped_feed_two_row_sorted_segments_and_broadcast_value():
+    """data_reader layout: tracks rows 0..B-1 then artists rows 0..B-1 (y_positions), values = ONE scalar."""
+    ctx = _lib.Context(0)
+    from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists
+    B, nt, na = 250, 5000, 900
+    pos, ones, _ = make_playlists(B, nt, na, seed=8)
+    for vals in (ones, np.ones(1, np.float32)):
+        rp, c, v, st = _run(ctx, pos, vals, B, nt + na)
+        rp0, c0, v0 = coo_to_csr(pos, vals, B, nt + na)
+        assert st == 0 and np.array_equal(rp, rp0) and np.array_equal(c, c0) and np.array_equal(v, v0)
+    ctx.close()
+
+
+def test_row_longer_than_the_lds_buffer_and_last_wins():
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(5)
+    n = 6000                                    # > 4096 entries in ONE row: the global-memory path
+    cols = rng.integers(0, 3000, n)
+    pos = np.stack([np.full(n, 2), cols], 1)
+    pos = np.concatenate([pos, [[0, 7], [0, 7], [0, 7], [3, 1]]], 0)
+    vals = np.concatenate([rng.random(n).astype(np.float32), np.array([1.0, 0.0, 0.25, 0.0], np.float32)])
+    rp, c, v, st = _run(ctx, pos, vals, 4, 3000)
+    rp0, c0, v0 = coo_to_csr(pos, vals, 4, 3000)
+    assert st == 0 and np.array_equal(rp, rp0) and np.array_equal(c, c0) and np.array_equal(v, v0)
+    assert rp[1] - rp[0] == 1 and v[0] == np.float32(0.25)      # the LAST of the three (0,7) entries
+    assert rp[4] - rp[3] == 0                                   # an explicit zero is dropped
+    ctx.close()
+
+
+def test_out_of_range_entries_are_flagged_and_skipped():
+    ctx = _lib.Context(0)
+    pos = np.array([[0, 1], [5, 2], [1, 99], [1, 3], [-1, 0]], np.int64)
+    rp, c, v, st = _run(ctx, pos, np.ones(5, np.float32), 3, 10)
+    assert st == 1
+    assert rp.tolist() == [0, 1, 2, 2] and c.tolist() == [1, 3]
+    with pytest.raises(ValueError):
+        coo_to_csr(pos, np.ones(5, np.float32), 3, 10)
+    ctx.close()
+
+
+def test_model_paths_agree_between_device_and_host_feed_builders():
+    from spotify_recsys_challenge_2018_amd.models.DAEs import DAE_tied
+    from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists
+
+    class C:
+        save = "/tmp/_csr_unused"; batch = 40; n_input = 2300; hidden = 64; lr = 0.01; reg_lambda = 0.0
+        n_tracks = 2000
+    a = DAE_tied(C()); a.fit()
+    pos, ones, seeds = make_playlists(C.batch, 2000, 300, seed=11)
+    pos = np.concatenate([pos, pos[:50]], 0); ones = np.concatenate([ones, ones[:50] * 0.5])   # duplicates
+    a.device_csr = True
+    i1, s1 = a.recommend(pos, ones, seeds, k=200)
+    a.device_csr = False
+    i2, s2 = a.recommend(pos, ones, seeds, k=200)
+    assert np.array_equal(i1, i2) and np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+    a.device_csr = True
+    with pytest.raises(ValueError):
+        a.recommend(np.array([[0, 5], [1, 99999]]), np.ones(2, np.float32), [[5], []] + [[]] * 38, k=10)
