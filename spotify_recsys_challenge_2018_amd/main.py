@@ -26,31 +26,64 @@ def _truth(text):
     return str(text).strip().lower() in ("1", "true", "yes", "on")
 
 
+def _seeds(text):
+    return ['test-' + t for t in _csv(text)]
+
+
+def _floats(text):
+    return _csv(text, float)
+
+
+def _ints(text):
+    return _csv(text, int)
+
+
+# config.ini schema (reference main.py:12-94) as data: section -> (attribute, key, cast).
+# "@dir" / "@result" casts join the value onto the run directory / the result directory.
+_SCHEMA = {
+    'BASE': (('data_dir', 'data_dir', str), ('result_dir', 'result_dir', str), ('testsize', 'testsize', int),
+             ('verbose', 'verbose', _truth)),
+    'DAE': (('epochs', 'epochs', int), ('batch', 'batch', int), ('lr', 'lr', float),
+            ('reg_lambda', 'reg_lambda', float), ('test_seed', 'test_seed', _seeds),
+            ('update_seed', 'update_seed', _seeds), ('input_kp', 'input_kp', _floats), ('kp', 'keep_prob', float),
+            ('firstN', 'firstN_range', _floats), ('initval', 'initval', '@dir'), ('save', 'save', '@dir'),
+            ('hidden', 'hidden', int)),
+    'PRETRAIN': (('epochs', 'epochs', int), ('batch', 'batch', int), ('lr', 'lr', float),
+                 ('reg_lambda', 'reg_lambda', float), ('save', 'save', '@dir')),
+    'TITLE': (('title_epochs', 'epochs', int), ('title_batch', 'batch', int), ('title_lr', 'lr', float),
+              ('title_input_kp', 'input_kp', _floats), ('title_kp', 'title_kp', str),
+              ('title_test_seed', 'test_seed', _seeds), ('title_update_seed', 'update_seed', _seeds),
+              ('char_emb', 'char_emb', int), ('char_model', 'char_model', str), ('DAEval', 'DAEval', '@dir'),
+              ('title_save', 'save', '@dir')),
+    'CHALLENGE': (('challenge_data', 'challenge_data', str), ('result', 'result', '@result'),
+                  ('batch', 'batch', int)),
+}
+
+
 class Conf:
-    """Plain attribute bag the drivers and models read (reference main.py:12-94)."""
+    """Plain attribute bag the drivers and models read."""
 
     def __init__(self, dir, ini):
         self.dir = dir
         self.ini = ini
-        base = ini['BASE']
-        self.data_dir = base['data_dir']
-        self.result_dir = base['result_dir']
-        self.testsize = int(base['testsize'])
-        self.verbose = _truth(base['verbose'])
+        self._load('BASE')
+
+    def _load(self, section):
+        sec = self.ini[section]
+        for attr, key, cast in _SCHEMA[section]:
+            raw = sec[key]
+            if cast == '@dir':
+                val = os.path.join(self.dir, raw)
+            elif cast == '@result':
+                val = os.path.join(self.result_dir, raw)
+            else:
+                val = cast(raw)
+            setattr(self, attr, val)
+        return sec
 
     def set_dae_conf(self):
-        s = self.ini['DAE']
-        self.epochs, self.batch = int(s['epochs']), int(s['batch'])
-        self.lr, self.reg_lambda = float(s['lr']), float(s['reg_lambda'])
-        self.test_seed = ['test-' + t for t in _csv(s['test_seed'])]
-        self.update_seed = ['test-' + t for t in _csv(s['update_seed'])]
-        self.input_kp = _csv(s['input_kp'], float)
-        self.kp = float(s['keep_prob'])
-        self.firstN = _csv(s['firstN_range'], float)
+        self._load('DAE')
         self._check_firstN(self.firstN)
-        self.initval = os.path.join(self.dir, s['initval'])
-        self.save = os.path.join(self.dir, s['save'])
-        self.hidden = int(s['hidden'])
         self.mode = 'dae'
 
     @staticmethod
@@ -68,38 +101,21 @@ class Conf:
             assert lo >= 1 and float(lo).is_integer() and float(hi).is_integer()
 
     def set_pretrain_conf(self):
-        s = self.ini['PRETRAIN']
-        self.epochs, self.batch = int(s['epochs']), int(s['batch'])
-        self.lr, self.reg_lambda = float(s['lr']), float(s['reg_lambda'])
+        self._load('PRETRAIN')
         self.is_pretrain = True
-        self.save = os.path.join(self.dir, s['save'])
         self.mode = 'pretrain'
 
     def set_title_conf(self):
-        """[TITLE] (main.py:58-86).  Only the fields the scoring path needs are acted on: the
-        title scorers (Char-CNN / Char-LSTM) are out of scope."""
-        s = self.ini['TITLE']
-        self.title_epochs, self.title_batch = int(s['epochs']), int(s['batch'])
-        self.title_lr = float(s['lr'])
-        self.title_input_kp = _csv(s['input_kp'], float)
-        self.title_kp = s['title_kp']
-        self.title_test_seed = ['test-' + t for t in _csv(s['test_seed'])]
-        self.title_update_seed = ['test-' + t for t in _csv(s['update_seed'])]
-        self.char_emb = int(s['char_emb'])
-        self.char_model = s['char_model']
+        """[TITLE] (main.py:58-86).  Parsed for compatibility: the title scorers (Char-CNN / Char-LSTM)
+        are out of scope; --challenge takes the frozen DAE weights `DAEval` from here."""
+        sec = self._load('TITLE')
         if self.char_model == 'Char_CNN':
-            self.filter_num = int(s['filter_num'])
-            self.filter_size = _csv(s['filter_size'], int)
-        self.DAEval = os.path.join(self.dir, s['DAEval'])
-        self.title_save = os.path.join(self.dir, s['save'])
+            self.filter_num = int(sec['filter_num'])
+            self.filter_size = _ints(sec['filter_size'])
 
-    def set_challenge_oonf(self):          # (sic) reference spelling, main.py:88
-        if not os.path.isdir(self.result_dir):
-            os.mkdir(self.result_dir)
-        s = self.ini['CHALLENGE']
-        self.challenge_data = s['challenge_data']
-        self.result = os.path.join(self.result_dir, s['result'])
-        self.batch = int(s['batch'])
+    def set_challenge_oonf(self):          # (sic) the reference's spelling, main.py:88
+        os.makedirs(self.result_dir, exist_ok=True)
+        self._load('CHALLENGE')
 
     set_challenge_conf = set_challenge_oonf
 

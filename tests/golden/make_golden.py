@@ -97,6 +97,21 @@ def main():
     train = json.load(open(os.path.join(DATA, "train")))
     n_tracks = len(train["track_uri2id"])
 
+    # the inputs of that preprocessing run travel too (gzip), so that this repo's own spotify_reader can
+    # be checked byte for byte against the files the reference wrote (tests/test_preprocess_cpu.py)
+    import gzip
+    os.makedirs(os.path.join(HERE, "mpd"), exist_ok=True)
+    for name in ("mpd.slice.0-59.json", "mpd.slice.60-99.json", "challenge_set.json"):
+        with open(os.path.join(tmp, name), "rb") as fi, gzip.GzipFile(os.path.join(HERE, "mpd", name + ".gz"), "wb",
+                                                                       mtime=0) as fo:
+            fo.write(fi.read())
+    titles = ["Chill #1 vibes!", "ROCK & roll_2", "  a..b,,c  ", "Summer/Fun <3 + more - 2018", "ÀÉÎõü ok",
+              "x" * 40, "", "1234567890/<>+-", "Tabs\tand\nnewlines", "UPPER lower MiXeD (feat. Someone) [live]"]
+    with open(os.path.join(HERE, "expected_titles.json"), "w") as f:
+        json.dump([{"title": t, "normalized": sr.normalize_name(t),
+                    "ixs_raw": sr.change_title2ixs(t), "ixs_norm": sr.change_title2ixs(sr.normalize_name(t))}
+                   for t in titles], f)
+
     # test split in the layout the reference's READER unpacks (data_reader.py:158):
     # [seed, seed_art, answer, seed_cls, answer_cls]
     test_pl = []

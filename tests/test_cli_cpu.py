@@ -54,3 +54,25 @@ def test_missing_dir_or_config_is_reported(tmp_path, capsys, monkeypatch):
     os.mkdir(tmp_path / "d")
     assert cli.main(["--dir", "d", "--dae"]) == 0
     assert "config.ini" in capsys.readouterr().out
+
+
+def test_merge_results_writes_what_pandas_would(tmp_path):
+    """merge_results.py of the reference goes through pandas; the csv-module version must write the
+    same bytes (header row, rows in file order, ragged rows padded with empty cells)."""
+    import pickle
+    import pandas as pd
+    from spotify_recsys_challenge_2018_amd import merge_results as mr
+    d = tmp_path / "challenge_results"
+    d.mkdir()
+    a = [[1000, "spotify:track:a", "spotify:track:b,c"], [1001, "spotify:track:d", 'spotify:track:"q"']]
+    b = [[7, "spotify:track:e"]]
+    with open(d / "0_cat", "wb") as f:
+        pickle.dump(a, f)
+    with open(d / "1_cat", "wb") as f:
+        pickle.dump(b, f)
+    out = tmp_path / "results.csv"
+    total = mr.merge(str(d), str(out))
+    assert total[0] == mr.TEAM_ROW and len(total) == 4
+    want = tmp_path / "want.csv"
+    pd.DataFrame([mr.TEAM_ROW] + a + b).to_csv(want, index=False, header=False)
+    assert out.read_bytes() == want.read_bytes()
