@@ -2,6 +2,7 @@
 // Context object, error plumbing, canonical scalar device functions, kernel launcher prototypes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,6 +71,7 @@ struct dae_ctx {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
     size_t prof_used = 0;
+    bool prof_armed = false;           // the next decode launch takes prof_ev[prof_used], [prof_used+1]
 };
 
 extern thread_local std::string g_dae_create_err;

@@ -833,8 +833,15 @@ int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
-                       ctx->stream, p);
+    if (ctx->prof_armed) {
+        hipExtLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
+                              ctx->stream, ctx->prof_ev[ctx->prof_used], ctx->prof_ev[ctx->prof_used + 1], 0, p);
+        ctx->prof_armed = false;
+        ctx->prof_used += 2;
+    } else {
+        hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
+                           ctx->stream, p);
+    }
     DAE_CHECK_LAUNCH(ctx, "decode_f32_kernel");
     return DAE_OK;
 }
@@ -1121,10 +1128,18 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->prof_armed) {
+            e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
+            ctx->prof_armed = false;
+            ctx->prof_used += 2;
+        }
         if (g.R_TILE == 256)
-            hipLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 8, 16, 4>), dim3(g.grid), dim3(256), lds, ctx->stream, p);
+            hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 8, 16, 4>), dim3(g.grid), dim3(256), lds,
+                                  ctx->stream, e0, e1, 0, p);
         else
-            hipLaunchKernelGGL((decode_bf16_h256_filter_kernel<2, 4, 16, 4>), dim3(g.grid), dim3(256), lds, ctx->stream, p);
+            hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<2, 4, 16, 4>), dim3(g.grid), dim3(256), lds,
+                                  ctx->stream, e0, e1, 0, p);
         DAE_CHECK_LAUNCH(ctx, "decode_bf16_h256_filter_kernel");
         return DAE_OK;
     }
