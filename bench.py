@@ -399,6 +399,35 @@ def main():
                                          "TensorFlow unavailable: this is the CPU restatement, not TF1"
                                          % (ns, V, k, cpu_s),
                                "host_cpus": os.cpu_count(), "gpu_matches_oracle_bitwise": ok}
+        # the reference's own DENSE formulation on all host cores: multi-hot matrix x W_enc,
+        # h x W_dec^T through the BLAS numpy links, then the literal argsort + list.remove + [:500] per row
+        try:
+            from oracle import dae_numpy as dn
+            nd = min(256, B)
+            r_d = rp[nd]
+            pos_d = np.stack([np.repeat(np.arange(nd), np.diff(rp[: nd + 1])), col[:r_d]], 1)
+            t0 = time.perf_counter()
+            x_d = dn.sparse_to_dense(pos_d, val[:r_d], nd, V)
+            _, _, z_d = dn.forward(x_d, W_enc, b_enc, W_dec, b_dec)
+            y_d = dn.sigmoid(z_d)[:, :n_tracks]
+            cand_d = [dn.cand_generate(y_d[i], sc[srp[i]:srp[i + 1]].tolist(), k) for i in range(nd)]
+            dense_s = time.perf_counter() - t0
+            gi = idx[:nd].cpu().numpy()
+            agree = float(np.mean([len(set(cand_d[i]) & set(gi[i].tolist())) / float(k) for i in range(nd)]))
+            try:
+                import threadpoolctl
+                thr = max([p_["num_threads"] for p_ in threadpoolctl.threadpool_info()] or [1])
+            except Exception:
+                thr = os.cpu_count()
+            out["cpu_baseline"]["dense_numpy"] = {
+                "value": round(nd / dense_s, 2), "unit": "playlists/s", "cores": thr,
+                "sample": "%d playlists, oracle/dae_numpy.py: dense multi-hot matmuls (BLAS threads) + the "
+                          "reference's argsort/list.remove/[:500] per row, %.1f s" % (nd, dense_s),
+                "top500_overlap_with_gpu": round(agree, 4),
+                "note": "sigmoid saturates to 1.0 in fp32 for the most popular tracks, so the dense path ranks "
+                        "ties by numpy's argsort order; overlap is of index SETS"}
+        except Exception as e:                      # never let the extra row break the contract line
+            out["cpu_baseline"]["dense_numpy"] = {"error": repr(e)}
     elif args.check and rank == 0:
         pass
 
