@@ -278,23 +278,39 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     u64 tmax = 0ull;                                             // this thread's largest key
     {
         u64 mn = ~0ull, mx = 0ull;
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
-            const u64 ck = ckey(z, colv, in);
-            const bool v = ck != 0ull;
-            const u64 bal = __ballot(v);
-            if (bal) {
-                const int leader = __ffsll((long long)__ballot(1)) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
-                base = __shfl(base, leader);
-                if (v) {
-                    const unsigned slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (slot < (unsigned)key_cap) keys[slot] = ck;
+        if (key_cap > 0) {
+            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+                const u64 ck = ckey(z, colv, in);
+                const bool v = ck != 0ull;
+                const u64 bal = __ballot(v);
+                if (bal) {
+                    const int leader = __ffsll((long long)__ballot(1)) - 1;
+                    unsigned base = 0;
+                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                    base = __shfl(base, leader);
+                    if (v) {
+                        const unsigned slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (slot < (unsigned)key_cap) keys[slot] = ck;
+                        mn = ck < mn ? ck : mn;
+                        mx = ck > mx ? ck : mx;
+                    }
+                }
+            });
+        } else {
+            // nothing is cached: count, min and max only -- one atomic per wave instead of one per element group
+            unsigned cnt = 0;
+            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+                const u64 ck = ckey(z, colv, in);
+                if (ck != 0ull) {
+                    ++cnt;
                     mn = ck < mn ? ck : mn;
                     mx = ck > mx ? ck : mx;
                 }
-            }
-        });
+            });
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        }
         tmax = mx;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __syncthreads();
     if (dbg_stop == 2) return;
     const unsigned m = s_cnt;                                   // valid elements
-    const bool in_lds = m <= (unsigned)key_cap;                 // all of them were kept in LDS
+    const bool in_lds = key_cap > 0 && m <= (unsigned)key_cap;  // all of them were kept in LDS
     unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;        // outputs of the row (final after seed removal)
     const unsigned k_sel = seed_blind ? (unsigned)(k + ns) : (unsigned)k;
     const unsigned k_rank = m < k_sel ? m : k_sel;               // rank the narrowing stages cut at
