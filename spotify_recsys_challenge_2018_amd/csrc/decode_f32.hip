@@ -63,8 +63,6 @@ struct DecP {
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
     // loss epilogue
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
-    int dbg_noepi;
-    int dbg_stagger;       // second wave group start delay, in units of 1024 cycles
 };
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
@@ -125,13 +123,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         }
     }
 
-    // Two waves per SIMD do the same work per tile and would stay in lockstep (both multiplying, then
-    // both in the per-tile scalar/VALU work with the matrix pipe idle): hold the second group back by
-    // about half a tile so that one wave's overhead falls under the other's MFMAs.
-    if (NW == 8 && wave >= 4) {
-        const int st = p.dbg_stagger;
-        for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(16);       // 16 * 64 cycles each
-    }
     float loss_acc = 0.0f;
     // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
     // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
@@ -282,15 +273,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
         const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
 
-        if (p.dbg_noepi & 1) {
-            // experiment: upper bound of what hiding the epilogue could buy (results are garbage)
-            float keep = 0.f;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) keep += acc[rb][e];
-            if (keep == 12345.678f) p.loss_part[0] = keep;      // never true: keeps the MFMAs alive
-        } else if (EPI == EPI_DENSE) {
+        if (EPI == EPI_DENSE) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
@@ -851,7 +834,6 @@ int launch_decode_rb(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
     // the shipped configs all use hidden = 256 (config.ini:12): G = 32 gets the unrolled body
     if (g.R_TILE == 128 && p.G == 32) {
-        if (g.waves == 8) return launch_decode<4, EPI, 32, 8, DT_F32>(ctx, g, p);
         return launch_decode<4, EPI, 32, 4, DT_F32>(ctx, g, p);
     }
     if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "bad wave count %d", g.waves);
@@ -904,10 +886,6 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     p.col_lo = pk.col_lo;
     p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg; p.Bpad = g.Bpad;
     p.ts = ts;
-    static const int noepi = getenv("DAE_DBG_NOEPI") ? atoi(getenv("DAE_DBG_NOEPI")) : 0;
-    p.dbg_noepi = noepi;
-    static const int stg = getenv("DAE_STAGGER") ? atoi(getenv("DAE_STAGGER")) : 0;   // no effect measured
-    p.dbg_stagger = stg;
     return DAE_OK;
 }
 
@@ -939,13 +917,9 @@ dae_rowgeom dae_row_geometry(int B, int Hp)
     if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
     g.nb_rg = nb;
     g.grid = g.n_rg * nb;
-    // waves per workgroup: 4 = one per SIMD (measured 505k vs 465k playlists/s against 8 = two per
-    // SIMD on the hidden=256 body, profiles/r01_notes.md).  DAE_DECODE_WAVES=8 re-enables the A/B.
+    // one wave per SIMD: with 4 independent accumulators it saturates the fp32 matrix pipe (two per SIMD
+    // measured slower, profiles/r01_notes.md)
     g.waves = 4;
-    if (const char* e = getenv("DAE_DECODE_WAVES")) {
-        const int w = atoi(e);
-        if ((w == 4 || w == 8) && rt == 128 && Hp == 256) g.waves = w;
-    }
     return g;
 }
 
