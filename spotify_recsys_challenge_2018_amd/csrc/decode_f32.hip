@@ -411,6 +411,199 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     }
 }
 
+// ---- fp32, hidden = 256, filter epilogue (phase B of the fused path): the generic kernel above with
+// one addition, TAIL BALANCE.  A launch of n tiles over n_ws wave slots runs floor(n / n_ws) whole rounds
+// and a last round with `rem` tiles; when that round is at most half full (222 of 512 slots at batch 256,
+// i.e. 10 rounds of time for 9.43 rounds of work) each of its tiles is split between TWO waves by row
+// blocks (128 playlists -> 2 x 64), so the round costs half a tile time.  The k chain of every output is
+// untouched (bit-exact), only which wave owns which row block changes.
+template <int N>
+struct IntC { static constexpr int value = N; };
+
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const DecP p)
+{
+    constexpr int RB = 4, G = 32, NW = 4, R_TILE = 128;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem_b = blockIdx.x % gs;
+    const int rg = rem_b / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem_b % DAE_NUM_XCD);
+
+    constexpr int n_h4 = RB * 64 * G;
+    {
+        const float4* src = p.hp + (size_t)rg * n_h4;
+        constexpr int NT = NW * 64;
+#pragma unroll
+        for (int i0 = 0; i0 < n_h4; i0 += 8 * NT) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * NT + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lds4[i0 + u * NT + tid] = v[u];
+        }
+    }
+    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    if (tid < R_TILE) lcnt[tid] = 0;
+    __syncthreads();
+
+    float tau_r[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rg * R_TILE + rb * 32 + j;
+        tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
+    }
+
+    // this wave's work: whole tiles ws + r * n_ws (r < R), then possibly one tile -- or half of one -- of
+    // the last round
+    const int n_items = p.ts.n_items;
+    const int n_ws = p.nb_rg * NW;
+    const int ws = wave * p.nb_rg + bir;
+    const int R = n_items / n_ws, rem = n_items - R * n_ws;
+    const bool split = rem > 0 && 2 * rem <= n_ws;
+    const int n_it = R + (ws < (split ? 2 * rem : rem) ? 1 : 0);
+    auto item_at = [&](int r) {
+        r = r < n_it - 1 ? r : n_it - 1;
+        return r < R ? ws + r * n_ws : R * n_ws + (split ? (ws >> 1) : ws);
+    };
+
+    float4 wb0, wb1, wb2, wb3;
+    float4 bA[RB], bB[RB];
+    int t_cur = 0, t_nxt = 0;
+    if (n_it > 0) {
+        t_cur = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_at(0)));
+        t_nxt = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_at(1)));
+        const float4* w0 = p.Wp + (size_t)t_cur * G * 64 + lane;
+        wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+    }
+
+    for (int r = 0; r < n_it; ++r) {
+        const int t = t_cur;
+        const float4* wp = p.Wp + (size_t)t * G * 64 + lane;
+        const float4* wn = p.Wp + (size_t)t_nxt * G * 64 + lane;
+        const int t_nn_v = tile_of_item(p.ts, item_at(r + 2));        // two tiles ahead (see decode_f32_kernel)
+        const float* bp = p.bias + (size_t)t * 32 + 4 * hi;
+        float4 bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *reinterpret_cast<const float4*>(bp + 8 * qd);
+        const int tcol0 = t * 32 + 4 * hi;
+        const bool rankable = (t * 32 < p.ncols) && (p.col_lo + t * 32 < p.n_valid_col);
+
+        // one tile over row blocks [R0, R0 + RN): GEMM with the 4-deep W ring, then the filter epilogue
+        auto tile = [&](auto r0c, auto rnc) {
+            constexpr int R0 = decltype(r0c)::value, RN = decltype(rnc)::value;
+            f32x16 acc[RN];
+#pragma unroll
+            for (int i = 0; i < RN; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+#define DAE_STEPR(WB, PF, BC, BN, GNEXT)                                                              \
+    {                                                                                                 \
+        const float4 a = WB;                                                                          \
+        WB = *(PF);                                                                                   \
+        const float4* hl = lds4 + (size_t)(GNEXT) * (RB * 64) + lane;                                 \
+        _Pragma("unroll") for (int i = 0; i < RN; ++i) BN[R0 + i] = hl[(R0 + i) * 64];                \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int i = 0; i < RN; ++i)                                                \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, BC[R0 + i].x, acc[i], 0, 0, 0);        \
+        _Pragma("unroll") for (int i = 0; i < RN; ++i)                                                \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, BC[R0 + i].y, acc[i], 0, 0, 0);        \
+        _Pragma("unroll") for (int i = 0; i < RN; ++i)                                                \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, BC[R0 + i].z, acc[i], 0, 0, 0);        \
+        _Pragma("unroll") for (int i = 0; i < RN; ++i)                                                \
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, BC[R0 + i].w, acc[i], 0, 0, 0);        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+            int g = 0;
+#pragma unroll
+            for (; g < G - 4; g += 4) {
+                const float4* pf = wp + (size_t)(g + 4) * 64;
+                DAE_STEPR(wb0, pf,       bA, bB, g + 1)
+                DAE_STEPR(wb1, pf + 64,  bB, bA, g + 2)
+                DAE_STEPR(wb2, pf + 128, bA, bB, g + 3)
+                DAE_STEPR(wb3, pf + 192, bB, bA, g + 4)
+            }
+            DAE_STEPR(wb0, wn,       bA, bB, g + 1)
+            DAE_STEPR(wb1, wn + 64,  bB, bA, g + 2)
+            DAE_STEPR(wb2, wn + 128, bA, bB, g + 3)
+            // the next tile may own OTHER row blocks (a full tile's successor is never narrower than
+            // ... a half tile is always last): fetch group 0 for ALL row blocks
+            {
+                const float4 a = wb3;
+                wb3 = wn[192];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bB[R0 + i].x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bB[R0 + i].y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bB[R0 + i].z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RN; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bB[R0 + i].w, acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef DAE_STEPR
+            if (!rankable) return;
+#pragma unroll
+            for (int i = 0; i < RN; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int rb = R0 + i;
+                const float tv = tau_r[rb];
+                float z[16];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    z[4 * qd + 0] = acc[i][4 * qd + 0] + bq[qd].x;
+                    z[4 * qd + 1] = acc[i][4 * qd + 1] + bq[qd].y;
+                    z[4 * qd + 2] = acc[i][4 * qd + 2] + bq[qd].z;
+                    z[4 * qd + 3] = acc[i][4 * qd + 3] + bq[qd].w;
+                }
+                float mx = z[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, z[e]);
+                if (mx >= tv) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int lc = tcol0 + (e & 3) + 8 * (e >> 2);
+                        if (z[e] >= tv && lc < p.ncols && p.col_lo + lc < p.n_valid_col) m |= 1u << e;
+                    }
+                    if (m) {
+                        const int rloc = rb * 32 + j;
+                        int base = atomicAdd(&lcnt[rloc], __popc(m));
+                        uint2* dst = p.cand + ((size_t)bir * p.Bpad + rg * R_TILE + rloc) * (size_t)p.cap;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (m & (1u << reg)) {
+                                const int lc = tcol0 + (reg & 3) + 8 * (reg >> 2);
+                                dst[base++] = make_uint2(__float_as_uint(z[reg]), (unsigned)(p.col_lo + lc));
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        if (!(split && r == R)) tile(IntC<0>{}, IntC<RB>{});
+        else if ((ws & 1) == 0) tile(IntC<0>{}, IntC<RB / 2>{});
+        else tile(IntC<RB / 2>{}, IntC<RB / 2>{});
+
+        t_cur = t_nxt;
+        t_nxt = __builtin_amdgcn_readfirstlane(t_nn_v);
+    }
+    __syncthreads();
+    if (tid < R_TILE) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + tid] = lcnt[tid];
+}
+
 // ---- bf16, hidden = 256, filter epilogue (phase B of the fused path) --------------------------------
 // One wave per SIMD owns NT column tiles x RB row blocks (8 accumulators = 128 registers):
 //   <NT = 1, RB = 8>  256-playlist row groups: every W fragment (1 KiB from L2 / HBM) feeds 8 MFMAs.
@@ -1092,6 +1285,25 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
+    static const bool f32_generic = getenv("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body
+    if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && g.waves == 4 && !f32_generic) {
+        const size_t lds = (size_t)4 * 64 * 32 * sizeof(float4) + 128 * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_f32_h256_filter_kernel<0>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->prof_armed) {
+            e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
+            ctx->prof_armed = false;
+            ctx->prof_used += 2;
+        }
+        hipExtLaunchKernelGGL(decode_f32_h256_filter_kernel<0>, dim3(g.grid), dim3(256), lds, ctx->stream, e0, e1, 0, p);
+        DAE_CHECK_LAUNCH(ctx, "decode_f32_h256_filter_kernel");
+        return DAE_OK;
+    }
     if (bf16_fast_filter(g, dtype, p.G)) {
         const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * sizeof(int);
         static bool attr_set = false;
