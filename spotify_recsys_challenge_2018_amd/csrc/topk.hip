@@ -35,6 +35,7 @@ typedef unsigned long long u64;
 
 struct DenseSrc {
     static constexpr int kSegs = 0;
+    static constexpr bool kFixedSlots = true;      // for_each visits q = tid, tid + 1024, ... in order
     dae_dense_src s;
     int max_keys() const { return s.n; }                  // host: most keys a row can hold
     __device__ __forceinline__ void prepare(int, int, int*) const {}
@@ -72,6 +73,7 @@ struct DenseSrc {
 
 struct PairSrc {
     static constexpr int kSegs = TK_MAX_SEG;
+    static constexpr bool kFixedSlots = false;
     dae_pair_group g0, g1;
     int max_keys() const { return 8192; }                 // typical rows are far below; larger rows re-read
     __device__ __forceinline__ int seg_count(const dae_pair_group& g, int seg, int row) const
@@ -153,6 +155,7 @@ struct PairSrc {
 
 struct SoaSrc {
     static constexpr int kSegs = 0;
+    static constexpr bool kFixedSlots = false;
     const float* logit; const int32_t* idx; int G, B, k;
     int max_keys() const { return G * k; }
     __device__ __forceinline__ void prepare(int, int, int*) const {}
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __shared__ unsigned wave_tot[TK_WAVES];
     __shared__ int s_bin;
     __shared__ unsigned s_above;
-    __shared__ unsigned s_cnt, s_cnt2;
+    __shared__ unsigned s_cnt, s_cnt2, s_slots;
     __shared__ u64 s_min, s_max, s_min2;
 
     const int tid = threadIdx.x;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     const int seed_e = a.seed_col ? a.seed_row_ptr[row + 1] : 0;
     const int ns = seed_e - seed_b;
     for (int w = tid; w < bm_words; w += TK_THREADS) bitmap[w] = 0;
-    if (tid == 0) { s_cnt = 0; s_min = ~0ull; s_max = 0ull; }
+    if (tid == 0) { s_cnt = 0; s_min = ~0ull; s_max = 0ull; s_slots = 0; }
     __syncthreads();
     if (!lean && a.seed_col && bm_words > 0) {
         for (int i = seed_b + tid; i < seed_e; i += TK_THREADS) {
@@ -278,7 +281,27 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     u64 tmax = 0ull;                                             // this thread's largest key
     {
         u64 mn = ~0ull, mx = 0ull;
-        if (key_cap > 0) {
+        const int n_src = src.count(row, seg_prefix);
+        if (Src::kFixedSlots && key_cap > 0 && n_src <= key_cap) {
+            // dense source: element q goes to cache slot q (0 = absent) -- no compaction, hence no
+            // ballot / leader atomic / shuffle per element group; the count is one atomic per wave
+            unsigned cnt = 0;
+            int calls = 0;
+            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+                const u64 ck = ckey(z, colv, in);
+                const int slot = tid + TK_THREADS * calls++;
+                if (slot < n_src) keys[slot] = ck;
+                if (ck != 0ull) {
+                    ++cnt;
+                    mn = ck < mn ? ck : mn;
+                    mx = ck > mx ? ck : mx;
+                }
+            });
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+            if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
+            if (tid == 0) s_slots = (unsigned)n_src;
+        } else if (key_cap > 0) {
             src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
                 const bool v = ck != 0ull;
@@ -323,7 +346,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     __syncthreads();
     if (dbg_stop == 2) return;
     const unsigned m = s_cnt;                                   // valid elements
-    const bool in_lds = key_cap > 0 && m <= (unsigned)key_cap;  // all of them were kept in LDS
+    const unsigned n_cached = s_slots ? s_slots : m;            // cache slots in use (fixed slots: the source size)
+    const bool in_lds = key_cap > 0 && n_cached <= (unsigned)key_cap;   // all of them were kept in LDS
     unsigned k_eff = m < (unsigned)k ? m : (unsigned)k;        // outputs of the row (final after seed removal)
     const unsigned k_sel = seed_blind ? (unsigned)(k + ns) : (unsigned)k;
     const unsigned k_rank = m < k_sel ? m : k_sel;               // rank the narrowing stages cut at
@@ -332,9 +356,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     // waves (key == 0 for lanes without an element) so it may use wave-level aggregation.
     auto for_keys = [&](auto f) {
         if (in_lds) {
-            for (unsigned i0 = 0; i0 < m; i0 += TK_THREADS) {
+            for (unsigned i0 = 0; i0 < n_cached; i0 += TK_THREADS) {
                 const unsigned i = i0 + tid;
-                f(i < m ? keys[i] : 0ull);
+                f(i < n_cached ? keys[i] : 0ull);
             }
         } else {
             src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
@@ -440,9 +464,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (in_lds) {
-        for (unsigned i0 = 0; i0 < m; i0 += TK_THREADS) {
+        for (unsigned i0 = 0; i0 < n_cached; i0 += TK_THREADS) {
             const unsigned i = i0 + tid;
-            const u64 ck = i < m ? keys[i] : 0ull;
+            const u64 ck = i < n_cached ? keys[i] : 0ull;
             const bool v = ck != 0ull && ck >= lo;
             const u64 bal = __ballot(v);
             if (bal) {
