@@ -110,3 +110,30 @@ def test_bf16_vs_fp32_r_precision_on_trained_model(tmp_path, capsys):
         assert abs(res["f32"] - res["bf16"]) <= 0.02, res
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("V,nt,B,k", [(40000, 33000, 1, 500), (40037, 39990, 37, 500), (52000, 52000, 129, 100),
+                                      (33000, 20011, 257, 500), (70000, 64000, 1024, 500), (36000, 30000, 128, 1)])
+def test_bf16_fused_equals_unfused_across_shapes(ctx, V, nt, B, k):
+    """The dedicated bf16 phase-B kernel (tile pairs, ragged last pair, bias through the matrix pipe)
+    against the dense bf16 path + the same ranking: identical indices and scores for every batch shape."""
+    import torch
+    H = 256
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=5, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=6)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc if sc.size else np.zeros(1, np.int32))]
+    ctx.prepack_decoder(d[5], d[6], dtype=BF)
+    s16 = torch.empty((B, k), device="cuda"); i16 = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s16, i16, dtype=BF)
+    assert ctx.last_plan()["fused"] == 1
+    h = torch.empty((B, H), device="cuda")
+    ctx.encode(d[0], d[1], d[2], d[3], d[4], h)
+    z = torch.empty((B, V), device="cuda")
+    ctx.decode_dense(h, z, apply_sigmoid=False, dtype=BF)
+    s_u = torch.empty_like(s16); i_u = torch.empty_like(i16)
+    ctx.topk_dense(z, nt, 0, d[7], d[8], k, s_u, i_u)
+    assert torch.equal(i16, i_u) and torch.equal(s16, s_u)
+    z_ref = oracle.decode(h.cpu().numpy(), W_dec, b_dec, bf16=True)
+    assert np.max(np.abs(z.cpu().numpy() - z_ref)) <= 3e-5
