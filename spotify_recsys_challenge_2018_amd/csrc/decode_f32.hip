@@ -605,15 +605,16 @@ __global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const De
 }
 
 // ---- bf16, hidden = 256, filter epilogue (phase B of the fused path) --------------------------------
-// One wave per SIMD owns NT column tiles x RB row blocks (8 accumulators = 128 registers):
-//   <NT = 1, RB = 8>  256-playlist row groups: every W fragment (1 KiB from L2 / HBM) feeds 8 MFMAs.
-//                     At batch 256 W is then read exactly once; at batch 1024 the L2 -> CU traffic
-//                     (the measured limit of the 128-row kernels: 790 MB per launch, 11 TB/s) halves.
-//   <NT = 2, RB = 4>  128-playlist row groups (batches <= 128): two column tiles share each hidden
-//                     fragment read from LDS.
-// The W ring is 16 steps deep per tile (the whole next tile group streams in while this one is
-// multiplied); tile indices are fetched two groups ahead; the accumulators start at the bias; the
-// epilogue is a max-reduction and one compare per row block unless some lane really passes.
+// A wave owns NT column tiles x RB row blocks.  Measured (profiles/r01_notes.md, us at batch 256 / 1024):
+//   <NT = 1, RB = 4, ring 8, 2 waves per SIMD>  19.9 / 55.7   <- default: 4 accumulators per wave
+//   <NT = 1, RB = 4, ring 16, 1 wave per SIMD>  23.9 / 65.3
+//   <NT = 2, RB = 4, ring 16, 1 wave per SIMD>  25.6 / 61.5   (DAE_BF16_PAIR: a hidden fragment feeds 2 MFMAs)
+//   <NT = 1, RB = 8, ring 16, 1 wave per SIMD>  27.6 / 64.1   (DAE_BF16_RTILE=256: W read once at batch 256)
+//   3 and 4 waves per SIMD spill (168 / 128 registers) and are slower.
+// A micro-benchmark of the inner pattern (scripts/micro/mfma_peak.hip: 4 accumulators, hidden fragments
+// from LDS one step ahead, no global memory) reaches 2.3-2.4 PFLOP/s, so neither LDS nor the MFMA issue
+// limits it; what the real kernel adds is the W ring, tile indices two groups ahead, the bias MFMA and the
+// epilogue (a max-reduction and one compare per row block unless some lane really passes).
 template <int NT, int RB, int QR, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(const DecP p)
 {
@@ -634,13 +635,21 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     {
         const float4* src = p.hp + (size_t)rg * n_h4;
         constexpr int NTH = NW * 64;
+        constexpr int PER = (n_h4 + NTH - 1) / NTH;              // float4 per thread
+        constexpr int CH = PER < 8 ? PER : 8;                    // loads in flight per thread
 #pragma unroll
-        for (int i0 = 0; i0 < n_h4; i0 += 8 * NTH) {
-            float4 v[8];
+        for (int i0 = 0; i0 < PER; i0 += CH) {
+            float4 v[CH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[i0 + u * NTH + tid];
+            for (int u = 0; u < CH; ++u) {
+                const int i = (i0 + u) * NTH + tid;
+                v[u] = src[i < n_h4 ? i : n_h4 - 1];              // unconditional: a guarded write would push v[] to scratch
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) lds4[i0 + u * NTH + tid] = v[u];
+            for (int u = 0; u < CH; ++u) {
+                const int i = (i0 + u) * NTH + tid;
+                if (i0 + u < PER && i < n_h4) lds4[i] = v[u];
+            }
         }
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
@@ -1055,6 +1064,11 @@ int launch_decode_rb_bf16(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
     return dae_fail(ctx, DAE_ERR_ARG, "bad R_TILE %d", g.R_TILE);
 }
 
+bool bf16_pair_variant()
+{
+    static const bool v = getenv("DAE_BF16_PAIR") != nullptr;     // A/B: two column tiles per wave, one wave per SIMD
+    return v;
+}
 // the dedicated phase-B kernel: hidden = 256 (16 steps), one wave per SIMD, 128- or 256-row groups
 bool bf16_fast_filter(const dae_rowgeom& g, int dtype, int G)
 {
@@ -1089,9 +1103,12 @@ int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp)
 {
     const int n_ws = g.nb_rg * g.waves;
     if (bf16_fast_filter(g, dtype, Hp / 16)) {
-        const int nt = g.R_TILE == 256 ? 1 : 2;
+        const bool pair = g.R_TILE != 256 && bf16_pair_variant();
+        const int nt = pair ? 2 : 1;
+        const int nw = (g.R_TILE == 256 || pair) ? 4 : 8;
         const int n_grp = (n_items + nt - 1) / nt;
-        return nt * g.waves * ((n_grp + n_ws - 1) / n_ws);
+        const int n_ws2 = g.nb_rg * nw;
+        return nt * nw * ((n_grp + n_ws2 - 1) / n_ws2);
     }
     return g.waves * ((n_items + n_ws - 1) / n_ws);
 }
@@ -1308,6 +1325,8 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
         const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * sizeof(int);
         static bool attr_set = false;
         if (!attr_set) {
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 4, 8, 8>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<2, 4, 16, 4>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 8, 16, 4>),
@@ -1323,8 +1342,11 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
         if (g.R_TILE == 256)
             hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 8, 16, 4>), dim3(g.grid), dim3(256), lds,
                                   ctx->stream, e0, e1, 0, p);
-        else
+        else if (bf16_pair_variant())
             hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<2, 4, 16, 4>), dim3(g.grid), dim3(256), lds,
+                                  ctx->stream, e0, e1, 0, p);
+        else
+            hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 4, 8, 8>), dim3(g.grid), dim3(512), lds,
                                   ctx->stream, e0, e1, 0, p);
         DAE_CHECK_LAUNCH(ctx, "decode_bf16_h256_filter_kernel");
         return DAE_OK;
