@@ -225,6 +225,26 @@ int dae_train_shard_finish(dae_ctx* ctx, const float* dh,
         float ikp, float kp, uint32_t seed, float reg_lambda,
         float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc);
 
+/* ---- title scorer of the challenge path (models/title_models/Char_CNN.py, models/DAEs.py:153-181) ---- */
+
+/* Char_CNN.py:23-62: titles [B,L] int32 character ids (-1 = padding, embeds to zero) -> embedding [n_char,E]
+ * -> for each of n_sizes filter sizes (host array filter_sizes) a VALID convolution with F filters
+ * (conv_w = the TF variables Conv_W0.. [fs_i, E, 1, F] back to back, conv_b = Conv_b0.. [n_sizes, F]) -> ReLU
+ * -> max over time -> concat -> dropout(keep_prob) -> feat [B, ld] (ld >= n_sizes*F, zero padded so that the
+ * result can go straight into dae_decode_dense as a "hidden" matrix of size ld).  argmax / feat_raw (both
+ * [B, n_sizes*F], nullable) keep the max positions and the pre-dropout features for the backward pass.
+ * The vocabulary-wide output layer sigmoid(feat . Output_W + Output_b) (:64-72) is the decoder GEMM:
+ * dae_prepack_decoder(Output_W^T [V, ld], Output_b) + dae_decode_dense(apply_sigmoid = 1). */
+int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char, int E,
+                       const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F,
+                       float keep_prob, uint32_t seed, float* feat, int64_t ld, int32_t* argmax, float* feat_raw);
+
+/* DAEs.py:180: dae_score[r, c] = title_score[r, c] * w_title[r] + dae_score[r, c] * w_playlist[r] over the first
+ * ncols columns; the weights are DAEs.py:159-162 (x_count = row_sum * input_keep_prob; u / (u + x_count + 1e-10),
+ * x_count / (u + x_count + 1e-10)), computed by the caller from the feed. */
+int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,
+                   const float* w_title, const float* w_playlist, int B, int ncols);
+
 /* TF1 AdamOptimizer update (DAEs.py:102): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr_t*m/(sqrt(v)+eps).  Dense over n elements.
  * t = 1-based step count. */

@@ -17,7 +17,8 @@ EXPORTS = [
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
     "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward",
-    "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_adam_step",
+    "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
+    "dae_mix_scores", "dae_adam_step",
 ]
 
 _lib = None
@@ -70,6 +71,9 @@ def load():
         [vp, vp, vp] + [vp] * 3 + [vp] * 3 + [c_int] * 6 + [c_f, c_u32, c_f] + [vp] * 4)
     lib.dae_train_shard_finish.argtypes = (
         [vp, vp] + [vp] * 3 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 4)
+    lib.dae_title_features.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(ctypes.c_int32),
+                                       c_int, c_int, c_f, c_u32, vp, c_i64, vp, vp]
+    lib.dae_mix_scores.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, c_int, c_int]
     lib.dae_adam_step.argtypes = [vp, vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_int]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes"):

@@ -537,6 +537,29 @@ int dae_train_shard_finish(dae_ctx* ctx, const float* dh,
                                       gW_enc_loc, gb_enc, gW_dec_loc, gb_dec_loc);
 }
 
+int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char, int E,
+                       const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F,
+                       float keep_prob, uint32_t seed, float* feat, int64_t ld, int32_t* argmax, float* feat_raw)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!titles || !emb || !conv_w || !conv_b || !filter_sizes || !feat) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0) return DAE_OK;
+    if (n_char < 1 || F < 1) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
+    if (!(keep_prob > 0.f && keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
+    return dae_launch_title_features(ctx, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F,
+                                     keep_prob, seed, feat, ld, argmax, feat_raw);
+}
+
+int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,
+                   const float* w_title, const float* w_playlist, int B, int ncols)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!title_score || !dae_score || !w_title || !w_playlist) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0 || ncols <= 0) return DAE_OK;
+    if (ld_title < ncols || ld_dae < ncols) return dae_fail(ctx, DAE_ERR_ARG, "leading dimension < %d columns", ncols);
+    return dae_launch_mix_scores(ctx, title_score, ld_title, dae_score, ld_dae, w_title, w_playlist, B, ncols);
+}
+
 int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                   float lr, float beta1, float beta2, float eps, int t)
 {

@@ -237,6 +237,14 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                           int32_t* status);
 
+// title.hip
+int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
+                              int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
+                              int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
+                              int32_t* argmax, float* feat_raw);
+int dae_launch_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_t, float* dae_score, int64_t ld_d,
+                          const float* w_title, const float* w_playlist, int B, int ncols);
+
 // topk.hip
 struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)
     const float* logits; int64_t ld; int n;

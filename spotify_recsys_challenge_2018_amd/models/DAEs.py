@@ -413,3 +413,67 @@ class Session:
                                 g(m.keep_prob, 1.0), g(m.input_keep_prob, 1.0))
             return None, cost
         raise ValueError("unsupported fetches %r" % (fetches,))
+
+
+class DAE_title(DAE):
+    """The challenge-time model (reference DAEs.py:153-201): a FROZEN DAE (its four arrays from `conf.DAEval`,
+    :165-171) whose scores are mixed with the title scorer's,
+
+        y = title_score * w_title + dae_score * w_playlist                                   (:180)
+        x_count = row_sum(x) * input_keep_prob;  w_title = u / (u + x_count + 1e-10);  w_playlist = x_count / (same)
+
+    with u = titles_use in {0, 1} per row (:156-162).  u = 0 gives w_playlist = 1.0f exactly, i.e. the plain
+    DAE -- those batches take the fused scoring path.  With titles the two vocabulary-wide
+    score matrices are materialised and mixed (`dae_mix_scores`), then ranked by `dae_topk_dense`: correct but
+    unfused (fusing the second GEMM into the threshold path is the follow-up)."""
+
+    def __init__(self, conf, title_model):
+        DAE.__init__(self, conf)
+        self.initval_dir = conf.DAEval                    # DAEs.py:157: the frozen weights
+        self.title_model = title_model
+
+    def _row_sums(self, x_positions, x_ones):
+        rp, _c, v = coo_to_csr(x_positions, x_ones, self.n_batch, self.n_input)
+        rows = np.repeat(np.arange(self.n_batch), np.diff(rp))
+        return np.bincount(rows, weights=v.astype(np.float64), minlength=self.n_batch).astype(np.float32)
+
+    def mixed_scores(self, x_positions, x_ones, titles, titles_use, input_keep_prob=1.0, title_keep_prob=1.0,
+                     seed=0):
+        """sess.run(model.y_pred, ...) of the title graph: dense mixed scores [n_batch, n_input] (CUDA tensor)."""
+        import torch
+        self._ensure_packed()
+        h = self.encode(x_positions, x_ones, 1.0, input_keep_prob, seed)
+        y = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=h.device)
+        self.ctx.decode_dense(h, y, apply_sigmoid=True)
+        ts = self.title_model.score(titles, self.n_batch, title_keep_prob, seed)
+        u = np.zeros(self.n_batch, np.float32)
+        tu = np.asarray(titles_use, np.float32).reshape(-1)
+        u[:len(tu)] = tu[:self.n_batch]
+        x_count = self._row_sums(x_positions, x_ones) * np.float32(input_keep_prob)
+        deno = u + x_count + np.float32(1e-10)
+        w_t = self._to_dev((u / deno).astype(np.float32), torch.float32)
+        w_p = self._to_dev((x_count / deno).astype(np.float32), torch.float32)
+        self.ctx.bind_stream()
+        P = _lib._ptr
+        self.ctx.check(self.ctx.lib.dae_mix_scores(self.ctx.h, P(ts), int(ts.stride(0)), P(y), int(y.stride(0)),
+                                                   P(w_t), P(w_p), self.n_batch, self.n_input))
+        return y
+
+    def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None, titles=None, titles_use=None):
+        if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
+            return DAE.recommend(self, x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
+        import torch
+        y = self.mixed_scores(x_positions, x_ones, titles, titles_use)
+        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
+        if sc.size == 0:
+            sc = np.zeros(1, np.int32)
+        d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
+        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=y.device)
+        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=y.device)
+        self.ctx.bind_stream()
+        # the mixed values are probabilities already: rank them as they are (no sigmoid on the way out)
+        self.ctx.topk_dense(y, self.n_tracks, 0, d_srp, d_sc, k, score, idx, out_kind=_lib.DAE_OUT_LOGIT)
+        n_rows = self.n_batch if n_rows is None else n_rows
+        res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
+        self._check_feed()
+        return res
