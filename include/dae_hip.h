@@ -245,6 +245,32 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
 int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,
                    const float* w_title, const float* w_playlist, int B, int ncols);
 
+/* Training of the title variables (main_train.py:214-221 feeds the playlist as x AND y, titles_use = 1; the DAE
+ * arrays are constants, DAEs.py:165-171).  The caller runs the forward pieces -- dae_encode (dropout on) +
+ * dae_decode_dense for the DAE scores, dae_title_features(argmax, feat_raw) + dae_decode_dense(apply_sigmoid = 0)
+ * for the title logits, dae_row_sums for x_count -- and then:
+ *
+ * dae_row_sums: out[r] = reduce_sum of DAEs.py:41, the row sums of the dropped-out input with dae_encode's draws.
+ *
+ * dae_title_loss_backward: cost = mean_rows(weighted BCE of the MIXED score) (DAEs.py:193-195) and the gradients
+ *   of the output layer: gOutput_WT [V, ld] (the transposed layout the library keeps Output_W in), gOutput_b [V],
+ *   and dfeat [B, ld] = d cost / d features (after dropout).  ld % 32 == 0, B <= 256.
+ *
+ * dae_title_conv_backward: dfeat back through dropout, max over time, ReLU, the convolutions and the embedding:
+ *   g_emb [n_char, E], g_conv_w / g_conv_b in the layout of dae_title_features (overwritten).
+ * Then dae_adam_step on each variable. */
+int dae_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
+                 float input_keep_prob, uint32_t seed, float* out);
+int dae_title_loss_backward(dae_ctx* ctx, const float* title_logits, int64_t ld_z, const float* dae_score, int64_t ld_d,
+                            const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                            const float* w_title, const float* w_playlist, int B, int V, int n_batch,
+                            const float* feat, int ld, const float* Output_WT, float* gOutput_WT, float* gOutput_b,
+                            float* dfeat, float* cost_out);
+int dae_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char, int E,
+                            const float* conv_w, const int32_t* filter_sizes, int n_sizes, int F,
+                            const int32_t* argmax, const float* feat_raw, const float* dfeat, int64_t ld,
+                            float keep_prob, uint32_t seed, float* g_emb, float* g_conv_w, float* g_conv_b);
+
 /* TF1 AdamOptimizer update (DAEs.py:102): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
  * m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= lr_t*m/(sqrt(v)+eps).  Dense over n elements.
  * t = 1-based step count. */

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Title path at the reference's shapes ([TITLE] batch = 150, filter sizes 3/5/7/9 x 100, char_emb 50) over the
+170 000-item vocabulary: mixed (unfused) scoring through DAE_title.recommend and one --title training step."""
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spotify_recsys_challenge_2018_amd.models.DAEs import DAE_title          # noqa: E402
+from spotify_recsys_challenge_2018_amd.models.title_models import get_model   # noqa: E402
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights   # noqa: E402
+
+
+def main():
+    import torch
+    nt, na, H, B = 140000, 30000, 256, 150
+    V = nt + na
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    path = "/tmp/_title_dae.pkl"
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        batch = B; n_input = V; n_output = V; n_tracks = nt; hidden = H; lr = 0.001; reg_lambda = 0.0
+        char_emb = 50; strmaxlen = 25; charsize = 41; char_model = 'Char_CNN'; filter_num = 100
+        filter_size = [3, 5, 7, 9]; save = "/tmp/_t_unused"; initval = "NULL"; DAEval = path; title_lr = 0.001
+    mt = get_model(C()); mt.fit()
+    m = DAE_title(C(), mt); m.fit()
+    pos, ones, seeds = make_playlists(B, nt, na, seed=1)
+    rng = np.random.default_rng(0)
+    titles = rng.integers(0, 41, (B, 25)); titles[:, 18:] = -1
+    use = np.ones(B, np.float32)
+    for _ in range(2):
+        m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use)
+    dt = (time.perf_counter() - t0) / n
+    print("DAE_title.recommend (mixed, unfused, host feed -> top-500): %.2f ms per batch of %d = %.0f playlists/s" % (dt * 1e3, B, B / dt))
+    yo = np.ones(len(pos), np.float32)
+    for _ in range(2):
+        m.train_step(pos, yo, pos, yo, 0.8, 0.01, titles=titles, title_keep_prob=0.8)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        m.train_step(pos, yo, pos, yo, 0.8, 0.01, titles=titles, title_keep_prob=0.8)
+    dt = (time.perf_counter() - t0) / n
+    print("--title training step: %.2f ms per batch of %d = %.0f playlists/s" % (dt * 1e3, B, B / dt))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ EXPORTS = [
     "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_adam_step",
+    "dae_mix_scores", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
 ]
 
 _lib = None
@@ -74,6 +74,11 @@ def load():
     lib.dae_title_features.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(ctypes.c_int32),
                                        c_int, c_int, c_f, c_u32, vp, c_i64, vp, vp]
     lib.dae_mix_scores.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, c_int, c_int]
+    lib.dae_row_sums.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp]
+    lib.dae_title_loss_backward.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, c_int, c_int, c_int,
+                                            vp, c_int, vp, vp, vp, vp, vp]
+    lib.dae_title_conv_backward.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, ctypes.POINTER(ctypes.c_int32),
+                                            c_int, c_int, vp, vp, vp, c_i64, c_f, c_u32, vp, vp, vp]
     lib.dae_adam_step.argtypes = [vp, vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_int]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes"):

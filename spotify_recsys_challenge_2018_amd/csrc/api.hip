@@ -560,6 +560,46 @@ int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, flo
     return dae_launch_mix_scores(ctx, title_score, ld_title, dae_score, ld_dae, w_title, w_playlist, B, ncols);
 }
 
+int dae_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
+                 float input_keep_prob, uint32_t seed, float* out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0) return DAE_OK;
+    if (!(input_keep_prob > 0.f && input_keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
+    return dae_launch_row_sums(ctx, row_ptr, col, val, B, input_keep_prob, seed, out);
+}
+
+int dae_title_loss_backward(dae_ctx* ctx, const float* title_logits, int64_t ld_z, const float* dae_score, int64_t ld_d,
+                            const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                            const float* w_title, const float* w_playlist, int B, int V, int n_batch,
+                            const float* feat, int ld, const float* Output_WT, float* gOutput_WT, float* gOutput_b,
+                            float* dfeat, float* cost_out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!title_logits || !dae_score || !y_row_ptr || !w_title || !w_playlist || !feat || !Output_WT || !gOutput_WT ||
+        !gOutput_b || !dfeat || !cost_out)
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0 || V <= 0 || n_batch <= 0 || ld_z < V || ld_d < V) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
+    return dae_launch_title_loss_backward(ctx, title_logits, ld_z, dae_score, ld_d, y_row_ptr, y_col, y_val, w_title,
+                                          w_playlist, B, V, n_batch, feat, ld, Output_WT, gOutput_WT, gOutput_b,
+                                          dfeat, cost_out);
+}
+
+int dae_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char, int E,
+                            const float* conv_w, const int32_t* filter_sizes, int n_sizes, int F,
+                            const int32_t* argmax, const float* feat_raw, const float* dfeat, int64_t ld,
+                            float keep_prob, uint32_t seed, float* g_emb, float* g_conv_w, float* g_conv_b)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!titles || !emb || !conv_w || !filter_sizes || !argmax || !feat_raw || !dfeat || !g_emb || !g_conv_w || !g_conv_b)
+        return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0) return DAE_OK;
+    if (!(keep_prob > 0.f && keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
+    return dae_launch_title_conv_backward(ctx, titles, B, L, emb, n_char, E, conv_w, filter_sizes, n_sizes, F, argmax,
+                                          feat_raw, dfeat, ld, keep_prob, seed, g_emb, g_conv_w, g_conv_b);
+}
+
 int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                   float lr, float beta1, float beta2, float eps, int t)
 {

@@ -229,6 +229,9 @@ int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_r
                                const float* b_dec_loc, int col_lo, int col_hi, int H, int B, int tied,
                                float ikp, float kp, uint32_t seed, float reg_lambda,
                                float* gW_enc_loc, float* gb_enc, float* gW_dec_loc, float* gb_dec_loc);
+int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* h, int H, int B, int V,
+                      float* gW, float* gb);
+int dae_launch_grad_h(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* W, int H, int V, int B, float* dh);
 int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                     float lr_t, float beta1, float beta2, float eps);
 
@@ -242,6 +245,17 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
                               int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
                               int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
                               int32_t* argmax, float* feat_raw);
+int dae_launch_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
+                        float ikp, uint32_t seed, float* out);
+int dae_launch_title_loss_backward(dae_ctx* ctx, const float* zt, int64_t ld_z, const float* dae_score, int64_t ld_d,
+                                   const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                                   const float* w_title, const float* w_playlist, int B, int V, int n_batch,
+                                   const float* feat, int ld, const float* Output_WT, float* gOutput_WT,
+                                   float* gOutput_b, float* dfeat, float* cost_out);
+int dae_launch_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
+                                   int E, const float* conv_w, const int32_t* filter_sizes, int n_sizes, int F,
+                                   const int32_t* argmax, const float* feat_raw, const float* dfeat, int64_t ld,
+                                   float kp, uint32_t seed, float* g_emb, float* g_conv_w, float* g_conv_b);
 int dae_launch_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_t, float* dae_score, int64_t ld_d,
                           const float* w_title, const float* w_playlist, int B, int ncols);
 

@@ -76,27 +76,226 @@ __global__ __launch_bounds__(256) void mix_scores_kernel(const float* __restrict
         d[c] = t[c] * a + d[c] * b;
 }
 
+// ---- training of the title variables (DAEs.py:183-198: the DAE constants are frozen) -------------------
+
+// reduce_sum of DAEs.py:41 -- the row sums of the dropped-out input, with the encode kernel's draws
+__global__ __launch_bounds__(256) void row_sums_kernel(const int32_t* __restrict__ row_ptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val, int B, float ikp,
+                                                       uint32_t seed, float* __restrict__ out)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= B) return;
+    float s = 0.0f;
+    for (int i = row_ptr[row]; i < row_ptr[row + 1]; ++i) {      // same order as the encode kernels
+        float x = val[i];
+        if (ikp < 1.0f) x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[i]));
+        s += x;
+    }
+    out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void title_scatter_y_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ col,
+                                                              const float* __restrict__ val, int B, int V,
+                                                              float* __restrict__ y)
+{
+    const int row = blockIdx.x;
+    for (int i = row_ptr[row] + threadIdx.x; i < row_ptr[row + 1]; i += 256)
+        if (col[i] >= 0 && col[i] < V) y[(size_t)row * V + col[i]] = val[i];
+}
+
+// Weighted BCE of the MIXED score and its gradient w.r.t. the title logits, written TRANSPOSED (the layout
+// the two backward GEMMs read), one 32 x 32 (column x playlist) tile per workgroup through LDS:
+//   yp = sigmoid(zt) * w_t + dae * w_p;  L = -[y log(yp + 1e-10) + 0.55 (1 - y) log(1 - yp + 1e-10)]
+//   dzt = dL/dyp * w_t * st (1 - st) / n_batch
+__global__ __launch_bounds__(256) void title_loss_kernel(const float* __restrict__ zt, int64_t ld_z,
+                                                         const float* __restrict__ dae, int64_t ld_d,
+                                                         const float* __restrict__ y, const float* __restrict__ wt,
+                                                         const float* __restrict__ wp, int B, int V, float inv_nb,
+                                                         float* __restrict__ dzT, int64_t ldT,
+                                                         float* __restrict__ loss_part)
+{
+    __shared__ float tile[32][33];
+    __shared__ float wsum[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int v0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    float loss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, v = v0 + tx;
+        float dz = 0.0f;
+        if (r < B && v < V) {
+            const float z = zt[(size_t)r * ld_z + v];
+            const float st = 1.0f / (1.0f + __expf(-z));
+            const float a = wt[r];
+            const float yp = st * a + dae[(size_t)r * ld_d + v] * wp[r];
+            const float t = y[(size_t)r * V + v];
+            const float a1 = yp + 1e-10f, a0 = 1.0f - yp + 1e-10f;
+            loss -= t * __logf(a1) + 0.55f * (1.0f - t) * __logf(a0);
+            dz = -(t / a1 - 0.55f * (1.0f - t) / a0) * inv_nb * a * st * (1.0f - st);
+        }
+        tile[ty + 8 * i][tx] = dz;                                    // [r local][v local]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = v0 + ty + 8 * i, r = r0 + tx;
+        if (v < V && r < ldT) dzT[(size_t)v * ldT + r] = tile[tx][ty + 8 * i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) loss += __shfl_xor(loss, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        loss_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * inv_nb;
+}
+
+__global__ void title_cost_kernel(const float* __restrict__ part, int n, float* __restrict__ cost)
+{
+    __shared__ double ws[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];   // fixed assignment, fixed tree
+    ws[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) ws[threadIdx.x] += ws[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *cost = (float)ws[0];
+}
+
+// back through dropout -> max over time -> ReLU -> convolution -> embedding (Char_CNN.py:23-63).  The gradient
+// of one feature goes to the single position that won the max (its argmax), and only if the ReLU was open.
+__global__ __launch_bounds__(256) void title_conv_backward_kernel(const TitleP p, const float* __restrict__ dfeat,
+                                                                  float* __restrict__ g_emb,
+                                                                  float* __restrict__ g_conv_w,
+                                                                  float* __restrict__ g_conv_b)
+{
+    extern __shared__ float xs[];                     // [L][E]
+    __shared__ int ts[T_MAX_LEN];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < p.L; i += 256) ts[i] = p.titles[(size_t)row * p.L + i];
+    __syncthreads();
+    for (int i = tid; i < p.L * p.E; i += 256) {
+        const int pos = i / p.E, c = i - pos * p.E;
+        const int t = ts[pos];
+        xs[i] = (t >= 0 && t < p.n_char) ? p.emb[(size_t)t * p.E + c] : 0.0f;
+    }
+    __syncthreads();
+    const int nf = p.n_sizes * p.F;
+    for (int fi = tid; fi < nf; fi += 256) {
+        if (p.feat_raw[(size_t)row * nf + fi] <= 0.0f) continue;          // ReLU closed (or every window at 0)
+        float d = dfeat[(size_t)row * p.ld + fi];
+        if (p.kp < 1.0f) d = (d / p.kp) * floorf(p.kp + dae_uniform(p.seed, 2U, (uint32_t)row, (uint32_t)fi));
+        if (d == 0.0f) continue;
+        const int i = fi / p.F, f = fi - i * p.F;
+        const int fs = p.fs[i];
+        const int pos = p.argmax[(size_t)row * nf + fi];
+        const float* W = p.conv_w + p.w_off[i] + f;
+        float* gW = g_conv_w + p.w_off[i] + f;
+        atomicAdd(&g_conv_b[fi], d);
+        for (int dp = 0; dp < fs; ++dp) {
+            const int t = ts[pos + dp];
+            const bool ok = t >= 0 && t < p.n_char;
+            for (int c = 0; c < p.E; ++c) {
+                const int q = dp * p.E + c;
+                atomicAdd(&gW[(size_t)q * p.F], d * xs[(pos + dp) * p.E + c]);
+                if (ok) atomicAdd(&g_emb[(size_t)t * p.E + c], d * W[(size_t)q * p.F]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
-int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
-                              int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
-                              int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
-                              int32_t* argmax, float* feat_raw)
+static int title_fill(dae_ctx* ctx, TitleP& p, const int32_t* titles, int B, int L, const float* emb, int n_char,
+                      int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes,
+                      int F, float kp, uint32_t seed, int64_t ld)
 {
     if (n_sizes < 1 || n_sizes > T_MAX_SIZES) return dae_fail(ctx, DAE_ERR_ARG, "n_sizes=%d out of [1,%d]", n_sizes, T_MAX_SIZES);
     if (L < 1 || L > T_MAX_LEN || E < 1 || E > T_MAX_EMB) return dae_fail(ctx, DAE_ERR_ARG, "title length %d / embedding %d too large", L, E);
     if (ld < (int64_t)n_sizes * F) return dae_fail(ctx, DAE_ERR_ARG, "ld=%lld < %d features", (long long)ld, n_sizes * F);
-    TitleP p;
     memset(&p, 0, sizeof(p));
     p.titles = titles; p.B = B; p.L = L; p.emb = emb; p.n_char = n_char; p.E = E;
-    p.conv_w = conv_w; p.conv_b = conv_b; p.n_sizes = n_sizes; p.F = F; p.kp = kp; p.seed = seed;
-    p.feat = feat; p.ld = ld; p.argmax = argmax; p.feat_raw = feat_raw;
+    p.conv_w = conv_w; p.conv_b = conv_b; p.n_sizes = n_sizes; p.F = F; p.kp = kp; p.seed = seed; p.ld = ld;
     int off = 0;
     for (int i = 0; i < n_sizes; ++i) {
         if (filter_sizes[i] < 1 || filter_sizes[i] > L) return dae_fail(ctx, DAE_ERR_ARG, "filter size %d outside [1,%d]", filter_sizes[i], L);
         p.fs[i] = filter_sizes[i]; p.w_off[i] = off;
         off += filter_sizes[i] * E * F;
     }
+    return DAE_OK;
+}
+
+int dae_launch_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
+                        float ikp, uint32_t seed, float* out)
+{
+    hipLaunchKernelGGL(row_sums_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, row_ptr, col, val, B, ikp,
+                       seed, out);
+    DAE_CHECK_LAUNCH(ctx, "row_sums_kernel");
+    return DAE_OK;
+}
+
+int dae_launch_title_loss_backward(dae_ctx* ctx, const float* zt, int64_t ld_z, const float* dae_score, int64_t ld_d,
+                                   const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
+                                   const float* w_title, const float* w_playlist, int B, int V, int n_batch,
+                                   const float* feat, int ld, const float* Output_WT, float* gOutput_WT,
+                                   float* gOutput_b, float* dfeat, float* cost_out)
+{
+    hipStream_t st = ctx->stream;
+    int rc;
+    const int Bpad64 = (B + 63) / 64 * 64;
+    if ((rc = dae_reserve(ctx, ctx->train_a, (size_t)B * V * sizeof(float)))) return rc;        // dense targets
+    if ((rc = dae_reserve(ctx, ctx->train_b, (size_t)V * Bpad64 * sizeof(float)))) return rc;   // dz^T
+    const dim3 grid((V + 31) / 32, Bpad64 / 32);
+    const size_t n_part = (size_t)grid.x * grid.y;
+    if ((rc = dae_reserve(ctx, ctx->train_c, n_part * sizeof(float)))) return rc;
+    float* y = static_cast<float*>(ctx->train_a.p);
+    float* dzT = static_cast<float*>(ctx->train_b.p);
+    float* part = static_cast<float*>(ctx->train_c.p);
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(y, 0, (size_t)B * V * sizeof(float), st));
+    hipLaunchKernelGGL(title_scatter_y_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, V, y);
+    DAE_CHECK_LAUNCH(ctx, "title_scatter_y_kernel");
+    hipLaunchKernelGGL(title_loss_kernel, grid, dim3(256), 0, st, zt, ld_z, dae_score, ld_d, y, w_title, w_playlist,
+                       B, V, 1.0f / (float)n_batch, dzT, (int64_t)Bpad64, part);
+    DAE_CHECK_LAUNCH(ctx, "title_loss_kernel");
+    hipLaunchKernelGGL(title_cost_kernel, dim3(1), dim3(256), 0, st, part, (int)n_part, cost_out);
+    DAE_CHECK_LAUNCH(ctx, "title_cost_kernel");
+    if ((rc = dae_launch_grad_w(ctx, dzT, Bpad64, feat, ld, B, V, gOutput_WT, gOutput_b))) return rc;
+    return dae_launch_grad_h(ctx, dzT, Bpad64, Output_WT, ld, V, B, dfeat);
+}
+
+int dae_launch_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
+                                   int E, const float* conv_w, const int32_t* filter_sizes, int n_sizes, int F,
+                                   const int32_t* argmax, const float* feat_raw, const float* dfeat, int64_t ld,
+                                   float kp, uint32_t seed, float* g_emb, float* g_conv_w, float* g_conv_b)
+{
+    TitleP p;
+    int rc = title_fill(ctx, p, titles, B, L, emb, n_char, E, conv_w, nullptr, filter_sizes, n_sizes, F, kp, seed, ld);
+    if (rc) return rc;
+    p.argmax = const_cast<int32_t*>(argmax);
+    p.feat_raw = const_cast<float*>(feat_raw);
+    size_t nw = 0;
+    for (int i = 0; i < n_sizes; ++i) nw += (size_t)filter_sizes[i] * E * F;
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(g_emb, 0, (size_t)n_char * E * sizeof(float), ctx->stream));
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(g_conv_w, 0, nw * sizeof(float), ctx->stream));
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(g_conv_b, 0, (size_t)n_sizes * F * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(title_conv_backward_kernel, dim3(B), dim3(256), (size_t)L * E * sizeof(float), ctx->stream, p,
+                       dfeat, g_emb, g_conv_w, g_conv_b);
+    DAE_CHECK_LAUNCH(ctx, "title_conv_backward_kernel");
+    return DAE_OK;
+}
+
+int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
+                              int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
+                              int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
+                              int32_t* argmax, float* feat_raw)
+{
+    TitleP p;
+    int rc = title_fill(ctx, p, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, kp, seed, ld);
+    if (rc) return rc;
+    p.feat = feat; p.argmax = argmax; p.feat_raw = feat_raw;
     hipLaunchKernelGGL(title_features_kernel, dim3(B), dim3(256), (size_t)L * E * sizeof(float), ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "title_features_kernel");
     return DAE_OK;

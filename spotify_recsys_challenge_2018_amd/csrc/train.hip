@@ -651,6 +651,69 @@ int train_encoder_backward(dae_ctx* ctx, const TrainPlan& t, const float* part, 
 
 }  // namespace
 
+// ---- the two backward GEMMs on caller-provided buffers (also used by the title scorer's output layer) ---
+// gW[v, :] = sum_r dzT[v, r] h[r, :]  and  gb[v] = sum_r dzT[v, r]   (H % 32 == 0, B <= 256)
+int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* h, int H, int B, int V,
+                      float* gW, float* gb)
+{
+    if ((H % 32) != 0 || B < 1 || B > 256) return dae_fail(ctx, DAE_ERR_ARG, "grad_w: H=%d B=%d unsupported", H, B);
+    const int NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
+    GwP p;
+    p.dzT = dzT; p.ldT = ldT; p.h = h; p.H = H; p.B = B; p.V = V; p.gW = gW; p.gb = gb;
+    p.accumulate = 0; p.dbg = 0;
+    p.n_half = H / (32 * NA);
+    int nb = (DAE_NUM_CU / p.n_half) / DAE_NUM_XCD * DAE_NUM_XCD;
+    if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
+    p.nb_half = nb;
+    const size_t lds = (size_t)((B + 31) & ~31) * 32 * NA * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const dim3 grid(p.n_half * nb), blk(256);
+    if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, ctx->stream, p);
+    else if (NA == 2) hipLaunchKernelGGL(grad_wdec_kernel<2>, grid, blk, lds, ctx->stream, p);
+    else hipLaunchKernelGGL(grad_wdec_kernel<1>, grid, blk, lds, ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "grad_wdec_kernel");
+    return DAE_OK;
+}
+
+// dh[r, :] = sum_v dzT[v, r] W[v, :]  (split over V into ctx scratch, reduced in fixed order)
+int dae_launch_grad_h(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* W, int H, int V, int B, float* dh)
+{
+    if ((H % 32) != 0 || B < 1 || B > 256) return dae_fail(ctx, DAE_ERR_ARG, "grad_h: H=%d B=%d unsupported", H, B);
+    const int NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
+    const int Bpad64 = (B + 63) / 64 * 64;
+    if (ldT < Bpad64) return dae_fail(ctx, DAE_ERR_ARG, "grad_h: ldT=%lld < %d", (long long)ldT, Bpad64);
+    const int n_out_tiles = (H / (32 * NA)) * (Bpad64 / 64);
+    int want_chunks = (DAE_NUM_CU * 4) / n_out_tiles;
+    if (want_chunks < 1) want_chunks = 1;
+    int chunk = ((V + want_chunks - 1) / want_chunks + 15) / 16 * 16;
+    if (chunk < 16) chunk = 16;
+    const int n_chunk = (V + chunk - 1) / chunk;
+    int rc = dae_reserve(ctx, ctx->train_d, (size_t)n_chunk * Bpad64 * H * sizeof(float));
+    if (rc) return rc;
+    float* part = static_cast<float*>(ctx->train_d.p);
+    DhP p;
+    p.dzT = dzT; p.ldT = ldT; p.W = W; p.H = H; p.V = V; p.part = part;
+    p.n_chunk = n_chunk; p.chunk = chunk; p.Bpad64 = Bpad64; p.n_half = H / (32 * NA);
+    p.n_rblk = Bpad64 / 64;
+    const int total = p.n_half * p.n_rblk * n_chunk;
+    int blocks = (total + 3) / 4;
+    if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
+    if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else if (NA == 2) hipLaunchKernelGGL(grad_hidden_kernel<2>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    else hipLaunchKernelGGL(grad_hidden_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "grad_hidden_kernel");
+    const size_t bh = (size_t)B * H;
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3(grid_for(bh)), dim3(256), 0, ctx->stream, part, n_chunk,
+                       (size_t)Bpad64 * H, bh, dh);
+    DAE_CHECK_LAUNCH(ctx, "sum_chunks_kernel");
+    return DAE_OK;
+}
+
 int dae_train_step_f32(dae_ctx* ctx,
         const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
         const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,

@@ -50,11 +50,13 @@ _SCHEMA = {
             ('hidden', 'hidden', int)),
     'PRETRAIN': (('epochs', 'epochs', int), ('batch', 'batch', int), ('lr', 'lr', float),
                  ('reg_lambda', 'reg_lambda', float), ('save', 'save', '@dir')),
-    'TITLE': (('title_epochs', 'epochs', int), ('title_batch', 'batch', int), ('title_lr', 'lr', float),
-              ('title_input_kp', 'input_kp', _floats), ('title_kp', 'title_kp', str),
-              ('title_test_seed', 'test_seed', _seeds), ('title_update_seed', 'update_seed', _seeds),
+    # [TITLE] OVERRIDES epochs / batch / lr / input_kp / test_seed / update_seed / save of [DAE] (main.py:59-83),
+    # for --title and, as in the reference, for --challenge as well; keep_prob stays the [DAE] one
+    'TITLE': (('epochs', 'epochs', int), ('batch', 'batch', int), ('lr', 'lr', float), ('title_lr', 'lr', float),
+              ('input_kp', 'input_kp', _floats), ('title_kp', 'title_kp', float),
+              ('test_seed', 'test_seed', _seeds), ('update_seed', 'update_seed', _seeds),
               ('char_emb', 'char_emb', int), ('char_model', 'char_model', str), ('DAEval', 'DAEval', '@dir'),
-              ('title_save', 'save', '@dir')),
+              ('save', 'save', '@dir'), ('title_save', 'save', '@dir')),
     'CHALLENGE': (('challenge_data', 'challenge_data', str), ('result', 'result', '@result'),
                   ('batch', 'batch', int)),
 }
@@ -106,12 +108,14 @@ class Conf:
         self.mode = 'pretrain'
 
     def set_title_conf(self):
-        """[TITLE] (main.py:58-86).  Parsed for compatibility: the title scorers (Char-CNN / Char-LSTM)
-        are out of scope; --challenge takes the frozen DAE weights `DAEval` from here."""
+        """[TITLE] (main.py:58-86): the character-CNN title scorer trained on top of the frozen DAE `DAEval`.
+        The variables are saved as `<save>.pkl` (the reference writes a TF checkpoint at `save`)."""
         sec = self._load('TITLE')
         if self.char_model == 'Char_CNN':
             self.filter_num = int(sec['filter_num'])
             self.filter_size = _ints(sec['filter_size'])
+        os.makedirs(os.path.dirname(self.save) or '.', exist_ok=True)      # main.py:80-82
+        self.mode = 'title'
 
     def set_challenge_oonf(self):          # (sic) the reference's spelling, main.py:88
         os.makedirs(self.result_dir, exist_ok=True)
@@ -157,8 +161,8 @@ def main(argv=None):
         conf.set_dae_conf()
         main_train.run(conf, args.testmode)
     elif args.title:
-        raise SystemExit("--title trains the character CNN on top of a frozen DAE; the title models "
-                         "are outside the DAE scoring path this package implements (SURVEY.md 8f)")
+        conf.set_title_conf()
+        main_train.run(conf, args.testmode)
     elif args.challenge:
         conf.set_title_conf()
         conf.set_challenge_oonf()

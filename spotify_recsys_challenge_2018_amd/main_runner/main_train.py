@@ -12,7 +12,8 @@ import random
 
 import numpy as np
 
-from ..models.DAEs import DAE, DAE_tied
+from ..models.DAEs import DAE, DAE_tied, DAE_title
+from ..models.title_models import get_model
 from ..utils import metrics as met
 from ..utils.data_reader import data_reader, data_reader_firstN, data_reader_test
 
@@ -32,8 +33,14 @@ def eval(reader_test, conf, model):
     keep-probs 1.0, rank the track columns, drop the seeds, top 500."""
     total, count = 0.0, len(reader_test.playlists)
     while True:
-        x_positions, test_seed, test_answer, _titles, x_ones = reader_test.next_batch_test()
-        idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))
+        x_positions, test_seed, test_answer, titles, x_ones = reader_test.next_batch_test()
+        if conf.mode == 'title':                                   # main_train.py:69-79: titles_use = 1 everywhere
+            pad = [-1] * conf.strmaxlen
+            titles = [t if t is not None else pad for t in titles]
+            idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed), titles=titles,
+                                     titles_use=np.ones(len(titles), np.float32))
+        else:
+            idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))
         for i in range(len(test_seed)):
             total += met.eval_topk(idx[i], test_answer[i])
         if reader_test.test_idx == 0:
@@ -93,12 +100,18 @@ def run(conf, only_testmode):
         if only_testmode:
             conf.initval = conf.save
         info, model = '[dae mode]', DAE(conf)
+    elif conf.mode == 'title':                                      # main_train.py:162-165
+        model_title = get_model(conf)
+        model_title.fit()
+        if only_testmode:
+            model_title.load(conf.save + '.pkl')
+        info, model = '[title mode]', DAE_title(conf, model_title)
     else:
-        raise ValueError("mode %r is outside the DAE scoring path" % conf.mode)
+        raise ValueError("unknown mode %r" % conf.mode)
     log_write(conf, '*' * 10)
     log_write(conf, info + ' start at ' + str(datetime.datetime.now()))
     model.fit()
-    if world > 1 and not only_testmode:
+    if world > 1 and not only_testmode and conf.mode != 'title':
         model.shard_training(rank, world)
 
     if only_testmode:                                               # main_train.py:181-191
@@ -116,12 +129,17 @@ def run(conf, only_testmode):
         trk_positions, art_positions, y_positions, _titles, trk_val, art_val = reader.next_batch()
         end_idx = reader.train_idx
         input_kp = random.uniform(kp_range[0], kp_range[-1])        # main_train.py:199
-        if np.random.randint(2) == 0:                               # :202 fair coin
-            x_pos, x_val = trk_positions, trk_val
+        if conf.mode == 'title':                                    # :214-221: the whole playlist is input and target
+            ones = np.ones(len(y_positions), np.float32)
+            l = model.train_step(y_positions, ones, y_positions, ones, conf.kp, input_kp, titles=_titles,
+                                 titles_use=np.ones(conf.batch, np.float32), title_keep_prob=conf.title_kp)
         else:
-            x_pos, x_val = art_positions, art_val
-        l = model.train_step(x_pos, x_val, y_positions, np.ones(len(y_positions), np.float32),
-                             conf.kp, input_kp)
+            if np.random.randint(2) == 0:                           # :202 fair coin
+                x_pos, x_val = trk_positions, trk_val
+            else:
+                x_pos, x_val = art_positions, art_val
+            l = model.train_step(x_pos, x_val, y_positions, np.ones(len(y_positions), np.float32),
+                                 conf.kp, input_kp)
         loss += l
         it += 1
         if start_idx > end_idx or end_idx == 0:                     # :227 reader wrapped
@@ -138,7 +156,10 @@ def run(conf, only_testmode):
             model.sync_params()            # collective when sharded: every rank, before rank 0 saves
             if cur_eval >= max_eval:                                # :243-249
                 if rank == 0:
-                    model.save_model()
+                    if conf.mode == 'title':
+                        model.title_model.save(conf.save + '.pkl')   # the reference: saver.save(sess, conf.save)
+                    else:
+                        model.save_model()
                 max_eval = cur_eval
                 log_write(conf, "The highest score is updated. Parameters are saved")
             loss, it = 0.0, 0

@@ -459,6 +459,51 @@ class DAE_title(DAE):
                                                    P(w_t), P(w_p), self.n_batch, self.n_input))
         return y
 
+    def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, titles=None,
+                   titles_use=None, title_keep_prob=1.0):
+        """sess.run([model.optimizer, model.cost], ...) of the title graph (main_train.py:214-221): one Adam step
+        on the title variables; the DAE arrays stay as loaded.  Returns the cost."""
+        import torch
+        if titles is None:
+            raise ValueError("DAE_title trains the title scorer: titles are required")
+        tm = self.title_model
+        seed = int(self._rng.randint(0, 2 ** 31 - 1))
+        self._ensure_packed()
+        self.ctx.bind_stream()
+        tm.ctx.bind_stream()
+        dev = self.weights["encoder_h"].device
+        # frozen DAE forward with its dropouts (model.keep_prob = conf.kp, input_keep_prob; main_train.py:219-220)
+        xr, xc, xv = self._upload_csr(x_positions, x_ones)
+        yr, yc, yv = self._upload_csr(y_positions, y_ones)
+        h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32, device=dev)
+        self.ctx.encode(xr, xc, xv, self.weights["encoder_h"], self.biases["encoder_b"], h,
+                        ikp=input_keep_prob, kp=keep_prob, seed=seed)
+        dae = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=dev)
+        self.ctx.decode_dense(h, dae, apply_sigmoid=True)
+        # mixing weights (DAEs.py:159-162) from the dropped-out row sums
+        s = torch.empty(self.n_batch, dtype=torch.float32, device=dev)
+        P = _lib._ptr
+        self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(xr), P(xc), P(xv), self.n_batch,
+                                                 float(input_keep_prob), seed, P(s)))
+        u = torch.zeros(self.n_batch, dtype=torch.float32, device=dev)
+        tu = np.ones(self.n_batch, np.float32) if titles_use is None else np.asarray(titles_use, np.float32).reshape(-1)
+        u[:min(len(tu), self.n_batch)] = torch.from_numpy(tu[:self.n_batch]).to(dev)
+        x_count = s * float(np.float32(input_keep_prob))
+        deno = u + x_count + 1e-10
+        w_t, w_p = (u / deno).contiguous(), (x_count / deno).contiguous()
+        # title forward, keeping what the backward pass needs
+        tm._ensure_packed()
+        feat, d_titles, arg, raw = tm.features(titles, self.n_batch, title_keep_prob, seed, keep_for_backward=True)
+        zt = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=dev)
+        tm.ctx.decode_dense(feat, zt, apply_sigmoid=False)
+        if getattr(self, "_tcost", None) is None:
+            self._tcost = torch.zeros(1, dtype=torch.float32, device=dev)
+        tm.backward_and_step(feat, d_titles, arg, raw, zt, dae, (yr, yc, yv), w_t, w_p, self.n_batch,
+                             title_keep_prob, seed, self._tcost)
+        cost = float(self._tcost.item())
+        self._check_feed()
+        return cost
+
     def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None, titles=None, titles_use=None):
         if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
             return DAE.recommend(self, x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)

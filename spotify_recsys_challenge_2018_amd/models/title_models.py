@@ -168,6 +168,39 @@ class Char_CNN:
         self.ctx.decode_dense(feat, out, apply_sigmoid=True)
         return out
 
+    # -- training (the DAE is frozen: only these variables move, DAEs.py:165-171, :198) -----------------
+    def _train_state(self):
+        import torch
+        if getattr(self, "_adam", None) is None:
+            self._step = 0
+            self._tvars = ["char_embedding", "conv_w", "conv_b", "Output_WT", "Output_b"]
+            self._grads = {n: torch.zeros_like(self.p[n]) for n in self._tvars}
+            self._adam = {n: (torch.zeros_like(self.p[n]), torch.zeros_like(self.p[n])) for n in self._tvars}
+        return self._grads
+
+    def backward_and_step(self, feat, d_titles, arg, raw, z_title, dae_score, y_csr, w_t, w_p, n_batch, keep_prob,
+                          seed, cost_out):
+        """Gradients of the mixed-score loss w.r.t. the title variables, then one TF1-Adam step on each."""
+        import torch
+        g = self._train_state()
+        ctx, lib, P = self.ctx, self.ctx.lib, _lib._ptr
+        B, V = z_title.shape
+        dfeat = torch.empty((B, self.ld), dtype=torch.float32, device=feat.device)
+        ctx.check(lib.dae_title_loss_backward(
+            ctx.h, P(z_title), int(z_title.stride(0)), P(dae_score), int(dae_score.stride(0)),
+            P(y_csr[0]), P(y_csr[1]), P(y_csr[2]), P(w_t), P(w_p), B, V, int(n_batch),
+            P(feat), self.ld, P(self.p["Output_WT"]), P(g["Output_WT"]), P(g["Output_b"]), P(dfeat), P(cost_out)))
+        ctx.check(lib.dae_title_conv_backward(
+            ctx.h, P(d_titles), B, self.input_len, P(self.p["char_embedding"]), self.char_size, self.embedding,
+            P(self.p["conv_w"]), self._fs, len(self.filter_sizes), self.filter_num, P(arg), P(raw), P(dfeat),
+            self.ld, float(keep_prob), int(seed), P(g["char_embedding"]), P(g["conv_w"]), P(g["conv_b"])))
+        self._step += 1
+        for n in self._tvars:
+            m, v = self._adam[n]
+            ctx.check(lib.dae_adam_step(ctx.h, P(self.p[n]), P(m), P(v), P(g[n]), self.p[n].numel(),
+                                        self.learning_rate, 0.9, 0.999, 1e-8, self._step))
+        self._packed_dirty = True
+
     def __str__(self):
         return '\n'.join(["Wide CNN", "Embedding Size : " + str(self.embedding),
                           "Number of Filters : " + str(self.filter_num), "Conv Layers : " + str(self.conv_layers)])

@@ -106,7 +106,7 @@ def test_adam_matches_tf_formulation():
 
 
 def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
-    """main.py --pretrain -> --dae -> --dae --testmode -> --challenge on the golden mini dataset
+    """main.py --pretrain -> --dae -> --dae --testmode -> --challenge -> --title -> --challenge on the golden mini dataset
     (BASELINE.json configs[0] shape: tied pretrain, then untied DAE from the pretrain pickle)."""
     import random
     from spotify_recsys_challenge_2018_amd import main as cli
@@ -129,12 +129,32 @@ def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
         assert len(losses) == 4 and losses[1] < losses[0] and losses[3] < losses[2]
         assert "rprecision" in log and "Parameters are saved" in log
         assert cli.main(["--dir", "run", "--dae", "--testmode"]) == 0
+        assert cli.main(["--dir", "run", "--challenge"]) == 0           # no title variables yet: plain DAE
+
+        def check(res):
+            assert len(res) == 13
+            for row in res:
+                assert isinstance(row[0], int) and 1 <= len(row) - 1 <= 500
+                assert all(u.startswith("spotify:track:") for u in row[1:])
+                assert len(set(row[1:])) == len(row) - 1
+        res_plain = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
+        check(res_plain)
+        assert "plain DAE" in open(work / "log.txt").read()
+        # --title: the character CNN on top of the frozen w_dae, then --challenge mixes its scores in
+        assert cli.main(["--dir", "run", "--title"]) == 0
+        tv = pickle.load(open(work / "graph" / "model.ckpt.pkl", "rb"))
+        assert tv["Output_W"].shape == (400, w2[0].shape[0]) and tv["char_embedding"].shape == (41, 50)
+        assert np.array_equal(pickle.load(open(work / "w_dae", "rb"))[1], w2[1])          # the DAE stayed frozen
+        log = open(work / "log.txt").read()
+        tl = [float(l.split(":")[1]) for l in log.splitlines() if l.startswith("training loss")][4:]
+        assert len(tl) == 2 and tl[1] < tl[0]
+        assert cli.main(["--dir", "run", "--title", "--testmode"]) == 0
         assert cli.main(["--dir", "run", "--challenge"]) == 0
-        res = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
-        assert len(res) == 13
-        for row in res:
-            assert isinstance(row[0], int) and 1 <= len(row) - 1 <= 500
-            assert all(u.startswith("spotify:track:") for u in row[1:])
-            assert len(set(row[1:])) == len(row) - 1
+        res_mixed = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
+        check(res_mixed)
+        assert "title scorer" in open(work / "log.txt").read()
+        named = [i for i in range(13) if (900000 + i) % 4]                # synth_challenge gives these a name
+        assert any(res_mixed[i] != res_plain[i] for i in named)
+        assert all(res_mixed[i] == res_plain[i] for i in range(13) if i not in named)      # titles_use = 0 rows
     finally:
         os.chdir(cwd)
