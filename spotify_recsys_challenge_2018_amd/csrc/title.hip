@@ -166,44 +166,74 @@ __global__ void title_cost_kernel(const float* __restrict__ part, int n, float* 
 }
 
 // back through dropout -> max over time -> ReLU -> convolution -> embedding (Char_CNN.py:23-63).  The gradient
-// of one feature goes to the single position that won the max (its argmax), and only if the ReLU was open.
-__global__ __launch_bounds__(256) void title_conv_backward_kernel(const TitleP p, const float* __restrict__ dfeat,
-                                                                  float* __restrict__ g_emb,
-                                                                  float* __restrict__ g_conv_w,
-                                                                  float* __restrict__ g_conv_b)
+// of one feature goes to the single window that won the max (its argmax), and only if the ReLU was open.
+// Three small kernels, none with an atomic per weight element:
+//   gate   dg[b, fi] = dfeat * dropout mask / kp if the feature's ReLU was open, else 0
+//   wgrad  gW[i][dp][c][f] = sum_b dg[b, i, f] * x[b][arg[b, i, f] + dp][c]   one thread per (dp, c, f), loop over b
+//          gb[i][f]        = sum_b dg[b, i, f]
+//   egrad  per playlist: gx[pos][c] = sum_{i, f, dp: arg + dp == pos} dg * W[i][dp][c][f] in LDS, then ONE global
+//          atomicAdd per (pos, c) into the embedding row of the character at pos
+__global__ __launch_bounds__(256) void title_gate_kernel(const TitleP p, const float* __restrict__ dfeat,
+                                                         float* __restrict__ dg)
 {
-    extern __shared__ float xs[];                     // [L][E]
-    __shared__ int ts[T_MAX_LEN];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < p.L; i += 256) ts[i] = p.titles[(size_t)row * p.L + i];
-    __syncthreads();
-    for (int i = tid; i < p.L * p.E; i += 256) {
-        const int pos = i / p.E, c = i - pos * p.E;
-        const int t = ts[pos];
-        xs[i] = (t >= 0 && t < p.n_char) ? p.emb[(size_t)t * p.E + c] : 0.0f;
+    const int nf = p.n_sizes * p.F;
+    const size_t n = (size_t)p.B * nf;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
+        const int row = (int)(o / nf), fi = (int)(o - (size_t)row * nf);
+        float d = 0.0f;
+        if (p.feat_raw[o] > 0.0f) {                       // ReLU open (a row whose windows are all <= 0 gets nothing)
+            d = dfeat[(size_t)row * p.ld + fi];
+            if (p.kp < 1.0f) d = (d / p.kp) * floorf(p.kp + dae_uniform(p.seed, 2U, (uint32_t)row, (uint32_t)fi));
+        }
+        dg[o] = d;
     }
+}
+
+// grid = (sum of filter sizes, E); block = F threads (rounded up to a wave)
+__global__ __launch_bounds__(256) void title_wgrad_kernel(const TitleP p, const float* __restrict__ dg,
+                                                          float* __restrict__ g_conv_w, float* __restrict__ g_conv_b)
+{
+    int i = 0, dp = blockIdx.x;
+    while (dp >= p.fs[i]) { dp -= p.fs[i]; ++i; }                     // (size index, offset in the window)
+    const int c = blockIdx.y, f = threadIdx.x;
+    if (f >= p.F) return;
+    const int nf = p.n_sizes * p.F, fi = i * p.F + f;
+    float acc = 0.0f, accb = 0.0f;
+    for (int b = 0; b < p.B; ++b) {
+        const float d = dg[(size_t)b * nf + fi];
+        accb += d;
+        if (d != 0.0f) {
+            const int t = p.titles[(size_t)b * p.L + p.argmax[(size_t)b * nf + fi] + dp];
+            if (t >= 0 && t < p.n_char) acc = fmaf(d, p.emb[(size_t)t * p.E + c], acc);
+        }
+    }
+    g_conv_w[p.w_off[i] + (size_t)(dp * p.E + c) * p.F + f] = acc;
+    if (dp == 0 && c == 0) g_conv_b[fi] = accb;
+}
+
+__global__ __launch_bounds__(256) void title_egrad_kernel(const TitleP p, const float* __restrict__ dg,
+                                                          float* __restrict__ g_emb)
+{
+    extern __shared__ float gx[];                     // [L][E]
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int q = tid; q < p.L * p.E; q += 256) gx[q] = 0.0f;
     __syncthreads();
     const int nf = p.n_sizes * p.F;
-    for (int fi = tid; fi < nf; fi += 256) {
-        if (p.feat_raw[(size_t)row * nf + fi] <= 0.0f) continue;          // ReLU closed (or every window at 0)
-        float d = dfeat[(size_t)row * p.ld + fi];
-        if (p.kp < 1.0f) d = (d / p.kp) * floorf(p.kp + dae_uniform(p.seed, 2U, (uint32_t)row, (uint32_t)fi));
-        if (d == 0.0f) continue;
+    // thread = (window offset dp, channel c) pairs walked for every open feature: conflict-free in c
+    for (int fi = 0; fi < nf; ++fi) {
+        const float d = dg[(size_t)row * nf + fi];
+        if (d == 0.0f) continue;                                       // uniform: dg is read by all threads alike
         const int i = fi / p.F, f = fi - i * p.F;
-        const int fs = p.fs[i];
         const int pos = p.argmax[(size_t)row * nf + fi];
         const float* W = p.conv_w + p.w_off[i] + f;
-        float* gW = g_conv_w + p.w_off[i] + f;
-        atomicAdd(&g_conv_b[fi], d);
-        for (int dp = 0; dp < fs; ++dp) {
-            const int t = ts[pos + dp];
-            const bool ok = t >= 0 && t < p.n_char;
-            for (int c = 0; c < p.E; ++c) {
-                const int q = dp * p.E + c;
-                atomicAdd(&gW[(size_t)q * p.F], d * xs[(pos + dp) * p.E + c]);
-                if (ok) atomicAdd(&g_emb[(size_t)t * p.E + c], d * W[(size_t)q * p.F]);
-            }
-        }
+        for (int q = tid; q < p.fs[i] * p.E; q += 256)                 // q = dp * E + c -> gx[(pos + dp) * E + c]
+            atomicAdd(&gx[pos * p.E + q], d * W[(size_t)q * p.F]);       // LDS add: waves run ahead of each other
+    }
+    __syncthreads();
+    for (int q = tid; q < p.L * p.E; q += 256) {
+        const int pos = q / p.E, c = q - pos * p.E;
+        const int t = p.titles[(size_t)row * p.L + pos];
+        if (t >= 0 && t < p.n_char && gx[q] != 0.0f) atomicAdd(&g_emb[(size_t)t * p.E + c], gx[q]);
     }
 }
 
@@ -276,14 +306,22 @@ int dae_launch_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, i
     if (rc) return rc;
     p.argmax = const_cast<int32_t*>(argmax);
     p.feat_raw = const_cast<float*>(feat_raw);
-    size_t nw = 0;
-    for (int i = 0; i < n_sizes; ++i) nw += (size_t)filter_sizes[i] * E * F;
     DAE_HIP_CHECK(ctx, hipMemsetAsync(g_emb, 0, (size_t)n_char * E * sizeof(float), ctx->stream));
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(g_conv_w, 0, nw * sizeof(float), ctx->stream));
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(g_conv_b, 0, (size_t)n_sizes * F * sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(title_conv_backward_kernel, dim3(B), dim3(256), (size_t)L * E * sizeof(float), ctx->stream, p,
-                       dfeat, g_emb, g_conv_w, g_conv_b);
-    DAE_CHECK_LAUNCH(ctx, "title_conv_backward_kernel");
+    if (F > 256) return dae_fail(ctx, DAE_ERR_ARG, "filter_num %d > 256", F);
+    p.B = B;
+    rc = dae_reserve(ctx, ctx->train_c, (size_t)B * n_sizes * F * sizeof(float));
+    if (rc) return rc;
+    float* dg = static_cast<float*>(ctx->train_c.p);
+    int blocks = (int)(((size_t)B * n_sizes * F + 255) / 256);
+    hipLaunchKernelGGL(title_gate_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, ctx->stream, p, dfeat, dg);
+    DAE_CHECK_LAUNCH(ctx, "title_gate_kernel");
+    int sum_fs = 0;
+    for (int i = 0; i < n_sizes; ++i) sum_fs += filter_sizes[i];
+    hipLaunchKernelGGL(title_wgrad_kernel, dim3(sum_fs, E), dim3((F + 63) / 64 * 64), 0, ctx->stream, p, dg, g_conv_w,
+                       g_conv_b);
+    DAE_CHECK_LAUNCH(ctx, "title_wgrad_kernel");
+    hipLaunchKernelGGL(title_egrad_kernel, dim3(B), dim3(256), (size_t)L * E * sizeof(float), ctx->stream, p, dg, g_emb);
+    DAE_CHECK_LAUNCH(ctx, "title_egrad_kernel");
     return DAE_OK;
 }
 
