@@ -38,11 +38,12 @@ struct DenseSrc {
     static constexpr bool kFixedSlots = true;      // for_each visits q = tid, tid + 1024, ... in order
     dae_dense_src s;
     int max_keys() const { return s.n; }                  // host: most keys a row can hold
-    __device__ __forceinline__ void prepare(int, int, int*) const {}
+    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return s.n; }
-    template <typename F>
+    template <int NTH, typename F>
     __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
+        constexpr int TK_THREADS = NTH;                // (shadows the file-level constant inside this body)
         const float* rp = s.logits + (size_t)row * s.ld;
         const int step = 32 * s.tile_stride;
         int base = 0;                                  // block-uniform loop bounds
@@ -81,8 +82,10 @@ struct PairSrc {
         return g.cnt ? g.cnt[(size_t)seg * g.cnt_seg_stride + row] : g.fixed_cnt;
     }
     // exclusive prefix of segment sizes in LDS: seg_prefix[0..nseg]
+    template <int NTH>
     __device__ __forceinline__ void prepare(int row, int tid, int* seg_prefix) const
     {
+        constexpr int TK_THREADS = NTH;
         const int nseg = g0.nseg + g1.nseg;
         for (int s = tid; s < nseg; s += TK_THREADS)
             seg_prefix[s + 1] = s < g0.nseg ? seg_count(g0, s, row) : seg_count(g1, s - g0.nseg, row);
@@ -108,9 +111,10 @@ struct PairSrc {
     {
         return seg_prefix[g0.nseg + g1.nseg];
     }
-    template <typename F>
+    template <int NTH, typename F>
     __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, F f) const
     {
+        constexpr int TK_THREADS = NTH, TK_WAVES = NTH / 64;
         // group 0 (few, long segments: the sample winners): flat over the whole workgroup
         for (int sg = 0; sg < g0.nseg; ++sg) {
             const int cnt = seg_prefix[sg + 1] - seg_prefix[sg];
@@ -158,11 +162,12 @@ struct SoaSrc {
     static constexpr bool kFixedSlots = false;
     const float* logit; const int32_t* idx; int G, B, k;
     int max_keys() const { return G * k; }
-    __device__ __forceinline__ void prepare(int, int, int*) const {}
+    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return G * k; }
-    template <typename F>
+    template <int NTH, typename F>
     __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
+        constexpr int TK_THREADS = NTH;
         const int total = G * k;
         for (int e0 = 0; e0 < total; e0 += TK_THREADS) {
             const int e = e0 + tid;
@@ -179,13 +184,18 @@ struct SoaSrc {
 };
 
 // Block-wide: which bin (scanning from the top) holds the `need`-th element, and how many
-// elements sit in bins above it.  Thread t owns bins 2047-2t and 2046-2t.
+// elements sit in bins above it.  Thread t owns the BPT bins from 2047 - BPT t downwards.
+template <int NTH>
 __device__ __forceinline__ void find_bin(const unsigned* hist, unsigned* wave_tot, int tid,
                                          unsigned need, int* s_bin, unsigned* s_above)
 {
-    const int b1 = TK_BINS - 1 - 2 * tid, b0 = b1 - 1;
-    const unsigned c1 = hist[b1], c0 = hist[b0];
-    unsigned v = c1 + c0;
+    constexpr int BPT = TK_BINS / NTH;
+    const int top = TK_BINS - 1 - BPT * tid;
+    unsigned c[BPT];
+    unsigned own = 0;
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) { c[e] = hist[top - e]; own += c[e]; }
+    unsigned v = own;
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -196,18 +206,30 @@ __device__ __forceinline__ void find_bin(const unsigned* hist, unsigned* wave_to
     __syncthreads();
     unsigned pre = 0;
     for (int w = 0; w < wv; ++w) pre += wave_tot[w];
-    const unsigned incl = pre + v, excl = incl - (c1 + c0);
+    const unsigned incl = pre + v, excl = incl - own;
     if (excl < need && need <= incl) {
-        if (excl + c1 >= need) { *s_bin = b1; *s_above = excl; }
-        else                   { *s_bin = b0; *s_above = excl + c1; }
+        unsigned run = excl;
+        bool done = false;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) {
+            if (!done && run + c[e] >= need) { *s_bin = top - e; *s_above = run; done = true; }
+            run += c[e];
+        }
     }
     __syncthreads();
 }
 
-template <typename Src>
-__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const dae_topk_args a,
-                                                          const int key_cap, const int dbg_stop)
+// NTH threads per row: 1024 for long rows (a phase-A sample, a dense row), 256 for short ones (candidate
+// lists, small shards, gathered shard lists) -- a short row is bound by the fixed cost of every stage
+// (histogram clears, bin scans, barriers joining 16 waves), which a quarter of the threads cuts to a
+// quarter, and up to 8 such workgroups share a CU.  Same stages, same results.
+template <typename Src, int NTH>
+__global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk_args a,
+                                                   const int key_cap, const int dbg_stop)
 {
+    constexpr int TK_THREADS = NTH, TK_WAVES = NTH / 64;       // shadow the file-level constants
+    constexpr int MAXES = 1024 / NTH;                            // per-thread maxima kept for the 3a cut (1024 in all)
+    constexpr int EMAX = TK_SORT_MAX / NTH;                      // sort-buffer keys per thread, at most
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ unsigned hist[TK_BINS];
     __shared__ int seg_prefix[Src::kSegs + 2];
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             if (pcol >= 0 && pcol < a.bitmap_n) atomicOr(&bitmap[pcol >> 5], 1u << (pcol & 31));
         }
     }
-    src.prepare(row, tid, seg_prefix);
+    src.template prepare<NTH>(row, tid, seg_prefix);
     __syncthreads();
     if (dbg_stop == 1) return;
 
@@ -278,7 +300,18 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
     };
 
     // ---- 2. first read: keys -> LDS (if they fit), count, min, max ---------------------------------
-    u64 tmax = 0ull;                                             // this thread's largest key
+    // this thread's largest keys, one per class of its elements (class = visit number mod MAXES): MAXES x NTH
+    // = 1024 distinct elements of the row in all
+    u64 tmaxv[MAXES];
+#pragma unroll
+    for (int c = 0; c < MAXES; ++c) tmaxv[c] = 0ull;
+    int visit = 0;
+    auto note_max = [&](u64 ck) {
+#pragma unroll
+        for (int c = 0; c < MAXES; ++c)
+            if ((visit % MAXES) == c) tmaxv[c] = ck > tmaxv[c] ? ck : tmaxv[c];
+        ++visit;
+    };
     {
         u64 mn = ~0ull, mx = 0ull;
         const int n_src = src.count(row, seg_prefix);
@@ -287,8 +320,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             // ballot / leader atomic / shuffle per element group; the count is one atomic per wave
             unsigned cnt = 0;
             int calls = 0;
-            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
+                note_max(ck);
                 const int slot = tid + TK_THREADS * calls++;
                 if (slot < n_src) keys[slot] = ck;
                 if (ck != 0ull) {
@@ -302,8 +336,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
             if (tid == 0) s_slots = (unsigned)n_src;
         } else if (key_cap > 0) {
-            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
+                note_max(ck);
                 const bool v = ck != 0ull;
                 const u64 bal = __ballot(v);
                 if (bal) {
@@ -322,8 +357,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         } else {
             // nothing is cached: count, min and max only -- one atomic per wave instead of one per element group
             unsigned cnt = 0;
-            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
+                note_max(ck);
                 if (ck != 0ull) {
                     ++cnt;
                     mn = ck < mn ? ck : mn;
@@ -334,7 +370,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
             if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
         }
-        tmax = mx;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             const u64 omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
@@ -361,7 +396,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 f(i < n_cached ? keys[i] : 0ull);
             }
         } else {
-            src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 f(ckey(z, colv, in));
             });
         }
@@ -394,12 +429,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         if (tid == 0) { s_cnt2 = 0; s_min2 = ~0ull; }
         __syncthreads();
         {
-            const bool has = tmax != 0ull;
-            const u64 bal = __ballot(has);
-            u64 wmn = has ? tmax : ~0ull;
+            unsigned nhas = 0;
+            u64 wmn = ~0ull;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_xor(wmn, d); wmn = o < wmn ? o : wmn; }
-            if (lane == 0 && bal) { atomicAdd(&s_cnt2, (unsigned)__popcll(bal)); atomicMin(&s_min2, wmn); }
+            for (int c = 0; c < MAXES; ++c) {
+                nhas += tmaxv[c] != 0ull ? 1u : 0u;
+                wmn = (tmaxv[c] != 0ull && tmaxv[c] < wmn) ? tmaxv[c] : wmn;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const u64 o = __shfl_xor(wmn, d); wmn = o < wmn ? o : wmn;
+                nhas += __shfl_xor(nhas, d);
+            }
+            if (lane == 0 && nhas) { atomicAdd(&s_cnt2, nhas); atomicMin(&s_min2, wmn); }
         }
         __syncthreads();
         const unsigned n_max = s_cnt2;
@@ -410,9 +452,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             if (shift < 0) shift = 0;
             for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
             __syncthreads();
-            if (tmax != 0ull) atomicAdd(&hist[(unsigned)((tmax - mlo) >> shift)], 1u);
+#pragma unroll
+            for (int c = 0; c < MAXES; ++c)
+                if (tmaxv[c] != 0ull) atomicAdd(&hist[(unsigned)((tmaxv[c] - mlo) >> shift)], 1u);
             __syncthreads();
-            find_bin(hist, wave_tot, tid, k_rank, &s_bin, &s_above);
+            find_bin<NTH>(hist, wave_tot, tid, k_rank, &s_bin, &s_above);
             const u64 cut = mlo + ((u64)(unsigned)s_bin << shift);   // <= k-th largest thread maximum
             __syncthreads();
             // count the row's keys >= cut
@@ -443,7 +487,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 hist_add(v ? (unsigned)((ck - lo) >> shift) : 0u, v);
             });
             __syncthreads();
-            find_bin(hist, wave_tot, tid, k_rank - above, &s_bin, &s_above);
+            find_bin<NTH>(hist, wave_tot, tid, k_rank - above, &s_bin, &s_above);
             const unsigned b = (unsigned)s_bin;
             const unsigned cnt_b = hist[b];
             const unsigned new_above = above + s_above;
@@ -479,7 +523,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             }
         }
     } else {
-        src.for_each(row, tid, seg_prefix, [&](float z, int colv, bool in) {
+        src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
             const u64 ck = ckey(z, colv, in);
             const bool v = ck != 0ull && ck >= lo;
             const u64 bal = __ballot(v);
@@ -497,11 +541,11 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
 
     // ---- 4a. lean mode: drop the seeds among the collected keys (order is irrelevant here) ------------
     if (seed_blind) {
-        u64 kk[2];
-        bool keep[2];
+        u64 kk[EMAX];
+        bool keep[EMAX];
         const unsigned c = s_cnt < (unsigned)sort_n ? s_cnt : (unsigned)sort_n;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < EMAX; ++e) {
             const unsigned i = (unsigned)(e * TK_THREADS + tid);
             kk[e] = i < c ? skey[i] : 0ull;
             keep[e] = kk[e] != 0ull && !is_seed((int)(~(unsigned)(kk[e] & 0xFFFFFFFFull)));
@@ -511,7 +555,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         for (int i = tid; i < sort_n; i += TK_THREADS) skey[i] = 0ull;
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < EMAX; ++e) {
             const u64 bal = __ballot(keep[e]);
             if (bal) {
                 const int leader = __ffsll((long long)bal) - 1;
@@ -536,9 +580,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             sort_n = 512;
         } else {
             const unsigned c = s_cnt < 1024u ? s_cnt : 1024u;
-            const u64 mine = (unsigned)tid < c ? skey[tid] : 0ull;
+            constexpr int PER = 1024 / NTH;                      // collected keys per thread (slot e * NTH + tid)
+            u64 mine[PER];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) mine[e] = (unsigned)(e * NTH + tid) < c ? skey[e * NTH + tid] : 0ull;
             // float keys are log-spaced, so one linear histogram over [cut, max] can leave the k-th
-            // key in a fat bin: re-bin inside that bin until what is kept fits (one key per thread,
+            // key in a fat bin: re-bin inside that bin until what is kept fits (<= 1024 keys in registers,
             // so every pass is a handful of barriers)
             u64 rlo = lo, rhi = s_max, cut2 = lo;
             unsigned rabove = 0, keep = c;
@@ -548,10 +595,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 if (shift < 0) shift = 0;
                 for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
                 __syncthreads();
-                if (mine != 0ull && mine >= rlo && mine <= rhi)
-                    atomicAdd(&hist[(unsigned)((mine - rlo) >> shift)], 1u);
+#pragma unroll
+                for (int e = 0; e < PER; ++e)
+                    if (mine[e] != 0ull && mine[e] >= rlo && mine[e] <= rhi)
+                        atomicAdd(&hist[(unsigned)((mine[e] - rlo) >> shift)], 1u);
                 __syncthreads();
-                find_bin(hist, wave_tot, tid, k_eff - rabove, &s_bin, &s_above);
+                find_bin<NTH>(hist, wave_tot, tid, k_eff - rabove, &s_bin, &s_above);
                 const unsigned bcnt = hist[s_bin];
                 cut2 = rlo + ((u64)(unsigned)s_bin << shift);
                 keep = rabove + s_above + bcnt;                  // keys >= cut2
@@ -563,19 +612,21 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             }
             if (keep <= 512u) {
                 if (tid == 0) s_cnt = 0;
+                __syncthreads();                                 // all old skey reads are done (mine[] holds them)
+                for (int i = tid; i < 512; i += TK_THREADS) skey[i] = 0ull;
                 __syncthreads();
-                const bool v = mine != 0ull && mine >= cut2;
-                const u64 bal = __ballot(v);
-                unsigned base = 0;
-                if (bal) {
-                    const int leader = __ffsll((long long)bal) - 1;
-                    if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
-                    base = __shfl(base, leader);
+#pragma unroll
+                for (int e = 0; e < PER; ++e) {
+                    const bool v = mine[e] != 0ull && mine[e] >= cut2;
+                    const u64 bal = __ballot(v);
+                    if (bal) {
+                        const int leader = __ffsll((long long)bal) - 1;
+                        unsigned base = 0;
+                        if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
+                        base = __shfl(base, leader);
+                        if (v) skey[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine[e];
+                    }
                 }
-                __syncthreads();                                 // all old skey reads are done
-                if (tid < 512) skey[tid] = 0ull;
-                __syncthreads();
-                if (v) skey[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine;
                 __syncthreads();
                 sort_n = 512;
                 cut_final = cut2;
@@ -585,9 +636,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             // threshold mode (phase A): >= k keys are >= cut_final, so its logit is a valid lower
             // bound of the k-th largest logit -- all phase B needs; survivors go out unsorted.
             const unsigned c2 = s_cnt;
-            if ((unsigned)tid < c2) {
-                const u64 ck = skey[tid];
-                a.out_pairs[(size_t)row * a.pairs_stride + tid] =
+            for (unsigned i = (unsigned)tid; i < c2; i += TK_THREADS) {
+                const u64 ck = skey[i];
+                a.out_pairs[(size_t)row * a.pairs_stride + i] =
                     make_uint2(__float_as_uint(dae_okey_inv((unsigned)(ck >> 32))),
                                ~(unsigned)(ck & 0xFFFFFFFFull));
             }
@@ -603,7 +654,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
         printf("SLOWPATH row %d m %u k_eff %u s_cnt %u sort_n %d narrowed %d tau_mode %d\n", row, m, k_eff,
                s_cnt, sort_n, (int)narrowed, a.out_cnt ? 1 : 0);
     if (dbg_stop == 5) return;
-    if (sort_n == 512) {
+    if (NTH >= 512 && sort_n == 512) {
         // <= 512 unique keys: bitonic network over the 8 waves that hold them (one key per thread);
         // strides < 64 through wave shuffles, 64..256 through LDS.  The other 8 waves only join
         // the barriers, so the network is not slowed by their instruction issue.
@@ -640,31 +691,27 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             if (a.out_tau && tid == k - 1) a.out_tau[row] = z;
         }
     } else
-    // Hybrid bitonic sort, descending.  Thread t holds elements t and t + 1024 (the second only
-    // when sort_n = 2048).  Strides < 64 exchange through wave shuffles, strides 64..512 through
-    // LDS, stride 1024 inside the thread.
+    // Hybrid bitonic sort, descending.  Thread t holds elements t, t + NTH, ... (E = sort_n / NTH of them,
+    // at least one).  Strides < 64 exchange through wave shuffles, larger ones through LDS -- also when both
+    // elements of a pair sit in the same thread (every key is in LDS for that step anyway).
     {
-        const int E = sort_n > TK_THREADS ? 2 : 1;
-        u64 kr[2];
-        kr[0] = tid < sort_n ? skey[tid] : 0ull;
-        kr[1] = E == 2 ? skey[tid + TK_THREADS] : 0ull;
+        const int E = sort_n > TK_THREADS ? sort_n / TK_THREADS : 1;
+        u64 kr[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) kr[e] = (e < E && e * TK_THREADS + tid < sort_n) ? skey[e * TK_THREADS + tid] : 0ull;
         for (int size = 2; size <= sort_n; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                if (stride >= TK_THREADS) {                      // 1024: the thread's own pair
-                    const bool desc = (((unsigned)tid & (unsigned)size) == 0);   // i = tid
-                    const u64 a0 = kr[0], a1 = kr[1];
-                    const bool sw = (a0 < a1) == desc;
-                    kr[0] = sw ? a1 : a0; kr[1] = sw ? a0 : a1;
-                } else if (stride >= 64) {
-                    __syncthreads();
-                    skey[tid] = kr[0];
-                    if (E == 2) skey[tid + TK_THREADS] = kr[1];
+                if (stride >= 64) {
                     __syncthreads();
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < EMAX; ++e)
+                        if (e < E && e * TK_THREADS + tid < sort_n) skey[e * TK_THREADS + tid] = kr[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < EMAX; ++e) {
                         if (e < E) {
                             const int i = e * TK_THREADS + tid;
-                            const u64 other = skey[i ^ stride];
+                            const u64 other = i < sort_n ? skey[i ^ stride] : 0ull;
                             const bool desc = ((i & size) == 0);
                             const bool lower = ((i & stride) == 0);
                             const u64 mx = kr[e] > other ? kr[e] : other;
@@ -674,7 +721,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
+                    for (int e = 0; e < EMAX; ++e) {
                         if (e < E) {
                             const int i = e * TK_THREADS + tid;
                             const u64 other = __shfl_xor(kr[e], stride);
@@ -689,7 +736,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
             }
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < EMAX; ++e) {
             const unsigned i = (unsigned)(e * TK_THREADS + tid);
             if (e < E && i < k_eff) {
                 const u64 mine = kr[e];
@@ -698,7 +745,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const Src src, const d
                 const size_t o = (size_t)row * k + i;
                 if (a.out_idx) a.out_idx[o] = colv;
                 if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
-                if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + (o - (size_t)row * k)] = make_uint2(__float_as_uint(z), (unsigned)colv);
+                if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + i] = make_uint2(__float_as_uint(z), (unsigned)colv);
                 if (a.out_tau && i == (unsigned)k - 1) a.out_tau[row] = z;
             }
         }
@@ -756,7 +803,10 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     }
     static bool attr_set = false;
     if (!attr_set) {
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src>),
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src, 1024>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(lds_total - lds_static)));
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src, 256>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)(lds_total - lds_static)));
         attr_set = true;
@@ -765,8 +815,17 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     // DAE_TOPK_STOP=-n the other launches (bisecting stage costs under rocprofv3)
     static const int dbg_env = getenv("DAE_TOPK_STOP") ? atoi(getenv("DAE_TOPK_STOP")) : 0;
     const int dbg_stop = dbg_env > 0 ? (a.out_tau ? dbg_env : 0) : (a.out_tau ? 0 : -dbg_env);
-    hipLaunchKernelGGL((topk_kernel<Src>), dim3(a.B), dim3(TK_THREADS), dyn, ctx->stream, src, aa,
-                       key_cap, dbg_stop);
+    // threads per row: 256 for rows known to be short (see topk_kernel): dense rows of <= 4096 columns (the
+    // sample of a small vocabulary shard) and gathered shard lists.  Candidate lists (PairSrc) keep 1024: their
+    // cost is walking the per-workgroup segments (one wave per segment), which 4 waves do slower than 16
+    // (measured: 407 vs 354 us per step at --sim-world 8).  DAE_TOPK_THREADS=1024|256 forces one shape (A/B).
+    static const int nth_env = getenv("DAE_TOPK_THREADS") ? atoi(getenv("DAE_TOPK_THREADS")) : 0;
+    const int bound = Src::kSegs ? 0 : src.max_keys();
+    const bool small = nth_env ? nth_env == 256 : (!Src::kSegs && bound <= 4096);
+    if (small)
+        hipLaunchKernelGGL((topk_kernel<Src, 256>), dim3(a.B), dim3(256), dyn, ctx->stream, src, aa, key_cap, dbg_stop);
+    else
+        hipLaunchKernelGGL((topk_kernel<Src, 1024>), dim3(a.B), dim3(1024), dyn, ctx->stream, src, aa, key_cap, dbg_stop);
     DAE_CHECK_LAUNCH(ctx, "topk_kernel");
     return DAE_OK;
 }
