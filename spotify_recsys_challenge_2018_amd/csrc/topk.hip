@@ -809,6 +809,7 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src, 256>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)(lds_total - lds_static)));
+
         attr_set = true;
     }
     // debug: DAE_TOPK_STOP=n stops the phase-A (tau-producing) kernel after stage n,
