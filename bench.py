@@ -62,7 +62,7 @@ def parse():
                          "exchange is a 1-rank all-gather, so communication is NOT included")
     ap.add_argument("--sim-rank", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="playlists the CPU oracle scores")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
     return ap.parse_args()
 
