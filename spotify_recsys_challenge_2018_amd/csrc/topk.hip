@@ -780,6 +780,8 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     //     gains, and the kernel alone is slower (re-reads its source), so it is not the default.
     static const bool want_lean = getenv("DAE_TOPK_LEAN") != nullptr;
     aa.lean = want_lean ? 1 : 0;
+    // a ranked range too wide for the LDS bitmap (> ~1 M columns) takes the bitmap-free mode instead of failing
+    if ((((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) + (size_t)sort_n * 8 + 22 * 1024 > (size_t)160 * 1024) aa.lean = 1;
     const size_t lds_total = 160 * 1024, lds_static = 14 * 1024;    // hist 8K + seg_prefix 4K + scalars
     size_t dyn;
     int key_cap;
