@@ -359,9 +359,53 @@ static int check_topk_args(dae_ctx* ctx, int dtype, int k, const int32_t* seed_r
     return DAE_OK;
 }
 
+// Batches are processed in slabs of DAE_ROW_SLAB rows: the worst-case candidate capacity grows with
+// (rows x tiles per workgroup), and a slab keeps it at a few GB whatever batch the caller passes.
+constexpr int DAE_ROW_SLAB = 4096;
+
+static int decode_topk_slab(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
+                            const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
+                            float* out_score, int32_t* out_idx);
+static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                           const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                           int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                           int k, int out_kind, float* out_score, int32_t* out_idx);
+
 int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
                     const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
                     float* out_score, int32_t* out_idx)
+{
+    for (int r0 = 0; r0 < B || r0 == 0; r0 += DAE_ROW_SLAB) {
+        const int nb = B - r0 < DAE_ROW_SLAB ? B - r0 : DAE_ROW_SLAB;
+        const int rc = decode_topk_slab(ctx, h ? h + (size_t)r0 * H : h, nb, H, dtype, n_tracks,
+                                        seed_row_ptr ? seed_row_ptr + r0 : nullptr, seed_col, k, out_kind,
+                                        out_score ? out_score + (size_t)r0 * k : out_score,
+                                        out_idx ? out_idx + (size_t)r0 * k : out_idx);
+        if (rc || B <= DAE_ROW_SLAB) return rc;
+    }
+    return DAE_OK;
+}
+
+int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                   const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                   int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                   int k, int out_kind, float* out_score, int32_t* out_idx)
+{
+    // row_ptr / seed_row_ptr hold ABSOLUTE offsets into col / val / seed_col, so a slab is a pointer shift
+    for (int r0 = 0; r0 < B || r0 == 0; r0 += DAE_ROW_SLAB) {
+        const int nb = B - r0 < DAE_ROW_SLAB ? B - r0 : DAE_ROW_SLAB;
+        const int rc = score_topk_slab(ctx, row_ptr ? row_ptr + r0 : row_ptr, col, val, W_enc, b_enc, V, H, nb, dtype,
+                                       n_tracks, seed_row_ptr ? seed_row_ptr + r0 : nullptr, seed_col, k, out_kind,
+                                       out_score ? out_score + (size_t)r0 * k : out_score,
+                                       out_idx ? out_idx + (size_t)r0 * k : out_idx);
+        if (rc || B <= DAE_ROW_SLAB) return rc;
+    }
+    return DAE_OK;
+}
+
+static int decode_topk_slab(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n_tracks,
+                            const int32_t* seed_row_ptr, const int32_t* seed_col, int k, int out_kind,
+                            float* out_score, int32_t* out_idx)
 {
     if (!ctx) return DAE_ERR_ARG;
     if (!h) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
@@ -377,10 +421,10 @@ int dae_decode_topk(dae_ctx* ctx, const float* h, int B, int H, int dtype, int n
                             out_score, out_idx, dtype);
 }
 
-int dae_score_topk(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
-                   const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
-                   int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                   int k, int out_kind, float* out_score, int32_t* out_idx)
+static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                           const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                           int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                           int k, int out_kind, float* out_score, int32_t* out_idx)
 {
     if (!ctx) return DAE_ERR_ARG;
     if (!row_ptr || !W_enc || !b_enc) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");

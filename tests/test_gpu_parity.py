@@ -297,3 +297,26 @@ def test_topk_dense_over_a_range_too_wide_for_the_seed_bitmap():
     s_ref, i_ref = oracle.topk(z, k, srp, sc, out_kind=1)
     assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
     ctx.close()
+
+
+def test_batch_larger_than_a_row_slab_equals_row_wise_calls():
+    """9 000 playlists in ONE call (the library walks them in slabs of 4096 rows) == the oracle on every row."""
+    import torch
+    ctx = _lib.Context(0)
+    V, nt, H, B, k = 3000, 2500, 64, 9000, 50
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=2, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=3)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+    ctx.prepack_decoder(d[5], d[6])
+    s = torch.empty((B, k), device="cuda"); i = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s, i)
+    s_ref, i_ref = oracle.score_batch(rp, col, val, W_enc, b_enc, W_dec, b_dec, V, nt, srp, sc, k)
+    assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+    h = torch.empty((B, H), device="cuda")
+    ctx.encode(d[0], d[1], d[2], d[3], d[4], h)
+    s2 = torch.empty_like(s); i2 = torch.empty_like(i)
+    ctx.decode_topk(h, nt, d[7], d[8], k, s2, i2)
+    assert torch.equal(i2, i) and torch.equal(s2, s)
+    ctx.close()
