@@ -320,3 +320,39 @@ def test_batch_larger_than_a_row_slab_equals_row_wise_calls():
     ctx.decode_topk(h, nt, d[7], d[8], k, s2, i2)
     assert torch.equal(i2, i) and torch.equal(s2, s)
     ctx.close()
+
+
+def test_scoring_step_is_capturable_in_a_hip_graph():
+    """After one warm-up call (scratch allocated, kernel attributes set) a scoring step issues no allocation and
+    no synchronisation, so it can be captured into a HIP graph and replayed with identical results."""
+    import torch
+    ctx = _lib.Context(0)
+    V, nt, H, B, k = 40000, 33000, 256, 96, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+    ctx.prepack_decoder(d[5], d[6])
+    s = torch.empty((B, k), device="cuda"); i = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx.bind_stream()
+        for _ in range(2):
+            ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s, i)
+        torch.cuda.synchronize()
+        ref_s, ref_i = s.clone(), i.clone()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin()
+        ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s, i)
+        g.capture_end()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        s.zero_(); i.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(i, ref_i) and torch.equal(s, ref_s)
+    s_ref, i_ref = oracle.score_batch(rp, col, val, W_enc, b_enc, W_dec, b_dec, V, nt, srp, sc, k)
+    assert np.array_equal(ref_i.cpu().numpy(), i_ref)
+    del g
+    ctx.close()
