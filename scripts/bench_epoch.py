@@ -1,0 +1,85 @@
+"""Training throughput THROUGH the host mirror (utils/data_reader.py -> models/DAEs.py:DAE.train_step),
+i.e. what `main.py --dae` sustains, at BASELINE.json configs[3] shape: V = 170 000 (140 000 tracks +
+30 000 artists), H = 256, batch 256, fp32.  A synthetic `train` file of N playlists (ids Zipf over popularity
+ranks, 20..100 tracks per playlist) is written to a temp dir, then the loop of main_runner/main_train.py is
+timed with its parts: reader.next_batch, train_step (upload + device CSR + step + cost fetch).
+
+  python scripts/bench_epoch.py [--playlists 20000] [--steps 200] [--tied]
+"""
+import argparse, json, os, random, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def write_train(path, n_playlists, n_tracks, n_artists, seed=0):
+    rng = np.random.default_rng(seed)
+    pls = []
+    for _ in range(n_playlists):
+        c = int(rng.integers(20, 101))
+        u = rng.random(c)
+        t = np.unique(np.minimum(n_tracks - 1, np.floor(np.exp(u * np.log(n_tracks))).astype(np.int64) - 1).clip(0))
+        a = np.unique(n_tracks + rng.integers(0, n_artists, size=max(1, c // 2)))
+        pls.append([[int(x) for x in t], [int(x) for x in a], [1, 2, 3]])
+    d = {"track_uri2id": {"t%d" % i: i for i in range(n_tracks)},
+         "artist_uri2id": {"a%d" % i: n_tracks + i for i in range(n_artists)},
+         "max_title_len": 25, "num_char": 41, "class_divpnt": [], "playlists": pls}
+    with open(path, "w") as f:
+        json.dump(d, f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--playlists", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--tied", action="store_true")
+    ap.add_argument("--async-cost", action="store_true", help="fetch the cost once at the end instead of per step")
+    args = ap.parse_args()
+    import torch
+    from spotify_recsys_challenge_2018_amd.models.DAEs import DAE, DAE_tied
+    from spotify_recsys_challenge_2018_amd.utils.data_reader import data_reader
+
+    nt, na = 140000, 30000
+    tmp = tempfile.mkdtemp()
+    write_train(os.path.join(tmp, "train"), args.playlists, nt, na)
+    reader = data_reader(data_dir=tmp, filename="train", batch_size=256)
+
+    class C: pass
+    conf = C()
+    conf.n_tracks, conf.n_input, conf.n_output = nt, nt + na, nt + na
+    conf.hidden, conf.batch, conf.lr, conf.reg_lambda = 256, 256, 0.005, 0.0
+    conf.initval, conf.save, conf.kp = "NULL", os.path.join(tmp, "w"), 0.8
+    conf.device_index = 0
+    model = (DAE_tied if args.tied else DAE)(conf)
+    model.fit()
+    random.seed(0); np.random.seed(0)
+
+    def one(fetch=True):
+        t0 = time.perf_counter()
+        trk, art, y, _t, tv, av = reader.next_batch()
+        t1 = time.perf_counter()
+        kp = random.uniform(0.5, 0.8)
+        x, xv = (trk, tv) if np.random.randint(2) == 0 else (art, av)
+        kw = {} if fetch else {"fetch_cost": False}
+        l = model.train_step(x, xv, y, np.ones(len(y), np.float32), 0.8, kp, **kw)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, l
+
+    for _ in range(10):
+        one()
+    torch.cuda.synchronize()
+    tr = ts = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b, l = one(fetch=not args.async_cost)
+        tr += a; ts += b
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({"what": "main_train loop through the host mirror (%s)" % ("tied" if args.tied else "untied"),
+                      "ms_per_step": round(wall / args.steps * 1e3, 3),
+                      "playlists_per_s": round(256 * args.steps / wall, 1),
+                      "reader_ms": round(tr / args.steps * 1e3, 3), "train_step_call_ms": round(ts / args.steps * 1e3, 3),
+                      "async_cost": bool(args.async_cost), "last_cost": float(l)}))
+
+
+if __name__ == "__main__":
+    main()

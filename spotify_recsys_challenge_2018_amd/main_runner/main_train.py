@@ -138,12 +138,18 @@ def run(conf, only_testmode):
                 x_pos, x_val = trk_positions, trk_val
             else:
                 x_pos, x_val = art_positions, art_val
+            # single GPU: the cost stays on the device (a 0-dim tensor, summed there and fetched once per epoch)
+            # so the reader builds the next batch while this step runs; the sharded path returns a float
+            kw = {} if world > 1 else {"fetch_cost": False}
             l = model.train_step(x_pos, x_val, y_positions, np.ones(len(y_positions), np.float32),
-                                 conf.kp, input_kp)
-        loss += l
+                                 conf.kp, input_kp, **kw)
+        loss = loss + l
         it += 1
         if start_idx > end_idx or end_idx == 0:                     # :227 reader wrapped
             epoch += 1
+            loss = float(loss)                                      # drains the stream
+            if hasattr(model, "check_feed"):
+                model.check_feed()
             log_write(conf, "epoch " + str(epoch))
             log_write(conf, "training loss: " + str(loss / it))
             cur_eval = 0.0

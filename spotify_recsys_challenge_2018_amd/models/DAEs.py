@@ -204,7 +204,10 @@ class DAE_tied:
             d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64)[:pos.shape[0]]
             d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32)
             rp, c, v, status = self.ctx.coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
-            self._csr_status = status            # checked lazily (no sync on the scoring path)
+            pending = (self._csr_status or []) + [status]      # checked lazily (no sync on the scoring path)
+            if len(pending) > 64:                               # un-fetched training steps: fold on the device
+                pending = [torch.cat(pending).max().reshape(1)]
+            self._csr_status = pending
             return rp, c, v
         rp, c, v = coo_to_csr(positions, values, self.n_batch, self.n_input)
         if c.size == 0:          # keep valid device pointers for empty batches
@@ -214,12 +217,15 @@ class DAE_tied:
     def _check_feed(self):
         """After the results of a call have been fetched (the stream is drained anyway): the device CSR
         builder skips entries whose row / column is out of range and raises the flag checked here."""
-        if self._csr_status is not None:
-            bad = int(self._csr_status.item())
+        if self._csr_status:
+            import torch
+            bad = int(torch.cat(self._csr_status).max().item())
             self._csr_status = None
             if bad:
                 raise ValueError("feed holds a row or column index out of range [0,%d) x [0,%d)"
                                  % (self.n_batch, self.n_input))
+
+    check_feed = _check_feed
 
     def _mark_dirty(self):
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
@@ -306,15 +312,20 @@ class DAE_tied:
         return res
 
     # -- training -----------------------------------------------------------------------------------
-    def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob):
-        """sess.run([model.optimizer, model.cost], ...) (main_train.py:204-213) -> cost (float)."""
+    def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, fetch_cost=True):
+        """sess.run([model.optimizer, model.cost], ...) (main_train.py:204-213) -> cost (float).
+        `fetch_cost=False` returns the cost as a 0-dim DEVICE tensor and does not wait for the step: the host
+        builds the next batch while this one runs (main_train accumulates the tensor and fetches it once per
+        epoch); the feed's range flag is then checked by the next fetching call or `check_feed()`."""
         import torch
         self.ctx.bind_stream()
         if self._sharded is not None:
             x = self._upload_csr(x_positions, x_ones)
             y = self._upload_csr(y_positions, y_ones)
             self._params_stale = True
-            return self._sharded.train_step(x, y, keep_prob, input_keep_prob)
+            cost = self._sharded.train_step(x, y, keep_prob, input_keep_prob)
+            self._check_feed()
+            return cost
         dev = self.weights["encoder_h"].device
         if self._adam is None:
             self._grads = {}
@@ -346,6 +357,8 @@ class DAE_tied:
             ctx.check(lib.dae_adam_step(ctx.h, P(p), P(m), P(v), P(grad), p.numel(),
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
         self._mark_dirty()
+        if not fetch_cost:
+            return self._cost[0].clone()
         cost = float(self._cost.item())
         self._check_feed()
         return cost

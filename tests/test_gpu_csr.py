@@ -101,3 +101,34 @@ def test_model_paths_agree_between_device_and_host_feed_builders():
     a.device_csr = True
     with pytest.raises(ValueError):
         a.recommend(np.array([[0, 5], [1, 99999]]), np.ones(2, np.float32), [[5], []] + [[]] * 38, k=10)
+
+
+def test_training_flags_a_bad_x_feed_even_when_the_y_feed_is_clean_and_can_run_unfetched():
+    """The range flag of EVERY feed of a call is kept (x's used to be overwritten by y's), and
+    `fetch_cost=False` returns the costs the fetching call returns, as device scalars."""
+    import torch
+    from spotify_recsys_challenge_2018_amd.models.DAEs import DAE_tied
+    from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists
+
+    class C:
+        save = "/tmp/_csr_unused"; batch = 24; n_input = 1200; hidden = 64; lr = 0.01; reg_lambda = 0.0
+        n_tracks = 1000
+    pos, ones, _ = make_playlists(C.batch, 1000, 200, seed=3)
+    y1 = np.ones(len(pos), np.float32)
+    a = DAE_tied(C()); a.fit()
+    b = DAE_tied(C()); b.fit()
+    got, want = [], []
+    for _ in range(70):                     # > 64 pending flags: folded on the device
+        want.append(a.train_step(pos, ones, pos, y1, 0.8, 0.7))
+        got.append(b.train_step(pos, ones, pos, y1, 0.8, 0.7, fetch_cost=False))
+    assert all(isinstance(g, torch.Tensor) and g.is_cuda for g in got)
+    # two runs of the training step agree to rounding only (float atomics in the sparse encoder gradient)
+    got = np.array([float(g) for g in got], np.float32)
+    assert np.allclose(got, np.array(want, np.float32), rtol=2e-4), np.abs(got / np.array(want) - 1).max()
+    b.check_feed()
+    bad = np.concatenate([pos, [[0, 5000]]], 0)
+    with pytest.raises(ValueError):
+        a.train_step(bad, np.append(ones, 1.0).astype(np.float32), pos, y1, 0.8, 0.7)
+    b.train_step(bad, np.append(ones, 1.0).astype(np.float32), pos, y1, 0.8, 0.7, fetch_cost=False)
+    with pytest.raises(ValueError):
+        b.check_feed()
