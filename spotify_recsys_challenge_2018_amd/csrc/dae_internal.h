@@ -200,11 +200,11 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
                                  int cap, int dtype = DAE_DTYPE_F32);
 
-// training forward: all tiles; the epilogue reads the dense targets scattered into `dz` ([B, ld]
-// row-major, read only), writes dL/dz TRANSPOSED ([ncols, ldT]: what both backward GEMMs read) and
-// one loss partial per workgroup (DAEs.py:98-100).
+// training forward: all tiles; the epilogue takes every element as a negative (target 0), writes dL/dz
+// TRANSPOSED ([ncols, ldT]: what both backward GEMMs read) and one loss partial per workgroup
+// (DAEs.py:98-100); the positives are redone afterwards by train.hip's loss_fixup_kernel.
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dz, int64_t ld, float* dzT, int64_t ldT, float* loss_part);
+                               float* dzT, int64_t ldT, float* loss_part);
 
 // train.hip
 int dae_train_step_f32(dae_ctx* ctx,

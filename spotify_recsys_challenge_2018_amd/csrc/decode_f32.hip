@@ -306,41 +306,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                 }
             }
         } else if (EPI == EPI_LOSS) {
-            // `out` holds the dense targets y (read only); dL/dz (mean over n_batch folded in) is
+            // Every element is treated as a NEGATIVE (target 0) here; the few positives of the batch (~100
+            // of 170 000 columns per row) are redone from their own dot products by loss_fixup_kernel
+            // (train.hip), so no dense target matrix exists.  dL/dz (mean over n_batch folded in) is
             // written transposed, the layout both backward GEMMs read.
-            // L = -[y log(p+1e-10) + 0.55 (1-y) log(1-p+1e-10)], p = sigmoid(z)   (DAEs.py:98-99)
+            // L = -[y log(p+1e-10) + 0.55 (1-y) log(1-p+1e-10)], p = sigmoid(z), y = 0   (DAEs.py:98-99)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
                 if (row >= p.B) continue;
-                const float* yrow = p.out + (size_t)row * p.ld + (size_t)t * 32 + 4 * hi;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const int lc = tcol0 + 8 * qd;
                     const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
-                    float yv[4];
-                    if (p.vec_ok && lc + 3 < p.ncols) {
-                        const float4 y4 = *reinterpret_cast<const float4*>(yrow + 8 * qd);
-                        yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) yv[e] = lc + e < p.ncols ? yrow[8 * qd + e] : 0.0f;
-                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (lc + e < p.ncols) {
                             // training only (parity by tolerance): hardware exp2 / log2 / rcp instead
                             // of the canonical sigmoid and IEEE divides the ranking path needs
-                            const float y = yv[e];
                             const float zz = acc[rb][4 * qd + e] + zb[e];
                             const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
-                            const float a1 = pr + 1e-10f, a0 = 1.0f - pr + 1e-10f;
-                            loss_acc -= 0.69314718f * (y * __builtin_amdgcn_logf(a1) +
-                                                       0.55f * (1.0f - y) * __builtin_amdgcn_logf(a0));
-                            const float dz = -(y * __builtin_amdgcn_rcpf(a1) -
-                                               0.55f * (1.0f - y) * __builtin_amdgcn_rcpf(a0)) *
-                                             pr * (1.0f - pr) * p.inv_nb;
-                            p.dzT[(size_t)(lc + e) * p.ldT + row] = dz;
+                            const float a0 = 1.0f - pr + 1e-10f;
+                            loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
+                            p.dzT[(size_t)(lc + e) * p.ldT + row] =
+                                0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
                         }
                     }
                 }
@@ -1283,14 +1272,18 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 }
 
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dz, int64_t ld, float* dzT, int64_t ldT, float* loss_part)
+                               float* dzT, int64_t ldT, float* loss_part)
 {
     DecP p;
     dae_tileset ts{ctx->pk_f32.ntiles, 1, 0, static_cast<const int*>(ctx->pk_f32.ident.p)};
     int rc = fill_common(ctx, g, B, ts, p);
     if (rc) return rc;
-    p.out = dz; p.ld = ld; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
-    p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(dz) % 16) == 0) ? 1 : 0;
+    p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
+    // A/B: DAE_LOSS_WAVES=8 runs two waves per SIMD on the 128-row image so that one wave's VALU epilogue
+    // (4 transcendentals per element) sits under the other's MFMAs; measured 240 us against 229 us for the
+    // default one wave per SIMD (V = 170 000, B = 256)
+    static const bool w8 = getenv("DAE_LOSS_WAVES") && atoi(getenv("DAE_LOSS_WAVES")) == 8;
+    if (g.R_TILE == 128 && p.G == 32 && w8) return launch_decode<4, EPI_LOSS, 32, 8, DT_F32>(ctx, g, p);
     return launch_decode_rb<EPI_LOSS>(ctx, g, p);
 }
 

@@ -20,20 +20,69 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// ---- dense targets: dz[r, c] = y value (buffer pre-zeroed) -------------------------------------
-// only columns of this shard [col_lo, col_hi) are kept, re-based to the shard's local index
-__global__ __launch_bounds__(256) void scatter_y_kernel(const int32_t* __restrict__ row_ptr,
-                                                        const int32_t* __restrict__ col,
-                                                        const float* __restrict__ val, int B,
-                                                        int col_lo, int col_hi,
-                                                        float* __restrict__ dz, int64_t ld)
+// ---- the positives of the loss -----------------------------------------------------------------------
+// K5 (decode_f32.hip, EPI_LOSS) treats all B x V elements as negatives.  A batch holds ~100 positives per row
+// out of 170 000 columns, so instead of a dense [B, V] target matrix (174 MB zeroed, scattered into and read
+// back per step) each target entry (row, col, y) is redone here: the same logit -- the fmaf chain over
+// k = 0..H-1 from +0, then + bias, which is what the fp32 MFMA computes -- then the full loss term and
+// dL/dz of DAEs.py:98-99; dL/dz OVERWRITES K5's value and the loss partial holds L(y) - L(0).
+// One workgroup per row (h row in LDS), one thread per target entry.  The target CSR holds one entry per
+// (row, col) (include/dae_hip.h: the CSR contract), so no two threads own the same element.
+constexpr int FIX_MAXH = 1024;
+__global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, int B, int H,
+                                                         int col_lo, int col_hi,
+                                                         const float* __restrict__ h,      // [B, H] after dropout
+                                                         const float* __restrict__ Wd,     // [col_hi - col_lo, H]
+                                                         const float* __restrict__ bias,   // local column index
+                                                         float inv_nb, float* __restrict__ dzT, int64_t ldT,
+                                                         float* __restrict__ loss_part)
 {
-    const int row = blockIdx.x;
-    if (row >= B) return;
-    for (int i = row_ptr[row] + threadIdx.x; i < row_ptr[row + 1]; i += 256) {
+    __shared__ float4 sh[FIX_MAXH / 4];
+    __shared__ float wsum[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int H4 = H >> 2;
+    for (int i = tid; i < H4; i += 256) sh[i] = reinterpret_cast<const float4*>(h + (size_t)row * H)[i];
+    __syncthreads();
+    float corr = 0.0f;
+    for (int i = row_ptr[row] + tid; i < row_ptr[row + 1]; i += 256) {
         const int c = col[i];
-        if (c >= col_lo && c < col_hi) dz[(size_t)row * ld + (c - col_lo)] = val[i];
+        if (c < col_lo || c >= col_hi) continue;
+        const int lc = c - col_lo;
+        const float y = val[i];
+        const float4* w = reinterpret_cast<const float4*>(Wd + (size_t)lc * H);
+        float z = 0.0f;
+        int k = 0;
+        for (; k + 8 <= H4; k += 8) {
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 hv = sh[k + u];
+                z = fmaf(wv[u].x, hv.x, z); z = fmaf(wv[u].y, hv.y, z);
+                z = fmaf(wv[u].z, hv.z, z); z = fmaf(wv[u].w, hv.w, z);
+            }
+        }
+        for (; k < H4; ++k) {
+            const float4 wv = w[k], hv = sh[k];
+            z = fmaf(wv.x, hv.x, z); z = fmaf(wv.y, hv.y, z); z = fmaf(wv.z, hv.z, z); z = fmaf(wv.w, hv.w, z);
+        }
+        z += bias[lc];
+        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * z));
+        const float a1 = pr + 1e-10f, a0 = 1.0f - pr + 1e-10f;
+        const float l1 = __builtin_amdgcn_logf(a1), l0 = __builtin_amdgcn_logf(a0);
+        // L(y) - L(0) = -ln2 * y * (log2 a1 - 0.55 log2 a0)
+        corr -= 0.69314718f * y * (l1 - 0.55f * l0);
+        dzT[(size_t)lc * ldT + row] = -(y * __builtin_amdgcn_rcpf(a1) - 0.55f * (1.0f - y) * __builtin_amdgcn_rcpf(a0)) *
+                                      pr * (1.0f - pr) * inv_nb;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) corr += __shfl_xor(corr, d);
+    if ((tid & 63) == 0) wsum[tid >> 6] = corr;
+    __syncthreads();
+    if (tid == 0) loss_part[row] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_nb;
 }
 
 // ---- K6: gW[v, hc] (+)= sum_r dz[r, v] * h[r, hc];  gb[v] = sum_r dz[r, v] ----------------------
@@ -426,17 +475,19 @@ __global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict
     if (threadIdx.x == 0) part[blockIdx.x] = 0.5 * (ws[0] + ws[1] + ws[2] + ws[3]);
 }
 
-// cost = sum(loss partials) + lambda * sum(l2 partials), fixed order, in double
-__global__ void finish_cost_kernel(const float* __restrict__ loss_part, int n_loss,
-                                   const double* __restrict__ l2_part, int n_l2, float lambda,
-                                   float* __restrict__ cost)
+// cost = sum(loss partials) + lambda * sum(l2 partials), in double, fixed order (lane-strided sums, then
+// a shuffle tree): one wave
+__global__ __launch_bounds__(64) void finish_cost_kernel(const float* __restrict__ loss_part, int n_loss,
+                                                         const double* __restrict__ l2_part, int n_l2, float lambda,
+                                                         float* __restrict__ cost)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0.0;
-    for (int i = 0; i < n_loss; ++i) s += (double)loss_part[i];
-    double l2 = 0.0;
-    for (int i = 0; i < n_l2; ++i) l2 += l2_part[i];
-    *cost = (float)(s + (double)lambda * l2);
+    const int lane = threadIdx.x;
+    double s = 0.0, l2 = 0.0;
+    for (int i = lane; i < n_loss; i += 64) s += (double)loss_part[i];
+    for (int i = lane; i < n_l2; i += 64) l2 += l2_part[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d); l2 += __shfl_xor(l2, d); }
+    if (lane == 0) *cost = (float)(s + (double)lambda * l2);
 }
 
 // ---- K9: TF1 AdamOptimizer, dense ------------------------------------------------
@@ -490,10 +541,10 @@ namespace {
 // scratch carved for one training step over a [Vl, H] weight (shard) and B rows; stable for a given
 // (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
 struct TrainPlan {
-    int NA, G, RB, Bpad64, n_chunk, chunk;
+    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix;
     dae_rowgeom g;
     size_t bh, hp_bytes;
-    float *dz, *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
+    float *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
     double* l2_part;
 };
 
@@ -510,7 +561,6 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     t.Bpad64 = (B + 63) / 64 * 64;
     t.hp_bytes = (size_t)t.g.n_rg * t.G * t.RB * 64 * sizeof(float4);
     if ((rc = dae_reserve(ctx, ctx->h_packed, t.hp_bytes))) return rc;
-    if ((rc = dae_reserve(ctx, ctx->train_a, (size_t)B * Vl * sizeof(float)))) return rc;
     if ((rc = dae_reserve(ctx, ctx->train_b, (size_t)Vl * t.Bpad64 * sizeof(float)))) return rc;
     // split of the V contraction of K7: about one (output tile, chunk) work item per wave slot
     const int n_out_tiles = (H / (32 * t.NA)) * (t.Bpad64 / 64);
@@ -520,9 +570,9 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     if (t.chunk < 16) t.chunk = 16;
     t.n_chunk = (Vl + t.chunk - 1) / t.chunk;
     t.bh = (size_t)B * H;
-    const size_t c_floats = 3 * t.bh + (size_t)t.n_chunk * t.Bpad64 * H + (size_t)t.g.grid + 64;
+    t.n_fix = B;                                   // loss partials of the positives: one per row
+    const size_t c_floats = 3 * t.bh + (size_t)t.n_chunk * t.Bpad64 * H + (size_t)t.g.grid + t.n_fix + 64;
     if ((rc = dae_reserve(ctx, ctx->train_c, c_floats * sizeof(float) + 4096 * sizeof(double)))) return rc;
-    t.dz = static_cast<float*>(ctx->train_a.p);
     t.dzT = static_cast<float*>(ctx->train_b.p);
     t.hbuf = static_cast<float*>(ctx->train_c.p);
     t.sg = t.hbuf + t.bh;
@@ -530,7 +580,7 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     t.part = t.dpre + t.bh;
     t.loss_part = t.part + (size_t)t.n_chunk * t.Bpad64 * H;
     t.l2_part = reinterpret_cast<double*>(
-        (reinterpret_cast<uintptr_t>(t.loss_part + t.g.grid) + 63) & ~(uintptr_t)63);
+        (reinterpret_cast<uintptr_t>(t.loss_part + t.g.grid + t.n_fix) + 63) & ~(uintptr_t)63);
     return DAE_OK;
 }
 
@@ -543,13 +593,14 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     hipStream_t st = ctx->stream;
     const int NA = t.NA;
     int rc;
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dz, 0, (size_t)B * Vl * sizeof(float), st));
+    if (H > FIX_MAXH) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H <= %d (H=%d)", FIX_MAXH, H);
     if (t.Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * sizeof(float), st));
-    hipLaunchKernelGGL(scatter_y_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B,
-                       col_lo, col_hi, t.dz, (int64_t)Vl);
-    DAE_CHECK_LAUNCH(ctx, "scatter_y_kernel");
-    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dz, Vl, t.dzT, t.Bpad64, t.loss_part);
+    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part);
     if (rc) return rc;
+    hipLaunchKernelGGL(loss_fixup_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo, col_hi,
+                       t.hbuf, Wd, static_cast<const float*>(ctx->pk_f32.bias.p), 1.0f / (float)n_batch,
+                       t.dzT, (int64_t)t.Bpad64, t.loss_part + t.g.grid);
+    DAE_CHECK_LAUNCH(ctx, "loss_fixup_kernel");
 
     // ---- K6: decoder gradient ------------------------------------------------------------------------
     {
@@ -608,7 +659,7 @@ int train_cost(dae_ctx* ctx, const TrainPlan& t, float reg_lambda, const float* 
             n_l2 += nb;
         }
     }
-    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(64), 0, st, t.loss_part, t.g.grid, t.l2_part, n_l2,
+    hipLaunchKernelGGL(finish_cost_kernel, dim3(1), dim3(64), 0, st, t.loss_part, t.g.grid + t.n_fix, t.l2_part, n_l2,
                        reg_lambda, cost_out);
     DAE_CHECK_LAUNCH(ctx, "finish_cost_kernel");
     return DAE_OK;
