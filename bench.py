@@ -61,6 +61,10 @@ def parse():
                          "would run (global batch N x batch-per-gpu, columns of shard --sim-rank); the "
                          "exchange is a 1-rank all-gather, so communication is NOT included")
     ap.add_argument("--sim-rank", type=int, default=0)
+    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="alltoall",
+                    help="N > 1: how the per-shard top-k lists meet.  alltoall: every rank receives and merges the rows "
+                         "it owns (1/N of the bytes and of the merge); allgather: every rank receives and merges all "
+                         "rows (BASELINE.json configs[2] as written; reported as an extra row when alltoall is timed)")
     ap.add_argument("--prime-ms", type=float, default=200.0,
                     help="setup: run the step for this long before the warm-up steps (device ramp; 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,7 +98,7 @@ def main():
 
     from spotify_recsys_challenge_2018_amd import _lib
     from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
-    from spotify_recsys_challenge_2018_amd.sharding import gather_shard_topk, shard_bounds
+    from spotify_recsys_challenge_2018_amd.sharding import exchange_shard_topk, gather_shard_topk, shard_bounds
     from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 
     n_tracks, V, H, k = args.n_tracks, args.n_tracks + args.n_artists, args.hidden, args.k
@@ -139,10 +143,16 @@ def main():
                    torch.empty((world * B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
         l_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
                    torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+        x_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
+                   torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+        B_own = B // world                       # rows whose final top-k this rank produces (alltoall)
+        own = [(torch.empty((B_own, k), dtype=torch.float32, device=dev),
+                torch.empty((B_own, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
             c.bind_stream()
     step_no = [0]
+    exchange = args.exchange
 
     def step():
         s = step_no[0] % n_str
@@ -155,8 +165,12 @@ def main():
             else:
                 c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[s][0],
                              l_bufs[s][1], out_kind=_lib.DAE_OUT_LOGIT, dtype=DT)
-                g_logit, g_idx = gather_shard_topk(l_bufs[s][0], l_bufs[s][1], out=g_bufs[s])
-                c.topk_merge(g_logit, g_idx, outs[s][0], outs[s][1])
+                if exchange == "alltoall":
+                    x_logit, x_idx = exchange_shard_topk(l_bufs[s][0], l_bufs[s][1], out=x_bufs[s])
+                    c.topk_merge(x_logit, x_idx, own[s][0], own[s][1])
+                else:
+                    g_logit, g_idx = gather_shard_topk(l_bufs[s][0], l_bufs[s][1], out=g_bufs[s])
+                    c.topk_merge(g_logit, g_idx, outs[s][0], outs[s][1])
 
     # setup, not warm-up: bring the device to its sustained state (clocks, Infinity Cache holding W) by running
     # the step for a fixed 0.2 s; measured throughput otherwise depends on how short the run is (1.07 M playlists/s
@@ -205,19 +219,37 @@ def main():
     achieved_tflops = flop_per_launch / (kern_avg_ms * 1e-3) / 1e12 if kern_avg_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 256 and not sim:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("bf16" if args.dtype == "bf16" else "f32", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-    roofline = {"kernel": ("decode_bf16_h256_filter_kernel" if args.dtype == "bf16" and H == 256 else
-                           "decode_f32_kernel<filter>") if plan["fused"] else "decode_f32_kernel<dense>",
-                "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": round(achieved_tflops / peak_tf, 4),
-                "traffic": traffic, "flop_per_launch": flop_per_launch,
-                "avg_launch_ms": round(kern_avg_ms, 4), "launches": kern_n}
+    # Which roof binds this launch: its matrix time at the dense MFMA peak, or the time to stream its algorithmic
+    # bytes (W tiles + bias + hidden + candidate lists) at the HBM peak.  fp32 is MFMA-bound at every
+    # batch size; bf16 at batch 256 is BELOW the ridge (256 flop per byte of W against 2.5 PF / 8 TB/s = 312).
+    esz = 2 if args.dtype == "bf16" else 4
+    alg_bytes = dom_tiles * 32 * H * esz + 4 * dom_tiles * 32 + B * H * esz + 8 * B * k
+    t_mfma = flop_per_launch / (peak_tf * 1e12)
+    t_hbm = alg_bytes / (PEAK_HBM_GBS * 1e9)
+    kname = ("decode_bf16_h256_filter_kernel" if args.dtype == "bf16" and H == 256 else
+             "decode_f32_kernel<filter>") if plan["fused"] else "decode_f32_kernel<dense>"
+    achieved_gbs = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    if t_hbm > t_mfma:
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(achieved_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": alg_bytes, "flop_per_launch": flop_per_launch,
+                    "avg_launch_ms": round(kern_avg_ms, 4), "launches": kern_n,
+                    "mfma": {"achieved": round(achieved_tflops, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                             "frac": round(achieved_tflops / peak_tf, 4)},
+                    "note": "launch is below the ridge: %.1f us to stream its bytes at the HBM peak, %.1f us of "
+                            "matrix time at the MFMA peak" % (t_hbm * 1e6, t_mfma * 1e6)}
+    else:
+        roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak_tf,
+                    "unit": "TFLOP/s", "frac": round(achieved_tflops / peak_tf, 4),
+                    "traffic": traffic, "flop_per_launch": flop_per_launch, "bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": round(kern_avg_ms, 4), "launches": kern_n}
 
     # the same kernel alone on the GPU (one stream, nothing overlapping it), after the timed region
     if n_str > 1:
@@ -235,8 +267,11 @@ def main():
         ctx.profile_enable(False)
         iso_avg = iso_ms / max(iso_n, 1)
         iso_tf = flop_per_launch / (iso_avg * 1e-3) / 1e12 if iso_avg > 0 else 0.0
-        roofline["isolated"] = {"avg_launch_ms": round(iso_avg, 4), "achieved": round(iso_tf, 2),
-                                "frac": round(iso_tf / peak_tf, 4),
+        iso_gbs = alg_bytes / (iso_avg * 1e-3) / 1e9 if iso_avg > 0 else 0.0
+        hbm_bound = roofline["bound"] == "hbm"
+        roofline["isolated"] = {"avg_launch_ms": round(iso_avg, 4),
+                                "achieved": round(iso_gbs, 1) if hbm_bound else round(iso_tf, 2),
+                                "frac": round(iso_gbs / PEAK_HBM_GBS, 4) if hbm_bound else round(iso_tf / peak_tf, 4),
                                 "note": "same launch with no second batch in flight; the timed region overlaps "
                                         "%d batches, which stretches each launch but raises throughput" % n_str}
 
@@ -294,11 +329,40 @@ def main():
                                                                args.dist, args.bias, 1 if world == 1 else 2),
                    "vocab": V, "n_tracks": n_tracks, "hidden": H, "global_batch": B, "k": k,
                    "parallelism": ("SIMULATED rank %d of %d (compute only, no exchange)" % (args.sim_rank, sim)) if sim else
-                                  ("1 GPU" if world == 1 else "vocab column shard x%d + RCCL all-gather" % world),
+                                  ("1 GPU" if world == 1 else
+                                   "vocab column shard x%d + RCCL %s of the per-shard top-%d" % (
+                                       world, "all-to-all (each rank merges the %d rows it owns)" % (B // world)
+                                       if args.exchange == "alltoall" else "all-gather (each rank merges all rows)", k)),
                    "plan": plan, "streams": n_str, "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,
     }
+
+    # ---- the exchange as BASELINE.json configs[2] words it: all-gather, every rank merges every row ----------
+    if sharded and not sim and args.exchange == "alltoall":
+        exchange = "allgather"
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_g = float(t.item())
+        r0_ = rank * B_own
+        agree = bool(torch.equal(outs[(step_no[0] - 1) % n_str][1][r0_:r0_ + B_own], own[(step_no[0] - 1) % n_str][1]))
+        out["allgather_exchange"] = {"value": round(B * args.steps / el_g, 1), "unit": "playlists/s",
+                                     "ms_per_step": round(el_g / args.steps * 1e3, 4),
+                                     "same_indices_as_alltoall": agree,
+                                     "note": "same shards, the per-shard lists all-gathered and ALL rows merged on "
+                                             "every rank"}
+        exchange = "alltoall"
 
     # ---- the same job with the PLAYLISTS partitioned over the ranks instead of the vocabulary -------------
     # Not the headline (BASELINE.json configs[2] names the vocabulary shard): every rank holds the whole
@@ -342,8 +406,8 @@ def main():
         # same rows, same model: the two partitionings must agree bit for bit
         step(); step()
         torch.cuda.synchronize()
-        same = bool(torch.equal(outs[0][1][r0:r0 + bpg], lo_out[0][1]) and
-                    torch.equal(outs[0][0][r0:r0 + bpg], lo_out[0][0])) if args.dtype == "f32" else None
+        got = own[0] if exchange == "alltoall" else (outs[0][0][r0:r0 + bpg], outs[0][1][r0:r0 + bpg])
+        same = bool(torch.equal(got[1], lo_out[0][1]) and torch.equal(got[0], lo_out[0][0])) if args.dtype == "f32" else None
         out["playlist_sharded"] = {"value": round(B * args.steps / el_r, 1), "unit": "playlists/s",
                                    "ms_per_step": round(el_r / args.steps * 1e3, 4),
                                    "identical_to_vocab_sharded": same,

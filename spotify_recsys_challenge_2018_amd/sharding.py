@@ -3,10 +3,11 @@
 
 Rank g owns the decoder rows (vocabulary columns) [lo_g, hi_g) -- tile aligned so every shard's
 packed image starts on a 32-column MFMA tile -- and W_enc is replicated, so every rank computes
-the same hidden activations with no collective.  The only exchange step of the path is the
-all-gather of the per-shard top-k lists ((logit, column) x k per playlist), after which every
-rank merges the G lists with the same (logit desc, column asc) rule.  The merge is exact because
-each shard's top-k contains that shard's share of the global top-k.
+the same hidden activations with no collective.  The only exchange step of the path is that of the
+per-shard top-k lists ((logit, column) x k per playlist): an all-gather after which every rank merges
+the G lists of every row, or an all-to-all after which every rank merges the G lists of the rows it
+owns -- same (logit desc, column asc) rule either way.  The merge is exact because each shard's
+top-k contains that shard's share of the global top-k.
 """
 import numpy as np
 
@@ -45,21 +46,58 @@ def gather_shard_topk(local_logit, local_idx, group=None, out=None):
     return g_logit.view(world, B, k), g_idx.view(world, B, k)
 
 
+def row_owner_bounds(n_rows, world, rank):
+    """Playlists [lo, hi) whose FINAL top-k rank `rank` produces in the "alltoall" exchange (equal blocks)."""
+    if n_rows % world:
+        raise ValueError("the row-owner exchange needs n_rows (%d) divisible by the world size (%d)" % (n_rows, world))
+    per = n_rows // world
+    return rank * per, (rank + 1) * per
+
+
+def exchange_shard_topk(local_logit, local_idx, group=None, out=None):
+    """All-to-all of the per-shard candidate lists: rank r keeps, from every shard, only the rows it OWNS
+    (`row_owner_bounds`): [B,k] -> [G, B/G, k].  Same lists as the all-gather restricted to the owned rows, so
+    the merge is the same and exact; each rank sends (G-1)/G of its 2 x B x k x 4 bytes ONCE in total instead of
+    once per peer, and merges B/G rows instead of B.  xGMI is point-to-point: every byte crosses one link."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    B, k = local_logit.shape
+    row_owner_bounds(B, world, 0)
+    if out is None:
+        out = (torch.empty_like(local_logit), torch.empty_like(local_idx))
+    x_logit, x_idx = out                       # source-rank-major along dim 0
+    dist.all_to_all_single(x_logit, local_logit.contiguous(), group=group)
+    dist.all_to_all_single(x_idx, local_idx.contiguous(), group=group)
+    return x_logit.view(world, B // world, k), x_idx.view(world, B // world, k)
+
+
 class ShardedRanker:
     """decode + top-k over this rank's vocabulary shard, exchange, merge.
 
     `local_topk(h, k) -> (logit [B,k], idx [B,k])` and `merge(g_logit, g_idx) -> (score, idx)` are
     the two device operations (libdae_hip: dae_decode_topk with DAE_OUT_LOGIT and dae_topk_merge);
-    they are injected so the exchange logic is testable with gloo on CPU."""
+    they are injected so the exchange logic is testable with gloo on CPU.
 
-    def __init__(self, local_topk, merge, group=None):
+    exchange = "allgather": every rank ends with the merged top-k of ALL B rows (BASELINE.json configs[2] as
+    written).  exchange = "alltoall": every rank ends with the merged top-k of the rows it owns
+    (`row_owner_bounds`) -- 1/G of the exchange bytes and of the merge work; the job's output is the
+    concatenation over ranks."""
+
+    def __init__(self, local_topk, merge, group=None, exchange="allgather"):
+        if exchange not in ("allgather", "alltoall"):
+            raise ValueError("unknown exchange %r" % (exchange,))
         self.local_topk = local_topk
         self.merge = merge
         self.group = group
+        self.exchange = exchange
 
     def rank_batch(self, h, k):
         l_logit, l_idx = self.local_topk(h, k)
-        g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group)
+        if self.exchange == "alltoall":
+            g_logit, g_idx = exchange_shard_topk(l_logit, l_idx, self.group)
+        else:
+            g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group)
         return self.merge(g_logit, g_idx)
 
 

@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from spotify_recsys_challenge_2018_amd.sharding import ShardedRanker, all_shard_bounds, shard_bounds
+from spotify_recsys_challenge_2018_amd.sharding import ShardedRanker, all_shard_bounds, row_owner_bounds, shard_bounds
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_weights
 
 
@@ -52,6 +52,11 @@ def _worker(rank, world, port, q):
     z_all = oracle.decode(h, W_dec, b_dec, 0, nt)
     s0, i0 = oracle.topk(z_all, k)
     ok = bool(np.array_equal(i.numpy(), i0) and np.array_equal(s.numpy().view(np.uint32), s0.view(np.uint32)))
+    # row-owner exchange: this rank ends with exactly its block of rows of the same result
+    s, i = ShardedRanker(local_topk, merge, exchange="alltoall").rank_batch(torch.from_numpy(h), k)
+    r0, r1 = row_owner_bounds(B, world, rank)
+    ok = ok and i.shape == (r1 - r0, k) and bool(
+        np.array_equal(i.numpy(), i0[r0:r1]) and np.array_equal(s.numpy().view(np.uint32), s0[r0:r1].view(np.uint32)))
     q.put((rank, ok))
     dist.destroy_process_group()
 
