@@ -67,6 +67,8 @@ def parse():
                          "rows (BASELINE.json configs[2] as written; reported as an extra row when alltoall is timed)")
     ap.add_argument("--prime-ms", type=float, default=200.0,
                     help="setup: run the step for this long before the warm-up steps (device ramp; 0 = off)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL (the product path).  gloo: development rehearsal of the N > 1 flow on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
@@ -81,6 +83,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        # development only: rehearse the N > 1 control flow with N processes on ONE GPU (RCCL refuses two ranks
+        # on a device); the collectives go through host memory, so the numbers mean nothing
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through torch.distributed.run (see docstring)")
@@ -94,7 +100,10 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if args.backend == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from spotify_recsys_challenge_2018_amd import _lib
     from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
@@ -177,7 +186,14 @@ def main():
     # over 10 steps, 1.12 M over 50, 1.23 M over 1000).  Reported as config.prime_ms; the W warm-up steps and the
     # K timed steps follow exactly as asked.
     t_prime = time.perf_counter()
-    while (time.perf_counter() - t_prime) < args.prime_ms * 1e-3:
+    while True:
+        more = (time.perf_counter() - t_prime) < args.prime_ms * 1e-3
+        if sharded:        # the step holds a collective: every rank must run the same number of them
+            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item())
+        if not more:
+            break
         for _ in range(8):
             step()
         torch.cuda.synchronize()

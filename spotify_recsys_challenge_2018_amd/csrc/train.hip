@@ -99,8 +99,8 @@ struct GwP {
 };
 
 // NA = hidden tiles per wave (4, 2 or 1): a "half" is 32*NA hidden units, hidden = hc0 + NA*i + a
-template <int NA>
-__global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
+template <int NA, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [Bp][32*NA] floats
     constexpr int HW = 32 * NA;
@@ -113,15 +113,39 @@ __global__ __launch_bounds__(256, 1) void grad_wdec_kernel(const GwP p)
     const int hc0 = half * HW;
     const int Bp = (p.B + 31) & ~31;           // rows padded to whole 32-row groups (zero rows)
 
-    for (int i = tid; i < Bp * HW; i += 256) {
-        const int r = i / HW, c = i - r * HW;
-        lds[i] = r < p.B ? p.h[(size_t)r * p.H + hc0 + c] : 0.0f;
+    // LDS image of h[:, hc0 : hc0 + HW]: 8 independent 16-byte loads in flight per thread.  (One 4-byte load ->
+    // wait -> ds_write per iteration, 128 iterations per thread, was ~80 us of this kernel's 280: every iteration
+    // pays an L2 round trip.)
+    if ((reinterpret_cast<uintptr_t>(p.h) & 15) == 0 && (p.H & 3) == 0) {
+        constexpr int HW4 = HW / 4, NT = NW * 64;
+        const int n4 = Bp * HW4;
+        float4* lds4 = reinterpret_cast<float4*>(lds);
+        for (int i0 = tid; i0 < n4; i0 += 8 * NT) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * NT, n4 - 1);
+                const int r = i / HW4, c4 = i - r * HW4;
+                v[u] = *reinterpret_cast<const float4*>(p.h + (size_t)min(r, p.B - 1) * p.H + hc0 + 4 * c4);
+                if (r >= p.B) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * NT;
+                if (i < n4) lds4[i] = v[u];
+            }
+        }
+    } else {
+        for (int i = tid; i < Bp * HW; i += NW * 64) {
+            const int r = i / HW, c = i - r * HW;
+            lds[i] = r < p.B ? p.h[(size_t)r * p.H + hc0 + c] : 0.0f;
+        }
     }
     __syncthreads();
 
     const int n_tiles = (p.V + 63) / 64;
-    const int n_ws = p.nb_half * 4;
-    for (int t = bir * 4 + wave; t < n_tiles; t += n_ws) {
+    const int n_ws = p.nb_half * NW;
+    for (int t = bir * NW + wave; t < n_tiles; t += n_ws) {
         const int v0 = t * 64;
         const int vcol = v0 + 2 * j;                                 // this lane's 2 columns
         const bool ok0 = vcol < p.V, ok1 = vcol + 1 < p.V;
@@ -621,7 +645,18 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
             attr = true;
         }
         const dim3 grid(p.n_half * nb), blk(256);
-        if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, st, p);
+        // two waves per SIMD on the shared h image: 241 us against 257 us with one (V = 170 000, B = H = 256); the
+        // second wave covers the dz^T load latency and the gW stores of the first (DAE_K6_WAVES=4 for the A/B)
+        static const bool k6w8 = !(getenv("DAE_K6_WAVES") && atoi(getenv("DAE_K6_WAVES")) == 4);
+        if (NA == 4 && k6w8) {
+            static bool attr8 = false;
+            if (!attr8) {
+                DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr8 = true;
+            }
+            hipLaunchKernelGGL((grad_wdec_kernel<4, 8>), grid, dim3(512), lds, st, p);
+        } else if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, st, p);
         else if (NA == 2) hipLaunchKernelGGL(grad_wdec_kernel<2>, grid, blk, lds, st, p);
         else hipLaunchKernelGGL(grad_wdec_kernel<1>, grid, blk, lds, st, p);
         DAE_CHECK_LAUNCH(ctx, "grad_wdec_kernel");

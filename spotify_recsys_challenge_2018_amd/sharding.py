@@ -41,9 +41,21 @@ def gather_shard_topk(local_logit, local_idx, group=None, out=None):
         out = (torch.empty((world * B, k), dtype=local_logit.dtype, device=local_logit.device),
                torch.empty((world * B, k), dtype=local_idx.dtype, device=local_idx.device))
     g_logit, g_idx = out                       # rank-major concatenation along dim 0
-    dist.all_gather_into_tensor(g_logit, local_logit.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_idx, local_idx.contiguous(), group=group)
+    _collective(dist.all_gather_into_tensor, g_logit, local_logit.contiguous(), group)
+    _collective(dist.all_gather_into_tensor, g_idx, local_idx.contiguous(), group)
     return g_logit.view(world, B, k), g_idx.view(world, B, k)
+
+
+def _collective(fn, dst, src, group):
+    """fn(dst, src, group=group).  RCCL takes device tensors as they are; gloo (CPU tests, and the one-GPU
+    rehearsal of the N > 1 flow) has no device all-gather / all-to-all, so device tensors go through the host."""
+    import torch.distributed as dist
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        d = dst.cpu()
+        fn(d, src.cpu(), group=group)
+        dst.copy_(d)
+    else:
+        fn(dst, src, group=group)
 
 
 def row_owner_bounds(n_rows, world, rank):
@@ -67,8 +79,8 @@ def exchange_shard_topk(local_logit, local_idx, group=None, out=None):
     if out is None:
         out = (torch.empty_like(local_logit), torch.empty_like(local_idx))
     x_logit, x_idx = out                       # source-rank-major along dim 0
-    dist.all_to_all_single(x_logit, local_logit.contiguous(), group=group)
-    dist.all_to_all_single(x_idx, local_idx.contiguous(), group=group)
+    _collective(dist.all_to_all_single, x_logit, local_logit.contiguous(), group)
+    _collective(dist.all_to_all_single, x_idx, local_idx.contiguous(), group)
     return x_logit.view(world, B // world, k), x_idx.view(world, B // world, k)
 
 
