@@ -298,37 +298,53 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
         const float* Wl = p.W + hc0 + NA * j;
         const float* Dl = p.dzT + r0 + 2 * j;
-        for (int v0 = v_beg; v0 < v_end; v0 += 16) {
-            float av[8][NA];
-            float2 d[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int v = v0 + 2 * s + hi;
-                const bool in = v < v_end;
-                const int vc = in ? v : v_beg;
-                const float* wr = Wl + (size_t)vc * p.H;
-                if (NA == 4) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(wr);
-                    av[s][0] = t4.x; av[s][1 % NA] = t4.y; av[s][2 % NA] = t4.z; av[s][3 % NA] = t4.w;
-                } else if (NA == 2) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(wr);
-                    av[s][0] = t2.x; av[s][1 % NA] = t2.y;
-                } else {
-                    av[s][0] = wr[0];
-                }
-                d[s] = in ? *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT)
-                          : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], d[s].x, acc[a][0], 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], d[s].y, acc[a][1], 0, 0, 0);
-            }
+        // 16 vocabulary rows (8 k-steps, 64 MFMAs) per block, two register sets: the loads of block n+1 are
+        // issued before the MFMAs of block n (one wave per SIMD: nothing else hides the ~2 us of HBM latency;
+        // without the second set this kernel ran at 0.6 of its matrix time).  Rows past the chunk read row
+        // v_beg and multiply by 0.
+#define DH_LOAD(AV, D, V0)                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
+            const int v = (V0) + 2 * s + hi;                                                   \
+            const bool in = v < v_end;                                                         \
+            const int vc = in ? v : v_beg;                                                     \
+            const float* wr = Wl + (size_t)vc * p.H;                                           \
+            if (NA == 4) {                                                                     \
+                const float4 t4 = *reinterpret_cast<const float4*>(wr);                        \
+                AV[s][0] = t4.x; AV[s][1 % NA] = t4.y; AV[s][2 % NA] = t4.z; AV[s][3 % NA] = t4.w; \
+            } else if (NA == 2) {                                                              \
+                const float2 t2 = *reinterpret_cast<const float2*>(wr);                        \
+                AV[s][0] = t2.x; AV[s][1 % NA] = t2.y;                                         \
+            } else {                                                                           \
+                AV[s][0] = wr[0];                                                              \
+            }                                                                                  \
+            D[s] = *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT);                  \
         }
+// the "past the chunk -> 0" select sits HERE, not next to the load: a select on a loaded value in the load
+// stage makes the compiler wait for that load before the sched_barrier, i.e. before the MFMAs it should hide under
+#define DH_MMA(AV, D, V0)                                                                      \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
+            const bool in = (V0) + 2 * s + hi < v_end;                                         \
+            const float dx = in ? D[s].x : 0.f, dy = in ? D[s].y : 0.f;                        \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dx, acc[a][0], 0, 0, 0); \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dy, acc[a][1], 0, 0, 0); \
+        }
+        float avA[8][NA], avB[8][NA];
+        float2 dA[8], dB[8];
+        DH_LOAD(avA, dA, v_beg)
+        for (int v0 = v_beg; v0 < v_end; v0 += 32) {
+            DH_LOAD(avB, dB, v0 + 16)
+            __builtin_amdgcn_sched_barrier(0);
+            DH_MMA(avA, dA, v0)
+            __builtin_amdgcn_sched_barrier(0);
+            DH_LOAD(avA, dA, v0 + 32)
+            __builtin_amdgcn_sched_barrier(0);
+            DH_MMA(avB, dB, v0 + 16)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef DH_LOAD
+#undef DH_MMA
         float* prow = p.part + ((size_t)ch * p.Bpad64) * p.H + hc0;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
