@@ -171,6 +171,12 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k,
 
 /* ---- training step (DAEs.py:98-102) ------------------------------------------------------ */
 
+/* Arithmetic of the training FORWARD GEMM (hidden x W_dec^T) of this context: DAE_DTYPE_F32 (default; fp32
+ * MFMA) or DAE_DTYPE_BF16 (BASELINE.json configs[3]: operands rounded to bf16, fp32 accumulate; the loss,
+ * dL/dz, both backward GEMMs, the parameters and Adam stay fp32).  Sticky; applies to
+ * dae_train_forward_backward and dae_train_shard_decode.  Replaces nothing in the reference (TF1 is fp32). */
+int dae_set_train_dtype(dae_ctx* ctx, int dtype);
+
 /* Forward + loss + backward for one batch.  x_* = input CSR (after the host coin flip
  * tracks-only / artists-only, main_train.py:202-213), y_* = target CSR (values are the y_ones
  * of the feed).  n_batch = the fixed graph batch the mean divides by (DAEs.py:100).

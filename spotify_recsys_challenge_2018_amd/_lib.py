@@ -16,7 +16,7 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
     "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
-    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_train_forward_backward",
+    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
 ]
@@ -64,6 +64,8 @@ def load():
                                    c_int, c_int, vp, vp]
     lib.dae_topk_dense.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_topk_merge.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]
+    lib.dae_set_train_dtype.argtypes = [vp, c_int]
+    lib.dae_set_train_dtype.restype = c_int
     lib.dae_train_forward_backward.argtypes = (
         [vp] + [vp] * 6 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 5)
     lib.dae_train_shard_encode.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_f, c_u32, vp]
@@ -136,6 +138,10 @@ class Context:
         self.check(self.lib.dae_coo_to_csr(self.h, _ptr(positions), _ptr(values), bcast, nnz, int(n_rows),
                                            int(n_cols), _ptr(rp), _ptr(col), _ptr(val), _ptr(status)))
         return rp, col, val, status
+
+    def set_train_dtype(self, dtype):
+        """Arithmetic of the training forward GEMM: DAE_DTYPE_F32 (default) or DAE_DTYPE_BF16."""
+        self.check(self.lib.dae_set_train_dtype(self.h, int(dtype)))
 
     def close(self):
         if getattr(self, "h", None):

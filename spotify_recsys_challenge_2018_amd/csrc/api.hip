@@ -501,6 +501,14 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k, const float* cand_logit,
     return dae_launch_topk_soa(ctx, G, cand_logit, cand_idx, ta);
 }
 
+int dae_set_train_dtype(dae_ctx* ctx, int dtype)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
+    ctx->train_dtype = dtype;
+    return DAE_OK;
+}
+
 int dae_train_forward_backward(dae_ctx* ctx,
         const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,
         const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,

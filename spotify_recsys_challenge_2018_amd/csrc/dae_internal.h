@@ -65,6 +65,7 @@ struct dae_ctx {
     dae_buf cand_cnt;          // [nb_rg][Bpad] int
     dae_buf dense_tmp;         // unfused fallback logits
     dae_buf train_a, train_b, train_c, train_d;
+    int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)
     dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
 
     // profiling of the dominant kernel
@@ -204,7 +205,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
 // TRANSPOSED ([ncols, ldT]: what both backward GEMMs read) and one loss partial per workgroup
 // (DAEs.py:98-100); the positives are redone afterwards by train.hip's loss_fixup_kernel.
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dzT, int64_t ldT, float* loss_part);
+                               float* dzT, int64_t ldT, float* loss_part, int dtype = DAE_DTYPE_F32);
 
 // train.hip
 int dae_train_step_f32(dae_ctx* ctx,

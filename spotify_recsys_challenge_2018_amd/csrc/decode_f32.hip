@@ -800,35 +800,92 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 }
 
 // ---- prepack: W_dec rows -> MFMA A-operand order ----------------------------------------------
-// out float4 index = (t*G + g)*64 + lane, lane = hi*32 + i; component e holds
-// W[col_lo + 32t + i][8g + 2e + hi]  (zero outside the matrix).
-__global__ __launch_bounds__(256) void prepack_f32_kernel(const float* __restrict__ W,
-                                                          const float* __restrict__ b, int H, int G,
-                                                          int col_lo, int col_hi, int ntiles,
-                                                          float4* __restrict__ Wp,
-                                                          float* __restrict__ bias)
+// One workgroup per 32-column tile: the tile's 32 rows of W (32 x H floats, contiguous 4 H bytes each) are read
+// with coalesced 16-byte loads into LDS and written out in operand order with coalesced 16-byte stores.
+// (A thread gathering its own 4 / 8 strided scalars straight from HBM took 139 us for the 174 MB matrix --
+// 2.5 TB/s of traffic; the training step re-tiles the decoder every step.)
+//   fp32: out float4 index = (t*G + g)*64 + lane, lane = hi*32 + i; component e = W[col_lo+32t+i][8g + 2e + hi]
+//   bf16: out uint4  index = (t*NS + s)*64 + lane: bf16 of W[col_lo+32t+i][16s + 8hi + 0..7]
+//         bias fragments: lane (hi = 0, i) of tile t carries b[col_lo + 32 t + i] = e0 + e1 + e2 in k-slots 0..2
+// (zero outside the matrix)
+constexpr int PP_PAD = 4;          // LDS row stride Hp + 4 floats: rows stay 16-byte aligned
+
+__device__ __forceinline__ unsigned bf16_rne(float f)
 {
-    const size_t total = (size_t)ntiles * G * 64;
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total;
-         o += (size_t)gridDim.x * 256) {
-        const int lane = (int)(o & 63);
-        const size_t tg = o >> 6;
-        const int g = (int)(tg % G);
-        const int t = (int)(tg / G);
-        const int hi = lane >> 5, i = lane & 31;
-        const int v = col_lo + t * 32 + i;
-        float e[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int k = 8 * g + 2 * x + hi;
-            e[x] = (v < col_hi && k < H) ? W[(size_t)v * H + k] : 0.0f;
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
+    return u >> 16;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void prepack_tile_kernel(const float* __restrict__ W,
+                                                           const float* __restrict__ b, int H, int Hp,
+                                                           int col_lo, int col_hi, int ntiles,
+                                                           void* __restrict__ Wp_,
+                                                           float* __restrict__ bias,
+                                                           uint4* __restrict__ bias16)
+{
+    extern __shared__ __attribute__((aligned(16))) float pp_tile[];      // [32][Hp + PP_PAD]
+    const int tid = threadIdx.x;
+    const int ldt = Hp + PP_PAD;
+    const int Hp4 = Hp >> 2;
+    const bool vec = (H & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int v0 = col_lo + t * 32;
+        for (int idx = tid; idx < 32 * Hp4; idx += 256) {
+            const int r = idx / Hp4, c4 = idx - r * Hp4;
+            const int v = v0 + r, k = 4 * c4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < col_hi) {
+                const float* src = W + (size_t)v * H + k;
+                if (vec && k + 3 < H) {
+                    x = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (k < H) x.x = src[0];
+                    if (k + 1 < H) x.y = src[1];
+                    if (k + 2 < H) x.z = src[2];
+                    if (k + 3 < H) x.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(pp_tile + r * ldt + k) = x;
         }
-        Wp[o] = make_float4(e[0], e[1], e[2], e[3]);
-    }
-    const int nb = ntiles * 32;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
-        const int v = col_lo + o;
-        bias[o] = v < col_hi ? b[v] : 0.0f;
+        __syncthreads();
+        if (DT == DT_F32) {
+            float4* Wp = static_cast<float4*>(Wp_);
+            const int G = Hp >> 3;
+            for (int o = tid; o < G * 64; o += 256) {
+                const int lane = o & 63, g = o >> 6;
+                const float* row = pp_tile + (lane & 31) * ldt + 8 * g + (lane >> 5);
+                Wp[(size_t)t * G * 64 + o] = make_float4(row[0], row[2], row[4], row[6]);
+            }
+        } else {
+            uint4* Wp = static_cast<uint4*>(Wp_);
+            const int NS = Hp >> 4;
+            for (int o = tid; o < NS * 64; o += 256) {
+                const int lane = o & 63, sidx = o >> 6;
+                const float* row = pp_tile + (lane & 31) * ldt + 16 * sidx + 8 * (lane >> 5);
+                const float4 lo = *reinterpret_cast<const float4*>(row), hi4 = *reinterpret_cast<const float4*>(row + 4);
+                Wp[(size_t)t * NS * 64 + o] =
+                    make_uint4(bf16_rne(lo.x) | (bf16_rne(lo.y) << 16), bf16_rne(lo.z) | (bf16_rne(lo.w) << 16),
+                               bf16_rne(hi4.x) | (bf16_rne(hi4.y) << 16), bf16_rne(hi4.z) | (bf16_rne(hi4.w) << 16));
+            }
+        }
+        if (tid < 32) bias[t * 32 + tid] = v0 + tid < col_hi ? b[v0 + tid] : 0.0f;
+        if (DT == DT_BF16 && tid < 64) {
+            const int v = v0 + (tid & 31);
+            uint4 f = make_uint4(0u, 0u, 0u, 0u);
+            if ((tid >> 5) == 0 && v < col_hi) {
+                const float bv = b[v];
+                const unsigned e0 = bf16_rne(bv);
+                const float r1 = bv - __uint_as_float(e0 << 16);
+                const unsigned e1 = bf16_rne(r1);
+                const float r2 = r1 - __uint_as_float(e1 << 16);
+                const unsigned e2 = bf16_rne(r2);
+                f.x = e0 | (e1 << 16); f.y = e2;
+            }
+            bias16[t * 64 + tid] = f;
+        }
+        __syncthreads();
     }
 }
 
@@ -916,59 +973,6 @@ __global__ __launch_bounds__(256) void pack_h_kernel(const float* __restrict__ h
             e[c] = (r < B && k < H) ? h[(size_t)r * H + k] : 0.0f;
         }
         hp[o] = make_float4(e[0], e[1], e[2], e[3]);
-    }
-}
-
-__device__ __forceinline__ unsigned bf16_rne(float f)
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
-    return u >> 16;
-}
-
-// out uint4 index = (t*NS + s)*64 + lane, lane = hi*32 + i: bf16 of W[col_lo+32t+i][16s+8hi+0..7]
-__global__ __launch_bounds__(256) void prepack_bf16_kernel(const float* __restrict__ W,
-                                                           const float* __restrict__ b, int H, int NS,
-                                                           int col_lo, int col_hi, int ntiles,
-                                                           uint4* __restrict__ Wp,
-                                                           float* __restrict__ bias,
-                                                           uint4* __restrict__ bias16)
-{
-    const size_t total = (size_t)ntiles * NS * 64;
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
-        const int lane = (int)(o & 63);
-        const size_t ts = o >> 6;
-        const int s = (int)(ts % NS), t = (int)(ts / NS);
-        const int hi = lane >> 5, i = lane & 31;
-        const int v = col_lo + t * 32 + i;
-        unsigned e[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int k = 16 * s + 8 * hi + x;
-            e[x] = (v < col_hi && k < H) ? bf16_rne(W[(size_t)v * H + k]) : 0u;
-        }
-        Wp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-    }
-    const int nb = ntiles * 32;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < nb; o += gridDim.x * 256) {
-        const int v = col_lo + o;
-        bias[o] = v < col_hi ? b[v] : 0.0f;
-    }
-    // bias fragments: lane (hi = 0, i) of tile t carries b[col_lo + 32 t + i] = e0 + e1 + e2 in k-slots 0..2
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < ntiles * 64; o += gridDim.x * 256) {
-        const int lane = o & 63, t = o >> 6;
-        const int v = col_lo + t * 32 + (lane & 31);
-        uint4 f = make_uint4(0u, 0u, 0u, 0u);
-        if ((lane >> 5) == 0 && v < col_hi) {
-            const float bv = b[v];
-            const unsigned e0 = bf16_rne(bv);
-            const float r1 = bv - __uint_as_float(e0 << 16);
-            const unsigned e1 = bf16_rne(r1);
-            const float r2 = r1 - __uint_as_float(e1 << 16);
-            const unsigned e2 = bf16_rne(r2);
-            f.x = e0 | (e1 << 16); f.y = e2;
-        }
-        bias16[o] = f;
     }
 }
 
@@ -1144,6 +1148,27 @@ dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
     return g;
 }
 
+namespace {
+template <int DT>
+int launch_prepack_tiles(dae_ctx* ctx, const float* W, const float* b, int H, int Hp, int col_lo, int col_hi,
+                         int ntiles, void* Wp, float* bias, uint4* bias16)
+{
+    if (ntiles <= 0) return DAE_OK;
+    const size_t lds = (size_t)32 * (Hp + PP_PAD) * sizeof(float);
+    static bool attr_set = false;     // per instantiation
+    if (!attr_set) {
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&prepack_tile_kernel<DT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
+    hipLaunchKernelGGL(prepack_tile_kernel<DT>, dim3(blocks), dim3(256), lds, ctx->stream, W, b, H, Hp, col_lo, col_hi,
+                       ntiles, Wp, bias, bias16);
+    DAE_CHECK_LAUNCH(ctx, "prepack_tile_kernel");
+    return DAE_OK;
+}
+}  // namespace
+
 int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,
                             int col_lo, int col_hi)
 {
@@ -1160,13 +1185,9 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
     if (rc) return rc;
     rc = dae_reserve(ctx, pk.bias16, (size_t)ntiles * 64 * sizeof(uint4));
     if (rc) return rc;
-    const size_t total = (size_t)ntiles * NS * 64;
-    int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(prepack_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, NS,
-                       col_lo, col_hi, ntiles, static_cast<uint4*>(pk.W.p), static_cast<float*>(pk.bias.p),
-                       static_cast<uint4*>(pk.bias16.p));
-    DAE_CHECK_LAUNCH(ctx, "prepack_bf16_kernel");
+    rc = launch_prepack_tiles<DT_BF16>(ctx, W, b, H, Hp, col_lo, col_hi, ntiles, pk.W.p,
+                                       static_cast<float*>(pk.bias.p), static_cast<uint4*>(pk.bias16.p));
+    if (rc) return rc;
     pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
     rc = dae_reserve(ctx, pk.ident, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int));
     if (rc) return rc;
@@ -1206,13 +1227,9 @@ int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, 
     if (rc) return rc;
     rc = dae_reserve(ctx, pk.bias, (size_t)ntiles * 32 * sizeof(float));
     if (rc) return rc;
-    const size_t total = (size_t)ntiles * G * 64;
-    int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(prepack_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, G,
-                       col_lo, col_hi, ntiles, static_cast<float4*>(pk.W.p),
-                       static_cast<float*>(pk.bias.p));
-    DAE_CHECK_LAUNCH(ctx, "prepack_f32_kernel");
+    rc = launch_prepack_tiles<DT_F32>(ctx, W, b, H, Hp, col_lo, col_hi, ntiles, pk.W.p,
+                                      static_cast<float*>(pk.bias.p), nullptr);
+    if (rc) return rc;
     pk.V = V; pk.H = H; pk.Hp = Hp; pk.col_lo = col_lo; pk.col_hi = col_hi; pk.ntiles = ntiles;
     rc = dae_reserve(ctx, pk.ident, (size_t)(ntiles > 0 ? ntiles : 1) * sizeof(int));
     if (rc) return rc;
@@ -1272,13 +1289,20 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 }
 
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dzT, int64_t ldT, float* loss_part)
+                               float* dzT, int64_t ldT, float* loss_part, int dtype)
 {
     DecP p;
-    dae_tileset ts{ctx->pk_f32.ntiles, 1, 0, static_cast<const int*>(ctx->pk_f32.ident.p)};
-    int rc = fill_common(ctx, g, B, ts, p);
+    const dae_packed& pk = dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16;
+    dae_tileset ts{pk.ntiles, 1, 0, static_cast<const int*>(pk.ident.p)};
+    int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
+    if (dtype == DAE_DTYPE_BF16) {
+        // bf16 operands, fp32 accumulate (BASELINE.json configs[3]): the matrix time drops to ~1/16, the launch is
+        // bound by its VALU epilogue and the dz^T store; two waves per SIMD overlap those with the MFMAs
+        if (g.R_TILE == 128 && p.G == 16) return launch_decode<4, EPI_LOSS, 16, 8, DT_BF16>(ctx, g, p);
+        return launch_decode_rb_bf16<EPI_LOSS>(ctx, g, p);
+    }
     // A/B: DAE_LOSS_WAVES=8 runs two waves per SIMD on the 128-row image so that one wave's VALU epilogue
     // (4 transcendentals per element) sits under the other's MFMAs; measured 240 us against 229 us for the
     // default one wave per SIMD (V = 170 000, B = 256)

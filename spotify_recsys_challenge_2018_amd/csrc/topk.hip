@@ -26,8 +26,7 @@
 
 namespace {
 
-constexpr int TK_THREADS = 1024;
-constexpr int TK_WAVES = TK_THREADS / 64;
+[[maybe_unused]] constexpr int TK_THREADS = 1024;      // shadowed by the per-kernel thread count NTH inside the templates
 constexpr int TK_BINS = 2048;
 constexpr int TK_MAX_SEG = 1024;
 constexpr int TK_SORT_MAX = 2048;

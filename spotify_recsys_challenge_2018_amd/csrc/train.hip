@@ -29,6 +29,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One workgroup per row (h row in LDS), one thread per target entry.  The target CSR holds one entry per
 // (row, col) (include/dae_hip.h: the CSR contract), so no two threads own the same element.
 constexpr int FIX_MAXH = 1024;
+// value of the bf16 nearest (ties to even) to f, as the prepack / pack_h kernels round the MFMA operands
+__device__ __forceinline__ float bf16_value(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+// BF16: the forward GEMM ran on bf16 operands (dae_set_train_dtype): W and h are rounded the same way here
+template <bool BF16>
 __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int B, int H,
@@ -43,7 +52,11 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
     __shared__ float wsum[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int H4 = H >> 2;
-    for (int i = tid; i < H4; i += 256) sh[i] = reinterpret_cast<const float4*>(h + (size_t)row * H)[i];
+    for (int i = tid; i < H4; i += 256) {
+        float4 v = reinterpret_cast<const float4*>(h + (size_t)row * H)[i];
+        if (BF16) v = make_float4(bf16_value(v.x), bf16_value(v.y), bf16_value(v.z), bf16_value(v.w));
+        sh[i] = v;
+    }
     __syncthreads();
     float corr = 0.0f;
     for (int i = row_ptr[row] + tid; i < row_ptr[row + 1]; i += 256) {
@@ -60,13 +73,16 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
             for (int u = 0; u < 8; ++u) wv[u] = w[k + u];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                if (BF16) wv[u] = make_float4(bf16_value(wv[u].x), bf16_value(wv[u].y), bf16_value(wv[u].z), bf16_value(wv[u].w));
                 const float4 hv = sh[k + u];
                 z = fmaf(wv[u].x, hv.x, z); z = fmaf(wv[u].y, hv.y, z);
                 z = fmaf(wv[u].z, hv.z, z); z = fmaf(wv[u].w, hv.w, z);
             }
         }
         for (; k < H4; ++k) {
-            const float4 wv = w[k], hv = sh[k];
+            float4 wv = w[k];
+            const float4 hv = sh[k];
+            if (BF16) wv = make_float4(bf16_value(wv.x), bf16_value(wv.y), bf16_value(wv.z), bf16_value(wv.w));
             z = fmaf(wv.x, hv.x, z); z = fmaf(wv.y, hv.y, z); z = fmaf(wv.z, hv.z, z); z = fmaf(wv.w, hv.w, z);
         }
         z += bias[lc];
@@ -581,7 +597,7 @@ namespace {
 // scratch carved for one training step over a [Vl, H] weight (shard) and B rows; stable for a given
 // (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
 struct TrainPlan {
-    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix;
+    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype;
     dae_rowgeom g;
     size_t bh, hp_bytes;
     float *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
@@ -596,7 +612,8 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     int rc;
     t.NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
     const int Hp = dae_round_up(H, DAE_HPAD);
-    t.g = dae_row_geometry(B, Hp);
+    t.dtype = ctx->train_dtype;
+    t.g = t.dtype == DAE_DTYPE_BF16 ? dae_row_geometry_bf16(B, Hp) : dae_row_geometry(B, Hp);
     t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
     t.Bpad64 = (B + 63) / 64 * 64;
     t.hp_bytes = (size_t)t.g.n_rg * t.G * t.RB * 64 * sizeof(float4);
@@ -628,18 +645,23 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
 // h (row-major in t.hbuf and tiled in ctx->h_packed) and ctx->pk_f32 must be current.
 int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B, int n_batch,
                           const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
-                          int col_lo, int col_hi, const float* Wd, float* gWd, float* gb_dec)
+                          int col_lo, int col_hi, const float* Wd, const float* b_dec, float* gWd, float* gb_dec)
 {
     hipStream_t st = ctx->stream;
     const int NA = t.NA;
     int rc;
     if (H > FIX_MAXH) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H <= %d (H=%d)", FIX_MAXH, H);
     if (t.Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * sizeof(float), st));
-    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part);
+    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype);
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_fixup_kernel, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo, col_hi,
-                       t.hbuf, Wd, static_cast<const float*>(ctx->pk_f32.bias.p), 1.0f / (float)n_batch,
-                       t.dzT, (int64_t)t.Bpad64, t.loss_part + t.g.grid);
+    if (t.dtype == DAE_DTYPE_BF16)
+        hipLaunchKernelGGL(loss_fixup_kernel<true>, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
+                           col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
+                           t.loss_part + t.g.grid);
+    else
+        hipLaunchKernelGGL(loss_fixup_kernel<false>, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
+                           col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
+                           t.loss_part + t.g.grid);
     DAE_CHECK_LAUNCH(ctx, "loss_fixup_kernel");
 
     // ---- K6: decoder gradient ------------------------------------------------------------------------
@@ -830,16 +852,24 @@ int dae_train_step_f32(dae_ctx* ctx,
     if (rc) return rc;
     const float* Wd = tied ? W_enc : W_dec;
     // decoder weights change every step: re-tile them for the forward GEMM
-    rc = dae_launch_prepack_f32(ctx, Wd, b_dec, V, H, 0, V);
+    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec, V, H, 0, V)
+                                   : dae_launch_prepack_f32(ctx, Wd, b_dec, V, H, 0, V);
     if (rc) return rc;
 
     // ---- forward ----------------------------------------------------------------------------------
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
+    if (t.dtype == DAE_DTYPE_F32) DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
     ctx->h_geom_key = -1;
-    rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
-                           static_cast<float*>(ctx->h_packed.p), t.G, t.RB, t.sg, nullptr);
+    if (t.dtype == DAE_DTYPE_BF16) {
+        rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
+                               nullptr, 0, 0, t.sg, nullptr);
+        if (rc) return rc;
+        rc = dae_launch_pack_h_bf16(ctx, t.hbuf, B, H, t.g);
+    } else {
+        rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
+                               static_cast<float*>(ctx->h_packed.p), t.G, t.RB, t.sg, nullptr);
+    }
     if (rc) return rc;
-    rc = train_decode_backward(ctx, t, V, H, B, n_batch, y_row_ptr, y_col, y_val, 0, V, Wd,
+    rc = train_decode_backward(ctx, t, V, H, B, n_batch, y_row_ptr, y_col, y_val, 0, V, Wd, b_dec,
                                tied ? gW_enc : gW_dec, gb_dec);
     if (rc) return rc;
 
@@ -853,7 +883,7 @@ int dae_train_step_f32(dae_ctx* ctx,
                                 ikp, kp, seed, reg_lambda, W_enc, b_enc, W_dec, b_dec,
                                 gW_enc, gb_enc, gW_dec, gb_dec);
     if (rc) return rc;
-    ctx->pk_f32.valid = true;
+    (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
     return DAE_OK;
 }
 
@@ -881,15 +911,17 @@ int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_en
     int rc = train_plan(ctx, Vl, H, B, t);
     if (rc) return rc;
     const float* Wd = tied ? W_enc_loc : W_dec_loc;
-    rc = dae_launch_prepack_f32(ctx, Wd, b_dec_loc, Vl, H, 0, Vl);
+    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec_loc, Vl, H, 0, Vl)
+                                   : dae_launch_prepack_f32(ctx, Wd, b_dec_loc, Vl, H, 0, Vl);
     if (rc) return rc;
     hipLaunchKernelGGL(activate_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, pre, b_enc, B, H, kp, seed,
                        t.hbuf, t.sg);
     DAE_CHECK_LAUNCH(ctx, "activate_kernel");
     ctx->h_geom_key = -1;
-    rc = dae_launch_pack_h(ctx, t.hbuf, B, H, t.g);
+    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_pack_h_bf16(ctx, t.hbuf, B, H, t.g)
+                                   : dae_launch_pack_h(ctx, t.hbuf, B, H, t.g);
     if (rc) return rc;
-    rc = train_decode_backward(ctx, t, Vl, H, B, n_batch, y_row_ptr, y_col, y_val, col_lo, col_hi, Wd,
+    rc = train_decode_backward(ctx, t, Vl, H, B, n_batch, y_row_ptr, y_col, y_val, col_lo, col_hi, Wd, b_dec_loc,
                                gW_out, gb_dec_loc);
     if (rc) return rc;
     // b_enc is replicated: its l2 term is counted once, by the shard that owns column 0
@@ -900,7 +932,7 @@ int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_en
     hipLaunchKernelGGL(sum_chunks_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, t.part, t.n_chunk,
                        (size_t)t.Bpad64 * H, t.bh, dh_partial);
     DAE_CHECK_LAUNCH(ctx, "sum_chunks_kernel");
-    ctx->pk_f32.valid = true;
+    (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
     return DAE_OK;
 }
 

@@ -136,6 +136,10 @@ class DAE_tied:
         # decode arithmetic of recommend(): "f32" (bit-exact path) or "bf16" (BASELINE configs[4])
         self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
             else _lib.DAE_DTYPE_F32
+        # arithmetic of the training forward GEMM: "f32" (default) or "bf16" (BASELINE configs[3]: bf16 operands,
+        # fp32 accumulate; loss, backward GEMMs, parameters and Adam stay fp32)
+        self.train_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "train_dtype", "f32")) == "bf16" \
+            else _lib.DAE_DTYPE_F32
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
         self.device_csr = bool(getattr(conf, "device_csr", True))
         self._csr_status = None
@@ -176,6 +180,8 @@ class DAE_tied:
     def fit(self):
         """DAEs.py:84-105.  Creates the device context, the parameters and the fetch handles."""
         self.ctx = _lib.Context(self.device_index)
+        if self.train_dtype != _lib.DAE_DTYPE_F32:
+            self.ctx.set_train_dtype(self.train_dtype)
         self.init_weight()
         self.y_pred = _Fetch("y_pred")
         self.cost = _Fetch("cost")

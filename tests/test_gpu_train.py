@@ -158,3 +158,51 @@ def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
         assert all(res_mixed[i] == res_plain[i] for i in range(13) if i not in named)      # titles_use = 0 rows
     finally:
         os.chdir(cwd)
+
+
+def _step(ctx, csr, d, V, H, B, tied, ikp, kp, seed, lam):
+    import torch
+    P = _lib._ptr
+    out = dict(gWe=torch.zeros((V, H), device="cuda"), gbe=torch.zeros(H, device="cuda"),
+               gWd=torch.zeros((V, H), device="cuda"), gbd=torch.zeros(V, device="cuda"),
+               cost=torch.zeros(1, device="cuda"))
+    ctx.check(ctx.lib.dae_train_forward_backward(
+        ctx.h, P(csr[0]), P(csr[1]), P(csr[2]), P(csr[3]), P(csr[4]), P(csr[5]),
+        P(d["We"]), P(d["be"]), P(d["Wd"]), P(d["bd"]), V, H, B, B, 1 if tied else 0,
+        float(ikp), float(kp), seed, float(lam), P(out["gWe"]), P(out["gbe"]),
+        None if tied else P(out["gWd"]), P(out["gbd"]), P(out["cost"])))
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("V,nt,H,B,tied", [(2100, 2000, 256, 250, False), (1500, 1200, 64, 64, True),
+                                           (5000, 4000, 256, 130, False)])
+def test_train_step_bf16_forward_gemm(V, nt, H, B, tied):
+    """dae_set_train_dtype(BF16) (BASELINE.json configs[3]): the forward GEMM runs on bf16 operands with fp32
+    accumulate, everything else stays fp32.  Stated tolerance against the fp32 step on the same draws:
+    cost within 3e-3 relative, every gradient within 2e-2 of its Frobenius norm (bf16 keeps 8 significant bits;
+    the error of a logit is ~2^-9 * |z|, averaged over the sums)."""
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt, tied=tied)
+    b_enc = (np.random.default_rng(2).standard_normal(H) * 0.1).astype(np.float32)
+    pos, ones, _ = make_playlists(B, nt, V - nt, seed=6, seed_counts=(3, 9, 20))
+    xr, xc, xv = coo_to_csr(pos[pos[:, 1] < nt], ones[pos[:, 1] < nt], B, V)
+    yr, yc, yv = coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)
+    csr = [_dev(a) for a in (xr, xc, xv, yr, yc, yv)]
+    d = dict(We=_dev(W_enc), be=_dev(b_enc), Wd=_dev(W_dec), bd=_dev(b_dec))
+    ctx = _lib.Context(0)
+    f32 = _step(ctx, csr, d, V, H, B, tied, 0.75, 0.8, 31337, 0.0)
+    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    b16 = _step(ctx, csr, d, V, H, B, tied, 0.75, 0.8, 31337, 0.0)
+    again = _step(ctx, csr, d, V, H, B, tied, 0.75, 0.8, 31337, 0.0)
+    ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
+    back = _step(ctx, csr, d, V, H, B, tied, 0.75, 0.8, 31337, 0.0)
+    assert b16["cost"][0] != f32["cost"][0]                       # the bf16 path really ran
+    assert abs(b16["cost"][0] - f32["cost"][0]) <= 3e-3 * abs(f32["cost"][0])
+    for k in ("gWe", "gbe", "gbd") + (() if tied else ("gWd",)):
+        err = np.linalg.norm(b16[k].astype(np.float64) - f32[k]) / np.linalg.norm(f32[k].astype(np.float64))
+        assert err <= 2e-2, (k, err)
+        assert np.allclose(again[k], b16[k], rtol=2e-4, atol=2e-7)
+        assert np.allclose(back[k], f32[k], rtol=2e-4, atol=2e-7)
+    with pytest.raises(_lib.DaeError):
+        ctx.set_train_dtype(7)
+    ctx.close()
