@@ -171,9 +171,10 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k,
 
 /* ---- training step (DAEs.py:98-102) ------------------------------------------------------ */
 
-/* Arithmetic of the training FORWARD GEMM (hidden x W_dec^T) of this context: DAE_DTYPE_F32 (default; fp32
- * MFMA) or DAE_DTYPE_BF16 (BASELINE.json configs[3]: operands rounded to bf16, fp32 accumulate; the loss,
- * dL/dz, both backward GEMMs, the parameters and Adam stay fp32).  Sticky; applies to
+/* Arithmetic of the three GEMMs of the training step of this context (forward hidden x W_dec^T, gW_dec = dz^T h,
+ * dh = dz W_dec): DAE_DTYPE_F32 (default; fp32 MFMA) or DAE_DTYPE_BF16 (BASELINE.json configs[3]: operands
+ * rounded to bf16 in registers / by the prepack, fp32 accumulate; the loss, dL/dz, the encoder gradient, the
+ * parameters and Adam stay fp32; the backward GEMMs switch only when H % 128 == 0).  Sticky; applies to
  * dae_train_forward_backward and dae_train_shard_decode.  Replaces nothing in the reference (TF1 is fp32). */
 int dae_set_train_dtype(dae_ctx* ctx, int dtype);
 

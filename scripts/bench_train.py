@@ -16,7 +16,7 @@ yr, yc, yv = coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 ctx = _lib.Context(0)
 if "--bf16" in sys.argv:
-    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)      # bf16 operands in the forward GEMM (BASELINE configs[3])
+    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)      # bf16 operands in the three GEMMs (BASELINE configs[3])
 P = _lib._ptr
 t = {k: dev(v) for k, v in dict(xr=xr, xc=xc, xv=xv, yr=yr, yc=yc, yv=yv, We=W_enc, be=b_enc, Wd=W_dec, bd=b_dec).items()}
 names = ["We", "be", "bd"] + ([] if tied else ["Wd"])
@@ -37,7 +37,7 @@ for i in range(K):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / K * 1e3
 flop = 3 * 2.0 * B * V * H
-print(json.dumps({"what": "training step (%s%s), fwd+loss+bwd+Adam" % ("tied" if tied else "untied", ", bf16 forward GEMM" if "--bf16" in sys.argv else ""), "ms_per_step": round(ms, 3),
+print(json.dumps({"what": "training step (%s%s), fwd+loss+bwd+Adam" % ("tied" if tied else "untied", ", bf16 GEMMs" if "--bf16" in sys.argv else ""), "ms_per_step": round(ms, 3),
                   "playlists_per_s": round(B / ms * 1e3, 1), "gemm_tflops_incl_everything": round(flop / ms / 1e9, 1),
                   "cost_first_last": [float(cost.item())]}))
 

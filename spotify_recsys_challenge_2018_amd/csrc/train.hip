@@ -19,6 +19,22 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ unsigned pk_bf16(float a, float b)
+{
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// eight floats -> the 8 k-slots a lane holds of one 32x32x16 bf16 MFMA operand
+__device__ __forceinline__ bf16x8_t pk_bf16x8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                              float a7)
+{
+    return __builtin_bit_cast(bf16x8_t, make_uint4(pk_bf16(a0, a1), pk_bf16(a2, a3), pk_bf16(a4, a5), pk_bf16(a6, a7)));
+}
 
 // ---- the positives of the loss -----------------------------------------------------------------------
 // K5 (decode_f32.hip, EPI_LOSS) treats all B x V elements as negatives.  A batch holds ~100 positives per row
@@ -115,7 +131,11 @@ struct GwP {
 };
 
 // NA = hidden tiles per wave (4, 2 or 1): a "half" is 32*NA hidden units, hidden = hc0 + NA*i + a
-template <int NA, int NW = 4>
+// BF16 (dae_set_train_dtype, NA = 4 only): the 8 k-steps of a GW_MMA group (16 playlists) become ONE
+// v_mfma_f32_32x32x16_bf16 per accumulator -- k-slot x of lane half hi is playlist R0 + 2x + hi in both
+// operands, which is exactly what the fp32 steps consume one at a time -- on operands rounded to bf16 in
+// registers; loads, LDS image, accumulators and stores are the fp32 kernel's.
+template <int NA, int NW = 4, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [Bp][32*NA] floats
@@ -213,6 +233,27 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 // optimizer turns that into a dynamically indexed vector extract, which lives in scratch memory.
 #define GW_SEL(A, Bv) __uint_as_float((__float_as_uint(Bv) & himask) | (__float_as_uint(A) & ~himask))
 #define GW_MMA(T0, T1, R0)                                                                     \
+        if (BF16) {                                                                            \
+            float avs[8][NA];                                                                  \
+            _Pragma("unroll") for (int x_ = 0; x_ < 8; ++x_) {                                 \
+                const float4 t4 = *reinterpret_cast<const float4*>(lds + (size_t)((R0) + 2 * x_ + hi) * HW + NA * j); \
+                avs[x_][0] = t4.x; avs[x_][1 % NA] = t4.y; avs[x_][2 % NA] = t4.z; avs[x_][3 % NA] = t4.w; \
+            }                                                                                  \
+            float dx[8], dy[8];                                                                \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                 \
+                dx[2 * q_] = GW_SEL(T0[q_].x, T0[q_].y); dx[2 * q_ + 1] = GW_SEL(T0[q_].z, T0[q_].w); \
+                dy[2 * q_] = GW_SEL(T1[q_].x, T1[q_].y); dy[2 * q_ + 1] = GW_SEL(T1[q_].z, T1[q_].w); \
+            }                                                                                  \
+            _Pragma("unroll") for (int x_ = 0; x_ < 8; ++x_) { cs0 += dx[x_]; cs1 += dy[x_]; } \
+            const bf16x8_t bx = pk_bf16x8(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], dx[6], dx[7]); \
+            const bf16x8_t by = pk_bf16x8(dy[0], dy[1], dy[2], dy[3], dy[4], dy[5], dy[6], dy[7]); \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                   \
+                const bf16x8_t af = pk_bf16x8(avs[0][a], avs[1][a], avs[2][a], avs[3][a], avs[4][a], avs[5][a], \
+                                              avs[6][a], avs[7][a]);                           \
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bx, acc[a][0], 0, 0, 0); \
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, by, acc[a][1], 0, 0, 0); \
+            }                                                                                  \
+        } else                                                                                 \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                     \
             const int r4 = (R0) + 4 * q_;                                                      \
             GW_STEP(GW_SEL(T0[q_].x, T0[q_].y), GW_SEL(T1[q_].x, T1[q_].y), r4)                \
@@ -290,7 +331,9 @@ struct DhP {
     int n_chunk, chunk, Bpad64, n_half, n_rblk;
 };
 
-template <int NA>
+// BF16 (dae_set_train_dtype, NA = 4 only): the 8 k-steps of a block (16 vocabulary rows) become ONE
+// v_mfma_f32_32x32x16_bf16 per accumulator: k-slot x of lane half hi is row V0 + 2x + hi in both operands.
+template <int NA, bool BF16 = false>
 __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
 {
     constexpr int HW = 32 * NA;
@@ -338,6 +381,21 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
 // the "past the chunk -> 0" select sits HERE, not next to the load: a select on a loaded value in the load
 // stage makes the compiler wait for that load before the sched_barrier, i.e. before the MFMAs it should hide under
 #define DH_MMA(AV, D, V0)                                                                      \
+        if (BF16) {                                                                            \
+            float dx[8], dy[8];                                                                \
+            _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
+                const bool in = (V0) + 2 * s + hi < v_end;                                     \
+                dx[s] = in ? D[s].x : 0.f; dy[s] = in ? D[s].y : 0.f;                          \
+            }                                                                                  \
+            const bf16x8_t bx = pk_bf16x8(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], dx[6], dx[7]); \
+            const bf16x8_t by = pk_bf16x8(dy[0], dy[1], dy[2], dy[3], dy[4], dy[5], dy[6], dy[7]); \
+            _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                   \
+                const bf16x8_t af = pk_bf16x8(AV[0][a], AV[1][a], AV[2][a], AV[3][a], AV[4][a], AV[5][a], \
+                                              AV[6][a], AV[7][a]);                             \
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bx, acc[a][0], 0, 0, 0); \
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, by, acc[a][1], 0, 0, 0); \
+            }                                                                                  \
+        } else                                                                                 \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
             const bool in = (V0) + 2 * s + hi < v_end;                                         \
             const float dx = in ? D[s].x : 0.f, dy = in ? D[s].y : 0.f;                        \
@@ -686,7 +744,16 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         // two waves per SIMD on the shared h image: 241 us against 257 us with one (V = 170 000, B = H = 256); the
         // second wave covers the dz^T load latency and the gW stores of the first (DAE_K6_WAVES=4 for the A/B)
         static const bool k6w8 = !(getenv("DAE_K6_WAVES") && atoi(getenv("DAE_K6_WAVES")) == 4);
-        if (NA == 4 && k6w8) {
+        static const bool bwd_f32 = getenv("DAE_BWD_F32") != nullptr;      // A/B: bf16 forward only
+        if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32) {
+            static bool attr16 = false;
+            if (!attr16) {
+                DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr16 = true;
+            }
+            hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
+        } else if (NA == 4 && k6w8) {
             static bool attr8 = false;
             if (!attr8) {
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8>),
@@ -709,7 +776,10 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         const int total = p.n_half * p.n_rblk * t.n_chunk;
         int blocks = (total + 3) / 4;
         if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
-        if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+        static const bool bwd_f32_7 = getenv("DAE_BWD_F32") != nullptr;
+        if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7)
+            hipLaunchKernelGGL((grad_hidden_kernel<4, true>), dim3(blocks), dim3(256), 0, st, p);
+        else if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
         else if (NA == 2) hipLaunchKernelGGL(grad_hidden_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(grad_hidden_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
         DAE_CHECK_LAUNCH(ctx, "grad_hidden_kernel");

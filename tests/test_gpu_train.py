@@ -177,11 +177,12 @@ def _step(ctx, csr, d, V, H, B, tied, ikp, kp, seed, lam):
 
 @pytest.mark.parametrize("V,nt,H,B,tied", [(2100, 2000, 256, 250, False), (1500, 1200, 64, 64, True),
                                            (5000, 4000, 256, 130, False)])
-def test_train_step_bf16_forward_gemm(V, nt, H, B, tied):
-    """dae_set_train_dtype(BF16) (BASELINE.json configs[3]): the forward GEMM runs on bf16 operands with fp32
-    accumulate, everything else stays fp32.  Stated tolerance against the fp32 step on the same draws:
+def test_train_step_bf16_gemms(V, nt, H, B, tied):
+    """dae_set_train_dtype(BF16) (BASELINE.json configs[3]): the three GEMMs of the step (forward, gW_dec, dh) run on
+    bf16 operands with fp32 accumulate (hidden = 256 / 128: the 4-tile kernels; other sizes keep fp32 backward
+    GEMMs); loss, dL/dz, parameters and Adam stay fp32.  Stated tolerance against the fp32 step on the same draws:
     cost within 3e-3 relative, every gradient within 2e-2 of its Frobenius norm (bf16 keeps 8 significant bits;
-    the error of a logit is ~2^-9 * |z|, averaged over the sums)."""
+    the error of an operand is ~2^-9 relative, averaged over the sums)."""
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt, tied=tied)
     b_enc = (np.random.default_rng(2).standard_normal(H) * 0.1).astype(np.float32)
     pos, ones, _ = make_playlists(B, nt, V - nt, seed=6, seed_counts=(3, 9, 20))
