@@ -1,9 +1,11 @@
 // train.hip -- the training step of the reference graph (models/DAEs.py:98-102; SURVEY.md 8a
-// rows a8-a10, App. B.5), fp32 on the CDNA4 matrix cores:
+// rows a8-a10, App. B.5), fp32 on the CDNA4 matrix cores (bf16 operands for the three GEMMs under
+// dae_set_train_dtype, BASELINE.json configs[3]):
 //
 //   forward   K1 encode with dropout (encode.hip) -> K5 decode GEMM whose epilogue turns logits
-//             into the weighted-BCE loss and dL/dz in place over the dense targets
-//             (decode_f32.hip EPI_LOSS), writing dz [B,V] and dz^T [V,B]
+//             into the weighted-BCE loss and dL/dz, every element taken as a negative
+//             (decode_f32.hip EPI_LOSS), writing dz^T [V,B]; loss_fixup_kernel redoes the positives
+//             of the target CSR (no dense target matrix)
 //   K6        gW_dec[v,:] = sum_r dz[r,v] h[r,:]   (+ gb_dec = column sums)      contraction B
 //   K7        dh[r,:]     = sum_v dz[r,v] W_dec[v,:]  split over V, partials reduced   contraction V
 //   K8        dpre = dh * dropout-mask/kp * s(1-s); gb_enc; gW_enc[c,:] += xhat[r,c] dpre[r,:]
@@ -613,18 +615,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const size_t n4 = n / 4;
     float4* p4 = reinterpret_cast<float4*>(p); float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v); const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n4; o += (size_t)gridDim.x * 256) {
+// TF1 ApplyAdam functor: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= (m alpha)/(sqrt(v)+eps)
+#define ADAM1(P, M, V, G, c)                                         \
+        M.c = M.c + (G.c - M.c) * (1.0f - b1);                       \
+        V.c = V.c + (G.c * G.c - V.c) * (1.0f - b2);                 \
+        P.c = P.c - (M.c * lr_t) / (sqrtf(V.c) + eps);
+    // two float4 groups per iteration: 8 independent 16-byte loads in flight per thread (HBM-bound: 7 passes
+    // over the tensor)
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; o + stride < n4; o += 2 * stride) {
+        const size_t o2 = o + stride;
+        float4 pa = p4[o], ma = m4[o], va = v4[o];
+        const float4 ga = g4[o];
+        float4 pb = p4[o2], mb = m4[o2], vb = v4[o2];
+        const float4 gb = g4[o2];
+        ADAM1(pa, ma, va, ga, x) ADAM1(pa, ma, va, ga, y) ADAM1(pa, ma, va, ga, z) ADAM1(pa, ma, va, ga, w)
+        ADAM1(pb, mb, vb, gb, x) ADAM1(pb, mb, vb, gb, y) ADAM1(pb, mb, vb, gb, z) ADAM1(pb, mb, vb, gb, w)
+        p4[o] = pa; m4[o] = ma; v4[o] = va;
+        p4[o2] = pb; m4[o2] = mb; v4[o2] = vb;
+    }
+    for (; o < n4; o += stride) {
         float4 pp = p4[o], mm = m4[o], vv = v4[o];
         const float4 gg = g4[o];
-// TF1 ApplyAdam functor: m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= (m alpha)/(sqrt(v)+eps)
-#define ADAM1(c)                                                     \
-        mm.c = mm.c + (gg.c - mm.c) * (1.0f - b1);                   \
-        vv.c = vv.c + (gg.c * gg.c - vv.c) * (1.0f - b2);            \
-        pp.c = pp.c - (mm.c * lr_t) / (sqrtf(vv.c) + eps);
-        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
-#undef ADAM1
+        ADAM1(pp, mm, vv, gg, x) ADAM1(pp, mm, vv, gg, y) ADAM1(pp, mm, vv, gg, z) ADAM1(pp, mm, vv, gg, w)
         p4[o] = pp; m4[o] = mm; v4[o] = vv;
     }
+#undef ADAM1
     for (size_t o = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; o < n;
          o += (size_t)gridDim.x * 256) {
         const float gg = g[o];
@@ -699,7 +716,7 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     return DAE_OK;
 }
 
-// dense targets -> K5 loss/dz over the prepacked decoder image -> K6 (gW, gb) -> K7 partials of dh.
+// K5 loss/dz over the prepacked decoder image + the positives' fix-up -> K6 (gW, gb) -> K7 partials of dh.
 // h (row-major in t.hbuf and tiled in ctx->h_packed) and ctx->pk_f32 must be current.
 int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B, int n_batch,
                           const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
