@@ -276,7 +276,11 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     const int n_simd = g.nb_rg * 4;
     int rounds = (int)(((double)ntiles / 8.0) / n_simd + 0.5);
     if (rounds < 1) rounds = 1;
+    static const int rounds_env = getenv("DAE_SAMPLE_ROUNDS") ? atoi(getenv("DAE_SAMPLE_ROUNDS")) : 0;   // experiments
+    if (rounds_env > 0) rounds = rounds_env;
     int S = (ntiles + rounds * n_simd - 1) / (rounds * n_simd);
+    static const int s_env = getenv("DAE_SAMPLE_S") ? atoi(getenv("DAE_SAMPLE_S")) : 0;                   // experiments
+    if (s_env > 1) S = s_env;
     const bool fused = S >= 2 && nrank > 0;
     const int n_samp = fused ? (ntiles + S - 1) / S : ntiles;
     const int n_other = ntiles - n_samp;
