@@ -62,6 +62,88 @@ __global__ __launch_bounds__(256) void title_features_kernel(const TitleP p)
     for (int fi = nf + tid; fi < p.ld; fi += 256) p.feat[(size_t)row * p.ld + fi] = 0.0f;
 }
 
+// The same features, organised for the machine: one WAVE per (filter size, block of 64 filters), a lane per
+// filter, and the accumulators of ALL window positions of that filter in registers.  The weight W[q][f] is
+// then loaded once per q (coalesced over the lanes) instead of once per (position, q), and the P positions
+// give P independent fmaf chains; x comes from LDS as a broadcast.  Every chain is the one the kernel above
+// runs (acc = b, then q ascending), so the two produce the same bits.  1.6 ms -> tens of us at the reference's
+// shapes (150 titles x 25 characters, sizes 3/5/7/9 x 100 filters, embedding 50).
+// PMAX = compile-time bound of the window positions (L - min(fs) + 1); the LDS image of the title is zero
+// padded so that the unused positions read in bounds (their accumulators are ignored).
+template <int PMAX, int NW>
+__global__ __launch_bounds__(NW * 64) void title_features_wave_kernel(const TitleP p, int lpad)
+{
+    extern __shared__ float xs[];                     // [lpad][E], rows >= L are zero
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < lpad * p.E; i += NW * 64) {
+        const int pos = i / p.E, c = i - pos * p.E;
+        float v = 0.0f;
+        if (pos < p.L) {
+            const int t = p.titles[(size_t)row * p.L + pos];
+            if (t >= 0 && t < p.n_char) v = p.emb[(size_t)t * p.E + c];
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int nf = p.n_sizes * p.F;
+    const int fblocks = (p.F + 63) >> 6;
+    for (int task = wave; task < p.n_sizes * fblocks; task += NW) {
+        const int i = task / fblocks, fb = task - i * fblocks;
+        const int fs = p.fs[i];
+        const int P = p.L - fs + 1;                   // >= 1 (checked by the launcher)
+        const int f = fb * 64 + lane;
+        const bool live = f < p.F;
+        const int fc = live ? f : p.F - 1;
+        const float* W = p.conv_w + p.w_off[i] + fc;
+        const float b = p.conv_b[i * p.F + fc];
+        float acc[PMAX];
+#pragma unroll
+        for (int pos = 0; pos < PMAX; ++pos) acc[pos] = b;
+        const int K = fs * p.E;
+        // weights in groups of 8: the next group's loads (one L2 round trip, ~600 cycles) are issued under this
+        // group's 8 * PMAX fmafs; a single weight ahead left the wave waiting on every q
+        constexpr int QB = 8;
+        float wb[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) wb[u] = W[(size_t)(u < K ? u : K - 1) * p.F];
+        for (int q0 = 0; q0 < K; q0 += QB) {
+            float wn[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int qn = q0 + QB + u;
+                wn[u] = W[(size_t)(qn < K ? qn : K - 1) * p.F];
+            }
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                if (q0 + u < K) {                     // wave-uniform
+                    const float* x = xs + q0 + u;
+#pragma unroll
+                    for (int pos = 0; pos < PMAX; ++pos) acc[pos] = fmaf(x[pos * p.E], wb[u], acc[pos]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QB; ++u) wb[u] = wn[u];
+        }
+        float best = 0.0f;
+        int arg = 0;
+#pragma unroll
+        for (int pos = 0; pos < PMAX; ++pos) {
+            const float a = acc[pos] > 0.0f ? acc[pos] : 0.0f;                // ReLU, then max over time
+            if (pos < P && (pos == 0 || a > best)) { best = a; arg = pos; }
+        }
+        if (live) {
+            const int fi = i * p.F + f;
+            if (p.argmax) p.argmax[(size_t)row * nf + fi] = arg;
+            if (p.feat_raw) p.feat_raw[(size_t)row * nf + fi] = best;
+            float v = best;
+            if (p.kp < 1.0f) v = (v / p.kp) * floorf(p.kp + dae_uniform(p.seed, 2U, (uint32_t)row, (uint32_t)fi));
+            p.feat[(size_t)row * p.ld + fi] = v;
+        }
+    }
+    for (int fi = nf + tid; fi < p.ld; fi += NW * 64) p.feat[(size_t)row * p.ld + fi] = 0.0f;
+}
+
 // y = title * w_title[row] + dae * w_playlist[row], written over the dae scores (DAEs.py:180)
 __global__ __launch_bounds__(256) void mix_scores_kernel(const float* __restrict__ ts, int64_t ld_t,
                                                          float* __restrict__ ds, int64_t ld_d,
@@ -334,6 +416,20 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
     int rc = title_fill(ctx, p, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, kp, seed, ld);
     if (rc) return rc;
     p.feat = feat; p.argmax = argmax; p.feat_raw = feat_raw;
+    int fs_min = L, fs_max = 1;
+    for (int i = 0; i < n_sizes; ++i) { fs_min = p.fs[i] < fs_min ? p.fs[i] : fs_min; fs_max = p.fs[i] > fs_max ? p.fs[i] : fs_max; }
+    const int p_max = L - fs_min + 1;                 // most window positions of any size
+    static const bool generic = getenv("DAE_TITLE_GENERIC") != nullptr;          // A/B against the first kernel
+    if (p_max >= 1 && p_max <= 32 && fs_max <= L && !generic) {
+        // positions up to PMAX - 1 + fs_max - 1 are read: pad the LDS image with zero rows
+        const int pm = p_max <= 24 ? 24 : 32;
+        const int lpad = pm + fs_max;
+        const size_t lds = (size_t)lpad * E * sizeof(float);
+        if (pm == 24) hipLaunchKernelGGL((title_features_wave_kernel<24, 8>), dim3(B), dim3(512), lds, ctx->stream, p, lpad);
+        else hipLaunchKernelGGL((title_features_wave_kernel<32, 8>), dim3(B), dim3(512), lds, ctx->stream, p, lpad);
+        DAE_CHECK_LAUNCH(ctx, "title_features_wave_kernel");
+        return DAE_OK;
+    }
     hipLaunchKernelGGL(title_features_kernel, dim3(B), dim3(256), (size_t)L * E * sizeof(float), ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "title_features_kernel");
     return DAE_OK;

@@ -14,6 +14,8 @@ scorer, never selected by the shipped configs) is not implemented.
 import ctypes
 import pickle
 
+import os
+
 import numpy as np
 
 from .. import _lib
@@ -41,7 +43,9 @@ class Char_CNN:
         self.filter_sizes = [int(c[1]) for c in conv_layers]
         self.filter_num = int(conv_layers[0][0])
         self.n_feat = self.filter_num * len(self.filter_sizes)
-        self.ld = (self.n_feat + 31) // 32 * 32                  # feature row length the GEMM kernels take
+        # feature row length the GEMM kernels take: a multiple of 64 lets the backward GEMMs own two hidden tiles
+        # per wave (400 features -> 448; 416 measured 4 % slower, 512 no better)
+        self.ld = (self.n_feat + 63) // 64 * 64
         self.device_index = int(getattr(conf, "device_index", 0))
         self.init_seed = int(getattr(conf, "title_init_seed", 0))
         self.learning_rate = float(getattr(conf, "title_lr", 0.001))
