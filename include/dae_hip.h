@@ -284,6 +284,41 @@ int dae_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, c
 int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad,
                   int64_t n, float lr, float beta1, float beta2, float eps, int t);
 
+/* The same dense Adam on a [n_rows, row_len] tensor whose gradient is ROW-SPARSE (the untied encoder: DAEs.py:66's
+ * sparse_tensor_dense_matmul has a non-zero gradient only on the rows the batch's input names), without the seven
+ * HBM passes over the rows that have none.  A row without gradient evolves by a recurrence nobody else reads, so its
+ * (param, m, v) may stay at the step they were last current for and be brought up to date later by running the SAME
+ * per-element update with g = 0 once per missed step, with the alpha of that step: the result is bit-identical to
+ * calling dae_adam_step every step (tests/test_gpu_train.py).  Replaces nothing in the reference (TF1 applies the
+ * dense update); it is how this build avoids 1.2 GB of traffic per step.
+ *
+ *   state   int32 [2 * n_rows], zero-initialised by the caller: the step each row is current for, and a claim mark
+ *   lr_tab  float [tab_cap]: alpha of every step so far, written by dae_adam_rows_apply (entry t); t < tab_cap
+ *   rows    int32 device list of the rows the coming / finished step touches (duplicates allowed, e.g. the column
+ *           array of the input CSR); its length is read on the DEVICE from *n_listed_dev (e.g. &row_ptr[B]) when
+ *           that pointer is not NULL, and is at most n_listed_max (which sizes the launch)
+ *
+ * Per step t = 1, 2, ...:
+ *   dae_adam_rows_begin(rows of step t)   listed rows become current for step t - 1 -- BEFORE anything reads them
+ *   ... forward / backward: the gradient rows land in the dense buffer `grad` (all other rows are zero) ...
+ *   dae_adam_rows_apply(same rows)        listed rows take the update of step t; their gradient rows are zeroed
+ *                                         again, so `grad` stays all-zero between steps (dae_set_enc_grad_prezeroed
+ *                                         tells dae_train_forward_backward not to clear it)
+ * and before anyone reads the WHOLE tensor (evaluation, saving, exchanging shards):
+ *   dae_adam_rows_flush(t)                every row becomes current for step t */
+int dae_adam_rows_begin(dae_ctx* ctx, float* param, float* m, float* v, int32_t* state, float* lr_tab, int tab_cap,
+                        int n_rows, int row_len, const int32_t* rows, const int32_t* n_listed_dev, int n_listed_max,
+                        float beta1, float beta2, float eps, int t);
+int dae_adam_rows_apply(dae_ctx* ctx, float* param, float* m, float* v, float* grad, int32_t* state, float* lr_tab,
+                        int tab_cap, int n_rows, int row_len, const int32_t* rows, const int32_t* n_listed_dev,
+                        int n_listed_max, float lr, float beta1, float beta2, float eps, int t);
+int dae_adam_rows_flush(dae_ctx* ctx, float* param, float* m, float* v, int32_t* state, const float* lr_tab,
+                        int tab_cap, int n_rows, int row_len, float beta1, float beta2, float eps, int t);
+
+/* on != 0: the untied gW_enc buffer handed to dae_train_forward_backward is all-zero on entry (kept so by
+ * dae_adam_rows_apply), so the step does not clear its 4*V*H bytes.  Sticky. */
+int dae_set_enc_grad_prezeroed(dae_ctx* ctx, int on);
+
 #ifdef __cplusplus
 }
 #endif

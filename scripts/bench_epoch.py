@@ -33,6 +33,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--tied", action="store_true")
     ap.add_argument("--async-cost", action="store_true", help="fetch the cost once at the end instead of per step")
+    ap.add_argument("--bf16", action="store_true", help="train_dtype = bf16 (the three GEMMs on bf16 operands)")
+    ap.add_argument("--encoder-adam", choices=["rows", "dense"], default="rows",
+                    help="untied encoder: dae_adam_rows_* (default) or the dense dae_adam_step")
+    ap.add_argument("--host-csr", action="store_true", help="device_csr = False: feed -> CSR with numpy on the host")
+    ap.add_argument("--flush-every", type=int, default=32, help="rows-Adam: all rows brought up to date every N steps")
     args = ap.parse_args()
     import torch
     from spotify_recsys_challenge_2018_amd.models.DAEs import DAE, DAE_tied
@@ -49,6 +54,11 @@ def main():
     conf.hidden, conf.batch, conf.lr, conf.reg_lambda = 256, 256, 0.005, 0.0
     conf.initval, conf.save, conf.kp = "NULL", os.path.join(tmp, "w"), 0.8
     conf.device_index = 0
+    conf.encoder_adam = args.encoder_adam
+    conf.device_csr = not args.host_csr
+    conf.rows_adam_flush_every = args.flush_every
+    if args.bf16:
+        conf.train_dtype = "bf16"
     model = (DAE_tied if args.tied else DAE)(conf)
     model.fit()
     random.seed(0); np.random.seed(0)
@@ -72,13 +82,15 @@ def main():
     for _ in range(args.steps):
         a, b, l = one(fetch=not args.async_cost)
         tr += a; ts += b
+    model.sync_params()                 # rows-Adam: every encoder row brought up to date (part of the epoch's work)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     print(json.dumps({"what": "main_train loop through the host mirror (%s)" % ("tied" if args.tied else "untied"),
                       "ms_per_step": round(wall / args.steps * 1e3, 3),
                       "playlists_per_s": round(256 * args.steps / wall, 1),
                       "reader_ms": round(tr / args.steps * 1e3, 3), "train_step_call_ms": round(ts / args.steps * 1e3, 3),
-                      "async_cost": bool(args.async_cost), "last_cost": float(l)}))
+                      "async_cost": bool(args.async_cost), "encoder_adam": "dense" if args.tied else args.encoder_adam,
+                      "train_dtype": "bf16" if args.bf16 else "f32", "last_cost": float(l)}))
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ EXPORTS = [
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
 ]
 
 _lib = None
@@ -82,6 +83,11 @@ def load():
     lib.dae_title_conv_backward.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, ctypes.POINTER(ctypes.c_int32),
                                             c_int, c_int, vp, vp, vp, c_i64, c_f, c_u32, vp, vp, vp]
     lib.dae_adam_step.argtypes = [vp, vp, vp, vp, vp, c_i64, c_f, c_f, c_f, c_f, c_int]
+    lib.dae_adam_rows_begin.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_int, c_f, c_f, c_f, c_int]
+    lib.dae_adam_rows_apply.argtypes = [vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, vp, c_int,
+                                        c_f, c_f, c_f, c_f, c_int]
+    lib.dae_adam_rows_flush.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_f, c_int]
+    lib.dae_set_enc_grad_prezeroed.argtypes = [vp, c_int]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes"):
             getattr(lib, name).restype = c_int

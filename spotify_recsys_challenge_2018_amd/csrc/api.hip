@@ -656,6 +656,22 @@ int dae_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, int L, c
                                           feat_raw, dfeat, ld, keep_prob, seed, g_emb, g_conv_w, g_conv_b);
 }
 
+}  // extern "C"
+
+// alpha_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) with the beta powers kept as fp32 running products, as TF's
+// beta1_power / beta2_power variables are.  The products are cached on the context (training calls this with
+// t, t, t, t, t+1, ...): restarting the O(t) loop on every call costs milliseconds per step after 10^5 steps.
+static float adam_alpha(dae_ctx* ctx, float lr, float beta1, float beta2, int t)
+{
+    if (ctx->adam_b1 != beta1 || ctx->adam_b2 != beta2 || t < ctx->adam_t) {
+        ctx->adam_b1 = beta1; ctx->adam_b2 = beta2; ctx->adam_t = 0; ctx->adam_b1p = 1.0f; ctx->adam_b2p = 1.0f;
+    }
+    while (ctx->adam_t < t) { ctx->adam_b1p *= beta1; ctx->adam_b2p *= beta2; ++ctx->adam_t; }
+    return lr * sqrtf(1.0f - ctx->adam_b2p) / (1.0f - ctx->adam_b1p);
+}
+
+extern "C" {
+
 int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                   float lr, float beta1, float beta2, float eps, int t)
 {
@@ -665,12 +681,60 @@ int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* g
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(grad)) % 16)
         return dae_fail(ctx, DAE_ERR_ARG, "param, m, v, grad must be 16-byte aligned");
-    // alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t) with the beta powers kept as fp32 running
-    // products, as TF's beta1_power / beta2_power variables are
-    float b1p = 1.0f, b2p = 1.0f;
-    for (int i = 0; i < t; ++i) { b1p *= beta1; b2p *= beta2; }
-    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    const float alpha = adam_alpha(ctx, lr, beta1, beta2, t);
     return dae_launch_adam(ctx, param, m, v, grad, n, alpha, beta1, beta2, eps);
+}
+
+int dae_set_enc_grad_prezeroed(dae_ctx* ctx, int on)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    ctx->enc_grad_prezeroed = on ? 1 : 0;
+    return DAE_OK;
+}
+
+static int adam_rows_check(dae_ctx* ctx, const void* param, const void* m, const void* v, const void* state,
+                           const void* lr_tab, int n_rows, int row_len, int tab_cap, int t)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!param || !m || !v || !state || !lr_tab) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (n_rows < 1 || row_len < 1) return dae_fail(ctx, DAE_ERR_ARG, "empty tensor");
+    if (t < 1) return dae_fail(ctx, DAE_ERR_ARG, "t is the 1-based step count");
+    if (t >= tab_cap) return dae_fail(ctx, DAE_ERR_ARG, "step %d does not fit the alpha table (%d entries)", t, tab_cap);
+    return DAE_OK;
+}
+
+int dae_adam_rows_begin(dae_ctx* ctx, float* param, float* m, float* v, int32_t* state, float* lr_tab, int tab_cap,
+                        int n_rows, int row_len, const int32_t* rows, const int32_t* n_listed_dev, int n_listed_max,
+                        float beta1, float beta2, float eps, int t)
+{
+    int rc = adam_rows_check(ctx, param, m, v, state, lr_tab, n_rows, row_len, tab_cap, t);
+    if (rc) return rc;
+    if (n_listed_max <= 0) return DAE_OK;
+    if (!rows) return dae_fail(ctx, DAE_ERR_ARG, "null row list");
+    return dae_launch_adam_rows(ctx, 0, param, m, v, nullptr, state, state + n_rows, lr_tab, n_rows, row_len, rows,
+                                n_listed_dev, n_listed_max, 0.0f, beta1, beta2, eps, t);
+}
+
+int dae_adam_rows_apply(dae_ctx* ctx, float* param, float* m, float* v, float* grad, int32_t* state, float* lr_tab,
+                        int tab_cap, int n_rows, int row_len, const int32_t* rows, const int32_t* n_listed_dev,
+                        int n_listed_max, float lr, float beta1, float beta2, float eps, int t)
+{
+    int rc = adam_rows_check(ctx, param, m, v, state, lr_tab, n_rows, row_len, tab_cap, t);
+    if (rc) return rc;
+    if (!grad || (n_listed_max > 0 && !rows)) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    const float alpha = adam_alpha(ctx, lr, beta1, beta2, t);
+    return dae_launch_adam_rows(ctx, 1, param, m, v, grad, state, state + n_rows, lr_tab, n_rows, row_len, rows,
+                                n_listed_dev, n_listed_max < 0 ? 0 : n_listed_max, alpha, beta1, beta2, eps, t);
+}
+
+int dae_adam_rows_flush(dae_ctx* ctx, float* param, float* m, float* v, int32_t* state, const float* lr_tab,
+                        int tab_cap, int n_rows, int row_len, float beta1, float beta2, float eps, int t)
+{
+    if (t == 0) return DAE_OK;
+    int rc = adam_rows_check(ctx, param, m, v, state, lr_tab, n_rows, row_len, tab_cap, t);
+    if (rc) return rc;
+    return dae_launch_adam_rows(ctx, 2, param, m, v, nullptr, state, nullptr, const_cast<float*>(lr_tab), n_rows, row_len,
+                                nullptr, nullptr, 0, 0.0f, beta1, beta2, eps, t);
 }
 
 }  // extern "C"

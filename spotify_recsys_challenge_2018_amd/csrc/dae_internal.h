@@ -65,6 +65,8 @@ struct dae_ctx {
     dae_buf cand_cnt;          // [nb_rg][Bpad] int
     dae_buf dense_tmp;         // unfused fallback logits
     dae_buf train_a, train_b, train_c, train_d;
+    int enc_grad_prezeroed = 0;        // untied gW_enc is all-zero on entry (dae_adam_rows_apply re-zeroes what it reads)
+    int adam_t = 0; float adam_b1 = 0.f, adam_b2 = 0.f, adam_b1p = 1.f, adam_b2p = 1.f;   // running beta powers of dae_adam_alpha
     int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)
     dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
 
@@ -233,6 +235,10 @@ int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_r
 int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* h, int H, int B, int V,
                       float* gW, float* gb);
 int dae_launch_grad_h(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* W, int H, int V, int B, float* dh);
+int dae_launch_adam_rows(dae_ctx* ctx, int mode, float* param, float* m, float* v, float* grad, int32_t* last,
+                         int32_t* mark, float* lr_tab, int n_rows, int row_len, const int32_t* rows,
+                         const int32_t* n_listed_dev, int n_listed_max, float lr_t, float beta1, float beta2,
+                         float eps, int step);
 int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float* grad, int64_t n,
                     float lr_t, float beta1, float beta2, float eps);
 

@@ -652,6 +652,91 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+// ---- K9 on a ROW-SPARSE gradient: the same dense TF1 Adam, without the HBM passes over rows that have none ------
+// The untied encoder's gradient is non-zero on the few thousand rows the batch's input names (4 % of 170 000).
+// Dense Adam still moves every row (m and v decay, p follows m), which costs 7 passes over 174 MB per step.  A row
+// without gradient, however, evolves by a recurrence nobody else reads: its state can stay at the step it was last
+// current for (`last[row]`) and be brought up to date -- by running the SAME per-element update with g = 0 once per
+// missed step, with the alpha each of those steps used (lr_tab[s]) -- when the row is next needed: before a step
+// whose input names it (dae_adam_rows_begin), or for everyone at a sync point (dae_adam_rows_flush).  Every element
+// sees exactly the operation sequence dense Adam would have applied, so the parameters are bit-identical
+// (tests/test_gpu_train.py); only the memory traffic of untouched rows is gone.
+// One wave per listed row; a row listed several times (a track in many playlists) is claimed once per launch through
+// mark[row] (atomicExch with a per-launch stamp).
+#define ADAM_EL(P, M, V, G, A)                                           \
+        M = M + (G - M) * (1.0f - b1);                                   \
+        V = V + (G * G - V) * (1.0f - b2);                               \
+        P = P - (M * A) / (sqrtf(V) + eps);
+
+// MODE 0: begin  (listed rows -> current at step - 1)
+// MODE 1: apply  (listed rows -> current at step - 1, then the update of `step` with their gradient row, which is
+//                 zeroed again so that the dense gradient buffer stays all-zero between steps)
+template <int MODE>
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ g,
+                                                        int* __restrict__ last, int* __restrict__ mark,
+                                                        float* __restrict__ lr_tab, int n_rows, int row_len,
+                                                        const int32_t* __restrict__ rows,
+                                                        const int32_t* __restrict__ n_listed_dev, int n_listed_max,
+                                                        float lr_t, float b1, float b2, float eps, int step)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0) lr_tab[step] = lr_t;
+    const int n_listed = n_listed_dev ? min(*n_listed_dev, n_listed_max) : n_listed_max;
+    if (w >= n_listed) return;
+    const int row = rows[w];
+    if (row < 0 || row >= n_rows) return;
+    const int stamp = 2 * step + MODE;
+    int claimed = 0;
+    if (lane == 0) claimed = atomicExch(&mark[row], stamp) != stamp;
+    claimed = __shfl(claimed, 0);
+    if (!claimed) return;
+    const int from = last[row];
+    const int upto = step - 1;
+    for (int c = lane; c < row_len; c += 64) {
+        const size_t o = (size_t)row * row_len + c;
+        float pp = p[o], mm = m[o], vv = v[o];
+        for (int s_ = from + 1; s_ <= upto; ++s_) {
+            const float a = lr_tab[s_];
+            const float z = 0.0f;
+            ADAM_EL(pp, mm, vv, z, a)
+        }
+        if (MODE == 1) {
+            const float gg = g[o];
+            ADAM_EL(pp, mm, vv, gg, lr_t)
+            g[o] = 0.0f;
+        }
+        p[o] = pp; m[o] = mm; v[o] = vv;
+    }
+    if (lane == 0) last[row] = MODE == 1 ? step : upto;
+}
+
+// every row -> current at `step` (sync points: evaluation, saving, sharding, ...); one wave per row
+__global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                              float* __restrict__ v, int* __restrict__ last,
+                                                              const float* __restrict__ lr_tab, int n_rows,
+                                                              int row_len, float b1, float b2, float eps, int step)
+{
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int from = last[row];
+        if (from >= step) continue;
+        for (int c = lane; c < row_len; c += 64) {
+            const size_t o = (size_t)row * row_len + c;
+            float pp = p[o], mm = m[o], vv = v[o];
+            for (int s_ = from + 1; s_ <= step; ++s_) {
+                const float a = lr_tab[s_];
+                const float z = 0.0f;
+                ADAM_EL(pp, mm, vv, z, a)
+            }
+            p[o] = pp; m[o] = mm; v[o] = vv;
+        }
+        if (lane == 0) last[row] = step;
+    }
+}
+#undef ADAM_EL
+
 int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -664,6 +749,31 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(work ? work : 1)), dim3(256), 0, ctx->stream, param, m, v,
                        grad, (size_t)n, lr_t, beta1, beta2, eps);
     DAE_CHECK_LAUNCH(ctx, "adam_kernel");
+    return DAE_OK;
+}
+
+int dae_launch_adam_rows(dae_ctx* ctx, int mode, float* param, float* m, float* v, float* grad, int32_t* last,
+                         int32_t* mark, float* lr_tab, int n_rows, int row_len, const int32_t* rows,
+                         const int32_t* n_listed_dev, int n_listed_max, float lr_t, float beta1, float beta2,
+                         float eps, int step)
+{
+    if (mode == 2) {
+        int blocks = (n_rows + 3) / 4;
+        if (blocks > 16 * DAE_NUM_CU) blocks = 16 * DAE_NUM_CU;
+        hipLaunchKernelGGL(adam_rows_flush_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, ctx->stream, param, m, v,
+                           last, lr_tab, n_rows, row_len, beta1, beta2, eps, step);
+        DAE_CHECK_LAUNCH(ctx, "adam_rows_flush_kernel");
+        return DAE_OK;
+    }
+    // mode 1 always launches: its first thread records this step's alpha even when no row is listed
+    const int blocks = (n_listed_max + 3) / 4 > 0 ? (n_listed_max + 3) / 4 : 1;
+    if (mode == 0)
+        hipLaunchKernelGGL(adam_rows_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, param, m, v, grad, last, mark,
+                           lr_tab, n_rows, row_len, rows, n_listed_dev, n_listed_max, lr_t, beta1, beta2, eps, step);
+    else
+        hipLaunchKernelGGL(adam_rows_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, param, m, v, grad, last, mark,
+                           lr_tab, n_rows, row_len, rows, n_listed_dev, n_listed_max, lr_t, beta1, beta2, eps, step);
+    DAE_CHECK_LAUNCH(ctx, "adam_rows_kernel");
     return DAE_OK;
 }
 
@@ -844,7 +954,8 @@ int train_encoder_backward(dae_ctx* ctx, const TrainPlan& t, const float* part, 
     DAE_CHECK_LAUNCH(ctx, "colsum_kernel");
 
     // ---- K8: encoder gradient (row-sparse) -----------------------------------------------------------
-    if (!tied) DAE_HIP_CHECK(ctx, hipMemsetAsync(gW_enc, 0, nW * sizeof(float), st));
+    // (the rows-Adam keeps the dense buffer all-zero itself: dae_set_enc_grad_prezeroed)
+    if (!tied && !ctx->enc_grad_prezeroed) DAE_HIP_CHECK(ctx, hipMemsetAsync(gW_enc, 0, nW * sizeof(float), st));
     hipLaunchKernelGGL(scatter_gwenc_kernel, dim3(B), dim3(256), 0, st, x_row_ptr, x_col, x_val, B, H,
                        ikp, seed, col_lo, col_hi, t.dpre, gW_enc);
     DAE_CHECK_LAUNCH(ctx, "scatter_gwenc_kernel");

@@ -16,6 +16,7 @@ The same calls work here through `Session` below.  Direct methods (`predict`, `r
 `train_step`) are what the drivers of this repo use; `recommend` is the fused
 encode -> decode -> top-k path that never materialises the [batch, n_input] matrix.
 """
+import ctypes
 import pickle
 
 import numpy as np
@@ -140,6 +141,14 @@ class DAE_tied:
         # fp32 accumulate; loss, backward GEMMs, parameters and Adam stay fp32)
         self.train_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "train_dtype", "f32")) == "bf16" \
             else _lib.DAE_DTYPE_F32
+        # untied model, reg_lambda == 0: the encoder's gradient is row-sparse, and its dense Adam runs through
+        # dae_adam_rows_* (bit-identical parameters, no HBM passes over the rows without gradient); "dense" keeps
+        # dae_adam_step on the whole matrix
+        self.encoder_adam = str(getattr(conf, "encoder_adam", "rows"))
+        # ... and every `rows_adam_flush_every` steps all rows are brought up to date, which bounds how many missed
+        # steps a rarely seen row has to replay when it is next named (a replay is sequential per element)
+        self.rows_adam_flush_every = int(getattr(conf, "rows_adam_flush_every", 32))
+        self._lazy = None
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
         self.device_csr = bool(getattr(conf, "device_csr", True))
         self._csr_status = None
@@ -248,8 +257,24 @@ class DAE_tied:
                                        device=self.weights["encoder_h"].device, rank=rank, world=world,
                                        group=group, seed=int(self._rng.randint(0, 2 ** 31 - 1)))
 
+    def _flush_rows_adam(self):
+        """Every encoder row current for the last training step (rows without gradient lag behind until someone
+        needs the whole matrix: evaluation, saving, sharding)."""
+        lz = self._lazy
+        if lz is None or lz["flushed"] == self._step:
+            return
+        self.ctx.bind_stream()
+        m, v = self._adam["encoder_h"]
+        P = _lib._ptr
+        self.ctx.check(self.ctx.lib.dae_adam_rows_flush(
+            self.ctx.h, P(self.weights["encoder_h"]), P(m), P(v), P(lz["state"]), P(lz["tab"]), lz["tab"].numel(),
+            self.n_input, self.n_hidden, 0.9, 0.999, 1e-8, self._step))
+        lz["flushed"] = self._step
+
     def sync_params(self):
-        """Collective when sharded (every rank must call it at the same point)."""
+        """Parameters current on this rank: pending row updates of the encoder applied, and -- collective when
+        sharded (every rank must call it at the same point) -- the replica refreshed from the shards."""
+        self._flush_rows_adam()
         if self._sharded is None or not self._params_stale:
             return
         import torch
@@ -348,6 +373,22 @@ class DAE_tied:
         g = self._grads
         lib, ctx = self.ctx.lib, self.ctx
         P = _lib._ptr
+        lz = None
+        if not self.tied and self.reg_lambda == 0.0 and self.encoder_adam == "rows":
+            if self._lazy is None:
+                self._lazy = {"state": torch.zeros(2 * self.n_input, dtype=torch.int32, device=dev),
+                              "tab": torch.zeros(1 << 16, dtype=torch.float32, device=dev), "flushed": self._step}
+                ctx.check(lib.dae_set_enc_grad_prezeroed(ctx.h, 1))
+            lz = self._lazy
+            if self._step + 2 >= lz["tab"].numel():                       # alpha of every step so far
+                lz["tab"] = torch.cat([lz["tab"], torch.zeros_like(lz["tab"])])
+            # the rows this step's input names (the CSR's column array, length read on the device from row_ptr[B])
+            # become current BEFORE the encode reads them
+            rows_arg = (P(xc), ctypes.c_void_p(xr.data_ptr() + 4 * self.n_batch), int(xc.numel()))
+            m_e, v_e = self._adam["encoder_h"]
+            ctx.check(lib.dae_adam_rows_begin(ctx.h, P(self.weights["encoder_h"]), P(m_e), P(v_e), P(lz["state"]),
+                                              P(lz["tab"]), lz["tab"].numel(), self.n_input, self.n_hidden,
+                                              rows_arg[0], rows_arg[1], rows_arg[2], 0.9, 0.999, 1e-8, self._step + 1))
         ctx.check(lib.dae_train_forward_backward(
             ctx.h, P(xr), P(xc), P(xv), P(yr), P(yc), P(yv),
             P(self.weights["encoder_h"]), P(self.biases["encoder_b"]),
@@ -360,6 +401,14 @@ class DAE_tied:
         for n, grad in g.items():
             p = self.weights[n] if n in self.weights else self.biases[n]
             m, v = self._adam[n]
+            if lz is not None and n == "encoder_h":
+                ctx.check(lib.dae_adam_rows_apply(ctx.h, P(p), P(m), P(v), P(grad), P(lz["state"]), P(lz["tab"]),
+                                                  lz["tab"].numel(), self.n_input, self.n_hidden, rows_arg[0],
+                                                  rows_arg[1], rows_arg[2], self.learning_rate, 0.9, 0.999, 1e-8,
+                                                  self._step))
+                if self.rows_adam_flush_every > 0 and self._step - lz["flushed"] >= self.rows_adam_flush_every:
+                    self._flush_rows_adam()
+                continue
             ctx.check(lib.dae_adam_step(ctx.h, P(p), P(m), P(v), P(grad), p.numel(),
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
         self._mark_dirty()

@@ -207,3 +207,83 @@ def test_train_step_bf16_gemms(V, nt, H, B, tied):
     with pytest.raises(_lib.DaeError):
         ctx.set_train_dtype(7)
     ctx.close()
+
+
+def test_rows_adam_is_bit_identical_to_dense_adam():
+    """dae_adam_rows_begin / _apply / _flush on a row-sparse gradient walk every element through exactly the
+    updates dae_adam_step applies every step: parameters and both moments bit-equal, the dense gradient buffer
+    left all-zero, whatever the pattern of touched rows (duplicates in the list, rows never touched, empty steps)."""
+    import torch
+    ctx = _lib.Context(0)
+    P = _lib._ptr
+    rng = np.random.default_rng(11)
+    n_rows, row_len, steps, cap = 300, 96, 40, 64
+    p0 = rng.standard_normal((n_rows, row_len)).astype(np.float32)
+    dense = [_dev(p0), _dev(np.zeros_like(p0)), _dev(np.zeros_like(p0))]
+    lazy = [_dev(p0), _dev(np.zeros_like(p0)), _dev(np.zeros_like(p0))]
+    state = torch.zeros(2 * n_rows, dtype=torch.int32, device="cuda")
+    tab = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    g_lazy = torch.zeros((n_rows, row_len), device="cuda")
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, 0.005
+    for t in range(1, steps + 1):
+        k = 0 if t % 7 == 0 else int(rng.integers(1, 40))
+        rows = rng.choice(n_rows // 2, size=k, replace=False) if k else np.zeros(0, np.int64)   # upper half: never touched
+        listed = np.concatenate([rows, rows[: k // 2]]).astype(np.int32)                       # duplicates
+        g = np.zeros((n_rows, row_len), np.float32)
+        g[rows] = rng.standard_normal((k, row_len)).astype(np.float32)
+        if k:
+            g[rows[0], ::3] = 0.0                                                              # zeros inside a listed row
+        d_list = _dev(listed if len(listed) else np.zeros(1, np.int32))
+        n_dev = _dev(np.array([len(listed)], np.int32))
+        ctx.check(ctx.lib.dae_adam_step(ctx.h, P(dense[0]), P(dense[1]), P(dense[2]), P(_dev(g)), n_rows * row_len,
+                                        lr, b1, b2, eps, t))
+        ctx.check(ctx.lib.dae_adam_rows_begin(ctx.h, P(lazy[0]), P(lazy[1]), P(lazy[2]), P(state), P(tab), cap,
+                                              n_rows, row_len, P(d_list), P(n_dev), len(listed) + 5, b1, b2, eps, t))
+        g_lazy[torch.from_numpy(rows).cuda().long()] = torch.from_numpy(g[rows]).cuda()
+        ctx.check(ctx.lib.dae_adam_rows_apply(ctx.h, P(lazy[0]), P(lazy[1]), P(lazy[2]), P(g_lazy), P(state), P(tab),
+                                              cap, n_rows, row_len, P(d_list), P(n_dev), len(listed) + 5,
+                                              lr, b1, b2, eps, t))
+        assert not g_lazy.any()                                     # re-zeroed by apply
+        if t in (13, steps):                                        # a sync point in the middle, and the end
+            ctx.check(ctx.lib.dae_adam_rows_flush(ctx.h, P(lazy[0]), P(lazy[1]), P(lazy[2]), P(state), P(tab), cap,
+                                                  n_rows, row_len, b1, b2, eps, t))
+            for a, b in zip(dense, lazy):
+                assert torch.equal(a, b)
+    with pytest.raises(_lib.DaeError):                               # the alpha table is full
+        ctx.lib.dae_adam_rows_begin.restype = ctypes.c_int
+        ctx.check(ctx.lib.dae_adam_rows_begin(ctx.h, P(lazy[0]), P(lazy[1]), P(lazy[2]), P(state), P(tab), cap,
+                                              n_rows, row_len, P(state), None, 1, b1, b2, eps, cap))
+    ctx.close()
+
+
+def test_model_rows_adam_follows_dense_adam():
+    """The untied model's default (encoder through dae_adam_rows_*) against encoder_adam = "dense": same costs and,
+    after the flush that get_params() triggers, the same parameters -- to the rounding of the float atomics in the
+    sparse encoder gradient, which differ between any two runs."""
+    from spotify_recsys_challenge_2018_amd.models.DAEs import DAE
+
+    class C:
+        save = "/tmp/_ra_unused"; batch = 32; n_input = 1500; hidden = 64; lr = 0.01; reg_lambda = 0.0
+        initval = "NULL"; n_tracks = 1200
+    rng = np.random.default_rng(5)
+    batches = []
+    for s in range(12):
+        pos, ones, _ = make_playlists(C.batch, 1200, 300, seed=100 + s, seed_counts=(3, 9, 20))
+        batches.append((pos[pos[:, 1] < 1200], ones[pos[:, 1] < 1200], pos, np.ones(len(pos), np.float32)))
+    a = DAE(C()); a.fit()
+    cd = C(); cd.encoder_adam = "dense"
+    b = DAE(cd); b.fit()
+    assert a.encoder_adam == "rows" and b.encoder_adam == "dense"
+    ca, cb = [], []
+    for i in range(36):
+        x, xv, y, yv = batches[i % len(batches)]
+        ca.append(a.train_step(x, xv, y, yv, 0.8, 0.75))
+        cb.append(b.train_step(x, xv, y, yv, 0.8, 0.75))
+        if i == 17:                                   # a scoring call in the middle: flush, then keep training
+            ia, _ = a.recommend(x, xv, [[] for _ in range(C.batch)], k=50)
+            ib, _ = b.recommend(x, xv, [[] for _ in range(C.batch)], k=50)
+            assert (ia == ib).mean() > 0.99
+    assert a._lazy is not None and b._lazy is None
+    assert np.allclose(ca, cb, rtol=2e-4)
+    for pa, pb in zip(a.get_params(), b.get_params()):
+        assert np.allclose(pa, pb, rtol=1e-3, atol=2e-6)
