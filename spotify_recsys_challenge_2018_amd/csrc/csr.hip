@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restr
 // One workgroup per row.  Entry i is KEPT iff its value is non-zero and no entry of the row with the
 // same column comes later in the feed; a kept entry's output slot is the number of kept entries with
 // a smaller column.  Kept entries go to k_col / k_val at the row's bucket offset, their number to kcnt.
+// The two cases are separate kernels: picking `s_col` or `t_col + b` through one pointer makes every access a FLAT
+// load (25 us per launch for rows of ~100 entries; 256 workgroups), while the LDS-only body is plain ds_reads.
 __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bptr,
                                                       const int* __restrict__ t_col,
                                                       const int* __restrict__ t_feed,
@@ -89,50 +91,76 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
     const int row = blockIdx.x, tid = threadIdx.x;
     const int b = bptr[row], n = bptr[row + 1] - b;
     if (tid == 0) s_n = 0;
-    const bool in_lds = n <= CSR_ROW_CAP;
-    if (in_lds)
-        for (int i = tid; i < n; i += 256) { s_col[i] = t_col[b + i]; s_feed[i] = t_feed[b + i]; }
+    if (n <= CSR_ROW_CAP) {
+        // ---- the row fits the LDS buffers (always, for playlist batches) ----
+        float my_val[CSR_ROW_CAP / 256];
+#pragma unroll
+        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
+            const int i = tid + u * 256;
+            if (i < n) { s_col[i] = t_col[b + i]; s_feed[i] = t_feed[b + i]; my_val[u] = t_val[b + i]; }
+        }
+        __syncthreads();
+        // pass 1: keep flags
+        for (int i = tid; i < n; i += 256) {
+            const int c = s_col[i], f = s_feed[i];
+            int later = 0;
+            for (int j = 0; j < n; ++j) later |= (s_col[j] == c) & (s_feed[j] > f);
+            s_keep[i] = 0;                         // (written below once the value is known)
+            if (!later) s_keep[i] = 2;             // provisional: survives the duplicate rule
+        }
+#pragma unroll
+        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
+            const int i = tid + u * 256;
+            if (i < n) s_keep[i] = (s_keep[i] == 2 && my_val[u] != 0.0f) ? 1 : 0;
+        }
+        __syncthreads();
+        // pass 2: slot among the kept entries, output written directly
+#pragma unroll
+        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
+            const int i = tid + u * 256;
+            if (i >= n || !s_keep[i]) continue;
+            const int c = s_col[i];
+            int slot = 0;
+            for (int j = 0; j < n; ++j) slot += (s_keep[j] != 0) & (s_col[j] < c);
+            atomicAdd(&s_n, 1);
+            k_col[b + slot] = c; k_val[b + slot] = my_val[u];
+        }
+        __syncthreads();
+        if (tid == 0) kcnt[row] = s_n;
+        return;
+    }
+    // ---- a row longer than the LDS buffers: the same steps over global memory ----
     __syncthreads();
-    const int* colp = in_lds ? s_col : t_col + b;
-    const int* feedp = in_lds ? s_feed : t_feed + b;
-    // pass 1: keep flags (rows beyond the LDS buffer keep them in the low bit of k_col's slot)
+    const int* colp = t_col + b;
+    const int* feedp = t_feed + b;
+    // pass 1: keep flags, kept in the low bit of k_col's slot until every reader is done
     for (int i = tid; i < n; i += 256) {
         const int c = colp[i], f = feedp[i];
         bool later = false;
         for (int j = 0; j < n; ++j) later = later || (colp[j] == c && feedp[j] > f);
-        const bool keep = !later && t_val[b + i] != 0.0f;
-        if (in_lds) s_keep[i] = keep ? 1 : 0;
-        else k_col[b + i] = keep ? 1 : 0;            // scratch use; rewritten below after a barrier
+        k_col[b + i] = (!later && t_val[b + i] != 0.0f) ? 1 : 0;      // scratch use; rewritten below after a barrier
     }
     __syncthreads();
-    // pass 2: slot among the kept entries.  LDS rows write their output directly; long rows keep their
-    // flags in k_col until every reader is done, so they park the SOURCE INDEX of slot s in k_val[s].
+    // pass 2: slot among the kept entries; the SOURCE INDEX of slot s is parked in k_val[s]
     for (int i = tid; i < n; i += 256) {
-        const bool keep = in_lds ? s_keep[i] != 0 : k_col[b + i] != 0;
-        if (!keep) continue;
+        if (k_col[b + i] == 0) continue;
         const int c = colp[i];
         int slot = 0;
-        for (int j = 0; j < n; ++j) {
-            const bool kj = in_lds ? s_keep[j] != 0 : k_col[b + j] != 0;
-            slot += (kj && colp[j] < c) ? 1 : 0;
-        }
+        for (int j = 0; j < n; ++j) slot += (k_col[b + j] != 0 && colp[j] < c) ? 1 : 0;
         atomicAdd(&s_n, 1);
-        if (in_lds) { k_col[b + slot] = c; k_val[b + slot] = t_val[b + i]; }
-        else k_val[b + slot] = __int_as_float(i);
+        k_val[b + slot] = __int_as_float(i);
     }
     __syncthreads();
-    if (!in_lds) {
-        const int m = s_n;
-        for (int s = tid; s < m; s += 256) {
-            const int i = __float_as_int(k_val[b + s]);
-            k_col[b + s] = -1 - i;                   // flags are dead now; mark as "source index"
-        }
-        __syncthreads();
-        for (int s = tid; s < m; s += 256) {
-            const int i = -1 - k_col[b + s];
-            k_col[b + s] = t_col[b + i];
-            k_val[b + s] = t_val[b + i];
-        }
+    const int m = s_n;
+    for (int s = tid; s < m; s += 256) {
+        const int i = __float_as_int(k_val[b + s]);
+        k_col[b + s] = -1 - i;                   // flags are dead now; mark as "source index"
+    }
+    __syncthreads();
+    for (int s = tid; s < m; s += 256) {
+        const int i = -1 - k_col[b + s];
+        k_col[b + s] = t_col[b + i];
+        k_val[b + s] = t_val[b + i];
     }
     if (tid == 0) kcnt[row] = s_n;
 }
@@ -146,6 +174,124 @@ __global__ __launch_bounds__(256) void csr_compact_kernel(const int* __restrict_
     const int row = blockIdx.x;
     const int b = bptr[row], o = row_ptr[row], m = row_ptr[row + 1] - o;
     for (int s = threadIdx.x; s < m; s += 256) { col[o + s] = k_col[b + s]; val[o + s] = k_val[b + s]; }
+}
+
+// ---- feeds of <= 4096 rows (every training / scoring batch): workgroup-private LDS counters ---------------------
+// The global-atomic kernels above spend ~20 us each on a few hundred hot counters.  Here a workgroup counts its 1024
+// entries per row in LDS and touches the global counter of a row ONCE (a feed is mostly row-ordered, so that is a
+// handful of rows per workgroup); the scatter reserves a slot range per (workgroup, row) the same way and scans the
+// row counts itself instead of waiting for a scan launch; the compaction sums the kept counts of the rows before its
+// own.  4 launches per feed (count, scatter, per-row order + dedup, compact) instead of 6.
+constexpr int CSR_SMALL_ROWS = 4096;     // 2 x 16 KiB of LDS counters in the scatter kernel
+
+__global__ __launch_bounds__(1024) void csr_count_lds_kernel(const int64_t* __restrict__ pos, int64_t nnz,
+                                                             int n_rows, int n_cols, int* __restrict__ cnt,
+                                                             int* __restrict__ status)
+{
+    extern __shared__ int sh_rows[];                 // [n_rows]
+    const int tid = threadIdx.x;
+    for (int r = tid; r < n_rows; r += 1024) sh_rows[r] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    if (i < nnz) {
+        const int64_t r = pos[2 * i], c = pos[2 * i + 1];
+        if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) atomicOr(status, 1);
+        else atomicAdd(&sh_rows[(int)r], 1);
+    }
+    __syncthreads();
+    for (int r = tid; r < n_rows; r += 1024) {
+        const int k = sh_rows[r];
+        if (k) atomicAdd(&cnt[r], k);
+    }
+}
+
+// exclusive scan of a[0..n) in LDS by one 1024-thread workgroup; returns the total (all threads)
+__device__ int block_exclusive_scan_1024(int* a, int n, int* wsum /*[16]*/)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? a[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        if (i < n) a[i] = carry + woff + x - v;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(1024) void csr_scatter_lds_kernel(const int64_t* __restrict__ pos,
+                                                               const float* __restrict__ val, int val_bcast,
+                                                               int64_t nnz, int n_rows, int n_cols,
+                                                               const int* __restrict__ cnt, int* __restrict__ cursor,
+                                                               int* __restrict__ bptr, int* __restrict__ t_col,
+                                                               int* __restrict__ t_feed, float* __restrict__ t_val)
+{
+    extern __shared__ int sh_rows[];                 // [n_rows] bucket starts | [n_rows] local counts -> slot bases
+    __shared__ int wsum[16];
+    int* start = sh_rows;
+    int* loc = sh_rows + n_rows;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < n_rows; r += 1024) { start[r] = cnt[r]; loc[r] = 0; }
+    __syncthreads();
+    const int total = block_exclusive_scan_1024(start, n_rows, wsum);
+    if (blockIdx.x == 0) {                           // the bucket starts, for the per-row kernel
+        for (int r = tid; r < n_rows; r += 1024) bptr[r] = start[r];
+        if (tid == 0) bptr[n_rows] = total;
+    }
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    int r = -1, c = 0, rank = 0;
+    if (i < nnz) {
+        const int64_t r64 = pos[2 * i], c64 = pos[2 * i + 1];
+        if (!(r64 < 0 || r64 >= n_rows || c64 < 0 || c64 >= n_cols)) {
+            r = (int)r64; c = (int)c64;
+            rank = atomicAdd(&loc[r], 1);            // rank among this workgroup's entries of the row
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < n_rows; q += 1024) {       // one global reservation per (workgroup, row)
+        const int k = loc[q];
+        if (k) loc[q] = start[q] + atomicAdd(&cursor[q], k);
+    }
+    __syncthreads();
+    if (r >= 0) {
+        const int slot = loc[r] + rank;
+        t_col[slot] = c;
+        t_feed[slot] = (int)i;
+        t_val[slot] = val[val_bcast ? 0 : i];
+    }
+}
+
+// one workgroup per row: output start = kept entries of the rows before it (summed here: no scan launch)
+__global__ __launch_bounds__(256) void csr_compact_sum_kernel(const int* __restrict__ bptr,
+                                                              const int* __restrict__ kcnt, int n_rows,
+                                                              const int* __restrict__ k_col,
+                                                              const float* __restrict__ k_val,
+                                                              int32_t* __restrict__ row_ptr,
+                                                              int32_t* __restrict__ col, float* __restrict__ val)
+{
+    __shared__ int ws[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    int s = 0;
+    for (int r = tid; r < row; r += 256) s += kcnt[r];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) ws[tid >> 6] = s;
+    __syncthreads();
+    const int o = ws[0] + ws[1] + ws[2] + ws[3];
+    const int b = bptr[row], m = kcnt[row];
+    if (tid == 0) {
+        row_ptr[row] = o;
+        if (row == n_rows - 1) row_ptr[n_rows] = o + m;
+    }
+    for (int s2 = tid; s2 < m; s2 += 256) { col[o + s2] = k_col[b + s2]; val[o + s2] = k_val[b + s2]; }
 }
 
 }  // namespace
@@ -169,6 +315,29 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     float* t_val = reinterpret_cast<float*>(t_feed + nnz);
     int* k_col = reinterpret_cast<int*>(t_val + nnz);
     float* k_val = reinterpret_cast<float*>(k_col + nnz);
+    static const bool no_small = getenv("DAE_CSR_GENERIC") != nullptr;            // A/B against the 6-launch path
+    if (n_rows <= CSR_SMALL_ROWS && !no_small) {
+        // cnt | cursor are adjacent, the caller's status word is cleared with them by one small kernel-free memset each
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, 2 * nr * sizeof(int), st));
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+        const int blocks = (int)((nnz + 1023) / 1024) > 0 ? (int)((nnz + 1023) / 1024) : 1;
+        const size_t lds = (size_t)n_rows * sizeof(int);
+        if (nnz > 0) {
+            hipLaunchKernelGGL(csr_count_lds_kernel, dim3(blocks), dim3(1024), lds, st, positions, nnz, n_rows, n_cols,
+                               cnt, status);
+            DAE_CHECK_LAUNCH(ctx, "csr_count_lds_kernel");
+        }
+        hipLaunchKernelGGL(csr_scatter_lds_kernel, dim3(blocks), dim3(1024), 2 * lds, st, positions, values,
+                           values_broadcast, nnz, n_rows, n_cols, cnt, cursor, bptr, t_col, t_feed, t_val);
+        DAE_CHECK_LAUNCH(ctx, "csr_scatter_lds_kernel");
+        hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
+                           kcnt);
+        DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
+        hipLaunchKernelGGL(csr_compact_sum_kernel, dim3(n_rows), dim3(256), 0, st, bptr, kcnt, n_rows, k_col, k_val,
+                           row_ptr, col, val);
+        DAE_CHECK_LAUNCH(ctx, "csr_compact_sum_kernel");
+        return DAE_OK;
+    }
     DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, 2 * nr * sizeof(int), st));          // cnt and cursor
     DAE_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
     if (nnz > 0) {

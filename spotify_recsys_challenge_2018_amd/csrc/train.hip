@@ -694,6 +694,29 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
     if (!claimed) return;
     const int from = last[row];
     const int upto = step - 1;
+    // four elements per lane at a time: the replay is a sequential recurrence per element (sqrt -> divide -> subtract),
+    // so independent chains are the only instruction-level parallelism there is
+    if ((row_len & 3) == 0) {
+        for (int c4 = lane; c4 < (row_len >> 2); c4 += 64) {
+            const size_t o = ((size_t)row * row_len >> 2) + c4;
+            float4 pp = reinterpret_cast<float4*>(p)[o], mm = reinterpret_cast<float4*>(m)[o],
+                   vv = reinterpret_cast<float4*>(v)[o];
+            for (int s_ = from + 1; s_ <= upto; ++s_) {
+                const float a = lr_tab[s_];
+                const float z = 0.0f;
+                ADAM_EL(pp.x, mm.x, vv.x, z, a) ADAM_EL(pp.y, mm.y, vv.y, z, a)
+                ADAM_EL(pp.z, mm.z, vv.z, z, a) ADAM_EL(pp.w, mm.w, vv.w, z, a)
+            }
+            if (MODE == 1) {
+                const float4 gg = reinterpret_cast<float4*>(g)[o];
+                ADAM_EL(pp.x, mm.x, vv.x, gg.x, lr_t) ADAM_EL(pp.y, mm.y, vv.y, gg.y, lr_t)
+                ADAM_EL(pp.z, mm.z, vv.z, gg.z, lr_t) ADAM_EL(pp.w, mm.w, vv.w, gg.w, lr_t)
+                reinterpret_cast<float4*>(g)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            reinterpret_cast<float4*>(p)[o] = pp; reinterpret_cast<float4*>(m)[o] = mm;
+            reinterpret_cast<float4*>(v)[o] = vv;
+        }
+    } else
     for (int c = lane; c < row_len; c += 64) {
         const size_t o = (size_t)row * row_len + c;
         float pp = p[o], mm = m[o], vv = v[o];
@@ -722,6 +745,21 @@ __global__ __launch_bounds__(256) void adam_rows_flush_kernel(float* __restrict_
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
         const int from = last[row];
         if (from >= step) continue;
+        if ((row_len & 3) == 0) {
+            for (int c4 = lane; c4 < (row_len >> 2); c4 += 64) {
+                const size_t o = ((size_t)row * row_len >> 2) + c4;
+                float4 pp = reinterpret_cast<float4*>(p)[o], mm = reinterpret_cast<float4*>(m)[o],
+                       vv = reinterpret_cast<float4*>(v)[o];
+                for (int s_ = from + 1; s_ <= step; ++s_) {
+                    const float a = lr_tab[s_];
+                    const float z = 0.0f;
+                    ADAM_EL(pp.x, mm.x, vv.x, z, a) ADAM_EL(pp.y, mm.y, vv.y, z, a)
+                    ADAM_EL(pp.z, mm.z, vv.z, z, a) ADAM_EL(pp.w, mm.w, vv.w, z, a)
+                }
+                reinterpret_cast<float4*>(p)[o] = pp; reinterpret_cast<float4*>(m)[o] = mm;
+                reinterpret_cast<float4*>(v)[o] = vv;
+            }
+        } else
         for (int c = lane; c < row_len; c += 64) {
             const size_t o = (size_t)row * row_len + c;
             float pp = p[o], mm = m[o], vv = v[o];
