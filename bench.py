@@ -70,9 +70,50 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL (the product path).  gloo: development rehearsal of the N > 1 flow on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-row", action="store_true", help="skip the extra training-step row")
     ap.add_argument("--cpu-sample", type=int, default=256, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
     return ap.parse_args()
+
+
+def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, b_dec, n_tracks, V, H, B):
+    """ms per training step (dae_train_forward_backward + dae_adam_step on the four variables) through the C ABI."""
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    P = _lib._ptr
+    m = pos[:, 1] < n_tracks
+    x = [dev(a) for a in coo_to_csr(pos[m], ones[m], B, V)]
+    y = [dev(a) for a in coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)]
+    t = {"We": dev(W_enc), "be": dev(b_enc), "Wd": dev(W_dec), "bd": dev(b_dec)}
+    g = {n: torch.zeros_like(t[n]) for n in t}
+    mom = {n: (torch.zeros_like(t[n]), torch.zeros_like(t[n])) for n in t}
+    cost = torch.zeros(1, device="cuda")
+    ctx.bind_stream()
+
+    def step(i):
+        ctx.check(ctx.lib.dae_train_forward_backward(
+            ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]),
+            V, H, B, B, 0, 0.75, 0.8, 100 + i, 0.0, P(g["We"]), P(g["be"]), P(g["Wd"]), P(g["bd"]), P(cost)))
+        for n in t:
+            ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(),
+                                            0.005, 0.9, 0.999, 1e-8, i + 1))
+    row = {"unit": "ms per step of %d playlists" % B, "what": "untied: forward (dropout) + loss + backward + dense "
+           "TF1-Adam on W_enc, W_dec, b_enc, b_dec; fp32 parameters and moments", "steps": 20}
+    k = 0
+    for name, dt in (("f32", _lib.DAE_DTYPE_F32), ("bf16_gemms", _lib.DAE_DTYPE_BF16)):
+        ctx.set_train_dtype(dt)
+        for _ in range(3):
+            step(k); k += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step(k); k += 1
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        row[name] = {"ms_per_step": round(ms, 3), "playlists_per_s": round(B / ms * 1e3, 1), "cost": round(float(cost.item()), 3)}
+    ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
+    row["note"] = ("NOT the headline.  scripts/bench_epoch.py times the same step through the model (reader, device CSR, "
+                   "rows-Adam on the encoder)")
+    return row
 
 
 def main():
@@ -521,6 +562,16 @@ def main():
             out["cpu_baseline"]["dense_numpy"] = {"error": repr(e)}
     elif args.check and rank == 0:
         pass
+
+    # ---- the training step that produces these weights (BASELINE.json configs[3]), NOT part of `value` --------------
+    # forward with dropout + weighted-BCE loss + backward + dense TF1-Adam on all four variables, same V / H / batch;
+    # 20 steps each with fp32 and with bf16 GEMM operands, after everything else (it overwrites the context's packed decoder image)
+    if not sharded and not args.no_train_row and H % 32 == 0 and args.batch_per_gpu <= 256:
+        try:
+            out["training_step"] = _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, b_dec,
+                                                 n_tracks, V, H, B)
+        except Exception as e:                       # the row is an extra: never lose the headline over it
+            out["training_step"] = {"error": repr(e)}
 
     if sharded:
         dist.barrier()
