@@ -207,7 +207,8 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
 // TRANSPOSED ([ncols, ldT]: what both backward GEMMs read) and one loss partial per workgroup
 // (DAEs.py:98-100); the positives are redone afterwards by train.hip's loss_fixup_kernel.
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dzT, int64_t ldT, float* loss_part, int dtype = DAE_DTYPE_F32);
+                               float* dzT, int64_t ldT, float* loss_part, int dtype = DAE_DTYPE_F32,
+                               int dz16 = 0);
 
 // train.hip
 int dae_train_step_f32(dae_ctx* ctx,

@@ -34,6 +34,13 @@ constexpr int DT_BF16 = 1;         // v_mfma_f32_32x32x16_bf16, fp32 accumulate 
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 
+__device__ __forceinline__ unsigned bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
+    return u >> 16;
+}
+
 // bf16 kernels take the bias through the matrix pipe: b = e0 + e1 + e2 (three bf16 terms, exact to
 // 2^-25 |b|) sits in k-slots 0..2 of an extra A fragment per tile and is multiplied by this B fragment
 // of ones, so the accumulators START at the bias: no bias loads or adds in any epilogue, and every
@@ -63,6 +70,7 @@ struct DecP {
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
     // loss epilogue
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
+    int dz16;                      // dzT holds bf16 (the bf16 backward GEMMs read it as such)
 };
 
 __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
@@ -328,8 +336,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                             const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
                             const float a0 = 1.0f - pr + 1e-10f;
                             loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
-                            p.dzT[(size_t)(lc + e) * p.ldT + row] =
-                                0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                            const float dzv = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                            if (DT == DT_BF16 && p.dz16)
+                                reinterpret_cast<unsigned short*>(p.dzT)[(size_t)(lc + e) * p.ldT + row] =
+                                    (unsigned short)bf16_rne(dzv);
+                            else
+                                p.dzT[(size_t)(lc + e) * p.ldT + row] = dzv;
                         }
                     }
                 }
@@ -810,13 +822,6 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 // (zero outside the matrix)
 constexpr int PP_PAD = 4;          // LDS row stride Hp + 4 floats: rows stay 16-byte aligned
 
-__device__ __forceinline__ unsigned bf16_rne(float f)
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
-    return u >> 16;
-}
-
 template <int DT>
 __global__ __launch_bounds__(256) void prepack_tile_kernel(const float* __restrict__ W,
                                                            const float* __restrict__ b, int H, int Hp,
@@ -1289,7 +1294,7 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 }
 
 int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float inv_n_batch,
-                               float* dzT, int64_t ldT, float* loss_part, int dtype)
+                               float* dzT, int64_t ldT, float* loss_part, int dtype, int dz16)
 {
     DecP p;
     const dae_packed& pk = dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16;
@@ -1297,6 +1302,7 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part; p.inv_nb = inv_n_batch;
+    p.dz16 = (dtype == DAE_DTYPE_BF16 && dz16) ? 1 : 0;
     if (dtype == DAE_DTYPE_BF16) {
         // bf16 operands, fp32 accumulate (BASELINE.json configs[3]): the matrix time drops to ~1/16, the launch is
         // bound by its VALU epilogue and the dz^T store; two waves per SIMD overlap those with the MFMAs

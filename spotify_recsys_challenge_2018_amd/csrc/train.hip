@@ -55,7 +55,8 @@ __device__ __forceinline__ float bf16_value(float f)
     return __uint_as_float(u & 0xFFFF0000u);
 }
 // BF16: the forward GEMM ran on bf16 operands (dae_set_train_dtype): W and h are rounded the same way here
-template <bool BF16>
+// DZ16: dL/dz is kept as bf16 (the bf16 backward GEMMs read it as such)
+template <bool BF16, bool DZ16 = false>
 __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int B, int H,
@@ -109,8 +110,10 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
         const float l1 = __builtin_amdgcn_logf(a1), l0 = __builtin_amdgcn_logf(a0);
         // L(y) - L(0) = -ln2 * y * (log2 a1 - 0.55 log2 a0)
         corr -= 0.69314718f * y * (l1 - 0.55f * l0);
-        dzT[(size_t)lc * ldT + row] = -(y * __builtin_amdgcn_rcpf(a1) - 0.55f * (1.0f - y) * __builtin_amdgcn_rcpf(a0)) *
-                                      pr * (1.0f - pr) * inv_nb;
+        const float dzv = -(y * __builtin_amdgcn_rcpf(a1) - 0.55f * (1.0f - y) * __builtin_amdgcn_rcpf(a0)) *
+                          pr * (1.0f - pr) * inv_nb;
+        if (DZ16) reinterpret_cast<unsigned short*>(dzT)[(size_t)lc * ldT + row] = (unsigned short)(pk_bf16(dzv, 0.0f) & 0xFFFFu);
+        else dzT[(size_t)lc * ldT + row] = dzv;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) corr += __shfl_xor(corr, d);
@@ -137,7 +140,7 @@ struct GwP {
 // v_mfma_f32_32x32x16_bf16 per accumulator -- k-slot x of lane half hi is playlist R0 + 2x + hi in both
 // operands, which is exactly what the fp32 steps consume one at a time -- on operands rounded to bf16 in
 // registers; loads, LDS image, accumulators and stores are the fp32 kernel's.
-template <int NA, int NW = 4, bool BF16 = false>
+template <int NA, int NW = 4, bool BF16 = false, bool DZ16 = false>
 __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [Bp][32*NA] floats
@@ -263,6 +266,58 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
         }
         const int Bp4 = Bp;                          // dz^T rows are zero padded to a multiple of 64
         const unsigned himask = hi ? 0xFFFFFFFFu : 0u;
+        if (DZ16) {
+            // dz^T stored as bf16: 16 playlists of a row = two 16-byte loads; the dword x of a row holds playlists
+            // (R0 + 2x, R0 + 2x + 1) and the lane half hi wants R0 + 2x + hi: one v_perm per operand dword
+            const unsigned short* z0 = reinterpret_cast<const unsigned short*>(p.dzT) + (size_t)(ok0 ? vcol : 0) * p.ldT;
+            const unsigned short* z1 = reinterpret_cast<const unsigned short*>(p.dzT) + (size_t)(ok1 ? vcol + 1 : 0) * p.ldT;
+            const unsigned sel = hi ? 0x07060302u : 0x05040100u;
+#define GW_LOAD16(U0, U1, R0)                                                                  \
+            _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                 \
+                const int r8 = min((R0) + 8 * q_, Bp4 - 8);                                    \
+                U0[q_] = *reinterpret_cast<const uint4*>(z0 + r8);                             \
+                U1[q_] = *reinterpret_cast<const uint4*>(z1 + r8);                             \
+            }
+#define GW_HALF(D) __uint_as_float(hi ? ((D) & 0xFFFF0000u) : ((D) << 16))
+#define GW_MMA16(U0, U1, R0)                                                                   \
+            {                                                                                  \
+                float avs[8][NA];                                                              \
+                _Pragma("unroll") for (int x_ = 0; x_ < 8; ++x_) {                             \
+                    const float4 t4 = *reinterpret_cast<const float4*>(lds + (size_t)((R0) + 2 * x_ + hi) * HW + NA * j); \
+                    avs[x_][0] = t4.x; avs[x_][1 % NA] = t4.y; avs[x_][2 % NA] = t4.z; avs[x_][3 % NA] = t4.w; \
+                }                                                                              \
+                const unsigned d0[8] = {U0[0].x, U0[0].y, U0[0].z, U0[0].w, U0[1].x, U0[1].y, U0[1].z, U0[1].w}; \
+                const unsigned d1[8] = {U1[0].x, U1[0].y, U1[0].z, U1[0].w, U1[1].x, U1[1].y, U1[1].z, U1[1].w}; \
+                _Pragma("unroll") for (int x_ = 0; x_ < 8; ++x_) { cs0 += GW_HALF(d0[x_]); cs1 += GW_HALF(d1[x_]); } \
+                const bf16x8_t bx = __builtin_bit_cast(bf16x8_t, make_uint4(                   \
+                    __builtin_amdgcn_perm(d0[1], d0[0], sel), __builtin_amdgcn_perm(d0[3], d0[2], sel), \
+                    __builtin_amdgcn_perm(d0[5], d0[4], sel), __builtin_amdgcn_perm(d0[7], d0[6], sel))); \
+                const bf16x8_t by = __builtin_bit_cast(bf16x8_t, make_uint4(                   \
+                    __builtin_amdgcn_perm(d1[1], d1[0], sel), __builtin_amdgcn_perm(d1[3], d1[2], sel), \
+                    __builtin_amdgcn_perm(d1[5], d1[4], sel), __builtin_amdgcn_perm(d1[7], d1[6], sel))); \
+                _Pragma("unroll") for (int a = 0; a < NA; ++a) {                               \
+                    const bf16x8_t af = pk_bf16x8(avs[0][a], avs[1][a], avs[2][a], avs[3][a], avs[4][a], avs[5][a], \
+                                                  avs[6][a], avs[7][a]);                       \
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bx, acc[a][0], 0, 0, 0); \
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, by, acc[a][1], 0, 0, 0); \
+                }                                                                              \
+            }
+            uint4 ua0[2], ua1[2], ub0[2], ub1[2];
+            GW_LOAD16(ua0, ua1, 0)
+            for (int r0 = 0; r0 < Bp; r0 += 32) {
+                GW_LOAD16(ub0, ub1, r0 + 16)
+                __builtin_amdgcn_sched_barrier(0);
+                GW_MMA16(ua0, ua1, r0)
+                __builtin_amdgcn_sched_barrier(0);
+                GW_LOAD16(ua0, ua1, r0 + 32)
+                __builtin_amdgcn_sched_barrier(0);
+                GW_MMA16(ub0, ub1, r0 + 16)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef GW_LOAD16
+#undef GW_HALF
+#undef GW_MMA16
+        } else {
         float4 ta0[4], ta1[4], tb0[4], tb1[4];
         GW_LOAD(ta0, ta1, 0)
         for (int r0 = 0; r0 < Bp; r0 += 32) {        // straight-line 16 k-steps per iteration
@@ -274,6 +329,7 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
             __builtin_amdgcn_sched_barrier(0);
             GW_MMA(tb0, tb1, r0 + 16)
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 #undef GW_LOAD
 #undef GW_STEP
@@ -335,7 +391,8 @@ struct DhP {
 
 // BF16 (dae_set_train_dtype, NA = 4 only): the 8 k-steps of a block (16 vocabulary rows) become ONE
 // v_mfma_f32_32x32x16_bf16 per accumulator: k-slot x of lane half hi is row V0 + 2x + hi in both operands.
-template <int NA, bool BF16 = false>
+// DZ16: dz^T is stored as bf16; a lane's two playlists (r0 + 2j, r0 + 2j + 1) of a row are one dword.
+template <int NA, bool BF16 = false, bool DZ16 = false>
 __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
 {
     constexpr int HW = 32 * NA;
@@ -359,6 +416,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
         const float* Wl = p.W + hc0 + NA * j;
         const float* Dl = p.dzT + r0 + 2 * j;
+        const unsigned short* Dl16 = reinterpret_cast<const unsigned short*>(p.dzT) + r0 + 2 * j;
         // 16 vocabulary rows (8 k-steps, 64 MFMAs) per block, two register sets: the loads of block n+1 are
         // issued before the MFMAs of block n (one wave per SIMD: nothing else hides the ~2 us of HBM latency;
         // without the second set this kernel ran at 0.6 of its matrix time).  Rows past the chunk read row
@@ -378,19 +436,33 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             } else {                                                                           \
                 AV[s][0] = wr[0];                                                              \
             }                                                                                  \
-            D[s] = *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT);                  \
+            if (DZ16) D[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(Dl16 + (size_t)vc * p.ldT)); \
+            else D[s] = *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT);             \
         }
 // the "past the chunk -> 0" select sits HERE, not next to the load: a select on a loaded value in the load
 // stage makes the compiler wait for that load before the sched_barrier, i.e. before the MFMAs it should hide under
 #define DH_MMA(AV, D, V0)                                                                      \
         if (BF16) {                                                                            \
+            bf16x8_t bx, by;                                                                   \
+            if (DZ16) {                                                                        \
+                unsigned dd[8];                                                                \
+                _Pragma("unroll") for (int s = 0; s < 8; ++s)                                  \
+                    dd[s] = (V0) + 2 * s + hi < v_end ? __float_as_uint(D[s].x) : 0u;          \
+                bx = __builtin_bit_cast(bf16x8_t, make_uint4(                                  \
+                    __builtin_amdgcn_perm(dd[1], dd[0], 0x05040100u), __builtin_amdgcn_perm(dd[3], dd[2], 0x05040100u), \
+                    __builtin_amdgcn_perm(dd[5], dd[4], 0x05040100u), __builtin_amdgcn_perm(dd[7], dd[6], 0x05040100u))); \
+                by = __builtin_bit_cast(bf16x8_t, make_uint4(                                  \
+                    __builtin_amdgcn_perm(dd[1], dd[0], 0x07060302u), __builtin_amdgcn_perm(dd[3], dd[2], 0x07060302u), \
+                    __builtin_amdgcn_perm(dd[5], dd[4], 0x07060302u), __builtin_amdgcn_perm(dd[7], dd[6], 0x07060302u))); \
+            } else {                                                                           \
             float dx[8], dy[8];                                                                \
             _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
                 const bool in = (V0) + 2 * s + hi < v_end;                                     \
                 dx[s] = in ? D[s].x : 0.f; dy[s] = in ? D[s].y : 0.f;                          \
             }                                                                                  \
-            const bf16x8_t bx = pk_bf16x8(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], dx[6], dx[7]); \
-            const bf16x8_t by = pk_bf16x8(dy[0], dy[1], dy[2], dy[3], dy[4], dy[5], dy[6], dy[7]); \
+            bx = pk_bf16x8(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], dx[6], dx[7]);            \
+            by = pk_bf16x8(dy[0], dy[1], dy[2], dy[3], dy[4], dy[5], dy[6], dy[7]);            \
+            }                                                                                  \
             _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                   \
                 const bf16x8_t af = pk_bf16x8(AV[0][a], AV[1][a], AV[2][a], AV[3][a], AV[4][a], AV[5][a], \
                                               AV[6][a], AV[7][a]);                             \
@@ -820,7 +892,7 @@ namespace {
 // scratch carved for one training step over a [Vl, H] weight (shard) and B rows; stable for a given
 // (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
 struct TrainPlan {
-    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype;
+    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype, dz16;
     dae_rowgeom g;
     size_t bh, hp_bytes;
     float *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
@@ -836,6 +908,10 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     t.NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
     const int Hp = dae_round_up(H, DAE_HPAD);
     t.dtype = ctx->train_dtype;
+    {   // bf16 GEMMs with the 4-tile backward kernels: dL/dz itself is stored as bf16 (DAE_BWD_F32 / DAE_DZ_F32: A/B)
+        static const bool dz_f32 = getenv("DAE_BWD_F32") != nullptr || getenv("DAE_DZ_F32") != nullptr;
+        t.dz16 = (t.dtype == DAE_DTYPE_BF16 && (H % 128) == 0 && !dz_f32) ? 1 : 0;
+    }
     t.g = t.dtype == DAE_DTYPE_BF16 ? dae_row_geometry_bf16(B, Hp) : dae_row_geometry(B, Hp);
     t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
     t.Bpad64 = (B + 63) / 64 * 64;
@@ -874,10 +950,15 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     const int NA = t.NA;
     int rc;
     if (H > FIX_MAXH) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H <= %d (H=%d)", FIX_MAXH, H);
-    if (t.Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * sizeof(float), st));
-    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype);
+    if (t.Bpad64 != B)
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * (t.dz16 ? sizeof(unsigned short) : sizeof(float)), st));
+    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype, t.dz16);
     if (rc) return rc;
-    if (t.dtype == DAE_DTYPE_BF16)
+    if (t.dtype == DAE_DTYPE_BF16 && t.dz16)
+        hipLaunchKernelGGL((loss_fixup_kernel<true, true>), dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
+                           col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
+                           t.loss_part + t.g.grid);
+    else if (t.dtype == DAE_DTYPE_BF16)
         hipLaunchKernelGGL(loss_fixup_kernel<true>, dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
                            col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
                            t.loss_part + t.g.grid);
@@ -917,7 +998,14 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr16 = true;
             }
-            hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
+            static bool attr16z = false;
+            if (!attr16z) {
+                DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr16z = true;
+            }
+            if (t.dz16) hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true, true>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
         } else if (NA == 4 && k6w8) {
             static bool attr8 = false;
             if (!attr8) {
@@ -942,7 +1030,9 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         int blocks = (total + 3) / 4;
         if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
         static const bool bwd_f32_7 = getenv("DAE_BWD_F32") != nullptr;
-        if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7)
+        if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7 && t.dz16)
+            hipLaunchKernelGGL((grad_hidden_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, p);
+        else if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7)
             hipLaunchKernelGGL((grad_hidden_kernel<4, true>), dim3(blocks), dim3(256), 0, st, p);
         else if (NA == 4) hipLaunchKernelGGL(grad_hidden_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
         else if (NA == 2) hipLaunchKernelGGL(grad_hidden_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
