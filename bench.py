@@ -89,18 +89,26 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
     cost = torch.zeros(1, device="cuda")
     ctx.bind_stream()
 
+    fuse = [False]
+
     def step(i):
+        if fuse[0]:      # W_dec's Adam inside the decoder-gradient kernel (bit-identical parameters)
+            ctx.check(ctx.lib.dae_arm_decoder_adam(ctx.h, P(mom["Wd"][0]), P(mom["Wd"][1]), 0.005, 0.9, 0.999, 1e-8, i + 1))
         ctx.check(ctx.lib.dae_train_forward_backward(
             ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]),
             V, H, B, B, 0, 0.75, 0.8, 100 + i, 0.0, P(g["We"]), P(g["be"]), P(g["Wd"]), P(g["bd"]), P(cost)))
         for n in t:
+            if fuse[0] and n == "Wd":
+                continue
             ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(),
                                             0.005, 0.9, 0.999, 1e-8, i + 1))
     row = {"unit": "ms per step of %d playlists" % B, "what": "untied: forward (dropout) + loss + backward + dense "
            "TF1-Adam on W_enc, W_dec, b_enc, b_dec; fp32 parameters and moments", "steps": 20}
     k = 0
-    for name, dt in (("f32", _lib.DAE_DTYPE_F32), ("bf16_gemms", _lib.DAE_DTYPE_BF16)):
+    for name, dt, fz in (("f32", _lib.DAE_DTYPE_F32, False), ("bf16_gemms", _lib.DAE_DTYPE_BF16, False),
+                         ("bf16_gemms_decoder_adam_in_kernel", _lib.DAE_DTYPE_BF16, H % 128 == 0)):
         ctx.set_train_dtype(dt)
+        fuse[0] = fz
         for _ in range(3):
             step(k); k += 1
         torch.cuda.synchronize()
@@ -111,8 +119,9 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
         ms = (time.perf_counter() - t0) / 20 * 1e3
         row[name] = {"ms_per_step": round(ms, 3), "playlists_per_s": round(B / ms * 1e3, 1), "cost": round(float(cost.item()), 3)}
     ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
-    row["note"] = ("NOT the headline.  scripts/bench_epoch.py times the same step through the model (reader, device CSR, "
-                   "rows-Adam on the encoder)")
+    row["note"] = ("NOT the headline.  The model (models/DAEs.py) runs the last variant plus rows-Adam on the encoder "
+                   "(dae_adam_rows_*: no HBM passes over rows without gradient); scripts/bench_epoch.py times that loop "
+                   "with the reader and the device CSR builds")
     return row
 
 

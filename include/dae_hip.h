@@ -315,6 +315,14 @@ int dae_adam_rows_apply(dae_ctx* ctx, float* param, float* m, float* v, float* g
 int dae_adam_rows_flush(dae_ctx* ctx, float* param, float* m, float* v, int32_t* state, const float* lr_tab,
                         int tab_cap, int n_rows, int row_len, float beta1, float beta2, float eps, int t);
 
+/* Arms the NEXT dae_train_forward_backward of this context (untied model, reg_lambda = 0, H % 128 == 0) to apply the
+ * dense Adam update of W_dec INSIDE the decoder-gradient kernel: each gradient tile is consumed in registers, W_dec
+ * (which the call then writes through its const pointer), m and v are updated in place and gW_dec is not written
+ * (it may be NULL).  The per-element operations are dae_adam_step's, so the parameters are bit-identical to writing
+ * the gradient and calling dae_adam_step(W_dec, m, v, gW_dec, V*H, lr, ..., t); what disappears is one pass over the
+ * gradient in each direction (1.2 GB -> 1.0 GB for Adam + the gradient at V = 170 000, H = 256).  m = NULL disarms. */
+int dae_arm_decoder_adam(dae_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, int t);
+
 /* on != 0: the untied gW_enc buffer handed to dae_train_forward_backward is all-zero on entry (kept so by
  * dae_adam_rows_apply), so the step does not clear its 4*V*H bytes.  Sticky. */
 int dae_set_enc_grad_prezeroed(dae_ctx* ctx, int on);

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--bf16", action="store_true", help="train_dtype = bf16 (the three GEMMs on bf16 operands)")
     ap.add_argument("--encoder-adam", choices=["rows", "dense"], default="rows",
                     help="untied encoder: dae_adam_rows_* (default) or the dense dae_adam_step")
+    ap.add_argument("--decoder-adam", choices=["fused", "dense"], default="fused",
+                    help="untied decoder: Adam inside the decoder-gradient kernel (default) or dae_adam_step")
     ap.add_argument("--host-csr", action="store_true", help="device_csr = False: feed -> CSR with numpy on the host")
     ap.add_argument("--flush-every", type=int, default=32, help="rows-Adam: all rows brought up to date every N steps")
     args = ap.parse_args()
@@ -55,6 +57,7 @@ def main():
     conf.initval, conf.save, conf.kp = "NULL", os.path.join(tmp, "w"), 0.8
     conf.device_index = 0
     conf.encoder_adam = args.encoder_adam
+    conf.decoder_adam = args.decoder_adam
     conf.device_csr = not args.host_csr
     conf.rows_adam_flush_every = args.flush_every
     if args.bf16:

@@ -524,7 +524,8 @@ int dae_train_forward_backward(dae_ctx* ctx,
     if (!ctx) return DAE_ERR_ARG;
     if (!x_row_ptr || !y_row_ptr || !W_enc || !b_enc || !b_dec || !gW_enc || !gb_enc || !gb_dec || !cost_out)
         return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
-    if (!tied && (!W_dec || !gW_dec)) return dae_fail(ctx, DAE_ERR_ARG, "untied model needs W_dec and gW_dec");
+    if (!tied && (!W_dec || (!gW_dec && !ctx->arm_m)))
+        return dae_fail(ctx, DAE_ERR_ARG, "untied model needs W_dec and gW_dec (or the armed decoder Adam)");
     if (V <= 0 || H <= 0 || B <= 0 || n_batch <= 0) return dae_fail(ctx, DAE_ERR_ARG, "bad shape");
     if (!(ikp > 0.f && ikp <= 1.f) || !(kp > 0.f && kp <= 1.f))
         return dae_fail(ctx, DAE_ERR_ARG, "keep probabilities must be in (0,1]");
@@ -683,6 +684,18 @@ int dae_adam_step(dae_ctx* ctx, float* param, float* m, float* v, const float* g
         return dae_fail(ctx, DAE_ERR_ARG, "param, m, v, grad must be 16-byte aligned");
     const float alpha = adam_alpha(ctx, lr, beta1, beta2, t);
     return dae_launch_adam(ctx, param, m, v, grad, n, alpha, beta1, beta2, eps);
+}
+
+int dae_arm_decoder_adam(dae_ctx* ctx, float* m, float* v, float lr, float beta1, float beta2, float eps, int t)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!m || !v) { ctx->arm_m = nullptr; ctx->arm_v = nullptr; return DAE_OK; }          // disarm
+    if (t < 1) return dae_fail(ctx, DAE_ERR_ARG, "t is the 1-based step count");
+    if ((reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) % 16)
+        return dae_fail(ctx, DAE_ERR_ARG, "m, v must be 16-byte aligned");
+    ctx->arm_m = m; ctx->arm_v = v; ctx->arm_alpha = adam_alpha(ctx, lr, beta1, beta2, t);
+    ctx->arm_b1 = beta1; ctx->arm_b2 = beta2; ctx->arm_eps = eps;
+    return DAE_OK;
 }
 
 int dae_set_enc_grad_prezeroed(dae_ctx* ctx, int on)

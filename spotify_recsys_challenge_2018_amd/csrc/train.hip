@@ -133,6 +133,8 @@ struct GwP {
     int accumulate;                   // gW += instead of =
     int dbg;                          // experiments: 1 = no stores, 2 = no dz^T loads
     int n_half, nb_half;              // H / 128 hidden halves, blocks per half
+    // dense TF1-Adam of the [V, H] tensor `ad_p` applied in the epilogue instead of writing gW (dae_arm_decoder_adam)
+    float* ad_p; float* ad_m; float* ad_v; float ad_alpha, ad_b1, ad_b2, ad_eps;
 };
 
 // NA = hidden tiles per wave (4, 2 or 1): a "half" is 32*NA hidden units, hidden = hc0 + NA*i + a
@@ -346,6 +348,47 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
             if (keep == 12345.678f) p.gW[0] = keep;
             continue;
         }
+        if (NA == 4 && p.ad_m) {
+            // the gradient tile goes straight into the Adam update of its parameters: W / m / v are read and written
+            // in place, gW never reaches memory (7 passes over the tensor + 1 of the gradient become 6).  Same
+            // per-element operations as adam_kernel, so the parameters are the bits dae_adam_step would produce.
+            const float b1 = p.ad_b1, b2 = p.ad_b2, eps = p.ad_eps, al = p.ad_alpha;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int v = vcol + b;
+                if (v >= p.V) continue;
+                const size_t rbase = (size_t)v * p.H + hc0;
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    float4 pp[4], mm[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int reg = r4 + u;
+                        const size_t o = rbase + 4 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi);
+                        pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o);
+                        mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o);
+                        vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int reg = r4 + u;
+                        const size_t o = rbase + 4 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi);
+                        const float g0 = acc[0][b][reg], g1 = acc[1 % NA][b][reg], g2 = acc[2 % NA][b][reg],
+                                    g3 = acc[3 % NA][b][reg];
+#define K6_ADAM(P, M, V, G)                                              \
+                        M = M + (G - M) * (1.0f - b1);                   \
+                        V = V + (G * G - V) * (1.0f - b2);               \
+                        P = P - (M * al) / (sqrtf(V) + eps);
+                        K6_ADAM(pp[u].x, mm[u].x, vv[u].x, g0) K6_ADAM(pp[u].y, mm[u].y, vv[u].y, g1)
+                        K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
+#undef K6_ADAM
+                        *reinterpret_cast<float4*>(p.ad_p + o) = pp[u];
+                        *reinterpret_cast<float4*>(p.ad_m + o) = mm[u];
+                        *reinterpret_cast<float4*>(p.ad_v + o) = vv[u];
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int v = vcol + b;
@@ -969,8 +1012,13 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     DAE_CHECK_LAUNCH(ctx, "loss_fixup_kernel");
 
     // ---- K6: decoder gradient ------------------------------------------------------------------------
-    {
+    auto run_k6 = [&]() -> int {
         GwP p;
+        p.ad_p = nullptr; p.ad_m = nullptr; p.ad_v = nullptr; p.ad_alpha = p.ad_b1 = p.ad_b2 = p.ad_eps = 0.0f;
+        if (ctx->arm_m) {           // dae_arm_decoder_adam: update Wd in place instead of writing gWd
+            p.ad_p = const_cast<float*>(Wd); p.ad_m = ctx->arm_m; p.ad_v = ctx->arm_v; p.ad_alpha = ctx->arm_alpha;
+            p.ad_b1 = ctx->arm_b1; p.ad_b2 = ctx->arm_b2; p.ad_eps = ctx->arm_eps;
+        }
         p.dzT = t.dzT; p.ldT = t.Bpad64; p.h = t.hbuf; p.H = H; p.B = B; p.V = Vl; p.gW = gWd; p.gb = gb_dec;
         p.accumulate = 0;
         static const int k6dbg = getenv("DAE_DBG_K6") ? atoi(getenv("DAE_DBG_K6")) : 0;
@@ -1018,10 +1066,11 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         else if (NA == 2) hipLaunchKernelGGL(grad_wdec_kernel<2>, grid, blk, lds, st, p);
         else hipLaunchKernelGGL(grad_wdec_kernel<1>, grid, blk, lds, st, p);
         DAE_CHECK_LAUNCH(ctx, "grad_wdec_kernel");
-    }
+        return DAE_OK;
+    };
 
     // ---- K7: dh, split over V ------------------------------------------------------------------------
-    {
+    auto run_k7 = [&]() -> int {
         DhP p;
         p.dzT = t.dzT; p.ldT = t.Bpad64; p.W = Wd; p.H = H; p.V = Vl; p.part = t.part;
         p.n_chunk = t.n_chunk; p.chunk = t.chunk; p.Bpad64 = t.Bpad64; p.n_half = H / (32 * NA);
@@ -1038,8 +1087,19 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         else if (NA == 2) hipLaunchKernelGGL(grad_hidden_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(grad_hidden_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
         DAE_CHECK_LAUNCH(ctx, "grad_hidden_kernel");
+        return DAE_OK;
+    };
+    // K6 and K7 are independent (both read dz^T).  With the armed Adam K6 rewrites Wd in place, and K7 multiplies by
+    // the weights the forward pass used: K7 first.
+    if (ctx->arm_m) {
+        if (NA != 4) { ctx->arm_m = nullptr; return dae_fail(ctx, DAE_ERR_ARG, "the armed decoder Adam needs H %% 128 == 0 (H=%d)", H); }
+        rc = run_k7(); if (rc) return rc;
+        rc = run_k6();
+        ctx->arm_m = nullptr; ctx->arm_v = nullptr;         // one step only
+        return rc;
     }
-    return DAE_OK;
+    rc = run_k6(); if (rc) return rc;
+    return run_k7();
 }
 
 // cost = sum of the loss partials + lambda * (l2 of the listed tensors)
@@ -1109,6 +1169,7 @@ int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* 
     if ((H % 32) != 0 || B < 1 || B > 256) return dae_fail(ctx, DAE_ERR_ARG, "grad_w: H=%d B=%d unsupported", H, B);
     const int NA = (H % 128) == 0 ? 4 : ((H % 64) == 0 ? 2 : 1);
     GwP p;
+    p.ad_p = nullptr; p.ad_m = nullptr; p.ad_v = nullptr; p.ad_alpha = p.ad_b1 = p.ad_b2 = p.ad_eps = 0.0f;
     p.dzT = dzT; p.ldT = ldT; p.h = h; p.H = H; p.B = B; p.V = V; p.gW = gW; p.gb = gb;
     p.accumulate = 0; p.dbg = 0;
     p.n_half = H / (32 * NA);
@@ -1176,6 +1237,10 @@ int dae_train_step_f32(dae_ctx* ctx,
     TrainPlan t;
     int rc = train_plan(ctx, V, H, B, t);
     if (rc) return rc;
+    if (ctx->arm_m && (tied || reg_lambda != 0.0f)) {
+        ctx->arm_m = nullptr; ctx->arm_v = nullptr;
+        return dae_fail(ctx, DAE_ERR_ARG, "the armed decoder Adam needs the untied model and reg_lambda = 0");
+    }
     const float* Wd = tied ? W_enc : W_dec;
     // decoder weights change every step: re-tile them for the forward GEMM
     rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec, V, H, 0, V)

@@ -145,6 +145,7 @@ class DAE_tied:
         # dae_adam_rows_* (bit-identical parameters, no HBM passes over the rows without gradient); "dense" keeps
         # dae_adam_step on the whole matrix
         self.encoder_adam = str(getattr(conf, "encoder_adam", "rows"))
+        self.decoder_adam = str(getattr(conf, "decoder_adam", "fused"))        # "fused" (dae_arm_decoder_adam) | "dense"
         # ... and every `rows_adam_flush_every` steps all rows are brought up to date, which bounds how many missed
         # steps a rarely seen row has to replay when it is next named (a replay is sequential per element)
         self.rows_adam_flush_every = int(getattr(conf, "rows_adam_flush_every", 32))
@@ -389,6 +390,14 @@ class DAE_tied:
             ctx.check(lib.dae_adam_rows_begin(ctx.h, P(self.weights["encoder_h"]), P(m_e), P(v_e), P(lz["state"]),
                                               P(lz["tab"]), lz["tab"].numel(), self.n_input, self.n_hidden,
                                               rows_arg[0], rows_arg[1], rows_arg[2], 0.9, 0.999, 1e-8, self._step + 1))
+        # untied, reg_lambda == 0, hidden a multiple of 128: the dense Adam update of W_dec is applied inside the
+        # decoder-gradient kernel (bit-identical parameters; the gradient never reaches memory)
+        fuse_dec = (not self.tied and self.reg_lambda == 0.0 and self.n_hidden % 128 == 0
+                    and self.decoder_adam == "fused")
+        if fuse_dec:
+            m_d, v_d = self._adam["decoder_h"]
+            ctx.check(lib.dae_arm_decoder_adam(ctx.h, P(m_d), P(v_d), self.learning_rate, 0.9, 0.999, 1e-8,
+                                               self._step + 1))
         ctx.check(lib.dae_train_forward_backward(
             ctx.h, P(xr), P(xc), P(xv), P(yr), P(yc), P(yv),
             P(self.weights["encoder_h"]), P(self.biases["encoder_b"]),
@@ -401,6 +410,8 @@ class DAE_tied:
         for n, grad in g.items():
             p = self.weights[n] if n in self.weights else self.biases[n]
             m, v = self._adam[n]
+            if fuse_dec and n == "decoder_h":
+                continue
             if lz is not None and n == "encoder_h":
                 ctx.check(lib.dae_adam_rows_apply(ctx.h, P(p), P(m), P(v), P(grad), P(lz["state"]), P(lz["tab"]),
                                                   lz["tab"].numel(), self.n_input, self.n_hidden, rows_arg[0],

@@ -287,3 +287,56 @@ def test_model_rows_adam_follows_dense_adam():
     assert np.allclose(ca, cb, rtol=2e-4)
     for pa, pb in zip(a.get_params(), b.get_params()):
         assert np.allclose(pa, pb, rtol=1e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_armed_decoder_adam_is_bit_identical(bf16):
+    """dae_arm_decoder_adam: the step applies the dense Adam update of W_dec inside the decoder-gradient kernel.
+    Same inputs, same draws: W_dec / m / v must be the bits of `write gW_dec, then dae_adam_step`, and every other
+    output of the step (cost, gW_enc, gb_enc, gb_dec) must be unchanged -- K7 still multiplies by the old W_dec."""
+    import torch
+    V, nt, H, B = 3000, 2400, 128, 100
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt)
+    pos, ones, _ = make_playlists(B, nt, V - nt, seed=6, seed_counts=(3, 9, 20))
+    xr, xc, xv = coo_to_csr(pos[pos[:, 1] < nt], ones[pos[:, 1] < nt], B, V)
+    yr, yc, yv = coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)
+    csr = [_dev(a) for a in (xr, xc, xv, yr, yc, yv)]
+    ctx = _lib.Context(0)
+    if bf16:
+        ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    P = _lib._ptr
+    rng = np.random.default_rng(1)
+    m0 = (rng.standard_normal((V, H)) * 1e-3).astype(np.float32)
+    v0 = (rng.random((V, H)) * 1e-6).astype(np.float32)
+    lr, t_step = 0.005, 7
+
+    def run(armed):
+        d = dict(We=_dev(W_enc), be=_dev(b_enc), Wd=_dev(W_dec), bd=_dev(b_dec))
+        m, v = _dev(m0), _dev(v0)
+        out = dict(gWe=torch.zeros((V, H), device="cuda"), gbe=torch.zeros(H, device="cuda"),
+                   gWd=torch.zeros((V, H), device="cuda"), gbd=torch.zeros(V, device="cuda"),
+                   cost=torch.zeros(1, device="cuda"))
+        if armed:
+            ctx.check(ctx.lib.dae_arm_decoder_adam(ctx.h, P(m), P(v), lr, 0.9, 0.999, 1e-8, t_step))
+        ctx.check(ctx.lib.dae_train_forward_backward(
+            ctx.h, P(csr[0]), P(csr[1]), P(csr[2]), P(csr[3]), P(csr[4]), P(csr[5]),
+            P(d["We"]), P(d["be"]), P(d["Wd"]), P(d["bd"]), V, H, B, B, 0, 0.75, 0.8, 99, 0.0,
+            P(out["gWe"]), P(out["gbe"]), None if armed else P(out["gWd"]), P(out["gbd"]), P(out["cost"])))
+        if not armed:
+            ctx.check(ctx.lib.dae_adam_step(ctx.h, P(d["Wd"]), P(m), P(v), P(out["gWd"]), V * H, lr, 0.9, 0.999, 1e-8, t_step))
+        torch.cuda.synchronize()
+        return d["Wd"], m, v, out
+
+    Wa, ma, va, oa = run(True)
+    Wb, mb, vb, ob = run(False)
+    assert torch.equal(Wa, Wb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(Wa, _dev(W_dec))
+    assert torch.equal(oa["cost"], ob["cost"]) and torch.equal(oa["gbe"], ob["gbe"]) and torch.equal(oa["gbd"], ob["gbd"])
+    assert np.allclose(oa["gWe"].cpu().numpy(), ob["gWe"].cpu().numpy(), rtol=2e-4, atol=2e-7)   # float atomics
+    # one step only: the next call needs gW_dec again
+    with pytest.raises(_lib.DaeError):
+        ctx.check(ctx.lib.dae_train_forward_backward(
+            ctx.h, P(csr[0]), P(csr[1]), P(csr[2]), P(csr[3]), P(csr[4]), P(csr[5]),
+            P(Wa), P(_dev(b_enc)), P(Wa), P(_dev(b_dec)), V, H, B, B, 0, 0.75, 0.8, 99, 0.0,
+            P(oa["gWe"]), P(oa["gbe"]), None, P(oa["gbd"]), P(oa["cost"])))
+    ctx.close()
