@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/dae_hip.h"
@@ -46,6 +47,9 @@ struct dae_packed {            // one prepacked decoder image
 
 struct dae_ctx {
     int device = 0;
+    // per-context (= per-device) one-time setup done so far, e.g. hipFuncSetAttribute of a kernel: a process-wide
+    // `static bool` would skip it for the second device of a multi-device process
+    std::unordered_set<const void*> first_use_done;
     hipStream_t stream = nullptr;
     std::string err;
     size_t scratch_total = 0;
@@ -237,6 +241,8 @@ int dae_train_shard_finish_f32(dae_ctx* ctx, const float* dh, const int32_t* x_r
 int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* h, int H, int B, int V,
                       float* gW, float* gb);
 int dae_launch_grad_h(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* W, int H, int V, int B, float* dh);
+inline bool dae_first_use(dae_ctx* ctx, const void* key) { return ctx->first_use_done.insert(key).second; }
+
 int dae_launch_adam_rows(dae_ctx* ctx, int mode, float* param, float* m, float* v, float* grad, int32_t* last,
                          int32_t* mark, float* lr_tab, int n_rows, int row_len, const int32_t* rows,
                          const int32_t* n_listed_dev, int n_listed_max, float lr_t, float beta1, float beta2,

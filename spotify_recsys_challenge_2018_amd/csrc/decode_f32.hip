@@ -1009,12 +1009,11 @@ template <int RB, int EPI, int GT, int NW, int DT>
 int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
     const size_t lds = (size_t)RB * 64 * p.G * sizeof(float4) + (size_t)RB * 32 * sizeof(int);
-    static bool attr_set = false;     // per template instantiation
-    if (!attr_set) {
+    static const char attr_set_key = 0;     // per template instantiation
+    if (dae_first_use(ctx, &attr_set_key)) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(
                                reinterpret_cast<const void*>(&decode_f32_kernel<RB, EPI, GT, NW, DT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     if (ctx->prof_armed) {
         hipExtLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
@@ -1160,11 +1159,10 @@ int launch_prepack_tiles(dae_ctx* ctx, const float* W, const float* b, int H, in
 {
     if (ntiles <= 0) return DAE_OK;
     const size_t lds = (size_t)32 * (Hp + PP_PAD) * sizeof(float);
-    static bool attr_set = false;     // per instantiation
-    if (!attr_set) {
+    static const char attr_set_key = 0;     // per instantiation
+    if (dae_first_use(ctx, &attr_set_key)) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&prepack_tile_kernel<DT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
     hipLaunchKernelGGL(prepack_tile_kernel<DT>, dim3(blocks), dim3(256), lds, ctx->stream, W, b, H, Hp, col_lo, col_hi,
@@ -1328,11 +1326,10 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     static const bool f32_generic = getenv("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body
     if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && g.waves == 4 && !f32_generic) {
         const size_t lds = (size_t)4 * 64 * 32 * sizeof(float4) + 128 * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static const char attr_set_key = 0;
+        if (dae_first_use(ctx, &attr_set_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_f32_h256_filter_kernel<0>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->prof_armed) {
@@ -1346,15 +1343,14 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     }
     if (bf16_fast_filter(g, dtype, p.G)) {
         const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static const char attr_set_key = 0;
+        if (dae_first_use(ctx, &attr_set_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 4, 8, 8>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<2, 4, 16, 4>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 8, 16, 4>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ctx->prof_armed) {

@@ -802,8 +802,8 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
         key_cap = (int)(want / 8);
         dyn = bm_bytes + (size_t)sort_n * 8 + want;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const char attr_set_key = 0;
+    if (dae_first_use(ctx, &attr_set_key)) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<Src, 1024>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)(lds_total - lds_static)));
@@ -811,7 +811,6 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)(lds_total - lds_static)));
 
-        attr_set = true;
     }
     // debug: DAE_TOPK_STOP=n stops the phase-A (tau-producing) kernel after stage n,
     // DAE_TOPK_STOP=-n the other launches (bisecting stage costs under rocprofv3)

@@ -1079,11 +1079,10 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
         p.nb_half = nb;
         const size_t lds = (size_t)((B + 31) & ~31) * 32 * NA * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
+        static const char attr_key = 0;
+        if (dae_first_use(ctx, &attr_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
         }
         const dim3 grid(p.n_half * nb), blk(256);
         // two waves per SIMD on the shared h image: 241 us against 257 us with one (V = 170 000, B = H = 256); the
@@ -1091,26 +1090,23 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         static const bool k6w8 = !(getenv("DAE_K6_WAVES") && atoi(getenv("DAE_K6_WAVES")) == 4);
         static const bool bwd_f32 = getenv("DAE_BWD_F32") != nullptr;      // A/B: bf16 forward only
         if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32) {
-            static bool attr16 = false;
-            if (!attr16) {
+            static const char attr16_key = 0;
+            if (dae_first_use(ctx, &attr16_key)) {
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr16 = true;
             }
-            static bool attr16z = false;
-            if (!attr16z) {
+            static const char attr16z_key = 0;
+            if (dae_first_use(ctx, &attr16z_key)) {
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr16z = true;
             }
             if (t.dz16) hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true, true>), grid, dim3(512), lds, st, p);
             else hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
         } else if (NA == 4 && k6w8) {
-            static bool attr8 = false;
-            if (!attr8) {
+            static const char attr8_key = 0;
+            if (dae_first_use(ctx, &attr8_key)) {
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr8 = true;
             }
             hipLaunchKernelGGL((grad_wdec_kernel<4, 8>), grid, dim3(512), lds, st, p);
         } else if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, st, p);
@@ -1228,11 +1224,10 @@ int dae_launch_grad_w(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* 
     if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
     p.nb_half = nb;
     const size_t lds = (size_t)((B + 31) & ~31) * 32 * NA * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static const char attr_key = 0;
+    if (dae_first_use(ctx, &attr_key)) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
     }
     const dim3 grid(p.n_half * nb), blk(256);
     if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, ctx->stream, p);
