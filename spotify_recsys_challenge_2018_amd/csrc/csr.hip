@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void csr_compact_sum_kernel(const int* __restr
                                                               const int* __restrict__ k_col,
                                                               const float* __restrict__ k_val,
                                                               int32_t* __restrict__ row_ptr,
-                                                              int32_t* __restrict__ col, float* __restrict__ val)
+                                                              int32_t* __restrict__ col, float* __restrict__ val,
+                                                              const int* __restrict__ sflag,
+                                                              int32_t* __restrict__ status)
 {
     __shared__ int ws[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void csr_compact_sum_kernel(const int* __restr
     if (tid == 0) {
         row_ptr[row] = o;
         if (row == n_rows - 1) row_ptr[n_rows] = o + m;
+        if (row == 0) *status = *sflag;              // the caller's flag, written once
     }
     for (int s2 = tid; s2 < m; s2 += 256) { col[o + s2] = k_col[b + s2]; val[o + s2] = k_val[b + s2]; }
 }
@@ -304,11 +307,12 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     int rc;
     // scratch: cnt | cursor | bptr | kcnt  (n_rows + 1 each), then t_col | t_feed | t_val | k_col | k_val
     const size_t nr = (size_t)n_rows + 1;
-    const size_t ints = 4 * nr + 5 * (size_t)(nnz > 0 ? nnz : 1);
+    const size_t ints = 4 * nr + 4 + 5 * (size_t)(nnz > 0 ? nnz : 1);
     if ((rc = dae_reserve(ctx, ctx->csr_tmp, ints * sizeof(int)))) return rc;
     int* cnt = static_cast<int*>(ctx->csr_tmp.p);
     int* cursor = cnt + nr;
-    int* bptr = cursor + nr;
+    int* sflag = cursor + nr;                      // range flag of this build, cleared with cnt | cursor in ONE fill
+    int* bptr = sflag + 4;
     int* kcnt = bptr + nr;
     int* t_col = kcnt + nr;
     int* t_feed = t_col + nnz;
@@ -318,13 +322,12 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     static const bool no_small = getenv("DAE_CSR_GENERIC") != nullptr;            // A/B against the 6-launch path
     if (n_rows <= CSR_SMALL_ROWS && !no_small) {
         // cnt | cursor are adjacent, the caller's status word is cleared with them by one small kernel-free memset each
-        DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, 2 * nr * sizeof(int), st));
-        DAE_HIP_CHECK(ctx, hipMemsetAsync(status, 0, sizeof(int32_t), st));
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, (2 * nr + 4) * sizeof(int), st));
         const int blocks = (int)((nnz + 1023) / 1024) > 0 ? (int)((nnz + 1023) / 1024) : 1;
         const size_t lds = (size_t)n_rows * sizeof(int);
         if (nnz > 0) {
             hipLaunchKernelGGL(csr_count_lds_kernel, dim3(blocks), dim3(1024), lds, st, positions, nnz, n_rows, n_cols,
-                               cnt, status);
+                               cnt, sflag);
             DAE_CHECK_LAUNCH(ctx, "csr_count_lds_kernel");
         }
         hipLaunchKernelGGL(csr_scatter_lds_kernel, dim3(blocks), dim3(1024), 2 * lds, st, positions, values,
@@ -334,7 +337,7 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
                            kcnt);
         DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
         hipLaunchKernelGGL(csr_compact_sum_kernel, dim3(n_rows), dim3(256), 0, st, bptr, kcnt, n_rows, k_col, k_val,
-                           row_ptr, col, val);
+                           row_ptr, col, val, sflag, status);
         DAE_CHECK_LAUNCH(ctx, "csr_compact_sum_kernel");
         return DAE_OK;
     }

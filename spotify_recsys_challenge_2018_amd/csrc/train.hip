@@ -1294,8 +1294,16 @@ int dae_train_step_f32(dae_ctx* ctx,
     if (rc) return rc;
 
     // ---- forward ----------------------------------------------------------------------------------
-    if (t.dtype == DAE_DTYPE_F32) DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
-    ctx->h_geom_key = -1;
+    // the pad rows / pad k of the fp32 image are never written by the encode kernel: zeroed once per geometry and
+    // buffer (same key as the scoring path: the two share the image)
+    if (t.dtype == DAE_DTYPE_F32) {
+        const long long key = ((long long)B << 32) | ((long long)H << 12) | (long long)t.g.R_TILE;
+        if (ctx->h_geom_key != key || ctx->h_geom_ptr != ctx->h_packed.p) {
+            DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
+            ctx->h_geom_key = key;
+            ctx->h_geom_ptr = ctx->h_packed.p;
+        }
+    }
     if (t.dtype == DAE_DTYPE_BF16) {
         rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
                                nullptr, 0, 0, t.sg, nullptr);
