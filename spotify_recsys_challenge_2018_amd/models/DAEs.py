@@ -149,6 +149,7 @@ class DAE_tied:
         # ... and every `rows_adam_flush_every` steps all rows are brought up to date, which bounds how many missed
         # steps a rarely seen row has to replay when it is next named (a replay is sequential per element)
         self.rows_adam_flush_every = int(getattr(conf, "rows_adam_flush_every", 32))
+        self.rows_adam_table = int(getattr(conf, "rows_adam_table", 1 << 16))      # alpha per step; doubles when full
         self._lazy = None
         self._rng = np.random.RandomState(int(getattr(conf, "dropout_seed", 1234)))
         self.device_csr = bool(getattr(conf, "device_csr", True))
@@ -378,7 +379,8 @@ class DAE_tied:
         if not self.tied and self.reg_lambda == 0.0 and self.encoder_adam == "rows":
             if self._lazy is None:
                 self._lazy = {"state": torch.zeros(2 * self.n_input, dtype=torch.int32, device=dev),
-                              "tab": torch.zeros(1 << 16, dtype=torch.float32, device=dev), "flushed": self._step}
+                              "tab": torch.zeros(max(8, int(self.rows_adam_table)), dtype=torch.float32, device=dev),
+                              "flushed": self._step}
                 ctx.check(lib.dae_set_enc_grad_prezeroed(ctx.h, 1))
             lz = self._lazy
             if self._step + 2 >= lz["tab"].numel():                       # alpha of every step so far
