@@ -201,12 +201,30 @@ class DAE_tied:
         self.hidden = _Fetch("hidden")
 
     # -- helpers ------------------------------------------------------------------------------------
-    def _to_dev(self, a, dtype):
+    def _to_dev(self, a, dtype, side_stream=False):
+        """Host array -> device tensor.  side_stream (the training loop): uploaded on a COPY stream.  A copy from pageable memory is stream-ordered
+        and blocks the host until it has happened; on the compute stream that means "until everything queued before
+        it has run", so the training loop could never get ahead of the GPU (0.25 ms per feed measured).  On its own
+        stream the copy waits for earlier copies only; the compute stream waits for its event.  (Pinned staging is
+        not an option here: torch's pinned host memory is uncached for CPU writes on this platform -- 3 ms to fill
+        400 KB.)"""
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(torch.device("cuda", self.device_index), dtype=dtype, non_blocking=False)
+        src = torch.from_numpy(np.ascontiguousarray(a))
+        dev = torch.device("cuda", self.device_index)
+        if not side_stream:                  # calls that fetch their result anyway (recommend, predict, ...)
+            return src.to(dev, dtype=dtype, non_blocking=False)
+        cs = self.__dict__.get("_copy_stream")
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(self.device_index)
+        with torch.cuda.stream(cs):
+            t = src.to(dev, dtype=dtype, non_blocking=False)
+            ev = cs.record_event()
+        cur.wait_event(ev)
+        t.record_stream(cur)
+        return t
 
-    def _upload_csr(self, positions, values):
+    def _upload_csr(self, positions, values, side_stream=False):
         """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
         and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
         restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
@@ -218,8 +236,8 @@ class DAE_tied:
                 raise ValueError("positions (%d) and values (%d) differ in length" % (pos.shape[0], vals.size))
             if pos.shape[0] == 0:
                 pos = np.zeros((0, 2), np.int64)
-            d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64)[:pos.shape[0]]
-            d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32)
+            d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
+            d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
             rp, c, v, status = self.ctx.coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
             pending = (self._csr_status or []) + [status]      # checked lazily (no sync on the scoring path)
             if len(pending) > 64:                               # un-fetched training steps: fold on the device
@@ -369,8 +387,8 @@ class DAE_tied:
                 self._grads[n] = torch.zeros_like(p)
                 self._adam[n] = (torch.zeros_like(p), torch.zeros_like(p))
             self._cost = torch.zeros(1, dtype=torch.float32, device=dev)
-        xr, xc, xv = self._upload_csr(x_positions, x_ones)
-        yr, yc, yv = self._upload_csr(y_positions, y_ones)
+        xr, xc, xv = self._upload_csr(x_positions, x_ones, side_stream=True)
+        yr, yc, yv = self._upload_csr(y_positions, y_ones, side_stream=True)
         seed = int(self._rng.randint(0, 2 ** 31 - 1))
         g = self._grads
         lib, ctx = self.ctx.lib, self.ctx
