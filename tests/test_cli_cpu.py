@@ -76,3 +76,19 @@ def test_merge_results_writes_what_pandas_would(tmp_path):
     want = tmp_path / "want.csv"
     pd.DataFrame([mr.TEAM_ROW] + a + b).to_csv(want, index=False, header=False)
     assert out.read_bytes() == want.read_bytes()
+
+
+def test_optional_dtype_keys_of_this_build(tmp_path):
+    """[BASE] train_dtype / decode_dtype are extensions: absent (the reference's files) -> attributes unset -> fp32."""
+    import configparser
+    c = _conf(tmp_path)
+    assert not hasattr(c, "train_dtype") and not hasattr(c, "decode_dtype")
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config.ini"))
+    ini["BASE"]["train_dtype"] = " BF16 "
+    ini["BASE"]["decode_dtype"] = "f32"
+    c2 = cli.Conf(str(tmp_path), ini)
+    assert c2.train_dtype == "bf16" and c2.decode_dtype == "f32"
+    ini["BASE"]["train_dtype"] = "fp8"
+    with pytest.raises(ValueError):
+        cli.Conf(str(tmp_path), ini)
