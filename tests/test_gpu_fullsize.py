@@ -134,3 +134,58 @@ def test_full_size_row_permutation_and_bf16(model):
     hit = np.mean([len(set(ia32[r, :100].tolist()) & set(ia16[r].tolist())) / 100.0 for r in range(B)])
     assert hit >= 0.99
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_step_at_full_size_agrees_with_the_scoring_kernels(model, dtype):
+    """BASELINE.json configs[3] shape (V = 170 000, H = 256, B = 256), where the float64 restatement needs minutes.
+    With both keep-probabilities 1 the training forward IS the scoring forward, so two independent kernel paths must
+    agree: the cost and gb_dec of dae_train_forward_backward (K5 negatives + the positives' fix-up, K6 column sums)
+    against the weighted BCE / its derivative evaluated in float64 from the DENSE scores of encode + decode_dense.
+    Tolerance: 1e-4 relative on the cost (hardware exp2 / log2 / rcp in K5), 2e-3 of the norm on gb_dec; with bf16
+    GEMM operands 3e-3 / 2e-2 as in tests/test_gpu_train.py.  Also: gb_enc = column sums of dpre and a spot check
+    that rows of gW_dec are dz^T h."""
+    import torch
+    W_enc, b_enc, W_dec, b_dec = model
+    B = 256
+    pos, ones, _ = make_playlists(B, NT, NA, seed=21, seed_counts=(20, 40, 66, 100))
+    m = pos[:, 1] < NT
+    x = [_dev(a) for a in coo_to_csr(pos[m], ones[m], B, V)]
+    y = [_dev(a) for a in coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)]
+    ctx = _lib.Context(0)
+    if dtype == "bf16":
+        ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    P = _lib._ptr
+    d = dict(We=_dev(W_enc), be=_dev(b_enc), Wd=_dev(W_dec), bd=_dev(b_dec))
+    g = dict(We=torch.zeros((V, H), device="cuda"), be=torch.zeros(H, device="cuda"),
+             Wd=torch.zeros((V, H), device="cuda"), bd=torch.zeros(V, device="cuda"))
+    cost = torch.zeros(1, device="cuda")
+    ctx.check(ctx.lib.dae_train_forward_backward(
+        ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(d["We"]), P(d["be"]), P(d["Wd"]), P(d["bd"]),
+        V, H, B, B, 0, 1.0, 1.0, 5, 0.0, P(g["We"]), P(g["be"]), P(g["Wd"]), P(g["bd"]), P(cost)))
+    # the scoring kernels on the same batch: hidden, dense sigmoid scores
+    h = torch.empty((B, H), device="cuda")
+    ctx.encode(x[0], x[1], x[2], d["We"], d["be"], h)
+    ctx.prepack_decoder(d["Wd"], d["bd"], 0, V)
+    p = torch.empty((B, V), device="cuda")
+    ctx.decode_dense(h, p, apply_sigmoid=True)
+    torch.cuda.synchronize()
+    p64 = p.double()
+    yd = torch.zeros((B, V), dtype=torch.float64, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(B, device="cuda"), (y[0][1:] - y[0][:-1]).long())
+    n_y = int(y[0][-1].item())
+    yd[rows, y[1][:n_y].long()] = y[2][:n_y].double()
+    loss = -(yd * torch.log(p64 + 1e-10) + 0.55 * (1 - yd) * torch.log(1 - p64 + 1e-10))
+    ref_cost = float(loss.sum(1).mean().item())
+    dz = -(yd / (p64 + 1e-10) - 0.55 * (1 - yd) / (1 - p64 + 1e-10)) * p64 * (1 - p64) / B
+    ref_gbd = dz.sum(0)
+    ctol, gtol = (1e-4, 2e-3) if dtype == "f32" else (3e-3, 2e-2)
+    assert abs(float(cost.item()) - ref_cost) <= ctol * abs(ref_cost), (float(cost.item()), ref_cost)
+    err = float((g["bd"].double() - ref_gbd).norm() / ref_gbd.norm())
+    assert err <= gtol, err
+    # rows of gW_dec = dz^T h (a few columns across the vocabulary, including a positive-heavy popular one)
+    for c in (0, 7, 139999, 140000, 169999, int(y[1][0].item())):
+        ref_row = (dz[:, c:c + 1] * h.double()).sum(0)
+        e = float((g["Wd"][c].double() - ref_row).norm() / (ref_row.norm() + 1e-30))
+        assert e <= gtol * 2, (c, e)
+    ctx.close()
