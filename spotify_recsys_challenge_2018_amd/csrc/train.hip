@@ -422,6 +422,158 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
     }
 }
 
+// ---- K6, transposed orientation (bf16 operands, dz^T stored as bf16, hidden a multiple of 128) --------------------
+// Same product gW[v, hc] = sum_r dz[r, v] h[r, hc] with the operand roles swapped: A = dz^T (M = vocabulary rows),
+// B = h^T (N = hidden units), so that an accumulator lane is a hidden unit and its registers are vocabulary rows.
+// What that buys is memory shape on both sides:
+//   * A fragments are plain 16-byte loads from the bf16 dz^T row of the lane (8 consecutive playlists): no selects,
+//     no permutes, no conversions;
+//   * a store instruction writes, per half-wave, 32 lanes x float4 = 512 contiguous bytes of ONE gW row (hidden =
+//     hc0 + 4 n + a), where the other orientation writes 16-byte pieces of 32 rows (57 of its 113 us were the store);
+//     the armed Adam update (dae_arm_decoder_adam) reads and writes W / m / v with the same shape.
+// LDS holds h^T for the workgroup's 128 hidden units as bf16 B fragments in operand order: 4 KB per k-step of 16
+// playlists, 64 KB at B = 256.  gb = dz^T 1 comes out of the matrix pipe as well (a ones fragment as B operand).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [S][4][64] B fragments
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gs = DAE_NUM_XCD * p.n_half;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int half = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int hc0 = half * 128;
+    const int Bp = (p.B + 31) & ~31;
+    const int S = Bp >> 4;                                             // k-steps of 16 playlists (2..16)
+
+    // B fragments: (s, a, lane (n, hi)) = bf16 of h[16 s + 8 hi + x][hc0 + 4 n + a], x = 0..7; rows past B are zero
+    for (int f = tid; f < S * 4 * 64; f += NW * 64) {
+        const int fl = f & 63, fa = (f >> 6) & 3, fs = f >> 8;
+        const int r0 = 16 * fs + 8 * (fl >> 5);
+        const float* src = p.h + hc0 + 4 * (fl & 31) + fa;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = r0 + e < p.B ? src[(size_t)(r0 + e) * p.H] : 0.0f;
+        ldsq[f] = make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
+    }
+    __syncthreads();
+
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const unsigned short* dz = reinterpret_cast<const unsigned short*>(p.dzT);
+    const int n_tiles = (p.V + 63) / 64;
+    const int n_ws = p.nb_half * NW;
+    constexpr int RING = 4;                                            // k-steps of A fragments in flight per wave (8: spills)
+    for (int t = bir * NW + wave; t < n_tiles; t += n_ws) {
+        const int v0 = t * 64;
+        const int va = v0 + n, vb = v0 + 32 + n;                       // this lane's two A rows
+        const unsigned short* ra = dz + (size_t)(va < p.V ? va : 0) * p.ldT + 8 * hi;
+        const unsigned short* rb = dz + (size_t)(vb < p.V ? vb : 0) * p.ldT + 8 * hi;
+        f32x16 acc[2][4], accg[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accg[m][e] = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][a][e] = 0.0f;
+        }
+        uint4 qa[RING], qb[RING];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const int su = u < S ? u : S - 1;
+            qa[u] = *reinterpret_cast<const uint4*>(ra + 16 * su);
+            qb[u] = *reinterpret_cast<const uint4*>(rb + 16 * su);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            if (s_ < S) {                                              // wave-uniform
+                const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, qa[s_ % RING]);
+                const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, qb[s_ % RING]);
+                if (s_ + RING < 16) {                                  // refill the slot (clamped: values unused past S)
+                    const int sn = s_ + RING < S ? s_ + RING : S - 1;
+                    qa[s_ % RING] = *reinterpret_cast<const uint4*>(ra + 16 * sn);
+                    qb[s_ % RING] = *reinterpret_cast<const uint4*>(rb + 16 * sn);
+                }
+                uint4 bq[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) bq[a] = ldsq[(s_ * 4 + a) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, bq[a]);
+                    acc[0][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, bf, acc[0][a], 0, 0, 0);
+                    acc[1][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, bf, acc[1][a], 0, 0, 0);
+                }
+                accg[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accg[0], 0, 0, 0);
+                accg[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, ones, accg[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.gb && half == 0 && n == 0) {                             // every lane holds the row sums; lanes 0 and 32 store
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int v = v0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                    if (v < p.V) p.gb[v] = accg[m][reg];
+                }
+        }
+        // lane n holds hidden units hc0 + 4 n + a (a = the 4 accumulators of a register), register reg the row
+        // v0 + 32 m + (reg & 3) + 8 (reg >> 2) + 4 hi: one float4 per (m, reg), 512 contiguous bytes per half-wave
+        if (p.ad_m) {
+            const float b1 = p.ad_b1, b2 = p.ad_b2, eps = p.ad_eps, al = p.ad_alpha;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    float4 pp[4], mm[4], vv[4];
+                    size_t o[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int reg = r4 + u;
+                        const int v = v0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                        ok[u] = v < p.V;
+                        o[u] = (size_t)(ok[u] ? v : 0) * p.H + hc0 + 4 * n;
+                        pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o[u]);
+                        mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o[u]);
+                        vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int reg = r4 + u;
+                        const float g0 = acc[m][0][reg], g1 = acc[m][1][reg], g2 = acc[m][2][reg], g3 = acc[m][3][reg];
+#define K6_ADAM(P, M, V, G)                                              \
+                        M = M + (G - M) * (1.0f - b1);                   \
+                        V = V + (G * G - V) * (1.0f - b2);               \
+                        P = P - (M * al) / (sqrtf(V) + eps);
+                        K6_ADAM(pp[u].x, mm[u].x, vv[u].x, g0) K6_ADAM(pp[u].y, mm[u].y, vv[u].y, g1)
+                        K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
+#undef K6_ADAM
+                        if (ok[u]) {
+                            *reinterpret_cast<float4*>(p.ad_p + o[u]) = pp[u];
+                            *reinterpret_cast<float4*>(p.ad_m + o[u]) = mm[u];
+                            *reinterpret_cast<float4*>(p.ad_v + o[u]) = vv[u];
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int v = v0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                    if (v < p.V)
+                        *reinterpret_cast<float4*>(p.gW + (size_t)v * p.H + hc0 + 4 * n) =
+                            make_float4(acc[m][0][reg], acc[m][1][reg], acc[m][2][reg], acc[m][3][reg]);
+                }
+        }
+    }
+}
+
 // ---- K7: dh partial [chunk][r][hc] = sum_{v in chunk} dzT[v, r] * W[v, hc] -----------------------
 // a wave owns one (hidden half of 128, 64 playlists) output tile for one chunk of V: 8 accumulators;
 // A = W rows (float4 per lane: hc0 + 4 i + a), B = dz^T rows (float2 per lane: r0 + 2 j + b); no LDS.
@@ -1100,7 +1252,15 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            if (t.dz16) hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true, true>), grid, dim3(512), lds, st, p);
+            static const bool k6_old = getenv("DAE_K6_ORIENT") && !strcmp(getenv("DAE_K6_ORIENT"), "hidden");   // A/B
+            if (t.dz16 && !k6_old) {
+                const size_t lds_t = (size_t)(((B + 31) & ~31) >> 4) * 4 * 64 * sizeof(uint4);
+                static const char k6t_key = 0;
+                if (dae_first_use(ctx, &k6t_key))
+                    DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t_kernel<8>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((grad_wdec_t_kernel<8>), grid, dim3(512), lds_t, st, p);
+            } else if (t.dz16) hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true, true>), grid, dim3(512), lds, st, p);
             else hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
         } else if (NA == 4 && k6w8) {
             static const char attr8_key = 0;
