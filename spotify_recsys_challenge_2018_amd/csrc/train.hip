@@ -142,7 +142,11 @@ struct GwP {
 // v_mfma_f32_32x32x16_bf16 per accumulator -- k-slot x of lane half hi is playlist R0 + 2x + hi in both
 // operands, which is exactly what the fp32 steps consume one at a time -- on operands rounded to bf16 in
 // registers; loads, LDS image, accumulators and stores are the fp32 kernel's.
-template <int NA, int NW = 4, bool BF16 = false, bool DZ16 = false>
+// TR (fp32, NA = 4): the two MFMA operands swapped -- D[i = vocabulary row of the lane pair][j = hidden lane] instead of
+// D[i = hidden][j = vocabulary row].  Loads, LDS image and column sums are unchanged; what changes is that a lane of the
+// accumulators is a hidden unit (hc0 + 4 j + a), so the epilogue writes 512 contiguous bytes of one gW row per half-wave
+// instead of 16-byte pieces of 32 rows -- the same shape the transposed bf16 kernel (grad_wdec_t_kernel) has.
+template <int NA, int NW = 4, bool BF16 = false, bool DZ16 = false, bool TR = false>
 __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [Bp][32*NA] floats
@@ -232,9 +236,11 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
             }                                                                                  \
             cs0 += (DX); cs1 += (DY);                                                          \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DX), acc[a][0], 0, 0, 0); \
+                acc[a][0] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32((DX), av[a], acc[a][0], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DX), acc[a][0], 0, 0, 0); \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DY), acc[a][1], 0, 0, 0); \
+                acc[a][1] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32((DY), av[a], acc[a][1], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], (DY), acc[a][1], 0, 0, 0); \
         }
 // the upper half-wave takes the odd playlist.  A bit blend (v_bfi), NOT `hi ? t.y : t.x`: the
 // optimizer turns that into a dynamically indexed vector extract, which lives in scratch memory.
@@ -348,6 +354,60 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
             if (keep == 12345.678f) p.gW[0] = keep;
             continue;
         }
+        if (TR && NA == 4) {
+            // register reg of accumulator (a, b) is row v0 + 2 i_idx + b, i_idx = (reg & 3) + 8 (reg >> 2) + 4 hi; lane j
+            // holds hidden units hc0 + 4 j + a: one float4 per (b, reg)
+            const float b1 = p.ad_b1, b2 = p.ad_b2, eps = p.ad_eps, al = p.ad_alpha;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int r4 = 0; r4 < 16; r4 += 4) {
+                    if (p.ad_m) {
+                        float4 pp[4], mm[4], vv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int reg = r4 + u;
+                            const int v = v0 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi) + b;
+                            const size_t o = (size_t)(v < p.V ? v : 0) * p.H + hc0 + 4 * j;
+                            pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o);
+                            mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o);
+                            vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int reg = r4 + u;
+                            const int v = v0 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi) + b;
+                            const size_t o = (size_t)(v < p.V ? v : 0) * p.H + hc0 + 4 * j;
+                            const float g0 = acc[0][b][reg], g1 = acc[1 % NA][b][reg], g2 = acc[2 % NA][b][reg],
+                                        g3 = acc[3 % NA][b][reg];
+#define K6_ADAM(P, M, V, G)                                              \
+                            M = M + (G - M) * (1.0f - b1);               \
+                            V = V + (G * G - V) * (1.0f - b2);           \
+                            P = P - (M * al) / (sqrtf(V) + eps);
+                            K6_ADAM(pp[u].x, mm[u].x, vv[u].x, g0) K6_ADAM(pp[u].y, mm[u].y, vv[u].y, g1)
+                            K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
+#undef K6_ADAM
+                            if (v < p.V) {
+                                *reinterpret_cast<float4*>(p.ad_p + o) = pp[u];
+                                *reinterpret_cast<float4*>(p.ad_m + o) = mm[u];
+                                *reinterpret_cast<float4*>(p.ad_v + o) = vv[u];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int reg = r4 + u;
+                            const int v = v0 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi) + b;
+                            if (v >= p.V) continue;
+                            float4* dst = reinterpret_cast<float4*>(p.gW + (size_t)v * p.H + hc0 + 4 * j);
+                            float4 o4 = make_float4(acc[0][b][reg], acc[1 % NA][b][reg], acc[2 % NA][b][reg], acc[3 % NA][b][reg]);
+                            if (p.accumulate) { const float4 old = *dst; o4.x += old.x; o4.y += old.y; o4.z += old.z; o4.w += old.w; }
+                            *dst = o4;
+                        }
+                    }
+                }
+            }
+        } else
         if (NA == 4 && p.ad_m) {
             // the gradient tile goes straight into the Adam update of its parameters: W / m / v are read and written
             // in place, gW never reaches memory (7 passes over the tensor + 1 of the gradient become 6).  Same
@@ -1268,7 +1328,14 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            hipLaunchKernelGGL((grad_wdec_kernel<4, 8>), grid, dim3(512), lds, st, p);
+            static const bool k6_old32 = getenv("DAE_K6_ORIENT") && !strcmp(getenv("DAE_K6_ORIENT"), "hidden");   // A/B
+            if (!k6_old32) {
+                static const char attr8t_key = 0;
+                if (dae_first_use(ctx, &attr8t_key))
+                    DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, false, false, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                hipLaunchKernelGGL((grad_wdec_kernel<4, 8, false, false, true>), grid, dim3(512), lds, st, p);
+            } else hipLaunchKernelGGL((grad_wdec_kernel<4, 8>), grid, dim3(512), lds, st, p);
         } else if (NA == 4) hipLaunchKernelGGL(grad_wdec_kernel<4>, grid, blk, lds, st, p);
         else if (NA == 2) hipLaunchKernelGGL(grad_wdec_kernel<2>, grid, blk, lds, st, p);
         else hipLaunchKernelGGL(grad_wdec_kernel<1>, grid, blk, lds, st, p);
