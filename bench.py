@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  -- the C oracle ("port", 1 thread) on a bounded sample of the same workload.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -70,6 +71,10 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL (the product path).  gloo: development rehearsal of the N > 1 flow on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gate", type=int, default=-1,
+                    help="two streams: alternate the dominant launches (dae_set_decode_gate).  Default: on for f32, where "
+                         "that launch takes every CU (128 KiB of LDS per workgroup); off for bf16, where two of them "
+                         "share the CUs (64 KiB each) and the gate costs 8 %% (3.52 against 3.8 M playlists/s)")
     ap.add_argument("--no-train-row", action="store_true", help="skip the extra training-step row")
     ap.add_argument("--cpu-sample", type=int, default=256, help="playlists the CPU oracle scores")
     ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
@@ -210,6 +215,17 @@ def main():
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
             c.bind_stream()
+    gate_events = []
+    if n_str == 2 and (args.gate == 1 or (args.gate < 0 and args.dtype == "f32")):
+        # the two contexts' dominant launches alternate instead of queueing behind each other (dae_set_decode_gate)
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)                    # materialises the hipEvent_t
+            gate_events.append(ev)
+        torch.cuda.synchronize()
+        for i, c in enumerate(ctxs):
+            c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[1 - i].cuda_event),
+                                              ctypes.c_void_p(gate_events[i].cuda_event)))
     step_no = [0]
     exchange = args.exchange
 
@@ -399,7 +415,7 @@ def main():
                                    "vocab column shard x%d + RCCL %s of the per-shard top-%d" % (
                                        world, "all-to-all (each rank merges the %d rows it owns)" % (B // world)
                                        if args.exchange == "alltoall" else "all-gather (each rank merges all rows)", k)),
-                   "plan": plan, "streams": n_str, "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
+                   "plan": plan, "streams": n_str, "decode_gate": bool(gate_events), "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,
     }
@@ -587,7 +603,6 @@ def main():
         dist.destroy_process_group()
     # the JSON line goes out LAST: RCCL prints its version banner through C stdio, which would
     # otherwise land after it
-    import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:

@@ -169,6 +169,13 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k,
                    const float* cand_logit, const int32_t* cand_idx,
                    int out_kind, float* out_score, int32_t* out_idx);
 
+/* Two batches in flight on two contexts / streams (bench.py): the dominant launch of the fused path (the threshold
+ * filter over ~90 % of the vocabulary) occupies every CU, so two of them in flight only queue behind each other.  With a
+ * gate, this context's launch waits for `wait_event` (a hipEvent_t the OTHER context records after its own launch) and
+ * records `record_event` after itself: the two dominant launches alternate, everything else still overlaps.  Events are
+ * caller-owned; NULL, NULL removes the gate.  Results are unaffected. */
+int dae_set_decode_gate(dae_ctx* ctx, void* wait_event, void* record_event);
+
 /* ---- training step (DAEs.py:98-102) ------------------------------------------------------ */
 
 /* Arithmetic of the three GEMMs of the training step of this context (forward hidden x W_dec^T, gW_dec = dz^T h,

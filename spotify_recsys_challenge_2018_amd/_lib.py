@@ -20,7 +20,7 @@ EXPORTS = [
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
-    "dae_arm_decoder_adam",
+    "dae_arm_decoder_adam", "dae_set_decode_gate",
 ]
 
 _lib = None
@@ -90,6 +90,7 @@ def load():
     lib.dae_adam_rows_flush.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_f, c_int]
     lib.dae_set_enc_grad_prezeroed.argtypes = [vp, c_int]
     lib.dae_arm_decoder_adam.argtypes = [vp, vp, vp, c_f, c_f, c_f, c_f, c_int]
+    lib.dae_set_decode_gate.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes"):
             getattr(lib, name).restype = c_int

@@ -336,12 +336,16 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
     if (rc) return rc;
     dae_tileset tsB{n_other, S, 3, order + n_samp};
+    // dae_set_decode_gate: the dominant launch takes every CU, so two of them in flight on two streams only queue
+    // behind each other; the gate makes this one wait for the other context's and announces its own end
+    if (ctx->gate_wait) DAE_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gate_wait, 0));
     rc = prof_begin(ctx); if (rc) return rc;
     rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
                                       n_valid_col, static_cast<uint2*>(ctx->cand.p),
                                       static_cast<int*>(ctx->cand_cnt.p), cap, dtype);
     if (rc) return rc;
     rc = prof_end(ctx); if (rc) return rc;
+    if (ctx->gate_record) DAE_HIP_CHECK(ctx, hipEventRecord(ctx->gate_record, ctx->stream));
 
     // final: exact top-k of (sample winners) U (filter survivors), seeds removed
     dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), sample_cnt, 0, pstride, 0, 1, 0};
@@ -695,6 +699,14 @@ int dae_arm_decoder_adam(dae_ctx* ctx, float* m, float* v, float lr, float beta1
         return dae_fail(ctx, DAE_ERR_ARG, "m, v must be 16-byte aligned");
     ctx->arm_m = m; ctx->arm_v = v; ctx->arm_alpha = adam_alpha(ctx, lr, beta1, beta2, t);
     ctx->arm_b1 = beta1; ctx->arm_b2 = beta2; ctx->arm_eps = eps;
+    return DAE_OK;
+}
+
+int dae_set_decode_gate(dae_ctx* ctx, void* wait_event, void* record_event)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    ctx->gate_wait = static_cast<hipEvent_t>(wait_event);
+    ctx->gate_record = static_cast<hipEvent_t>(record_event);
     return DAE_OK;
 }
 

@@ -70,6 +70,7 @@ struct dae_ctx {
     dae_buf dense_tmp;         // unfused fallback logits
     dae_buf train_a, train_b, train_c, train_d;
     float* arm_m = nullptr; float* arm_v = nullptr; float arm_alpha = 0.f, arm_b1 = 0.f, arm_b2 = 0.f, arm_eps = 0.f;  // dae_arm_decoder_adam
+    hipEvent_t gate_wait = nullptr, gate_record = nullptr;   // dae_set_decode_gate (caller-owned events)
     int enc_grad_prezeroed = 0;        // untied gW_enc is all-zero on entry (dae_adam_rows_apply re-zeroes what it reads)
     int adam_t = 0; float adam_b1 = 0.f, adam_b2 = 0.f, adam_b1p = 1.f, adam_b2p = 1.f;   // running beta powers of dae_adam_alpha
     int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)

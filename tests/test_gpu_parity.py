@@ -356,3 +356,45 @@ def test_scoring_step_is_capturable_in_a_hip_graph():
     assert np.array_equal(ref_i.cpu().numpy(), i_ref)
     del g
     ctx.close()
+
+
+def test_decode_gate_alternates_two_contexts_without_changing_results():
+    """dae_set_decode_gate: two contexts on two streams, each waiting for the other's dominant launch and announcing its
+    own.  Many alternating steps must neither deadlock nor change a bit of the output; removing the gate works too."""
+    import ctypes
+    import torch
+    V, nt, H, B, k = 40000, 33000, 256, 96, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+    ctxs = [_lib.Context(0), _lib.Context(0)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(torch.empty((B, k), device="cuda"), torch.empty((B, k), dtype=torch.int32, device="cuda")) for _ in ctxs]
+    evs = []
+    for c, st in zip(ctxs, streams):
+        with torch.cuda.stream(st):
+            c.bind_stream()
+            c.prepack_decoder(d[5], d[6])
+        ev = torch.cuda.Event(); ev.record(st); evs.append(ev)
+    torch.cuda.synchronize()
+    for i, c in enumerate(ctxs):
+        c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(evs[1 - i].cuda_event), ctypes.c_void_p(evs[i].cuda_event)))
+    for step in range(40):
+        j = step % 2
+        with torch.cuda.stream(streams[j]):
+            ctxs[j].score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, outs[j][0], outs[j][1])
+    torch.cuda.synchronize()
+    s_ref, i_ref = oracle.score_batch(rp, col, val, W_enc, b_enc, W_dec, b_dec, V, nt, srp, sc, k)
+    for s, i in outs:
+        assert np.array_equal(i.cpu().numpy(), i_ref)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+    for c in ctxs:
+        c.check(c.lib.dae_set_decode_gate(c.h, None, None))
+    with torch.cuda.stream(streams[0]):
+        ctxs[0].score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, outs[0][0], outs[0][1])
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0][1].cpu().numpy(), i_ref)
+    for c in ctxs:
+        c.close()
