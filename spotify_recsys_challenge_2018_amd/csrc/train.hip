@@ -1198,7 +1198,7 @@ namespace {
 // scratch carved for one training step over a [Vl, H] weight (shard) and B rows; stable for a given
 // (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
 struct TrainPlan {
-    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype, dz16;
+    int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype, dz16, rm;
     dae_rowgeom g;
     size_t bh, hp_bytes;
     float *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
@@ -1220,6 +1220,10 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     }
     t.g = t.dtype == DAE_DTYPE_BF16 ? dae_row_geometry_bf16(B, Hp) : dae_row_geometry(B, Hp);
     t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
+    {   // fp32, hidden 256: K5 reads the row-major decoder and hidden activations directly -- no per-step prepack
+        static const bool k5_packed = getenv("DAE_K5_PACKED") != nullptr;                 // A/B
+        t.rm = (t.dtype == DAE_DTYPE_F32 && H == 256 && t.g.R_TILE == 128 && t.g.waves == 4 && !k5_packed) ? 1 : 0;
+    }
     t.Bpad64 = (B + 63) / 64 * 64;
     t.hp_bytes = (size_t)t.g.n_rg * t.G * t.RB * 64 * sizeof(float4);
     if ((rc = dae_reserve(ctx, ctx->h_packed, t.hp_bytes))) return rc;
@@ -1258,7 +1262,11 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     if (H > FIX_MAXH) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H <= %d (H=%d)", FIX_MAXH, H);
     if (t.Bpad64 != B)
         DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * (t.dz16 ? sizeof(unsigned short) : sizeof(float)), st));
-    rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype, t.dz16);
+    if (t.rm)
+        rc = dae_launch_decode_loss_rowmajor(ctx, t.g, B, Vl, H, Wd, b_dec, t.hbuf, 1.0f / (float)n_batch, t.dzT, t.Bpad64,
+                                             t.loss_part);
+    else
+        rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype, t.dz16);
     if (rc) return rc;
     if (t.dtype == DAE_DTYPE_BF16 && t.dz16)
         hipLaunchKernelGGL((loss_fixup_kernel<true, true>), dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
@@ -1516,14 +1524,16 @@ int dae_train_step_f32(dae_ctx* ctx,
     }
     const float* Wd = tied ? W_enc : W_dec;
     // decoder weights change every step: re-tile them for the forward GEMM
-    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec, V, H, 0, V)
-                                   : dae_launch_prepack_f32(ctx, Wd, b_dec, V, H, 0, V);
-    if (rc) return rc;
+    if (!t.rm) {
+        rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec, V, H, 0, V)
+                                       : dae_launch_prepack_f32(ctx, Wd, b_dec, V, H, 0, V);
+        if (rc) return rc;
+    }
 
     // ---- forward ----------------------------------------------------------------------------------
     // the pad rows / pad k of the fp32 image are never written by the encode kernel: zeroed once per geometry and
     // buffer (same key as the scoring path: the two share the image)
-    if (t.dtype == DAE_DTYPE_F32) {
+    if (t.dtype == DAE_DTYPE_F32 && !t.rm) {
         const long long key = ((long long)B << 32) | ((long long)H << 12) | (long long)t.g.R_TILE;
         if (ctx->h_geom_key != key || ctx->h_geom_ptr != ctx->h_packed.p) {
             DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed.p, 0, t.hp_bytes, st));
@@ -1531,7 +1541,10 @@ int dae_train_step_f32(dae_ctx* ctx,
             ctx->h_geom_ptr = ctx->h_packed.p;
         }
     }
-    if (t.dtype == DAE_DTYPE_BF16) {
+    if (t.rm) {
+        rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
+                               nullptr, 0, 0, t.sg, nullptr);
+    } else if (t.dtype == DAE_DTYPE_BF16) {
         rc = dae_launch_encode(ctx, x_row_ptr, x_col, x_val, W_enc, b_enc, V, H, B, ikp, kp, seed, t.hbuf,
                                nullptr, 0, 0, t.sg, nullptr);
         if (rc) return rc;
@@ -1555,7 +1568,7 @@ int dae_train_step_f32(dae_ctx* ctx,
                                 ikp, kp, seed, reg_lambda, W_enc, b_enc, W_dec, b_dec,
                                 gW_enc, gb_enc, gW_dec, gb_dec);
     if (rc) return rc;
-    (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
+    if (!t.rm) (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
     return DAE_OK;
 }
 
@@ -1583,16 +1596,20 @@ int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_en
     int rc = train_plan(ctx, Vl, H, B, t);
     if (rc) return rc;
     const float* Wd = tied ? W_enc_loc : W_dec_loc;
-    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec_loc, Vl, H, 0, Vl)
-                                   : dae_launch_prepack_f32(ctx, Wd, b_dec_loc, Vl, H, 0, Vl);
-    if (rc) return rc;
+    if (!t.rm) {
+        rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_prepack_bf16(ctx, Wd, b_dec_loc, Vl, H, 0, Vl)
+                                       : dae_launch_prepack_f32(ctx, Wd, b_dec_loc, Vl, H, 0, Vl);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(activate_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, pre, b_enc, B, H, kp, seed,
                        t.hbuf, t.sg);
     DAE_CHECK_LAUNCH(ctx, "activate_kernel");
     ctx->h_geom_key = -1;
-    rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_pack_h_bf16(ctx, t.hbuf, B, H, t.g)
-                                   : dae_launch_pack_h(ctx, t.hbuf, B, H, t.g);
-    if (rc) return rc;
+    if (!t.rm) {
+        rc = t.dtype == DAE_DTYPE_BF16 ? dae_launch_pack_h_bf16(ctx, t.hbuf, B, H, t.g)
+                                       : dae_launch_pack_h(ctx, t.hbuf, B, H, t.g);
+        if (rc) return rc;
+    }
     rc = train_decode_backward(ctx, t, Vl, H, B, n_batch, y_row_ptr, y_col, y_val, col_lo, col_hi, Wd, b_dec_loc,
                                gW_out, gb_dec_loc);
     if (rc) return rc;
@@ -1604,7 +1621,7 @@ int dae_train_shard_decode_f32(dae_ctx* ctx, const float* pre, const float* b_en
     hipLaunchKernelGGL(sum_chunks_kernel, dim3(grid_for(t.bh)), dim3(256), 0, st, t.part, t.n_chunk,
                        (size_t)t.Bpad64 * H, t.bh, dh_partial);
     DAE_CHECK_LAUNCH(ctx, "sum_chunks_kernel");
-    (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
+    if (!t.rm) (t.dtype == DAE_DTYPE_BF16 ? ctx->pk_bf16 : ctx->pk_f32).valid = true;
     return DAE_OK;
 }
 
