@@ -218,7 +218,7 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
 
 int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, int V, int H, const float* W,
                                     const float* bias, const float* h, float inv_n_batch, float* dzT, int64_t ldT,
-                                    float* loss_part);
+                                    float* loss_part, int dtype = DAE_DTYPE_F32, int dz16 = 0);
 
 // train.hip
 int dae_train_step_f32(dae_ctx* ctx,

@@ -554,6 +554,123 @@ __global__ __launch_bounds__(256, 1) void decode_loss_rowmajor_kernel(const Loss
     if (tid == 0) p.loss_part[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * p.inv_nb;
 }
 
+// The same with bf16 operands (dae_set_train_dtype): a lane reads W[32 t + i][16 s + 8 hi .. + 7] as two 16-byte loads
+// and rounds them to the 8 bf16 k-slots of its MFMA operand in registers; the hidden fragments are rounded once while
+// LDS is filled (64 KB).  Twice the bytes of the bf16 image are read (fp32 rows), but the image no longer has to be
+// built every step (58 us); the bias is added in fp32 in the epilogue.  Two waves per SIMD: the launch is bound by its
+// epilogue.  dz16: dL/dz stored as bf16.
+__global__ __launch_bounds__(512, 1) void decode_loss_rowmajor_bf16_kernel(const LossRmP p, int dz16)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];       // uint4 [NS = 16][RB = 4][64]
+    uint4* ldsq = reinterpret_cast<uint4*>(lds4);
+    constexpr int RB = 4, NS = 16, R_TILE = 128, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int H4 = p.H >> 2;
+    const float4* h4 = reinterpret_cast<const float4*>(p.h);
+    for (int f = tid; f < NS * RB * 64; f += NW * 64) {
+        const int fl = f & 63, frb = (f >> 6) & 3, fs = f >> 8;
+        const int row = rg * R_TILE + frb * 32 + (fl & 31);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (row < p.B) {
+            const float4* src = h4 + (size_t)row * H4 + 4 * fs + 2 * (fl >> 5);
+            a = src[0]; b = src[1];
+        }
+        ldsq[f] = make_uint4(bf16_rne(a.x) | (bf16_rne(a.y) << 16), bf16_rne(a.z) | (bf16_rne(a.w) << 16),
+                             bf16_rne(b.x) | (bf16_rne(b.y) << 16), bf16_rne(b.z) | (bf16_rne(b.w) << 16));
+    }
+    __syncthreads();
+
+    float loss_acc = 0.0f;
+    const int n_tiles = (p.V + 31) >> 5;
+    const int n_ws = p.nb_rg * NW;
+    const float4* W4 = reinterpret_cast<const float4*>(p.W);
+    auto wrow = [&](int t) {
+        const int v = t * 32 + j;
+        return W4 + (size_t)(v < p.V ? v : p.V - 1) * H4 + 2 * hi;
+    };
+    constexpr int QR = 4;                                                // k-steps of W in flight
+    float4 wa[QR], wb[QR];
+    const int item0 = wave * p.nb_rg + bir;
+    if (item0 < n_tiles) {
+        const float4* w0 = wrow(item0);
+#pragma unroll
+        for (int u = 0; u < QR; ++u) { wa[u] = w0[4 * u]; wb[u] = w0[4 * u + 1]; }
+    }
+    for (int t = item0; t < n_tiles; t += n_ws) {
+        const float4* wp = wrow(t);
+        const float4* wn = wrow(t + n_ws < n_tiles ? t + n_ws : t);
+        float4 bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int c = t * 32 + 4 * hi + 8 * qd;
+            bq[qd] = make_float4(c < p.V ? p.bias[c] : 0.f, c + 1 < p.V ? p.bias[c + 1] : 0.f,
+                                 c + 2 < p.V ? p.bias[c + 2] : 0.f, c + 3 < p.V ? p.bias[c + 3] : 0.f);
+        }
+        f32x16 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float4 a0 = wa[s_ % QR], a1 = wb[s_ % QR];
+            const float4* nx = (s_ + QR < NS) ? wp + 4 * (s_ + QR) : wn + 4 * (s_ + QR - NS);
+            wa[s_ % QR] = nx[0]; wb[s_ % QR] = nx[1];
+            uint4 bf[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) bf[rb] = ldsq[(s_ * RB + rb) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            typedef float f32x8_t __attribute__((ext_vector_type(8)));
+            const f32x8_t a8 = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const bf16x8 af = __builtin_convertvector(a8, bf16x8);             // 4 x v_cvt_pk_bf16_f32 (RNE)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, as_bf16x8(bf[rb]), acc[rb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int tcol0 = t * 32 + 4 * hi;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = rg * R_TILE + rb * 32 + j;
+            if (row >= p.B) continue;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int lc = tcol0 + 8 * qd;
+                const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (lc + e < p.V) {
+                        const float zz = acc[rb][4 * qd + e] + zb[e];
+                        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                        const float a0 = 1.0f - pr + 1e-10f;
+                        loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
+                        const float dzv = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                        if (dz16)
+                            reinterpret_cast<unsigned short*>(p.dzT)[(size_t)(lc + e) * p.ldT + row] = (unsigned short)bf16_rne(dzv);
+                        else
+                            p.dzT[(size_t)(lc + e) * p.ldT + row] = dzv;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
+    __shared__ float wsum[NW];
+    if (lane == 0) wsum[wave] = loss_acc;
+    __syncthreads();
+    if (tid == 0) {
+        float sm = 0.0f;
+        for (int w = 0; w < NW; ++w) sm += wsum[w];
+        p.loss_part[blockIdx.x] = sm * p.inv_nb;
+    }
+}
+
 // ---- fp32, hidden = 256, filter epilogue (phase B of the fused path): the generic kernel above with
 // one addition, TAIL BALANCE.  A launch of n tiles over n_ws wave slots runs floor(n / n_ws) whole rounds
 // and a last round with `rem` tiles; when that round is at most half full (222 of 512 slots at batch 256,
@@ -1436,12 +1553,18 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 // K5 from the row-major decoder (fp32, hidden = 256, 128-row groups); returns DAE_ERR_STATE when the shape does not apply
 int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, int V, int H, const float* W,
                                     const float* bias, const float* h, float inv_n_batch, float* dzT, int64_t ldT,
-                                    float* loss_part)
+                                    float* loss_part, int dtype, int dz16)
 {
     if (H != 256 || g.R_TILE != 128 || g.waves != 4) return DAE_ERR_STATE;
     LossRmP p;
     p.W = W; p.bias = bias; p.h = h; p.V = V; p.H = H; p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg;
     p.inv_nb = inv_n_batch; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part;
+    if (dtype == DAE_DTYPE_BF16) {
+        const size_t lds16 = (size_t)16 * 4 * 64 * sizeof(uint4);
+        hipLaunchKernelGGL(decode_loss_rowmajor_bf16_kernel, dim3(g.grid), dim3(512), lds16, ctx->stream, p, dz16);
+        DAE_CHECK_LAUNCH(ctx, "decode_loss_rowmajor_bf16_kernel");
+        return DAE_OK;
+    }
     const size_t lds = (size_t)32 * 4 * 64 * sizeof(float4);
     static const char rm_key = 0;
     if (dae_first_use(ctx, &rm_key))

@@ -1220,9 +1220,10 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     }
     t.g = t.dtype == DAE_DTYPE_BF16 ? dae_row_geometry_bf16(B, Hp) : dae_row_geometry(B, Hp);
     t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
-    {   // fp32, hidden 256: K5 reads the row-major decoder and hidden activations directly -- no per-step prepack
+    {   // hidden 256: K5 reads the row-major decoder and hidden activations directly (fp32, or rounded to bf16 in
+        // registers) -- no per-step prepack
         static const bool k5_packed = getenv("DAE_K5_PACKED") != nullptr;                 // A/B
-        t.rm = (t.dtype == DAE_DTYPE_F32 && H == 256 && t.g.R_TILE == 128 && t.g.waves == 4 && !k5_packed) ? 1 : 0;
+        t.rm = (H == 256 && t.g.R_TILE == 128 && t.g.waves == 4 && !k5_packed) ? 1 : 0;
     }
     t.Bpad64 = (B + 63) / 64 * 64;
     t.hp_bytes = (size_t)t.g.n_rg * t.G * t.RB * 64 * sizeof(float4);
@@ -1264,7 +1265,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * (t.dz16 ? sizeof(unsigned short) : sizeof(float)), st));
     if (t.rm)
         rc = dae_launch_decode_loss_rowmajor(ctx, t.g, B, Vl, H, Wd, b_dec, t.hbuf, 1.0f / (float)n_batch, t.dzT, t.Bpad64,
-                                             t.loss_part);
+                                             t.loss_part, t.dtype, t.dz16);
     else
         rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype, t.dz16);
     if (rc) return rc;
