@@ -721,17 +721,19 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                   \
                 const bf16x8_t af = pk_bf16x8(AV[0][a], AV[1][a], AV[2][a], AV[3][a], AV[4][a], AV[5][a], \
                                               AV[6][a], AV[7][a]);                             \
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bx, acc[a][0], 0, 0, 0); \
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, by, acc[a][1], 0, 0, 0); \
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx, af, acc[a][0], 0, 0, 0); \
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(by, af, acc[a][1], 0, 0, 0); \
             }                                                                                  \
         } else                                                                                 \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
             const bool in = (V0) + 2 * s + hi < v_end;                                         \
             const float dx = in ? D[s].x : 0.f, dy = in ? D[s].y : 0.f;                        \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dx, acc[a][0], 0, 0, 0); \
+                acc[a][0] = NA == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(dx, AV[s][a], acc[a][0], 0, 0, 0) \
+                                    : __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dx, acc[a][0], 0, 0, 0); \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dy, acc[a][1], 0, 0, 0); \
+                acc[a][1] = NA == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(dy, AV[s][a], acc[a][1], 0, 0, 0) \
+                                    : __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dy, acc[a][1], 0, 0, 0); \
         }
         float avA[8][NA], avB[8][NA];
         float2 dA[8], dB[8];
@@ -756,7 +758,9 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             for (int reg = 0; reg < 16; ++reg) {
                 const int i_idx = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
                 if (NA == 4) {
-                    *reinterpret_cast<float4*>(prow + (size_t)r * p.H + 4 * i_idx) =
+                    // operands swapped (NA = 4): the lane is the hidden unit hc0 + 4 j + a, the register the playlist
+                    // r0 + 2 i_idx + b -- 512 contiguous bytes of one partial row per half-wave
+                    *reinterpret_cast<float4*>(prow + (size_t)(r0 + 2 * i_idx + b) * p.H + 4 * j) =
                         make_float4(acc[0][b][reg], acc[1 % NA][b][reg], acc[2 % NA][b][reg], acc[3 % NA][b][reg]);
                 } else {
 #pragma unroll
