@@ -21,6 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int N> struct IntC { static constexpr int value = N; };
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
 #define DH_LOAD(AV, D, V0)                                                                     \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
             const int v = (V0) + 2 * s + hi;                                                   \
-            const bool in = v < v_end;                                                         \
+            const bool in = FASTV || v < v_end;                                                \
             const int vc = in ? v : v_beg;                                                     \
             const float* wr = Wl + (size_t)vc * p.H;                                           \
             if (NA == 4) {                                                                     \
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             if (DZ16) {                                                                        \
                 unsigned dd[8];                                                                \
                 _Pragma("unroll") for (int s = 0; s < 8; ++s)                                  \
-                    dd[s] = (V0) + 2 * s + hi < v_end ? __float_as_uint(D[s].x) : 0u;          \
+                    dd[s] = (FASTV || (V0) + 2 * s + hi < v_end) ? __float_as_uint(D[s].x) : 0u; \
                 bx = __builtin_bit_cast(bf16x8_t, make_uint4(                                  \
                     __builtin_amdgcn_perm(dd[1], dd[0], 0x05040100u), __builtin_amdgcn_perm(dd[3], dd[2], 0x05040100u), \
                     __builtin_amdgcn_perm(dd[5], dd[4], 0x05040100u), __builtin_amdgcn_perm(dd[7], dd[6], 0x05040100u))); \
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             } else {                                                                           \
             float dx[8], dy[8];                                                                \
             _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
-                const bool in = (V0) + 2 * s + hi < v_end;                                     \
+                const bool in = FASTV || (V0) + 2 * s + hi < v_end;                            \
                 dx[s] = in ? D[s].x : 0.f; dy[s] = in ? D[s].y : 0.f;                          \
             }                                                                                  \
             bx = pk_bf16x8(dx[0], dx[1], dx[2], dx[3], dx[4], dx[5], dx[6], dx[7]);            \
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             }                                                                                  \
         } else                                                                                 \
         _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                        \
-            const bool in = (V0) + 2 * s + hi < v_end;                                         \
+            const bool in = FASTV || (V0) + 2 * s + hi < v_end;                                \
             const float dx = in ? D[s].x : 0.f, dy = in ? D[s].y : 0.f;                        \
             _Pragma("unroll") for (int a = 0; a < NA; ++a)                                     \
                 acc[a][0] = NA == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(dx, AV[s][a], acc[a][0], 0, 0, 0) \
@@ -735,19 +736,28 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
                 acc[a][1] = NA == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(dy, AV[s][a], acc[a][1], 0, 0, 0) \
                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(AV[s][a], dy, acc[a][1], 0, 0, 0); \
         }
-        float avA[8][NA], avB[8][NA];
-        float2 dA[8], dB[8];
-        DH_LOAD(avA, dA, v_beg)
-        for (int v0 = v_beg; v0 < v_end; v0 += 32) {
-            DH_LOAD(avB, dB, v0 + 16)
-            __builtin_amdgcn_sched_barrier(0);
-            DH_MMA(avA, dA, v0)
-            __builtin_amdgcn_sched_barrier(0);
-            DH_LOAD(avA, dA, v0 + 32)
-            __builtin_amdgcn_sched_barrier(0);
-            DH_MMA(avB, dB, v0 + 16)
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // A chunk that is whole (a multiple of 32 rows, and the prefetch past its end stays inside the matrix -- every
+        // chunk but the last) needs no "row past the chunk" clamps and selects: its addresses are then a uniform part
+        // plus a per-lane constant, and the ~120 VALU instructions per block that a single wave per SIMD executes
+        // with the matrix pipe idle shrink accordingly.
+        auto body = [&](auto fastc) {
+            constexpr bool FASTV = decltype(fastc)::value;
+            float avA[8][NA], avB[8][NA];
+            float2 dA[8], dB[8];
+            DH_LOAD(avA, dA, v_beg)
+            for (int v0 = v_beg; v0 < v_end; v0 += 32) {
+                DH_LOAD(avB, dB, v0 + 16)
+                __builtin_amdgcn_sched_barrier(0);
+                DH_MMA(avA, dA, v0)
+                __builtin_amdgcn_sched_barrier(0);
+                DH_LOAD(avA, dA, v0 + 32)
+                __builtin_amdgcn_sched_barrier(0);
+                DH_MMA(avB, dB, v0 + 16)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (((v_end - v_beg) & 31) == 0 && v_end + 16 <= p.V) body(IntC<1>{});
+        else body(IntC<0>{});
 #undef DH_LOAD
 #undef DH_MMA
         float* prow = p.part + ((size_t)ch * p.Bpad64) * p.H + hc0;
