@@ -166,3 +166,62 @@ def test_model_shard_training_world1_syncs_replica_before_scoring():
     assert np.mean(ia[:, :20] == ib[:, :20]) > 0.9
     wa, wb = a.get_params(), b.get_params()
     assert wb[0] is not None and float(np.mean(np.abs(wa[0] - wb[0]) > 1e-3)) < 1e-3
+
+
+@pytest.mark.parametrize("tied,world", [(False, 2), (True, 3)])
+def test_sharded_stages_with_bf16_gemms_match_the_unsharded_bf16_step(tied, world):
+    """dae_set_train_dtype(BF16) on the sharded stages (hidden 256: the row-major bf16 K5, the transposed K6 and the
+    bf16 K7 on every shard): concatenated gradients and the summed cost against the unsharded bf16 step on the same
+    draws.  The per-element arithmetic is the same; only K7's split over vocabulary chunks differs -> 1e-3 of the norm."""
+    import torch
+    V, nt, H, B = 4200, 3800, 256, 200
+    ctx = _lib.Context(0)
+    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    st = HipTrainStages(ctx)
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt, tied=tied)
+    b_enc = (np.random.default_rng(2).standard_normal(H) * 0.1).astype(np.float32)
+    pos, ones, _ = make_playlists(B, nt, V - nt, seed=6, seed_counts=(3, 9, 20))
+    x = tuple(_dev(a) for a in coo_to_csr(pos, ones, B, V))
+    y = tuple(_dev(a) for a in coo_to_csr(pos, np.ones(len(pos), np.float32), B, V))
+    seed, ikp, kp, lam = 977, 0.75, 0.8, 0.0
+    be = _dev(b_enc)
+    sh = []
+    for lo, hi in all_shard_bounds(V, world):
+        d = dict(lo=lo, hi=hi, We=_dev(W_enc[lo:hi]), bd=_dev(b_dec[lo:hi]), Wd=None if tied else _dev(W_dec[lo:hi]))
+        d.update(gWe=torch.zeros((hi - lo, H), device="cuda"), gbd=torch.zeros(hi - lo, device="cuda"),
+                 gWd=None if tied else torch.zeros((hi - lo, H), device="cuda"), gbe=torch.zeros(H, device="cuda"),
+                 pre=torch.zeros((B, H), device="cuda"), dh=torch.zeros((B, H), device="cuda"),
+                 cost=torch.zeros(1, device="cuda"))
+        sh.append(d)
+    for d in sh:
+        st.encode(x, d["We"], d["lo"], d["hi"], ikp, seed, d["pre"])
+    pre = sum(d["pre"] for d in sh)
+    for d in sh:
+        st.decode(pre, be, y, d["We"], d["Wd"], d["bd"], d["lo"], d["hi"], B, tied, kp, seed, lam,
+                  d["gWe"] if tied else d["gWd"], d["gbd"], d["dh"], d["cost"])
+    dh = sum(d["dh"] for d in sh)
+    cost = float(sum(d["cost"] for d in sh).item())
+    for d in sh:
+        st.decode(pre, be, y, d["We"], d["Wd"], d["bd"], d["lo"], d["hi"], B, tied, kp, seed, lam,
+                  d["gWe"] if tied else d["gWd"], d["gbd"], d["dh"], d["cost"])      # re-establish this shard's scratch
+        st.finish(dh, x, d["We"], be, d["Wd"], d["bd"], d["lo"], d["hi"], tied, ikp, kp, seed, lam,
+                  d["gWe"], d["gbe"], d["gWd"], d["gbd"])
+    torch.cuda.synchronize()
+    got = dict(We=torch.cat([d["gWe"] for d in sh]), bd=torch.cat([d["gbd"] for d in sh]), be=sh[0]["gbe"])
+    if not tied:
+        got["Wd"] = torch.cat([d["gWd"] for d in sh])
+    P = _lib._ptr
+    d0 = dict(We=_dev(W_enc), Wd=_dev(W_dec), bd=_dev(b_dec))
+    u = dict(We=torch.zeros((V, H), device="cuda"), be=torch.zeros(H, device="cuda"),
+             Wd=torch.zeros((V, H), device="cuda"), bd=torch.zeros(V, device="cuda"))
+    ucost = torch.zeros(1, device="cuda")
+    ctx.check(ctx.lib.dae_train_forward_backward(
+        ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(d0["We"]), P(be), P(d0["Wd"]), P(d0["bd"]),
+        V, H, B, B, 1 if tied else 0, float(ikp), float(kp), seed, float(lam),
+        P(u["We"]), P(u["be"]), None if tied else P(u["Wd"]), P(u["bd"]), P(ucost)))
+    torch.cuda.synchronize()
+    assert abs(cost - float(ucost.item())) <= 1e-4 * abs(cost)
+    for k in got:
+        err = float((got[k].double() - u[k].double()).norm() / u[k].double().norm())
+        assert err <= 1e-3, (k, err)
+    ctx.close()
