@@ -437,8 +437,16 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el_g = float(t.item())
+        # both exchanges once more on drained streams, then compare (not buffers left over from the timed loops)
         r0_ = rank * B_own
-        agree = bool(torch.equal(outs[(step_no[0] - 1) % n_str][1][r0_:r0_ + B_own], own[(step_no[0] - 1) % n_str][1]))
+        torch.cuda.synchronize()
+        step(); step()
+        torch.cuda.synchronize()
+        exchange = "alltoall"
+        step(); step()
+        torch.cuda.synchronize()
+        agree = bool(torch.equal(outs[0][1][r0_:r0_ + B_own], own[0][1]) and
+                     torch.equal(outs[1 % n_str][1][r0_:r0_ + B_own], own[1 % n_str][1]))
         out["allgather_exchange"] = {"value": round(B * args.steps / el_g, 1), "unit": "playlists/s",
                                      "ms_per_step": round(el_g / args.steps * 1e3, 4),
                                      "same_indices_as_alltoall": agree,
