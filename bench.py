@@ -399,6 +399,12 @@ def main():
                                       "note": "at batch %d the step's encode launch is latency-bound (a chain of small "
                                               "dependent loads per row); this is the same gather where bandwidth matters" % B}
     del hL, dL
+    # the two side measurements above bound context 0 to the default stream: back to its own stream, where step() puts
+    # the exchange and the merge of its batches (a context on another stream than its collectives races with them)
+    torch.cuda.synchronize()
+    for c, st in zip(ctxs, streams):
+        with torch.cuda.stream(st):
+            c.bind_stream()
 
     out = {
         "metric": "playlists scored/sec (encode+decode+top-500) at |vocab|~170k",
