@@ -35,10 +35,14 @@ def eval(reader_test, conf, model):
     while True:
         x_positions, test_seed, test_answer, titles, x_ones = reader_test.next_batch_test()
         if conf.mode == 'title':                                   # main_train.py:69-79: titles_use = 1 everywhere
+            # ... for rows that HAVE a title (every row of a file this repo's or the reference's generator
+            # writes).  A 5-field row (the snapshot reader's layout) carries none: mixing in the score of an
+            # all-padding title would rank a 0-seed row on noise, so such rows take titles_use = 0.
             pad = [-1] * conf.strmaxlen
+            use = np.array([0.0 if t is None else 1.0 for t in titles], np.float32)
             titles = [t if t is not None else pad for t in titles]
             idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed), titles=titles,
-                                     titles_use=np.ones(len(titles), np.float32))
+                                     titles_use=use)
         else:
             idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))
         for i in range(len(test_seed)):

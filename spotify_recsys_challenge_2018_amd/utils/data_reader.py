@@ -156,10 +156,12 @@ class data_reader_firstN(data_reader):
 class data_reader_test:
     """Evaluation batches (data_reader.py:131-196).  File rows are either the layout the
     reference's generator writes, [seed_trk, seed_art, title_ixs, answers]
-    (spotify_reader.py:286), or the 5-field layout its reader unpacks,
-    [seed, seed_art, answer, seed_cls, answer_cls] (data_reader.py:158); both are accepted.
+    (spotify_reader.py:286; what this repo's Spotify_test writes), or the 5-field layout its reader
+    unpacks, [seed, seed_art, answer, seed_cls, answer_cls] (data_reader.py:158), which carries no
+    title; both are accepted.
     Returns what main_train.py:64 unpacks: (x_positions, test_seed, test_answer, titles, x_ones):
-    seed TRACKS only, weight 1 (main_train.py:66-68)."""
+    seed TRACKS only, weight 1 (main_train.py:66-68); `titles[i]` is the row's title indices, or None
+    for a 5-field row (`has_titles` says whether the file carries them)."""
 
     def __init__(self, data_dir, filename, batch_size, test_num):
         print("now processing: " + filename)
@@ -181,6 +183,7 @@ class data_reader_test:
             self._answers.append(answer)
             self._titles.append(title)
         self._seeds = seeds
+        self.has_titles = bool(self._titles) and all(t is not None for t in self._titles)
         self._seed_flat, self._seed_off = _flatten(seeds)
 
     def next_batch_test(self):

@@ -13,10 +13,15 @@ popularity rank, which the scoring path exploits (threshold sample).
 Repairs of snapshot defects, each marked REPAIR below:
   * create_uri2id: the snapshot finds the cut with list.index(min_count - 1), which raises when no
     item has exactly that count; the intent -- keep items seen >= min_count times -- is implemented.
-  * Spotify_test: the snapshot reads self.class_divpnt / self.get_class, which do not exist, and
-    writes 4-field rows while its own reader unpacks 5 fields (data_reader.py:158).  Here the class
-    divide points come from the train file and rows are written in the reader's 5-field layout
-    [seed_tracks, seed_artists, answers, seed_classes, answer_classes].
+  * Spotify_test: the snapshot reads self.class_divpnt / self.get_class, which do not exist (the
+    popularity-class bookkeeping is a research leftover).  The class divide points
+    come from the train file here; rows are written in the layout the snapshot's generator writes
+    (spotify_reader.py:286): [seed_tracks, seed_artists, title_ixs, answers] -- the title indices
+    are what `--title` evaluation feeds (main_train.py:69-79).  This repo's data_reader_test accepts
+    that layout and the 5-field one the snapshot's reader unpacks (data_reader.py:158).
+  * the module RNG: the snapshot seeds `random` once at import (spotify_reader.py:13) and
+    data_generator builds every split in one process, so the splits draw from ONE stream; here the
+    caller passes one `random.Random(180610)` to every Spotify_test (data_generator.main does).
 """
 import json
 import os
@@ -169,6 +174,7 @@ class Spotify_test:
         track_uri2id, artist_uri2id = train['track_uri2id'], train['artist_uri2id']
         track_total = set(train['track_total'])
         class_divpnt = train['class_divpnt']                            # REPAIR: was never loaded
+        normalize = bool(train['is_title_normalize'])                   # :186
         rng = rng if rng is not None else random.Random(180610)         # :13 seeds the module RNG
         n = test_seeds_num
         self.playlists = []
@@ -197,9 +203,9 @@ class Spotify_test:
             for t in tracks[n:]:                                        # :267-273: -1 (OOV) answers repeat
                 if t not in seed_trk and (t == -1 or t not in answers):
                     answers.append(t)
-            self.playlists.append([seed_trk, seed_art, answers,
-                                   [get_class(class_divpnt, t) for t in seed_trk],
-                                   [t if t == -1 else get_class(class_divpnt, t) for t in answers]])
+            name_ = playlist['name']                                    # :279-282
+            ixs = change_title2ixs(normalize_name(name_) if normalize else name_)
+            self.playlists.append([seed_trk, seed_art, ixs, answers])   # :286
         self.num_playlists = len(self.playlists)
         name = 'test-' + str(n) + ('r' if is_shuffle else '')
         print(name)

@@ -26,7 +26,7 @@ def test_conf_sections_and_inheritance(tmp_path):
     assert c.verbose is False and c.testsize == 1000 and c.data_dir == "./data"
     c.set_dae_conf()
     assert (c.epochs, c.batch, c.lr, c.hidden, c.kp) == (2, 16, 0.005, 32, 0.8)
-    assert c.test_seed == ["test-5"] and c.update_seed == ["test-5"] and c.input_kp == [0.5, 0.8]
+    assert c.test_seed == ["test-0", "test-1", "test-5", "test-25r"] and c.update_seed == ["test-5"] and c.input_kp == [0.5, 0.8]
     assert c.firstN == [0.0, 0.3] and c.initval.endswith("w_pretrain") and c.save.endswith("w_dae")
     c.set_pretrain_conf()               # pretrain keeps hidden / kp / input_kp / firstN from [DAE]
     assert c.mode == "pretrain" and c.lr == 0.01 and c.hidden == 32 and c.kp == 0.8

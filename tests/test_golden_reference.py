@@ -72,13 +72,14 @@ def test_data_reader_challenge_matches_reference(exp, capsys):
 
 
 def test_data_reader_test_matches_reference(exp, capsys):
-    r = dr.data_reader_test(DATA, "test-5", 6, 1000)
+    r = dr.data_reader_test(DATA, "test-reader5f", 6, 1000)
     for want in exp["test"]:
         xp, seed, answer, _titles, x_ones = r.next_batch_test()
         assert np.array_equal(xp, _pos(want["x"]))
         assert seed == want["seed"] and answer == want["answer"]
         assert np.array_equal(x_ones, np.ones(len(xp), np.float32))
-    assert r.test_idx == 0
+        assert _titles == [None] * len(seed)                  # the 5-field layout carries no title
+    assert r.test_idx == 0 and not r.has_titles
 
 
 def test_metrics_match_reference():
