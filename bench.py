@@ -77,8 +77,71 @@ def parse():
                          "share the CUs (64 KiB each) and the gate costs 8 %% (3.52 against 3.8 M playlists/s)")
     ap.add_argument("--no-train-row", action="store_true", help="skip the extra training-step row")
     ap.add_argument("--cpu-sample", type=int, default=256, help="playlists the CPU oracle scores")
-    ap.add_argument("--check", action="store_true", help="verify a few rows against the oracle")
+    ap.add_argument("--no-bf16-row", action="store_true", help="skip the extra bf16-decode row (configs[4])")
     return ap.parse_args()
+
+
+def _probe_tensorflow():
+    """a CPU row may be labelled TF only if TensorFlow imports on THIS box at run time."""
+    try:
+        import tensorflow as tf          # noqa: F401
+        return str(getattr(tf, "__version__", "unknown"))
+    except Exception as e:               # ModuleNotFoundError on the images this was built on
+        return None if isinstance(e, ImportError) else "import failed: %r" % (e,)
+
+
+def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k, V, n_steps, n_warm, idx_f32, peaks):
+    """Extra row of the default run (BASELINE.json configs[4]): the same step with the decode GEMM on bf16 operands
+    (v_mfma_f32_32x32x16_bf16, fp32 accumulate; encode, threshold and top-k stay fp32)."""
+    PEAK_BF16_TFLOPS, PEAK_HBM_GBS = peaks
+    prepack(_lib.DAE_DTYPE_BF16)
+    outs, step = step_fn_factory(_lib.DAE_DTYPE_BF16)
+    for _ in range(max(n_warm, 4)):
+        step()
+    torch.cuda.synchronize()
+    for c in ctxs:
+        c.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kms, kn = 0.0, 0
+    for c in ctxs:
+        a, b = c.profile_read()
+        kms += a; kn += b
+        c.profile_enable(False)
+    plan = ctxs[0].last_plan()
+    tiles = plan["n_filter_tiles"] if plan["fused"] else plan["n_tiles"]
+    flop = 2.0 * B * H * tiles * 32
+    w_bytes = tiles * 32 * H * 2
+    alg_bytes = w_bytes + 4 * tiles * 32 + B * H * 2 + 8 * B * k
+    avg = kms / max(kn, 1)
+    tf_ = flop / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+    gbs = alg_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    t_mfma, t_hbm = flop / (PEAK_BF16_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
+    a16, a32 = outs[0][1].cpu().numpy(), idx_f32.cpu().numpy()
+    rprec = {}
+    for R in (10, 100, 500):
+        rprec["R=%d" % R] = round(float(np.mean([met.get_r_precision(a32[r, :R].tolist(), a16[r].tolist())
+                                                  for r in range(a32.shape[0])])), 4)
+    row = {"value": round(B * n_steps / el, 1), "unit": "playlists/s", "ms_per_step": round(el / n_steps * 1e3, 4),
+           "steps": n_steps, "dtype": "bf16 decode GEMM (fp32 accumulate), fp32 encode / threshold / top-k",
+           "roofline": {"kernel": ctxs[0].profile_kernel(),
+                        "bound": "hbm" if t_hbm > t_mfma else "mfma",
+                        "mfma": {"achieved": round(tf_, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf_ / PEAK_BF16_TFLOPS, 4)},
+                        "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(gbs / PEAK_HBM_GBS, 4)},
+                        "flop_per_launch": flop, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg, 4),
+                        "launches": kn,
+                        "note": "%.1f us of matrix time at the bf16 peak, %.1f us to stream the launch's bytes at the "
+                                "HBM peak: the binding roof is the larger" % (t_mfma * 1e6, t_hbm * 1e6)},
+           "r_precision_vs_fp32_lists": rprec,
+           "note": "NOT the headline (the headline is the bit-exact fp32 path).  r-precision: the fp32 path's top-R of "
+                   "the same batch taken as the answers, the bf16 top-500 as the candidates (utils/metrics.py)"}
+    prepack(_lib.DAE_DTYPE_F32)
+    return row
 
 
 def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, b_dec, n_tracks, V, H, B):
@@ -162,7 +225,7 @@ def main():
 
     from spotify_recsys_challenge_2018_amd import _lib
     from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
-    from spotify_recsys_challenge_2018_amd.sharding import exchange_shard_topk, gather_shard_topk, shard_bounds
+    from spotify_recsys_challenge_2018_amd.sharding import HipRankStages, ShardedRanker, shard_bounds
     from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 
     n_tracks, V, H, k = args.n_tracks, args.n_tracks + args.n_artists, args.hidden, args.k
@@ -202,16 +265,20 @@ def main():
     outs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
              torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
     score, idx = outs[0]
+    B_own = B // world                           # rows whose final top-k this rank produces (alltoall)
+    feed = (d_rp, d_col, d_val, d_srp, d_sc)
+    rankers = {}
     if sharded:
-        g_bufs = [(torch.empty((world * B, k), dtype=torch.float32, device=dev),
-                   torch.empty((world * B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
-        l_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
-                   torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
-        x_bufs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
-                   torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
-        B_own = B // world                       # rows whose final top-k this rank produces (alltoall)
-        own = [(torch.empty((B_own, k), dtype=torch.float32, device=dev),
-                torch.empty((B_own, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+        # the product's own sharded-scoring objects (what DAE.shard_scoring builds): one ShardedRanker per batch in
+        # flight and exchange, with preallocated receive buffers
+        for ex in ("alltoall", "allgather"):
+            rankers[ex] = []
+            for c in ctxs:
+                st = HipRankStages(c, d_We, d_be, n_tracks, DT)
+                rows = B if ex == "alltoall" else world * B
+                bufs = (torch.empty((rows, k), dtype=torch.float32, device=dev),
+                        torch.empty((rows, k), dtype=torch.int32, device=dev))
+                rankers[ex].append(ShardedRanker(st.local_topk, st.merge, exchange=ex, bufs=bufs))
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
             c.bind_stream()
@@ -227,7 +294,8 @@ def main():
             c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[1 - i].cuda_event),
                                               ctypes.c_void_p(gate_events[i].cuda_event)))
     step_no = [0]
-    exchange = args.exchange
+    exchange = [args.exchange]
+    last = [None] * n_str                        # (score, idx) of the last batch of each stream
 
     def step():
         s = step_no[0] % n_str
@@ -237,15 +305,9 @@ def main():
             if not sharded:
                 c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[s][0], outs[s][1],
                              dtype=DT)
+                last[s] = outs[s]
             else:
-                c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[s][0],
-                             l_bufs[s][1], out_kind=_lib.DAE_OUT_LOGIT, dtype=DT)
-                if exchange == "alltoall":
-                    x_logit, x_idx = exchange_shard_topk(l_bufs[s][0], l_bufs[s][1], out=x_bufs[s])
-                    c.topk_merge(x_logit, x_idx, own[s][0], own[s][1])
-                else:
-                    g_logit, g_idx = gather_shard_topk(l_bufs[s][0], l_bufs[s][1], out=g_bufs[s])
-                    c.topk_merge(g_logit, g_idx, outs[s][0], outs[s][1])
+                last[s] = rankers[exchange[0]][s].rank_batch(feed, k)
 
     # setup, not warm-up: bring the device to its sustained state (clocks, Infinity Cache holding W) by running
     # the step for a fixed 0.2 s; measured throughput otherwise depends on how short the run is (1.07 M playlists/s
@@ -303,8 +365,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
     if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 256 and not sim:
         try:
-            tj = json.load(open(tpath))
-            traffic = tj.get("bf16" if args.dtype == "bf16" else "f32", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get("bf16" if args.dtype == "bf16" else "f32", {})
+            # PMC passes are separate rocprofv3 runs (scripts/gpu_pmc_traffic.sh); the figure is quoted only when it
+            # was collected for the kernel this run timed
+            traffic = tj.get("hbm_bytes_per_launch") if tj.get("kernel") == ctx.profile_kernel() else None
         except Exception:
             traffic = None
     peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -315,8 +379,7 @@ def main():
     alg_bytes = dom_tiles * 32 * H * esz + 4 * dom_tiles * 32 + B * H * esz + 8 * B * k
     t_mfma = flop_per_launch / (peak_tf * 1e12)
     t_hbm = alg_bytes / (PEAK_HBM_GBS * 1e9)
-    kname = ("decode_bf16_h256_filter_kernel" if args.dtype == "bf16" and H == 256 else
-             "decode_f32_kernel<filter>") if plan["fused"] else "decode_f32_kernel<dense>"
+    kname = ctx.profile_kernel()          # the symbol the event pairs bracketed, as rocprofv3's kernel trace prints it
     achieved_gbs = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
     if t_hbm > t_mfma:
         roofline = {"kernel": kname, "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS,
@@ -342,8 +405,7 @@ def main():
             if not sharded:
                 ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[0][0], outs[0][1], dtype=DT)
             else:
-                ctx.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, l_bufs[0][0], l_bufs[0][1],
-                               out_kind=_lib.DAE_OUT_LOGIT, dtype=DT)
+                rankers[exchange[0]][0].local_topk(feed, k)
         torch.cuda.synchronize()
         iso_ms, iso_n = ctx.profile_read()
         ctx.profile_enable(False)
@@ -370,7 +432,9 @@ def main():
     enc_ms = e0.elapsed_time(e1) / enc_iters
     enc_bytes = col.size * (4 * H + 8) + B * 4 * H          # nnz*(4H+8) + 4H per row
     enc_gbs = enc_bytes / (enc_ms * 1e-3) / 1e9
-    roofline_encode = {"kernel": "encode_kernel", "bound": "hbm", "achieved": round(enc_gbs, 1),
+    enc_kernel = lambda b: ("encode_split_kernel<4>" if b <= 1024 and H % 16 == 0 and H >= 64 else      # noqa: E731
+                            "encode_kernel<1>" if b <= 2048 else "encode_kernel<4>")   # csrc/encode.hip dae_launch_encode
+    roofline_encode = {"kernel": enc_kernel(B), "bound": "hbm", "achieved": round(enc_gbs, 1),
                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(enc_gbs / PEAK_HBM_GBS, 4),
                        "traffic": None, "bytes_per_launch": enc_bytes,
                        "avg_launch_ms": round(enc_ms, 4), "mean_nnz": round(mean_nnz, 1),
@@ -392,13 +456,47 @@ def main():
     torch.cuda.synchronize()
     encL_ms = e0.elapsed_time(e1) / 5
     encL_bytes = colL.size * (4 * H + 8) + Bl * 4 * H
-    roofline_encode["large_batch"] = {"batch": Bl, "bytes_per_launch": encL_bytes,
+    roofline_encode["large_batch"] = {"batch": Bl, "kernel": enc_kernel(Bl), "bytes_per_launch": encL_bytes,
                                       "avg_launch_ms": round(encL_ms, 4),
                                       "achieved": round(encL_bytes / (encL_ms * 1e-3) / 1e9, 1),
                                       "frac": round(encL_bytes / (encL_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                       "note": "at batch %d the step's encode launch is latency-bound (a chain of small "
                                               "dependent loads per row); this is the same gather where bandwidth matters" % B}
     del hL, dL
+    if args.dist != "uniform":
+        # the same gather with UNIFORM ids: no popular rows for L2 / the Infinity Cache to serve, every W_enc row a
+        # playlist names comes from HBM -- this is the row where algorithmic bytes / time IS HBM bandwidth
+        posU, onesU, _ = make_playlists(Bl, n_tracks, args.n_artists, seed=6, dist="uniform")
+        rpU, colU, valU = coo_to_csr(posU, onesU, Bl, V)
+        dU = (up(rpU, torch.int32), up(colU, torch.int32), up(valU, torch.float32))
+        hU = torch.empty((Bl, H), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            ctx.encode(dU[0], dU[1], dU[2], d_We, d_be, hU)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            ctx.encode(dU[0], dU[1], dU[2], d_We, d_be, hU)
+        e1.record()
+        torch.cuda.synchronize()
+        encU_ms = e0.elapsed_time(e1) / 5
+        encU_bytes = colU.size * (4 * H + 8) + Bl * 4 * H
+        roofline_encode["uniform_ids"] = {"batch": Bl, "kernel": enc_kernel(Bl), "bytes_per_launch": encU_bytes, "avg_launch_ms": round(encU_ms, 4),
+                                          "achieved": round(encU_bytes / (encU_ms * 1e-3) / 1e9, 1),
+                                          "frac": round(encU_bytes / (encU_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                          "distinct_rows_bytes": int(np.unique(colU).size) * 4 * H,
+                                          "note": "ids uniform over the vocabulary (worst case for locality)"}
+        del hU, dU
+    tpath_e = os.path.join(ROOT, "profiles", "traffic_encode.json")
+    if os.path.exists(tpath_e):
+        try:                                  # PMC passes of scripts/gpu_pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE per launch)
+            te = json.load(open(tpath_e))
+            roofline_encode["traffic"] = te.get("step_batch", {}).get("hbm_bytes_per_launch")
+            roofline_encode["kernel"] = te.get("step_batch", {}).get("kernel", roofline_encode["kernel"])
+            for key in ("large_batch", "uniform_ids"):
+                if key in roofline_encode and key in te:
+                    roofline_encode[key]["traffic"] = te[key].get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     # the two side measurements above bound context 0 to the default stream: back to its own stream, where step() puts
     # the exchange and the merge of its batches (a context on another stream than its collectives races with them)
     torch.cuda.synchronize()
@@ -428,7 +526,7 @@ def main():
 
     # ---- the exchange as BASELINE.json configs[2] words it: all-gather, every rank merges every row ----------
     if sharded and not sim and args.exchange == "alltoall":
-        exchange = "allgather"
+        exchange[0] = "allgather"
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -448,11 +546,12 @@ def main():
         torch.cuda.synchronize()
         step(); step()
         torch.cuda.synchronize()
-        exchange = "alltoall"
+        ag = [(last[i][0].clone(), last[i][1].clone()) for i in range(n_str)]
+        exchange[0] = "alltoall"
         step(); step()
         torch.cuda.synchronize()
-        agree = bool(torch.equal(outs[0][1][r0_:r0_ + B_own], own[0][1]) and
-                     torch.equal(outs[1 % n_str][1][r0_:r0_ + B_own], own[1 % n_str][1]))
+        agree = bool(all(torch.equal(ag[i][1][r0_:r0_ + B_own], last[i][1]) and
+                         torch.equal(ag[i][0][r0_:r0_ + B_own], last[i][0]) for i in range(n_str)))
         out["allgather_exchange"] = {"value": round(B * args.steps / el_g, 1), "unit": "playlists/s",
                                      "ms_per_step": round(el_g / args.steps * 1e3, 4),
                                      "same_indices_as_alltoall": agree,
@@ -502,7 +601,7 @@ def main():
         # same rows, same model: the two partitionings must agree bit for bit
         step(); step()
         torch.cuda.synchronize()
-        got = own[0] if exchange == "alltoall" else (outs[0][0][r0:r0 + bpg], outs[0][1][r0:r0 + bpg])
+        got = last[0] if exchange[0] == "alltoall" else (last[0][0][r0:r0 + bpg], last[0][1][r0:r0 + bpg])
         same = bool(torch.equal(got[1], lo_out[0][1]) and torch.equal(got[0], lo_out[0][0])) if args.dtype == "f32" else None
         out["playlist_sharded"] = {"value": round(B * args.steps / el_r, 1), "unit": "playlists/s",
                                    "ms_per_step": round(el_r / args.steps * 1e3, 4),
@@ -561,14 +660,19 @@ def main():
         s_ref, i_ref = oracle.score_batch(rp_s, col_s, val_s, W_enc, b_enc, W_dec, b_dec, V, n_tracks,
                                           srp_s, sc_s, k)
         cpu_s = time.perf_counter() - t0
+        tf_ver = _probe_tensorflow()
+        tf_label = ("TensorFlow not importable on this box (probed at run time): this is the CPU restatement, not TF1"
+                    if tf_ver is None else
+                    "tensorflow %s imports here, but the reference graph needs the TF1 API (tf.contrib, "
+                    "tf.placeholder): this is the CPU restatement, not TF1" % tf_ver)
         ok = bool(np.array_equal(idx[rows].cpu().numpy(), i_ref) and
                   np.array_equal(score[rows].cpu().numpy().view(np.uint32), s_ref.view(np.uint32)))
         out["cpu_baseline"] = {"value": round(ns / cpu_s, 2), "unit": "playlists/s", "cores": 1,
                                "kind": "port",
                                "sample": "%d playlists of the same batch, oracle/dae_oracle.c "
-                                         "orc_score_batch (encode+decode %d cols+top-%d), %.1f s; "
-                                         "TensorFlow unavailable: this is the CPU restatement, not TF1"
-                                         % (ns, V, k, cpu_s),
+                                         "orc_score_batch (encode+decode %d cols+top-%d), %.1f s; %s"
+                                         % (ns, V, k, cpu_s, tf_label),
+                               "tensorflow": tf_ver,
                                "host_cpus": os.cpu_count(), "gpu_matches_oracle_bitwise": ok}
         # the reference's own DENSE formulation on all host cores: multi-hot matrix x W_enc,
         # h x W_dec^T through the BLAS numpy links, then the literal argsort + list.remove + [:500] per row
@@ -599,8 +703,42 @@ def main():
                         "ties by numpy's argsort order; overlap is of index SETS"}
         except Exception as e:                      # never let the extra row break the contract line
             out["cpu_baseline"]["dense_numpy"] = {"error": repr(e)}
-    elif args.check and rank == 0:
-        pass
+
+    # ---- bf16 decode (BASELINE.json configs[4]) as an extra row of the default run ---------------------------
+    if not sharded and args.dtype == "f32" and not args.no_bf16_row:
+        try:
+            from spotify_recsys_challenge_2018_amd.utils import metrics as met
+            step(); step()
+            torch.cuda.synchronize()
+            idx_f32 = outs[0][1].clone()
+            for c in ctxs:                                  # the bf16 launch runs ungated (two share a CU)
+                c.check(c.lib.dae_set_decode_gate(c.h, None, None))
+
+            def prepack_all(dt):
+                for c in ctxs:
+                    c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
+                torch.cuda.synchronize()
+
+            def factory(dt):
+                o16 = [(torch.empty((B, k), dtype=torch.float32, device=dev),
+                        torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+                cnt = [0]
+
+                def st():
+                    s_ = cnt[0] % n_str
+                    cnt[0] += 1
+                    with torch.cuda.stream(streams[s_]):
+                        ctxs[s_].score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, o16[s_][0],
+                                            o16[s_][1], dtype=dt)
+                return o16, st
+            out["bf16_decode"] = _bf16_row(torch, _lib, met, ctxs, streams, factory, prepack_all, B, H, k, V,
+                                           args.steps, args.warmup, idx_f32, (PEAK_BF16_TFLOPS, PEAK_HBM_GBS))
+            if gate_events:
+                for i, c in enumerate(ctxs):
+                    c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[1 - i].cuda_event),
+                                                      ctypes.c_void_p(gate_events[i].cuda_event)))
+        except Exception as e:                              # the row is an extra: never lose the headline over it
+            out["bf16_decode"] = {"error": repr(e)}
 
     # ---- the training step that produces these weights (BASELINE.json configs[3]), NOT part of `value` --------------
     # forward with dropout + weighted-BCE loss + backward + dense TF1-Adam on all four variables, same V / H / batch;

@@ -71,6 +71,8 @@ size_t dae_scratch_bytes(const dae_ctx* ctx);
  * synchronises those events and returns total milliseconds and the launch count, then resets. */
 int dae_profile_enable(dae_ctx* ctx, int on);
 int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches);
+/* Symbol (as rocprofv3's kernel trace prints it) of the kernel the last event pair bracketed; "" before the first. */
+const char* dae_profile_kernel(const dae_ctx* ctx);
 
 /* Geometry of the last dae_decode_topk issued from the calling thread, for roofline accounting:
  * {R_TILE, n_row_groups, blocks_per_row_group, sample_stride S, n_sample_tiles (phase A),

@@ -14,7 +14,7 @@ DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
 # every symbol include/dae_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
-    "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_last_plan",
+    "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_last_plan",
     "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
@@ -56,6 +56,8 @@ def load():
     lib.dae_scratch_bytes.restype = ctypes.c_size_t
     lib.dae_profile_enable.argtypes = [vp, c_int]
     lib.dae_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
+    lib.dae_profile_kernel.argtypes = [vp]
+    lib.dae_profile_kernel.restype = ctypes.c_char_p
     lib.dae_last_plan.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.dae_coo_to_csr.argtypes = [vp, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
@@ -92,7 +94,7 @@ def load():
     lib.dae_arm_decoder_adam.argtypes = [vp, vp, vp, c_f, c_f, c_f, c_f, c_int]
     lib.dae_set_decode_gate.argtypes = [vp, vp, vp]
     for name in EXPORTS:
-        if name not in ("dae_last_error", "dae_scratch_bytes"):
+        if name not in ("dae_last_error", "dae_scratch_bytes", "dae_profile_kernel"):
             getattr(lib, name).restype = c_int
     _lib = lib
     return lib
@@ -221,6 +223,10 @@ class Context:
         n = ctypes.c_int()
         self.check(self.lib.dae_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def profile_kernel(self):
+        """Symbol of the kernel the last profiled launch ran (what rocprofv3's kernel trace calls it)."""
+        return self.lib.dae_profile_kernel(self.h).decode()
 
     def last_plan(self):
         arr = (ctypes.c_int32 * 8)()

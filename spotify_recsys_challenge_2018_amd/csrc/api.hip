@@ -181,6 +181,8 @@ int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches)
     return DAE_OK;
 }
 
+const char* dae_profile_kernel(const dae_ctx* ctx) { return ctx ? ctx->prof_kernel.c_str() : ""; }
+
 /* geometry of the last dae_decode_topk on this thread:
  * {R_TILE, n_rg, nb_rg, S, n_sample_tiles, n_filter_tiles, fused(0/1), ntiles} */
 int dae_last_plan(int32_t out[8])

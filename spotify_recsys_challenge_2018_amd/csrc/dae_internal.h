@@ -81,6 +81,7 @@ struct dae_ctx {
     std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
     size_t prof_used = 0;
     bool prof_armed = false;           // the next decode launch takes prof_ev[prof_used], [prof_used+1]
+    std::string prof_kernel;           // symbol of the kernel the last armed pair bracketed (dae_profile_kernel)
 };
 
 extern thread_local std::string g_dae_create_err;

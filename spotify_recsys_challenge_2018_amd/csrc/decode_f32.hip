@@ -1300,6 +1300,9 @@ int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
                               ctx->stream, ctx->prof_ev[ctx->prof_used], ctx->prof_ev[ctx->prof_used + 1], 0, p);
         ctx->prof_armed = false;
         ctx->prof_used += 2;
+        char name[96];
+        snprintf(name, sizeof(name), "decode_f32_kernel<%d, %d, %d, %d, %d>", RB, EPI, GT, NW, DT);
+        ctx->prof_kernel = name;
     } else {
         hipLaunchKernelGGL((decode_f32_kernel<RB, EPI, GT, NW, DT>), dim3(g.grid), dim3(NW * 64), lds,
                            ctx->stream, p);
@@ -1641,6 +1644,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
             e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
             ctx->prof_armed = false;
             ctx->prof_used += 2;
+            ctx->prof_kernel = "decode_f32_h256_filter_kernel<0>";
         }
         hipExtLaunchKernelGGL(decode_f32_h256_filter_kernel<0>, dim3(g.grid), dim3(256), lds, ctx->stream, e0, e1, 0, p);
         DAE_CHECK_LAUNCH(ctx, "decode_f32_h256_filter_kernel");
@@ -1662,6 +1666,9 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
             e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
             ctx->prof_armed = false;
             ctx->prof_used += 2;
+            ctx->prof_kernel = g.R_TILE == 256 ? "decode_bf16_h256_filter_kernel<1, 8, 16, 4>"
+                             : bf16_pair_variant() ? "decode_bf16_h256_filter_kernel<2, 4, 16, 4>"
+                                                   : "decode_bf16_h256_filter_kernel<1, 4, 8, 8>";
         }
         if (g.R_TILE == 256)
             hipExtLaunchKernelGGL((decode_bf16_h256_filter_kernel<1, 8, 16, 4>), dim3(g.grid), dim3(256), lds,

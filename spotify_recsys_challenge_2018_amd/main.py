@@ -7,7 +7,7 @@ the same config.ini schema:
     [DAE] epochs batch lr reg_lambda hidden test_seed update_seed keep_prob input_kp firstN_range initval save
     [PRETRAIN] epochs batch lr reg_lambda save
     [TITLE] ... (parsed for compatibility; the title models are outside the scoring path)
-    [CHALLENGE] batch challenge_data result
+    [CHALLENGE] batch challenge_data result   (+ optional, this build only: allow_no_title, shard_exchange)
 
 Kept on purpose: `[DAE]` is always read first, so --pretrain inherits hidden / keep_prob /
 input_kp / firstN_range / test_seed from it (main.py:121, load-bearing per SURVEY App. A).
@@ -128,7 +128,17 @@ class Conf:
 
     def set_challenge_oonf(self):          # (sic) the reference's spelling, main.py:88
         os.makedirs(self.result_dir, exist_ok=True)
-        self._load('CHALLENGE')
+        sec = self._load('CHALLENGE')
+        # two OPTIONAL [CHALLENGE] keys this build adds (absent from the reference's files):
+        #   allow_no_title = True        score with the plain DAE when <[TITLE] save>.pkl is missing (default: error)
+        #   shard_exchange = allgather | alltoall    under torch.distributed.run: how the per-shard top-500 meet
+        if 'allow_no_title' in sec:
+            self.allow_no_title = _truth(sec['allow_no_title'])
+        if 'shard_exchange' in sec:
+            val = sec['shard_exchange'].strip().lower()
+            if val not in ('allgather', 'alltoall'):
+                raise ValueError("[CHALLENGE] shard_exchange must be allgather or alltoall, not %r" % val)
+            self.shard_exchange = val
 
     set_challenge_conf = set_challenge_oonf
 

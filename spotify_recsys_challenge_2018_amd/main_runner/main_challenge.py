@@ -17,18 +17,40 @@ import datetime
 import os
 import pickle
 
-from ..models.DAEs import DAE, DAE_title
-from ..models.title_models import get_model
 from ..utils.data_reader import data_reader_challenge
 
 
 def log_write(conf, log):
-    """main_challenge.py:17-23."""
+    """main_challenge.py:17-23 (rank 0 only under torch.distributed.run)."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
     with open(os.path.join(conf.dir, 'log.txt'), "a") as f:
         f.write(log)
         f.write('\n')
     if conf.verbose:
         print(log)
+
+
+def _init_distributed(conf):
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the env): the RCCL
+    process group (backend "nccl"; DAE_DIST_BACKEND=gloo rehearses the flow on CPU or with several ranks on one
+    GPU) and this rank's device.  Returns (rank, world).  BASELINE.json configs[2]: the vocabulary columns are
+    sharded over the ranks, every rank reads the same challenge file and feeds the same batches."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    backend = os.environ.get("DAE_DIST_BACKEND", "nccl")
+    if torch.cuda.is_available():
+        n_dev = torch.cuda.device_count()
+        conf.device_index = int(os.environ.get("LOCAL_RANK", rank)) % max(n_dev, 1) if backend == "gloo" \
+            else int(os.environ.get("LOCAL_RANK", rank))
+        torch.cuda.set_device(conf.device_index)
+    if not dist.is_initialized():
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
 
 
 def cand_to_uris(cand_idx, id2uri):
@@ -37,6 +59,9 @@ def cand_to_uris(cand_idx, id2uri):
 
 
 def run(conf, model=None):
+    """`model`: None -> built from conf (DAE / DAE_title on the GPU); tests pass their own object with the same
+    `recommend` / `shard_scoring` / `owned_rows` protocol."""
+    rank, world = _init_distributed(conf)
     reader = data_reader_challenge(data_dir=conf.data_dir, filename=conf.challenge_data,
                                    batch_size=conf.batch)
     conf.n_tracks = reader.num_tracks                      # main_challenge.py:49-53
@@ -50,7 +75,10 @@ def run(conf, model=None):
     log_write(conf, '[challenge mode] start at ' + str(datetime.datetime.now()))
 
     use_titles = False
+    exchange = getattr(conf, 'shard_exchange', 'allgather')
     if model is None:
+        from ..models.DAEs import DAE, DAE_title
+        from ..models.title_models import get_model
         conf.initval = getattr(conf, 'DAEval', conf.initval)   # weights the TITLE stage froze
         title_pkl = str(getattr(conf, 'title_save', '')) + '.pkl'
         if getattr(conf, 'char_model', None) == 'Char_CNN' and os.path.exists(title_pkl):
@@ -61,26 +89,69 @@ def run(conf, model=None):
             use_titles = True
             log_write(conf, 'title scorer: ' + title_pkl)
         else:
+            # The reference fails here (saver.restore of a missing checkpoint, main_challenge.py:68-69).  A silent
+            # plain-DAE run would turn a mistyped path into a submission without title mixing -- and on playlists
+            # without seed tracks every row would get the same popularity ranking -- so it needs an explicit opt-in:
+            # optional key of this build, [CHALLENGE] allow_no_title = True.
+            seedless = sum(1 for p in reader.playlists if not p[0] and not p[1])
+            if not getattr(conf, 'allow_no_title', False) or seedless:
+                raise FileNotFoundError(
+                    "title variables %s not found (train them with --title)%s; set [CHALLENGE] allow_no_title = True "
+                    "to score with the plain DAE (titles_use = 0)" % (
+                        title_pkl, "; %d playlists of %s have no seeds and can only be ranked by title"
+                        % (seedless, conf.challenge_data) if seedless else ""))
             model = DAE(conf)
-            log_write(conf, 'no title variables at %s: plain DAE (titles_use = 0)' % title_pkl)
+            log_write(conf, 'no title variables at %s: plain DAE (titles_use = 0), allow_no_title is set' % title_pkl)
+        sharded = world > 1 and not use_titles
+        if sharded:
+            # optional key of this build, [CHALLENGE] shard_exchange = allgather (default; configs[2] as written:
+            # every rank ends with every row) | alltoall (every rank ends with the rows it owns)
+            model.shard_scoring(rank, world, exchange=exchange)
         model.fit()
     else:
-        use_titles = isinstance(model, DAE_title)
+        use_titles = bool(getattr(model, 'title_model', None))
+        sharded = world > 1 and not use_titles
+        if sharded:
+            model.shard_scoring(rank, world, exchange=exchange)
+    if sharded:
+        log_write(conf, 'vocabulary columns sharded over %d ranks (%s exchange of the per-shard top-500)'
+                  % (world, exchange))
+    elif world > 1:
+        # title-mixed scores are not vocabulary-sharded: the batches are dealt round-robin to the ranks instead
+        # (whole model on every GPU, no collective in the data path)
+        log_write(conf, 'title model: batches partitioned over %d ranks' % world)
 
-    total_cands = []
+    cands = []                  # (position in the file, [pid, uris...]) of the rows THIS rank holds results for
+    n_seen, n_batches = 0, 0
     while True:
         x_positions, seed, titles, titles_exist, pid, x_ones = reader.next_batch()
-        if use_titles:
+        mine = sharded or world == 1 or n_batches % world == rank
+        if mine and use_titles:
             idx, _score = model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed), titles=titles,
                                           titles_use=[t[0] for t in titles_exist])
-        else:
+        elif mine:
             idx, _score = model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed))
-        for i in range(len(seed)):
-            total_cands.append([pid[i]] + cand_to_uris(idx[i], reader.id2uri))
+        if mine and not (sharded and exchange == 'allgather' and rank != 0):   # all-gather: rank 0 formats and writes
+            r0, _r1 = model.owned_rows() if sharded else (0, len(seed))
+            for j in range(len(idx)):                       # rows r0 .. of the batch (all of them unless alltoall)
+                i = r0 + j
+                cands.append((n_seen + i, [pid[i]] + cand_to_uris(idx[j], reader.id2uri)))
+        n_seen += len(seed)
+        n_batches += 1
         if reader.ch_idx == 0:
             break
 
-    with open(conf.result, 'wb') as f:                     # main_challenge.py:95-96
-        pickle.dump(total_cands, f)
-    log_write(conf, 'wrote %d playlists to %s' % (len(total_cands), conf.result))
+    if world > 1:
+        import torch.distributed as dist
+        if not (sharded and exchange == 'allgather'):
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(cands, parts, dst=0)         # every rank's rows -> rank 0, back in file order
+            if rank == 0:
+                cands = sorted((c for part in parts for c in part), key=lambda c: c[0])
+        dist.barrier()
+    total_cands = [c for _pos, c in cands]
+    if rank == 0:
+        with open(conf.result, 'wb') as f:                 # main_challenge.py:95-96
+            pickle.dump(total_cands, f)
+        log_write(conf, 'wrote %d playlists to %s' % (len(total_cands), conf.result))
     return total_cands

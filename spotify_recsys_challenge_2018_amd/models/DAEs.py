@@ -134,6 +134,7 @@ class DAE_tied:
         self._adam = None
         self._step = 0
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+        self._packed_cols = {}
         # decode arithmetic of recommend(): "f32" (bit-exact path) or "bf16" (BASELINE configs[4])
         self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
             else _lib.DAE_DTYPE_F32
@@ -156,6 +157,7 @@ class DAE_tied:
         self._csr_status = None
         self._sharded = None          # sharding.ShardedTrainer when training is row-sharded over ranks
         self._params_stale = False
+        self._score_shard = None      # shard_scoring(): this rank's vocabulary columns + the ShardedRanker
 
     # -- parameters ---------------------------------------------------------------------------------
     def _xavier(self, rng, shape):
@@ -263,7 +265,49 @@ class DAE_tied:
     check_feed = _check_feed
 
     def _mark_dirty(self):
+        """The packed decoder images of the context no longer hold the current weights."""
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+        self._packed_cols = {}
+
+    # -- multi-GPU scoring (SURVEY.md 8e; BASELINE.json configs[2]): vocabulary columns sharded over the ranks ----
+    def shard_scoring(self, rank, world, group=None, exchange="allgather"):
+        """`recommend` through sharding.ShardedRanker: this rank decodes and ranks only the vocabulary columns
+        `shard_bounds(n_input, world, rank)` (W_enc is replicated, so every rank computes the same hidden
+        activations with no collective), the per-shard top-k lists meet in ONE exchange (RCCL all-gather, or an
+        all-to-all of the rows each rank owns) and are merged with the same key -- exact, since a shard's top-k
+        holds its share of the global top-k.  Every rank feeds the same batches.
+
+        exchange = "allgather": `recommend` returns all rows on every rank (main_challenge: rank 0 writes).
+        exchange = "alltoall":  `recommend` returns the rows this rank owns (`owned_rows()`); n_batch is rounded
+        up to a multiple of the world size (the extra rows are empty)."""
+        from ..sharding import shard_bounds
+        if exchange not in ("allgather", "alltoall"):
+            raise ValueError("unknown exchange %r" % (exchange,))
+        if exchange == "alltoall" and self.n_batch % world:
+            if self.ctx is not None:
+                raise _lib.DaeError("shard_scoring(alltoall) must round n_batch up before fit()")
+            self.n_batch += world - self.n_batch % world
+        lo, hi = shard_bounds(self.n_input, world, rank)
+        self._score_shard = {"rank": int(rank), "world": int(world), "group": group, "exchange": exchange,
+                             "cols": (lo, hi), "rankers": {}}
+        self._mark_dirty()
+
+    def owned_rows(self):
+        """Rows of a batch whose final top-k `recommend` returns on this rank: all of them, except under
+        shard_scoring(exchange="alltoall")."""
+        sh = self._score_shard
+        if sh is None or sh["exchange"] != "alltoall":
+            return 0, self.n_batch
+        from ..sharding import row_owner_bounds
+        return row_owner_bounds(self.n_batch, sh["world"], sh["rank"])
+
+    def _shard_ranker(self, dtype):
+        sh = self._score_shard
+        if dtype not in sh["rankers"]:
+            from ..sharding import HipRankStages, ShardedRanker
+            st = HipRankStages(self.ctx, self.weights["encoder_h"], self.biases["encoder_b"], self.n_tracks, dtype)
+            sh["rankers"][dtype] = ShardedRanker(st.local_topk, st.merge, group=sh["group"], exchange=sh["exchange"])
+        return sh["rankers"][dtype]
 
     # -- multi-GPU training (SURVEY.md 8e): rows of W_enc / W_dec / b_dec sharded over the ranks ---------
     def shard_training(self, rank, world, group=None):
@@ -307,13 +351,17 @@ class DAE_tied:
         self._params_stale = False
         self._mark_dirty()
 
-    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
+    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32, cols=None):
+        """The context's packed decoder image of `dtype` holds columns `cols` (default: all) of the current
+        weights.  (A context keeps one image per dtype: a sharded `recommend` and a dense `predict` on the same
+        model re-tile when they alternate -- 0.13 ms.)"""
         self.sync_params()
-        if self._packed_dirty[dtype]:
+        cols = (0, self.n_input) if cols is None else (int(cols[0]), int(cols[1]))
+        if self._packed_dirty[dtype] or self._packed_cols.get(dtype) != cols:
             self.ctx.bind_stream()
-            self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0,
-                                     self.n_input, dtype)
+            self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], cols[0], cols[1], dtype)
             self._packed_dirty[dtype] = False
+            self._packed_cols[dtype] = cols
 
     def encode(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
         """DAEs.py:40-42 + :64-70 -> hidden [n_batch, n_hidden] (torch CUDA tensor)."""
@@ -345,7 +393,8 @@ class DAE_tied:
         import torch
         dtype = self.decode_dtype if dtype is None else (
             _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
-        self._ensure_packed(dtype)
+        sh = self._score_shard
+        self._ensure_packed(dtype, None if sh is None else sh["cols"])
         self.ctx.bind_stream()
         dev = self.weights["encoder_h"].device
         rp, c, v = self._upload_csr(x_positions, x_ones)
@@ -353,11 +402,19 @@ class DAE_tied:
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
         d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
+        n_rows = self.n_batch if n_rows is None else n_rows
+        if sh is not None:
+            # vocabulary-sharded: local top-k over this rank's columns, one exchange, merge (sharding.ShardedRanker)
+            score, idx = self._shard_ranker(dtype).rank_batch((rp, c, v, d_srp, d_sc), k)
+            r0, r1 = self.owned_rows()
+            n_own = max(0, min(r1, n_rows) - r0)
+            res = idx[:n_own].cpu().numpy(), score[:n_own].cpu().numpy()
+            self._check_feed()
+            return res
         score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
         idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
         self.ctx.score_topk(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"],
                             self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
-        n_rows = self.n_batch if n_rows is None else n_rows
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
         self._check_feed()
         return res
@@ -607,6 +664,9 @@ class DAE_title(DAE):
         if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
             return DAE.recommend(self, x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
         import torch
+        if self._score_shard is not None:
+            raise _lib.DaeError("title-mixed batches are not vocabulary-sharded: run --challenge with titles on one "
+                                "GPU per process group (playlist partitioning), or without the title variables")
         y = self.mixed_scores(x_positions, x_ones, titles, titles_use)
         srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
         if sc.size == 0:

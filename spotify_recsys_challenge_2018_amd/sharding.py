@@ -85,32 +85,82 @@ def exchange_shard_topk(local_logit, local_idx, group=None, out=None):
 
 
 class ShardedRanker:
-    """decode + top-k over this rank's vocabulary shard, exchange, merge.
+    """decode + top-k over this rank's vocabulary shard, exchange, merge -- the N > 1 form of
+    main_challenge.py:80-90 (one batch) that `DAE.shard_scoring` and bench.py both run.
 
-    `local_topk(h, k) -> (logit [B,k], idx [B,k])` and `merge(g_logit, g_idx) -> (score, idx)` are
-    the two device operations (libdae_hip: dae_decode_topk with DAE_OUT_LOGIT and dae_topk_merge);
-    they are injected so the exchange logic is testable with gloo on CPU.
+    `local_topk(feed, k) -> (logit [B,k], idx [B,k])` and `merge(g_logit, g_idx) -> (score, idx)` are
+    the two device operations (HipRankStages below: dae_score_topk / dae_decode_topk with DAE_OUT_LOGIT
+    over the rank's prepacked columns, and dae_topk_merge); they are injected so the exchange logic is
+    testable with gloo on CPU.  `feed` is whatever local_topk takes (the batch's device CSR + seeds, or
+    hidden activations).
 
     exchange = "allgather": every rank ends with the merged top-k of ALL B rows (BASELINE.json configs[2] as
     written).  exchange = "alltoall": every rank ends with the merged top-k of the rows it owns
     (`row_owner_bounds`) -- 1/G of the exchange bytes and of the merge work; the job's output is the
-    concatenation over ranks."""
+    concatenation over ranks.
 
-    def __init__(self, local_topk, merge, group=None, exchange="allgather"):
+    bufs: optional preallocated (logit, idx) receive buffers of the exchange ([G*B,k] for the all-gather, [B,k]
+    for the all-to-all), reused by every call.  gather: optional replacement of the collective,
+    `gather(l_logit, l_idx) -> (g_logit [G,rows,k], g_idx)` (single-process tests that hold every shard)."""
+
+    def __init__(self, local_topk, merge, group=None, exchange="allgather", bufs=None, gather=None):
         if exchange not in ("allgather", "alltoall"):
             raise ValueError("unknown exchange %r" % (exchange,))
         self.local_topk = local_topk
         self.merge = merge
         self.group = group
         self.exchange = exchange
+        self.bufs = bufs
+        self.gather = gather
 
-    def rank_batch(self, h, k):
-        l_logit, l_idx = self.local_topk(h, k)
-        if self.exchange == "alltoall":
-            g_logit, g_idx = exchange_shard_topk(l_logit, l_idx, self.group)
+    def rank_batch(self, feed, k):
+        l_logit, l_idx = self.local_topk(feed, k)
+        if self.gather is not None:
+            g_logit, g_idx = self.gather(l_logit, l_idx)
+        elif self.exchange == "alltoall":
+            g_logit, g_idx = exchange_shard_topk(l_logit, l_idx, self.group, out=self.bufs)
         else:
-            g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group)
+            g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group, out=self.bufs)
         return self.merge(g_logit, g_idx)
+
+
+class HipRankStages:
+    """The two device stages of vocabulary-sharded scoring through the C ABI (include/dae_hip.h), on the context
+    whose prepacked decoder image holds this rank's columns [lo, hi):
+
+      local_topk   dae_score_topk(DAE_OUT_LOGIT): encode (W_enc is replicated: every rank computes the same hidden
+                   activations, no collective) -> decode + top-k over the shard; GLOBAL column ids come back
+      merge        dae_topk_merge: G lists per row -> the global top-k, same (logit desc, column asc) key
+
+    feed = (row_ptr, col, val, seed_row_ptr, seed_col) device tensors of the WHOLE batch.  Output tensors are
+    allocated once per (rows, k) and reused."""
+
+    def __init__(self, ctx, W_enc, b_enc, n_tracks, dtype=0, out_kind=0):
+        self.ctx, self.W_enc, self.b_enc = ctx, W_enc, b_enc
+        self.n_tracks, self.dtype, self.out_kind = int(n_tracks), int(dtype), int(out_kind)
+        self._loc, self._out = {}, {}
+
+    def _pair(self, cache, rows, k):
+        import torch
+        key = (int(rows), int(k))
+        if key not in cache:
+            dev = self.W_enc.device
+            cache[key] = (torch.empty(key, dtype=torch.float32, device=dev),
+                          torch.empty(key, dtype=torch.int32, device=dev))
+        return cache[key]
+
+    def local_topk(self, feed, k):
+        from ._lib import DAE_OUT_LOGIT
+        rp, col, val, srp, sc = feed
+        logit, idx = self._pair(self._loc, rp.numel() - 1, k)
+        self.ctx.score_topk(rp, col, val, self.W_enc, self.b_enc, self.n_tracks, srp, sc, k, logit, idx,
+                            out_kind=DAE_OUT_LOGIT, dtype=self.dtype)
+        return logit, idx
+
+    def merge(self, g_logit, g_idx):
+        score, idx = self._pair(self._out, g_logit.shape[1], g_logit.shape[2])
+        self.ctx.topk_merge(g_logit, g_idx, score, idx, out_kind=self.out_kind)
+        return score, idx
 
 
 # ---- training: vocabulary rows sharded, two all-reduces per step (SURVEY.md 8e) ------------------

@@ -80,9 +80,15 @@ def test_bf16_fused_topk_equals_unfused_and_tracks_fp32(ctx):
     assert np.max(np.abs(s16.cpu().numpy()[:, 0] - s32.cpu().numpy()[:, 0])) < 5e-3
 
 
-def test_bf16_vs_fp32_r_precision_on_trained_model(tmp_path, capsys):
-    """configs[4]: r-precision@500 of bf16 decode within 0.02 of fp32 on a trained model (golden
-    mini dataset, 3 epochs of --pretrain on the GPU)."""
+SPLITS = ("test-0", "test-1", "test-5", "test-25r")        # readme.md:69 seed patterns BASELINE.json configs[4] names
+RPREC_TOL = 0.02                                             # stated tolerance of configs[4]
+
+
+def test_bf16_vs_fp32_r_precision_on_trained_model_per_split(tmp_path, capsys):
+    """configs[4]: r-precision@500 of the bf16 decode within 0.02 of fp32 on EACH of the seed-0/1/5/25r test splits
+    (golden mini dataset: splits written by the repaired generator from a held-out slice; 3 epochs of --pretrain on
+    the GPU).  The 0-seed split feeds all-zero rows: h = sigmoid(b_enc), a pure popularity ranking."""
+    import json
     import random
     from spotify_recsys_challenge_2018_amd import main as cli
     from spotify_recsys_challenge_2018_amd.main_runner import main_train
@@ -96,20 +102,76 @@ def test_bf16_vs_fp32_r_precision_on_trained_model(tmp_path, capsys):
         random.seed(1); np.random.seed(1)
         assert cli.main(["--dir", "run", "--pretrain"]) == 0
         conf = cli.load_conf("./run"); conf.set_dae_conf(); conf.initval = conf.save = str(work / "w_pretrain")
-        conf.n_tracks, conf.n_input = None, None
-        rd = data_reader_test("./data", "test-5", conf.batch, 1000)
-        import json
         tr = json.load(open("./data/train"))
         conf.n_tracks = len(tr["track_uri2id"]); conf.n_input = conf.n_tracks + len(tr["artist_uri2id"])
-        res = {}
+        models = {}
         for name in ("f32", "bf16"):
             conf.decode_dtype = name
-            m = DAE(conf); m.fit()
-            res[name] = main_train.eval(rd, conf, m)
-        assert res["f32"] > 0.05                       # the model learnt something
-        assert abs(res["f32"] - res["bf16"]) <= 0.02, res
+            models[name] = DAE(conf); models[name].fit()
+        res = {}
+        for split in SPLITS:
+            rd = data_reader_test("./data", split, conf.batch, 1000)
+            assert len(rd.playlists) >= 8
+            if split == "test-0":
+                assert all(len(p[0]) == 0 for p in rd.playlists)
+            res[split] = {name: main_train.eval(rd, conf, m) for name, m in models.items()}
+        assert res["test-5"]["f32"] > 0.05 and res["test-25r"]["f32"] > 0.05          # the model learnt something
+        assert res["test-0"]["f32"] > 0.0                                              # popularity alone hits
+        for split in SPLITS:
+            assert abs(res[split]["f32"] - res[split]["bf16"]) <= RPREC_TOL, (split, res)
     finally:
         os.chdir(cwd)
+
+
+def test_bf16_vs_fp32_r_precision_full_vocabulary_per_seed_pattern(ctx):
+    """The same tolerance at BASELINE's full size (|vocab| = 170 000, hidden 256, 256 rows per split) on SYNTHETIC
+    splits of the four seed patterns -- real splits need the MPD, which is licence-gated.  Inputs are what
+    data_reader_test feeds: the seed TRACKS with weight 1 (none for seed-0: every row is the popularity ranking).
+    Answers per row: 40 tracks drawn from the fp32 path's top-500 plus 20 tracks it does not rank (misses), so that
+    fp32 r-precision sits where a trained model's does; bf16 must stay within 0.02 on every split."""
+    import torch
+    V, nt, H, B, k = 170000, 140000, 256, 256, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    d_We, d_be, d_Wd, d_bd = _dev(W_enc), _dev(b_enc), _dev(W_dec), _dev(b_dec)
+    ctx.prepack_decoder(d_Wd, d_bd, dtype=BF)
+    ctx.prepack_decoder(d_Wd, d_bd, dtype=_lib.DAE_DTYPE_F32)
+    rng = np.random.default_rng(2018)
+    out = {}
+    for n_seed, label in ((0, "seed-0"), (1, "seed-1"), (5, "seed-5"), (25, "seed-25r")):
+        seeds = []
+        for r in range(B):
+            ids = np.minimum(nt - 1, np.floor(np.exp(rng.random(n_seed * 2) * np.log(nt))).astype(np.int64) - 1).clip(0)
+            ids = list(dict.fromkeys(ids.tolist()))[:n_seed]
+            if label.endswith("r"):
+                rng.shuffle(ids)
+            seeds.append(ids)
+        rows = np.repeat(np.arange(B), [len(s_) for s_ in seeds])
+        pos = np.stack([rows, np.array([t for s_ in seeds for t in s_], np.int64)], 1) if n_seed else np.zeros((0, 2), np.int64)
+        rp, col, val = coo_to_csr(pos, np.ones(len(pos), np.float32), B, V)
+        srp, sc = seeds_to_csr(seeds, B, nt)
+        d = [_dev(a) for a in (rp, col if col.size else np.zeros(1, np.int32), val if val.size else np.zeros(1, np.float32),
+                               srp, sc if sc.size else np.zeros(1, np.int32))]
+        lists = {}
+        for name, dt in (("f32", _lib.DAE_DTYPE_F32), ("bf16", BF)):
+            s_ = torch.empty((B, k), device="cuda"); i_ = torch.empty((B, k), dtype=torch.int32, device="cuda")
+            ctx.score_topk(d[0], d[1], d[2], d_We, d_be, nt, d[3], d[4], k, s_, i_, dtype=dt)
+            assert ctx.last_plan()["fused"] == 1
+            lists[name] = i_.cpu().numpy()
+        if n_seed == 0:
+            assert np.all(lists["f32"] == lists["f32"][0])                    # identical rows: pure popularity
+        rp_ = {"f32": 0.0, "bf16": 0.0}
+        for r in range(B):
+            top = lists["f32"][r]
+            hits = rng.choice(top, size=40, replace=False).tolist()
+            misses = [int(t) for t in rng.integers(0, nt, 40) if t not in set(top.tolist()) and t not in seeds[r]][:20]
+            answers = hits + misses
+            rng.shuffle(answers)
+            for name in rp_:
+                rp_[name] += met.eval_topk(lists[name][r], answers) / B
+        out[label] = rp_
+        assert 0.02 < rp_["f32"] < 0.6, (label, rp_)
+        assert abs(rp_["f32"] - rp_["bf16"]) <= RPREC_TOL, (label, rp_)
+    print("full-size r-precision fp32 vs bf16 per seed pattern:", out)
 
 
 @pytest.mark.parametrize("V,nt,B,k", [(40000, 33000, 1, 500), (40037, 39990, 37, 500), (52000, 52000, 129, 100),

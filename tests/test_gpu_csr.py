@@ -1,9 +1,13 @@
 """GPU (-m gpu): the device feed builder dae_coo_to_csr (csrc/csr.hip; reference DAEs.py:33-35 scatter
-semantics) against the numpy restatement models.DAEs.coo_to_csr -- integer work,
-so the bar is entry-for-entry equality."""
+semantics).  Checked against the ORACLE: the dense matrix rebuilt from the device CSR must
+equal oracle.dae_numpy.sparse_to_dense -- the literal restatement of tf.sparse_tensor_to_dense's assignment --
+element for element on the same feeds; and, as a second view, entry-for-entry against the product's host-side
+builder models.DAEs.coo_to_csr (the `device_csr = False` path), which pins the CSR FORM (columns ascending, one
+entry per cell, zeros dropped).  Integer / copy work: the bar is equality."""
 import numpy as np
 import pytest
 
+from oracle import dae_numpy as dn
 from spotify_recsys_challenge_2018_amd import _lib
 from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr
 
@@ -27,6 +31,22 @@ def _run(ctx, pos, vals, B, V):
     return rp, c.cpu().numpy()[:n], v.cpu().numpy()[:n], int(st.item())
 
 
+def _dense(rp, c, v, B, V):
+    x = np.zeros((B, V), np.float32)
+    x[np.repeat(np.arange(B), np.diff(rp)), c] = v
+    return x
+
+
+def _equals_oracle_dense(pos, vals, rp, c, v, B, V):
+    """The device CSR, expanded, IS the matrix the reference's graph would see (oracle restatement of DAEs.py:33-35)."""
+    assert np.all(np.diff(rp) >= 0) and rp[0] == 0
+    for r in range(B):
+        assert np.all(np.diff(c[rp[r]:rp[r + 1]]) > 0)          # strictly ascending: one entry per cell
+    assert np.all(v != 0)                                        # explicit zeros are dropped
+    want = dn.sparse_to_dense(pos, vals, B, V)
+    assert np.array_equal(_dense(rp, c, v, B, V).view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("B,V,nnz,seed", [(256, 170000, 25000, 0), (7, 50, 400, 1), (1, 10, 1, 2), (64, 3000, 0, 3),
                                           (300, 1000, 60000, 4)])
 def test_random_feeds_with_duplicates_zeros_and_any_order(B, V, nnz, seed):
@@ -39,6 +59,7 @@ def test_random_feeds_with_duplicates_zeros_and_any_order(B, V, nnz, seed):
     rp, c, v, st = _run(ctx, pos, vals, B, V)
     rp0, c0, v0 = coo_to_csr(pos, vals, B, V)
     assert st == 0
+    _equals_oracle_dense(pos, vals, rp, c, v, B, V)
     assert np.array_equal(rp, rp0) and np.array_equal(c, c0) and np.array_equal(v.view(np.uint32), v0.view(np.uint32))
     ctx.close()
 
@@ -53,6 +74,7 @@ def test_reader_shaped_feed_two_row_sorted_segments_and_broadcast_value():
         rp, c, v, st = _run(ctx, pos, vals, B, nt + na)
         rp0, c0, v0 = coo_to_csr(pos, vals, B, nt + na)
         assert st == 0 and np.array_equal(rp, rp0) and np.array_equal(c, c0) and np.array_equal(v, v0)
+        _equals_oracle_dense(pos, vals, rp, c, v, B, nt + na)
     ctx.close()
 
 

@@ -128,8 +128,14 @@ def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
         losses = [float(l.split(":")[1]) for l in log.splitlines() if l.startswith("training loss")]
         assert len(losses) == 4 and losses[1] < losses[0] and losses[3] < losses[2]
         assert "rprecision" in log and "Parameters are saved" in log
+        for split in ("test-0", "test-1", "test-5", "test-25r"):        # readme.md:69 seed patterns, every epoch
+            assert log.count("seed num: %s rprecision" % split) == 4
         assert cli.main(["--dir", "run", "--dae", "--testmode"]) == 0
-        assert cli.main(["--dir", "run", "--challenge"]) == 0           # no title variables yet: plain DAE
+        with pytest.raises(FileNotFoundError):                          # no title variables yet: the reference fails
+            cli.main(["--dir", "run", "--challenge"])                    # too (saver.restore); opt in explicitly
+        ini = open(work / "config.ini").read()
+        open(work / "config.ini", "w").write(ini.replace("[CHALLENGE]", "[CHALLENGE]\nallow_no_title = True"))
+        assert cli.main(["--dir", "run", "--challenge"]) == 0           # plain DAE, titles_use = 0
 
         def check(res):
             assert len(res) == 13
