@@ -205,7 +205,8 @@ class Context:
     def topk_dense(self, logits, ncols, col_base, seed_row_ptr, seed_col, k, out_score, out_idx,
                    out_kind=DAE_OUT_SCORE):
         B = logits.shape[0]
-        self.check(self.lib.dae_topk_dense(self.h, _ptr(logits), int(logits.stride(0)), B,
+        ld = int(logits.stride(0)) if B > 1 else max(int(logits.stride(0)), int(logits.shape[1]))   # a 1-row view may carry stride 0
+        self.check(self.lib.dae_topk_dense(self.h, _ptr(logits), ld, B,
                                            int(ncols), int(col_base), _ptr(seed_row_ptr),
                                            _ptr(seed_col), int(k), int(out_kind),
                                            _ptr(out_score), _ptr(out_idx)))

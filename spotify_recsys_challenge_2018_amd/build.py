@@ -11,6 +11,8 @@ SOURCES = ["api.hip", "encode.hip", "decode_f32.hip", "topk.hip", "train.hip", "
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+if os.environ.get("DAE_EXPERIMENTS"):          # A/B switches and stage early-outs (csrc/dae_internal.h); never the default
+    FLAGS.append("-DDAE_EXPERIMENTS")
 
 
 def _deps_mtime():

@@ -133,7 +133,7 @@ int dae_destroy(dae_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
-                       &ctx->cand_cnt, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
+                       &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -278,10 +278,10 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     const int n_simd = g.nb_rg * 4;
     int rounds = (int)(((double)ntiles / 8.0) / n_simd + 0.5);
     if (rounds < 1) rounds = 1;
-    static const int rounds_env = getenv("DAE_SAMPLE_ROUNDS") ? atoi(getenv("DAE_SAMPLE_ROUNDS")) : 0;   // experiments
+    static const int rounds_env = dae_exp_env("DAE_SAMPLE_ROUNDS") ? atoi(dae_exp_env("DAE_SAMPLE_ROUNDS")) : 0;   // experiments
     if (rounds_env > 0) rounds = rounds_env;
     int S = (ntiles + rounds * n_simd - 1) / (rounds * n_simd);
-    static const int s_env = getenv("DAE_SAMPLE_S") ? atoi(getenv("DAE_SAMPLE_S")) : 0;                   // experiments
+    static const int s_env = dae_exp_env("DAE_SAMPLE_S") ? atoi(dae_exp_env("DAE_SAMPLE_S")) : 0;                   // experiments
     if (s_env > 1) S = s_env;
     const bool fused = S >= 2 && nrank > 0;
     const int n_samp = fused ? (ntiles + S - 1) / S : ntiles;
@@ -307,8 +307,17 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
         order = static_cast<const int*>(pkm.order.p);
     }
     dae_tileset tsA{n_samp, fused ? S : 1, fused ? 3 : 0, order};
+    float* gmax = nullptr;
+    // one maximum per (workgroup of the row group, round of sample tiles, position in the tile)
+    const int n_ws_a = g.nb_rg * g.waves;
+    const int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
+    if (fused) {
+        rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
+        if (rc) return rc;
+        gmax = static_cast<float*>(ctx->gmax.p);
+    }
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
-    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype);
+    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype, gmax, ld_g);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
@@ -318,17 +327,19 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
         return dae_launch_topk_dense(ctx, ds, ta);
     }
 
+    // tau: the (k + n_seeds)-th largest of the sample's group maxima (written by the phase-A launch: the maximum
+    // over the tiles a workgroup decodes together, per position in the tile) -- a valid lower bound of the row's k-th
+    // largest rankable non-seed logit -- and, from the same launch, the sample logits >= tau as one flat list per row.
+    // No selection over the 15 k dense sample logits of a row happens any more.
     rc = dae_reserve(ctx, ctx->tau, (size_t)g.Bpad * sizeof(float));
     if (rc) return rc;
-    const int pstride = DAE_MAX_K;                         // room for k or the <= 512 unsorted survivors
+    const int64_t pstride = ld_s;                          // worst case (tau = -inf): every sample logit survives
     rc = dae_reserve(ctx, ctx->sample_top, ((size_t)g.Bpad * pstride) * sizeof(uint2) + (size_t)g.Bpad * sizeof(int));
     if (rc) return rc;
     int* sample_cnt = reinterpret_cast<int*>(static_cast<uint2*>(ctx->sample_top.p) + (size_t)g.Bpad * pstride);
-    ta.out_kind = DAE_OUT_LOGIT;
-    ta.out_pairs = static_cast<uint2*>(ctx->sample_top.p);
-    ta.out_tau = static_cast<float*>(ctx->tau.p);
-    ta.out_cnt = sample_cnt; ta.pairs_stride = pstride;
-    rc = dae_launch_topk_dense(ctx, ds, ta);
+    rc = dae_launch_tau_select(ctx, gmax, ld_g, (int)ld_g, sample, ld_s, (int)ld_s, order, pk->col_lo, B, k,
+                               seed_row_ptr, static_cast<float*>(ctx->tau.p), static_cast<uint2*>(ctx->sample_top.p),
+                               pstride, sample_cnt);
     if (rc) return rc;
 
     // phase B: everything else through the threshold filter
@@ -349,7 +360,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = prof_end(ctx); if (rc) return rc;
     if (ctx->gate_record) DAE_HIP_CHECK(ctx, hipEventRecord(ctx->gate_record, ctx->stream));
 
-    // final: exact top-k of (sample winners) U (filter survivors), seeds removed
+    // final: exact top-k of (sample survivors) U (phase-B survivors), seeds removed
     dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), sample_cnt, 0, pstride, 0, 1, 0};
     dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
@@ -447,15 +458,22 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
     if (!pk) return DAE_ERR_STATE;
     if (B <= 0) return DAE_OK;
     if (dtype == DAE_DTYPE_BF16) {
-        // encode stays fp32 (north_star: bf16 decode GEMM + fp32 encode / top-k); the hidden rows are
-        // rounded to bf16 while being re-tiled for the MFMA
+        // encode stays fp32 (north_star: bf16 decode GEMM + fp32 encode / top-k); the hidden rows leave the encode
+        // kernel rounded to bf16, already in the MFMA operand order (no [B,H] round trip, no re-tiling launch)
         const dae_rowgeom g16 = dae_row_geometry_bf16(B, pk->Hp);
-        rc = dae_reserve(ctx, ctx->h_scratch, (size_t)B * H * sizeof(float));
+        const int NS = pk->Hp / 16, RB16 = g16.R_TILE / 32;
+        const size_t bytes16 = (size_t)g16.n_rg * NS * RB16 * 64 * sizeof(uint4);
+        rc = dae_reserve(ctx, ctx->h_packed16, bytes16);
         if (rc) return rc;
-        float* hs = static_cast<float*>(ctx->h_scratch.p);
-        rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, hs, nullptr, 0, 0);
-        if (rc) return rc;
-        rc = dae_launch_pack_h_bf16(ctx, hs, B, H, g16);
+        const long long key16 = geom_key(B, H, g16.R_TILE);
+        if (ctx->h16_geom_key != key16 || ctx->h16_geom_ptr != ctx->h_packed16.p) {
+            // pad rows / pad k of the image are never written by the encode kernel: zero them once
+            DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->h_packed16.p, 0, bytes16, ctx->stream));
+            ctx->h16_geom_key = key16;
+            ctx->h16_geom_ptr = ctx->h_packed16.p;
+        }
+        rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, nullptr, nullptr, 0, RB16,
+                               nullptr, nullptr, static_cast<unsigned short*>(ctx->h_packed16.p), NS);
         if (rc) return rc;
         return decode_topk_core(ctx, pk, g16, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
                                 out_score, out_idx, dtype);

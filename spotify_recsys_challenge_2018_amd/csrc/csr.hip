@@ -319,7 +319,7 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     float* t_val = reinterpret_cast<float*>(t_feed + nnz);
     int* k_col = reinterpret_cast<int*>(t_val + nnz);
     float* k_val = reinterpret_cast<float*>(k_col + nnz);
-    static const bool no_small = getenv("DAE_CSR_GENERIC") != nullptr;            // A/B against the 6-launch path
+    static const bool no_small = dae_exp_env("DAE_CSR_GENERIC") != nullptr;            // A/B against the 6-launch path
     if (n_rows <= CSR_SMALL_ROWS && !no_small) {
         // cnt | cursor are adjacent, the caller's status word is cleared with them by one small kernel-free memset each
         DAE_HIP_CHECK(ctx, hipMemsetAsync(cnt, 0, (2 * nr + 4) * sizeof(int), st));

@@ -62,7 +62,10 @@ struct dae_ctx {
     dae_buf h_scratch;         // [B,H] fp32 hidden activations when the caller does not keep them
     long long h_geom_key = -1; // (B, H, R_TILE) whose pad region of h_packed is known to be zero
     void* h_geom_ptr = nullptr;
+    long long h16_geom_key = -1;   // the same for the bf16 image h_packed16 when the encode writes it directly
+    void* h16_geom_ptr = nullptr;
     dae_buf sample;            // phase-A dense logits [Bpad][n_sample_cols]
+    dae_buf gmax;              // phase-A group maxima [Bpad][4 * n_sample_tiles]
     dae_buf tau;               // [Bpad] fp32
     dae_buf sample_top;        // [Bpad][k] (logit, idx) pairs
     dae_buf cand;              // [nb_rg][Bpad][cap] pairs
@@ -107,6 +110,17 @@ int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes);
 
 static inline int dae_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Experiment switches (A/B variants, stage bisection: DESIGN.md section 6b) exist only in builds made with
+// -DDAE_EXPERIMENTS (`DAE_EXPERIMENTS=1 python -m spotify_recsys_challenge_2018_amd.build --force`): the default
+// library reads no environment variable and its kernels carry no early-outs.
+#ifdef DAE_EXPERIMENTS
+static inline const char* dae_exp_env(const char* name) { return getenv(name); }
+#define DAE_EXP_ON(x) (x)
+#else
+static inline const char* dae_exp_env(const char*) { return nullptr; }
+#define DAE_EXP_ON(x) false
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // canonical scalar device functions -- the SPECIFICATION is DESIGN.md "canonical order"; the
 // oracle (oracle/dae_oracle.c) restates the same arithmetic independently.  Built with
@@ -130,6 +144,14 @@ __device__ __forceinline__ float dae_sigmoidf(float x)
     float s = __uint_as_float((uint32_t)((int)n + 127) << 23);
     float e = p * s;
     return 1.0f / (1.0f + e);
+}
+
+// fp32 -> bf16, round to nearest even (oracle: bf16_round)
+__device__ __forceinline__ unsigned dae_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
 }
 
 __device__ __forceinline__ uint32_t dae_mix32(uint32_t x)
@@ -185,7 +207,7 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
                       const float* W_enc, const float* b_enc, int V, int H, int B,
                       float ikp, float kp, uint32_t seed, float* h_out,
                       float* h_packed, int G, int RB, float* sg_out = nullptr,
-                      float* xhat_out = nullptr);
+                      float* xhat_out = nullptr, unsigned short* h_packed16 = nullptr, int NS = 0);
 
 // decode_f32.hip
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
@@ -202,9 +224,12 @@ struct dae_tileset {        // which wave tiles a decode launch walks
     const int* list;        // tile of item i; never null
 };
 // dense epilogue: out[row*ld + item*32 + vl] (item = position of the tile in the set)
+// gmax (nullable): [B][ld_gmax] maxima of every lane's two 8-column groups, 4 per (row, item) -- the threshold
+// sample's input to dae_launch_tau_select
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad, int dtype = DAE_DTYPE_F32);
+                                int fill_pad, int dtype = DAE_DTYPE_F32, float* gmax = nullptr,
+                                int64_t ld_gmax = 0);
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
@@ -305,6 +330,14 @@ struct dae_topk_args {
     int lean, sort_cap;           // set by the launcher (topk.hip): LDS mode, sort buffer keys
 };
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);
+// Threshold of the fused path + the sample's survivors (topk.hip tau_select_kernel):
+//   tau[row] = a valid lower bound of the row's k-th largest rankable non-seed logit: the (k + n_seeds(row))-th
+//   largest of gmax[row][0..n_g) (-inf = absent) to 16 key bits; -inf when the row holds fewer finite maxima;
+//   out_pairs[row * pairs_stride + i], i < out_cnt[row]: the (logit, column) of every dense sample logit
+//   samp[row][0..n_s) >= tau (column of element q = col_lo + samp_list[q >> 5] * 32 + (q & 31)), unordered
+int dae_launch_tau_select(dae_ctx* ctx, const float* gmax, int64_t ld_g, int n_g, const float* samp, int64_t ld_s,
+                          int n_s, const int* samp_list, int col_lo, int B, int k, const int32_t* seed_row_ptr,
+                          float* tau, uint2* out_pairs, int64_t pairs_stride, int* out_cnt);
 int dae_launch_topk_pairs(dae_ctx* ctx, const dae_pair_group& g0, const dae_pair_group& g1,
                           const dae_topk_args& a);
 int dae_launch_topk_soa(dae_ctx* ctx, int G, const float* logit, const int32_t* idx,

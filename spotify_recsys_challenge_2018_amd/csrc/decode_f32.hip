@@ -34,12 +34,7 @@ constexpr int DT_BF16 = 1;         // v_mfma_f32_32x32x16_bf16, fp32 accumulate 
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 
-__device__ __forceinline__ unsigned bf16_rne(float f)
-{
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);               // round to nearest even (oracle: bf16_round)
-    return u >> 16;
-}
+__device__ __forceinline__ unsigned bf16_rne(float f) { return dae_bf16_rne(f); }
 
 // bf16 kernels take the bias through the matrix pipe: b = e0 + e1 + e2 (three bf16 terms, exact to
 // 2^-25 |b|) sits in k-slots 0..2 of an extra A fragment per tile and is multiplied by this B fragment
@@ -53,6 +48,7 @@ __device__ __forceinline__ uint4 bf16_ones_fragment(int hi)
 constexpr int EPI_DENSE = 0;
 constexpr int EPI_FILTER = 1;
 constexpr int EPI_LOSS = 2;        // training: logits -> loss + dL/dz (DAEs.py:98-100)
+constexpr int EPI_GMAX = 3;        // EPI_DENSE (raw logits) + cross-wave group maxima: the threshold sample (phase A)
 
 struct DecP {
     const float4* Wp;      // f32: [ntiles][G][64] float4   bf16: [ntiles][G][64] uint4 (8 bf16)
@@ -66,6 +62,15 @@ struct DecP {
     dae_tileset ts;
     // dense epilogue
     float* out; int64_t ld; int apply_sigmoid; int mask_from_col; int fill_pad; int vec_ok;
+    // EPI_GMAX (threshold sample, phase A of the fused path): besides the dense logits, the maximum over the NW
+    // tiles a workgroup decodes in one round of every (row, position in the tile):
+    //   gmax[row * ld_gmax + (round * nb_rg + bir) * 32 + c]  = max over waves of z[row][tile(wave)][c]
+    // The groups are disjoint sets of columns, so the maxima are distinct elements of the row and their k-th
+    // largest is a valid lower bound of the row's k-th largest logit (tau_select_kernel, topk.hip).  The tiles of
+    // one workgroup sit nb_rg items apart in the bias-ordered list, i.e. in different popularity bands: with ids
+    // = popularity ranks the winners are packed into the first tiles, and a group then holds at most one of them
+    // (maxima over neighbouring columns would lose 7 of 8: measured, 4 000 instead of 600 survivors per row).
+    float* gmax; int64_t ld_gmax;
     // filter epilogue
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
     // loss epilogue
@@ -117,18 +122,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         for (; i < n_h4; i += NT) lds4[i] = src[i];
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
     if (EPI == EPI_FILTER) {
-        if (tid < R_TILE) lcnt[tid] = 0;
+        for (int i = tid; i < R_TILE; i += NW * 64) {
+            lcnt[i] = 0;
+            ltau[i] = rg * R_TILE + i < p.B ? p.tau[rg * R_TILE + i] : __builtin_inff();
+        }
     }
     __syncthreads();
 
     float tau_r[RB];
     if (EPI == EPI_FILTER) {
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int row = rg * R_TILE + rb * 32 + j;
-            tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
-        }
+        for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
     }
 
     float loss_acc = 0.0f;
@@ -172,6 +178,45 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
             for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
         }
     }
+
+    // EPI_GMAX: one exchange per round of tiles, joined by EVERY wave of the workgroup (a wave without a tile in
+    // the round contributes -inf): row block by row block through 16 B x 256 slots per wave behind the hidden
+    // tile -- wave w writes its masked logits as float4 (slot = (quad, half, playlist): conflict-free), thread
+    // (quad, half, playlist) takes the maximum over the waves and stores 4 maxima of its playlist's row
+    auto gmax_round = [&](bool has, int round, const f32x16* accv, const float4* bqv, int tcol0v) {
+        float4* xl = reinterpret_cast<float4*>(lcnt + R_TILE);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            __syncthreads();                                     // the previous row block's slots were read
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float4 v = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+                if (has) {
+                    const int lc = tcol0v + 8 * qd;
+                    float z[4] = {accv[rb][4 * qd + 0] + bqv[qd].x, accv[rb][4 * qd + 1] + bqv[qd].y,
+                                  accv[rb][4 * qd + 2] + bqv[qd].z, accv[rb][4 * qd + 3] + bqv[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (p.col_lo + lc + e >= p.mask_from_col || lc + e >= p.ncols) z[e] = -__builtin_inff();
+                    v = make_float4(z[0], z[1], z[2], z[3]);
+                }
+                xl[wave * 256 + (qd * 2 + hi) * 32 + j] = v;
+            }
+            __syncthreads();
+            for (int sl = tid; sl < 256; sl += NW * 64) {
+                float4 m = xl[sl];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const float4 o = xl[w * 256 + sl];
+                    m = make_float4(fmaxf(m.x, o.x), fmaxf(m.y, o.y), fmaxf(m.z, o.z), fmaxf(m.w, o.w));
+                }
+                const int row = rg * R_TILE + rb * 32 + (sl & 31);
+                if (row < p.B)
+                    *reinterpret_cast<float4*>(p.gmax + (size_t)row * p.ld_gmax +
+                                               ((size_t)round * p.nb_rg + bir) * 32 + (sl >> 5) * 4) = m;
+            }
+        }
+    };
 
     for (int item = item0; item < p.ts.n_items; item += n_ws) {
         const int t = t_cur;
@@ -281,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
         const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
 
-        if (EPI == EPI_DENSE) {
+        if (EPI == EPI_DENSE || EPI == EPI_GMAX) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
@@ -313,6 +358,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                     }
                 }
             }
+            if (EPI == EPI_GMAX) gmax_round(true, (item - item0) / n_ws, acc, bq, tcol0);
         } else if (EPI == EPI_LOSS) {
             // Every element is treated as a NEGATIVE (target 0) here; the few positives of the batch (~100
             // of 170 000 columns per row) are redone from their own dot products by loss_fixup_kernel
@@ -392,6 +438,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         t_nxt = __builtin_amdgcn_readfirstlane(t_nn_v);
     }
 
+    if (EPI == EPI_GMAX) {
+        // rounds this wave had no tile for: still joins the exchange (block-uniform trip count in total)
+        const int rounds = (p.ts.n_items + n_ws - 1) / n_ws;
+        const int mine = item0 < p.ts.n_items ? (p.ts.n_items - item0 + n_ws - 1) / n_ws : 0;
+        f32x16 dummy_acc[RB];
+        float4 dummy_b[4];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dummy_acc[rb][e] = 0.0f;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) dummy_b[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = mine; r < rounds; ++r) gmax_round(false, r, dummy_acc, dummy_b, 0);
+    }
     if (EPI == EPI_FILTER) {
         __syncthreads();
         if (tid < R_TILE) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + tid] = lcnt[tid];
@@ -731,15 +791,16 @@ __global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const De
         }
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
-    if (tid < R_TILE) lcnt[tid] = 0;
+    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
+    if (tid < R_TILE) {
+        lcnt[tid] = 0;
+        ltau[tid] = rg * R_TILE + tid < p.B ? p.tau[rg * R_TILE + tid] : __builtin_inff();
+    }
     __syncthreads();
 
     float tau_r[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int row = rg * R_TILE + rb * 32 + j;
-        tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
-    }
+    for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
 
     // this wave's work: whole tiles ws + r * n_ws (r < R), then possibly one tile -- or half of one -- of
     // the last round
@@ -934,15 +995,16 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
         }
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
-    for (int i = tid; i < R_TILE; i += NW * 64) lcnt[i] = 0;
+    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
+    for (int i = tid; i < R_TILE; i += NW * 64) {
+        lcnt[i] = 0;
+        ltau[i] = rg * R_TILE + i < p.B ? p.tau[rg * R_TILE + i] : __builtin_inff();
+    }
     __syncthreads();
 
     float tau_r[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int row = rg * R_TILE + rb * 32 + j;
-        tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
-    }
+    for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
 
     const int n_items = p.ts.n_items;
     const int n_grp = (n_items + NT - 1) / NT;                   // groups of NT tiles
@@ -1288,7 +1350,9 @@ __global__ __launch_bounds__(256) void pack_h_bf16_kernel(const float* __restric
 template <int RB, int EPI, int GT, int NW, int DT>
 int launch_decode(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 {
-    const size_t lds = (size_t)RB * 64 * p.G * sizeof(float4) + (size_t)RB * 32 * sizeof(int);
+    const size_t lds = (size_t)RB * 64 * p.G * sizeof(float4) + (size_t)RB * 32 * sizeof(int) +
+                       (EPI == EPI_GMAX ? (size_t)NW * 256 * sizeof(float4) : 0) +
+                       (EPI == EPI_FILTER ? (size_t)RB * 32 * sizeof(float) : 0);
     static const char attr_set_key = 0;     // per template instantiation
     if (dae_first_use(ctx, &attr_set_key)) {
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(
@@ -1346,13 +1410,13 @@ int launch_decode_rb_bf16(dae_ctx* ctx, const dae_rowgeom& g, const DecP& p)
 
 bool bf16_pair_variant()
 {
-    static const bool v = getenv("DAE_BF16_PAIR") != nullptr;     // A/B: two column tiles per wave, one wave per SIMD
+    static const bool v = dae_exp_env("DAE_BF16_PAIR") != nullptr;     // A/B: two column tiles per wave, one wave per SIMD
     return v;
 }
 // the dedicated phase-B kernel: hidden = 256 (16 steps), one wave per SIMD, 128- or 256-row groups
 bool bf16_fast_filter(const dae_rowgeom& g, int dtype, int G)
 {
-    static const bool off = getenv("DAE_BF16_GENERIC") != nullptr;                // A/B against the generic body
+    static const bool off = dae_exp_env("DAE_BF16_GENERIC") != nullptr;                // A/B against the generic body
     return dtype == DAE_DTYPE_BF16 && G == 16 && g.waves == 4 && (g.R_TILE == 128 || g.R_TILE == 256) && !off;
 }
 
@@ -1421,7 +1485,7 @@ dae_rowgeom dae_row_geometry_bf16(int B, int Hp)
     // 128-playlist row groups.  256-row groups (every W fragment feeds 8 MFMAs, a batch of 256 reads W
     // exactly once) measured the same kernel time but a slower phase A: DAE_BF16_RTILE=256 for the A/B.
     int rt = 128;
-    if (const char* e = getenv("DAE_BF16_RTILE")) { if (atoi(e) == 256 && Hp == 256 && B > 128) rt = 256; }
+    if (const char* e = dae_exp_env("DAE_BF16_RTILE")) { if (atoi(e) == 256 && Hp == 256 && B > 128) rt = 256; }
     while (rt > 32 && (size_t)rt * Hp * 2 > 128 * 1024) rt >>= 1;
     while (rt > 32 && B <= rt / 2) rt >>= 1;
     g.R_TILE = rt;
@@ -1496,6 +1560,8 @@ int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae
     hipLaunchKernelGGL(pack_h_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, h, B, H, NS, RB,
                        g.n_rg, static_cast<uint4*>(ctx->h_packed16.p));
     DAE_CHECK_LAUNCH(ctx, "pack_h_bf16_kernel");
+    ctx->h16_geom_key = ((long long)B << 32) | ((long long)H << 12) | (long long)g.R_TILE;   // whole image rewritten, pads zero
+    ctx->h16_geom_ptr = ctx->h_packed16.p;
     return DAE_OK;
 }
 
@@ -1531,7 +1597,7 @@ int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, i
     if (pk.order_nrank == nrank && pk.order_nsamp == n_samp && pk.order.p) return DAE_OK;
     int rc = dae_reserve(ctx, pk.order, (size_t)pk.ntiles * sizeof(int));
     if (rc) return rc;
-    static const bool strided = getenv("DAE_SAMPLE") && !strcmp(getenv("DAE_SAMPLE"), "strided");
+    static const bool strided = dae_exp_env("DAE_SAMPLE") && !strcmp(dae_exp_env("DAE_SAMPLE"), "strided");
     if (pk.ntiles > ORDER_MAX_TILES || strided) {
         hipLaunchKernelGGL(tile_order_strided_kernel, dim3((pk.ntiles + 255) / 256), dim3(256), 0, ctx->stream,
                            pk.ntiles, n_samp, S, static_cast<int*>(pk.order.p));
@@ -1561,15 +1627,20 @@ int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowg
 
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad, int dtype)
+                                int fill_pad, int dtype, float* gmax, int64_t ld_gmax)
 {
     DecP p;
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
+    p.gmax = gmax; p.ld_gmax = ld_gmax;
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
+    if (gmax) {
+        if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "group maxima need 4-wave workgroups");
+        return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_GMAX>(ctx, g, p) : launch_decode_rb_bf16<EPI_GMAX>(ctx, g, p);
+    }
     return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_DENSE>(ctx, g, p)
                                   : launch_decode_rb_bf16<EPI_DENSE>(ctx, g, p);
 }
@@ -1618,7 +1689,7 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
     // A/B: DAE_LOSS_WAVES=8 runs two waves per SIMD on the 128-row image so that one wave's VALU epilogue
     // (4 transcendentals per element) sits under the other's MFMAs; measured 240 us against 229 us for the
     // default one wave per SIMD (V = 170 000, B = 256)
-    static const bool w8 = getenv("DAE_LOSS_WAVES") && atoi(getenv("DAE_LOSS_WAVES")) == 8;
+    static const bool w8 = dae_exp_env("DAE_LOSS_WAVES") && atoi(dae_exp_env("DAE_LOSS_WAVES")) == 8;
     if (g.R_TILE == 128 && p.G == 32 && w8) return launch_decode<4, EPI_LOSS, 32, 8, DT_F32>(ctx, g, p);
     return launch_decode_rb<EPI_LOSS>(ctx, g, p);
 }
@@ -1631,9 +1702,9 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
-    static const bool f32_generic = getenv("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body
+    static const bool f32_generic = dae_exp_env("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body
     if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && g.waves == 4 && !f32_generic) {
-        const size_t lds = (size_t)4 * 64 * 32 * sizeof(float4) + 128 * sizeof(int);
+        const size_t lds = (size_t)4 * 64 * 32 * sizeof(float4) + 128 * sizeof(int) + 128 * sizeof(float);
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_f32_h256_filter_kernel<0>),
@@ -1651,7 +1722,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
         return DAE_OK;
     }
     if (bf16_fast_filter(g, dtype, p.G)) {
-        const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * sizeof(int);
+        const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * (sizeof(int) + sizeof(float));
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 4, 8, 8>),

@@ -51,6 +51,8 @@ struct EncP {
     float* h_out;        // [B,H] row-major or null
     float* hp;           // packed [n_rg][G][RB][2][32][4] or null
     int G, RB;           // packed geometry (G = Hp/8, RB = R_TILE/32)
+    unsigned short* hp16;   // bf16 image [n_rg][NS][RB][64][8] (decode_f32.hip pack_h_bf16_kernel's layout) or null:
+    int NS;                 // the bf16 decode reads the hidden rows rounded (RNE) straight from the encode; NS = Hp/16
     float* sg_out;       // [B,H] sigmoid BEFORE hidden dropout (training backward) or null
     float* xhat_out;     // [nnz] normalised, dropped-out input weights (training backward) or null
     unsigned w_bytes;    // V * H * 4 (< 4 GiB: buffer descriptor range)
@@ -171,6 +173,16 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
                     base4[e2 + 1] = hv[2];             // hi = 0, slot e2 + 1
                     base4[32 * 4 + e2 + 1] = hv[3];    // hi = 1, slot e2 + 1
                 }
+                if (p.hp16) {
+                    // k = hoff + e -> step s = k >> 4, lane half hi = (k >> 3) & 1, slot k & 7: 4 consecutive slots
+                    const int R_TILE = p.RB * 32;
+                    const int rg = row / R_TILE, rl = row - rg * R_TILE;
+                    const int rb = rl >> 5, j = rl & 31;
+                    const int st = hoff >> 4, hi2 = (hoff >> 3) & 1, e0 = hoff & 7;
+                    unsigned short* d = p.hp16 + ((((size_t)rg * p.NS + st) * p.RB + rb) * 64 + hi2 * 32 + j) * 8 + e0;
+                    *reinterpret_cast<uint2*>(d) = make_uint2(dae_bf16_rne(hv[0]) | (dae_bf16_rne(hv[1]) << 16),
+                                                              dae_bf16_rne(hv[2]) | (dae_bf16_rne(hv[3]) << 16));
+                }
             }
         }
     }
@@ -189,10 +201,10 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
     const int hq = H / HS;                       // hidden units of this wave (multiple of 4)
     const int hbytes = H * 4;
     const __amdgpu_buffer_rsrc_t rs = w_rsrc(p.W, p.w_bytes);
-    if (p.dbg_stop == 1) return;
+    if (DAE_EXP_ON(p.dbg_stop == 1)) return;
     const int beg = p.row_ptr[row], end = p.row_ptr[row + 1];
     const int nnz = end - beg;
-    if (p.dbg_stop == 2) { if (nnz == -7) p.h_out[0] = 0.f; return; }
+    if (DAE_EXP_ON(p.dbg_stop == 2)) { if (nnz == -7) p.h_out[0] = 0.f; return; }
 
     // Typical rows (<= 256 non-zeros: a playlist holds <= 250 items, spotify_reader.py:84) keep
     // their (column, value) entries in 4 registers per lane, fetched by 8 INDEPENDENT loads; the
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
             if (64 * c + lane < nnz)
                 xl[c] = (xl[c] / p.ikp) * floorf(p.ikp + dae_uniform(p.seed, 0U, (uint32_t)row, (uint32_t)cl[c]));
     }
-    if (p.dbg_stop == 3) { if (xl[0] + xl[1] + xl[2] + xl[3] + cl[0] == -7.f) p.h_out[0] = 0.f; return; }
+    if (DAE_EXP_ON(p.dbg_stop == 3)) { if (xl[0] + xl[1] + xl[2] + xl[3] + cl[0] == -7.f) p.h_out[0] = 0.f; return; }
     // s = sum of the weights in column order (sequential: canonical order)
     float s = 0.0f;
 #pragma unroll
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
         for (int i = 0; i < n; ++i) s += rl_f(x, i);
     }
     const float denom = s + 1e-10f;
-    if (p.dbg_stop == 4) { if (denom == -7.f) p.h_out[0] = 0.f; return; }
+    if (DAE_EXP_ON(p.dbg_stop == 4)) { if (denom == -7.f) p.h_out[0] = 0.f; return; }
     float wl[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
             ENC_ISSUE(xa, c_l, n)
             ENC_CHAIN(xa, w_l, n)
         }
-        if (p.dbg_stop == 5) { if (acc == -7.f) p.h_out[0] = 0.f; return; }
+        if (DAE_EXP_ON(p.dbg_stop == 5)) { if (acc == -7.f) p.h_out[0] = 0.f; return; }
         if (active) {
             float hv = dae_sigmoidf(acc + p.b_enc[hu]);
             if (p.sg_out) p.sg_out[(size_t)row * H + hu] = hv;
@@ -307,6 +319,14 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
                 const int g = hu >> 3, e2 = (hu & 7) >> 1, hi2 = hu & 1;
                 p.hp[((((size_t)rg * p.G + g) * p.RB + rb) * 64 + hi2 * 32 + j) * 4 + e2] = hv;
             }
+            if (p.hp16) {
+                const int R_TILE = p.RB * 32;
+                const int rg = row / R_TILE, rl = row - rg * R_TILE;
+                const int rb = rl >> 5, j = rl & 31;
+                const int st = hu >> 4, hi2 = (hu >> 3) & 1, e0 = hu & 7;
+                p.hp16[((((size_t)rg * p.NS + st) * p.RB + rb) * 64 + hi2 * 32 + j) * 8 + e0] =
+                    (unsigned short)dae_bf16_rne(hv);
+            }
         }
     }
 #undef ENC_ISSUE
@@ -318,10 +338,11 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
                       const float* W_enc, const float* b_enc, int V, int H, int B,
                       float ikp, float kp, uint32_t seed, float* h_out,
-                      float* h_packed, int G, int RB, float* sg_out, float* xhat_out)
+                      float* h_packed, int G, int RB, float* sg_out, float* xhat_out, unsigned short* h_packed16, int NS)
 {
     if (B <= 0) return DAE_OK;
     EncP p;
+    p.hp16 = h_packed16; p.NS = NS;
     p.row_ptr = row_ptr; p.col = col; p.val = val; p.W = W_enc; p.b_enc = b_enc;
     p.H = H; p.B = B; p.ikp = ikp; p.kp = kp; p.seed = seed;
     p.h_out = h_out; p.hp = h_packed; p.G = G; p.RB = RB;
@@ -329,9 +350,9 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
     if ((size_t)V * H * 4 >= 0xFFFFFFFFull)
         return dae_fail(ctx, DAE_ERR_ARG, "W_enc of %d x %d exceeds the 4 GiB buffer range", V, H);
     p.w_bytes = (unsigned)((size_t)V * H * 4);
-    static const int dbg_row0 = getenv("DAE_DBG_ENC_ROW0") ? atoi(getenv("DAE_DBG_ENC_ROW0")) : 0;
+    static const int dbg_row0 = dae_exp_env("DAE_DBG_ENC_ROW0") ? atoi(dae_exp_env("DAE_DBG_ENC_ROW0")) : 0;
     p.dbg_row0 = dbg_row0;
-    static const int dbg_stop = getenv("DAE_DBG_ENC_STOP") ? atoi(getenv("DAE_DBG_ENC_STOP")) : 0;
+    static const int dbg_stop = dae_exp_env("DAE_DBG_ENC_STOP") ? atoi(dae_exp_env("DAE_DBG_ENC_STOP")) : 0;
     p.dbg_stop = dbg_stop;
     if (B <= 1024 && (H % 16) == 0 && H >= 64) {
         // small batch: latency bound -> 4 waves per row (by hidden units), 4x the bytes in flight

@@ -419,7 +419,7 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
     int fs_min = L, fs_max = 1;
     for (int i = 0; i < n_sizes; ++i) { fs_min = p.fs[i] < fs_min ? p.fs[i] : fs_min; fs_max = p.fs[i] > fs_max ? p.fs[i] : fs_max; }
     const int p_max = L - fs_min + 1;                 // most window positions of any size
-    static const bool generic = getenv("DAE_TITLE_GENERIC") != nullptr;          // A/B against the first kernel
+    static const bool generic = dae_exp_env("DAE_TITLE_GENERIC") != nullptr;          // A/B against the first kernel
     if (p_max >= 1 && p_max <= 32 && fs_max <= L && !generic) {
         // positions up to PMAX - 1 + fs_max - 1 are read: pad the LDS image with zero rows
         const int pm = p_max <= 24 ? 24 : 32;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
     }
     src.template prepare<NTH>(row, tid, seg_prefix);
     __syncthreads();
-    if (dbg_stop == 1) return;
+    if (DAE_EXP_ON(dbg_stop == 1)) return;
 
     int sort_n = 1;
     while (sort_n < k) sort_n <<= 1;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
     }
     __syncthreads();
-    if (dbg_stop == 2) return;
+    if (DAE_EXP_ON(dbg_stop == 2)) return;
     const unsigned m = s_cnt;                                   // valid elements
     const unsigned n_cached = s_slots ? s_slots : m;            // cache slots in use (fixed slots: the source size)
     const bool in_lds = key_cap > 0 && n_cached <= (unsigned)key_cap;   // all of them were kept in LDS
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         }
     }
 
-    if (dbg_stop == 3) return;
+    if (DAE_EXP_ON(dbg_stop == 3)) return;
     // ---- 4. collect keys >= lo, sort descending, emit -------------------------------------------------
     for (int i = tid; i < sort_n; i += TK_THREADS) skey[i] = 0ull;
     if (tid == 0) s_cnt = 0;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         k_eff = s_cnt < (unsigned)k ? s_cnt : (unsigned)k;
     }
 
-    if (dbg_stop == 4) return;
+    if (DAE_EXP_ON(dbg_stop == 4)) return;
     // ---- 4b. k <= 512: get down to <= 512 keys so that the cheap ordering stage applies.  If more
     // than 512 were collected, cut at the k-th key with one more histogram over the collected keys
     // (one per thread).
@@ -649,45 +649,40 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         }
     }
 
-    if (dbg_stop == 99 && tid == 0)
+    if (DAE_EXP_ON(dbg_stop == 99) && tid == 0)
         printf("SLOWPATH row %d m %u k_eff %u s_cnt %u sort_n %d narrowed %d tau_mode %d\n", row, m, k_eff,
                s_cnt, sort_n, (int)narrowed, a.out_cnt ? 1 : 0);
-    if (dbg_stop == 5) return;
+    if (DAE_EXP_ON(dbg_stop == 5)) return;
     if (NTH >= 512 && sort_n == 512) {
-        // <= 512 unique keys: bitonic network over the 8 waves that hold them (one key per thread);
-        // strides < 64 through wave shuffles, 64..256 through LDS.  The other 8 waves only join
-        // the barriers, so the network is not slowed by their instruction issue.
-        const bool act = tid < 512;
-        u64 kr = act ? skey[tid] : 0ull;
-        for (int size = 2; size <= 512; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                if (stride >= 64) {
-                    __syncthreads();
-                    if (act) skey[tid] = kr;
-                    __syncthreads();
-                    if (act) {
-                        const u64 other = skey[tid ^ stride];
-                        const bool desc = ((tid & size) == 0), lower = ((tid & stride) == 0);
-                        const u64 mx = kr > other ? kr : other, mn = kr > other ? other : kr;
-                        kr = (lower == desc) ? mx : mn;
-                    }
-                } else if (act) {
-                    const u64 other = __shfl_xor(kr, stride);
-                    const bool desc = ((tid & size) == 0), lower = ((tid & stride) == 0);
-                    const u64 mx = kr > other ? kr : other, mn = kr > other ? other : kr;
-                    kr = (lower == desc) ? mx : mn;
-                }
-            }
+        // <= 512 unique keys (0 = empty slot): the position of a key in the output IS the number of keys above it.
+        // Thread (key, part) counts over its part of the buffer with 16-byte LDS reads at a wave-uniform address (a
+        // broadcast: one LDS cycle per wave) -- 128 reads + 256 compares per thread with 1024 threads -- instead of
+        // the 45-stage bitonic network (13.9 us of shuffles and 2-barrier LDS stages, profiles/r01_notes.md).
+        constexpr int PARTS = NTH / 512;
+        const int me = tid & 511, part = tid >> 9;
+        const u64 kr = skey[me];
+        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(skey) + part * (256 / PARTS);
+        unsigned above = 0;
+#pragma unroll 8
+        for (int m = 0; m < 256 / PARTS; ++m) {
+            const ulonglong2 v = s2[m];
+            above += (v.x > kr ? 1u : 0u) + (v.y > kr ? 1u : 0u);
         }
-        if (act && (unsigned)tid < k_eff) {
+        if (PARTS > 1) {
+            __syncthreads();                                     // hist is free after the narrowing stages
+            if (part) hist[me] = above;
+            __syncthreads();
+            if (!part) above += hist[me];
+        }
+        if (!part && kr != 0ull && above < k_eff) {
             const float z = dae_okey_inv((unsigned)(kr >> 32));
             const int colv = (int)(~(unsigned)(kr & 0xFFFFFFFFull));
-            const size_t o = (size_t)row * k + tid;
+            const size_t o = (size_t)row * k + above;
             if (a.out_idx) a.out_idx[o] = colv;
             if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
-            if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + tid] =
+            if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + above] =
                 make_uint2(__float_as_uint(z), (unsigned)colv);
-            if (a.out_tau && tid == k - 1) a.out_tau[row] = z;
+            if (a.out_tau && above == (unsigned)k - 1) a.out_tau[row] = z;
         }
     } else
     // Hybrid bitonic sort, descending.  Thread t holds elements t, t + NTH, ... (E = sort_n / NTH of them,
@@ -760,6 +755,210 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
     if (a.out_cnt && tid == 0) a.out_cnt[row] = k;
 }
 
+// ---- tau of the fused path from the sample's group maxima, and the sample's survivors ---------------------------
+// Phase A leaves, per row, the dense logits of the sample tiles and the maxima of disjoint groups of sample columns
+// (one column from each of the popularity bands a workgroup decodes; non-rankable columns masked to -inf).  The
+// maxima are distinct elements of the row, at most n_seeds of them seeds, so the (k + n_seeds)-th largest of them is
+// <= the row's k-th largest rankable non-seed logit: a valid threshold for phase B.
+// One 256-thread workgroup per row.
+//   1. the row's dense sample logits are requested first (up to 16 float4 per thread stay in registers: their
+//      latency hides under the search);
+//   2. tau: 4-ary search on the 16 leading bits of the order-preserving key for the largest prefix P with
+//      count(maxima >= P << 16) >= k + n_seeds -- 8 steps, each 3 x 16 compares per thread counted with s_bcnt1 on
+//      the compare mask and ONE barrier (histogram passes cost more: the logits of a row share a few exponents, so
+//      4 096 LDS atomics land on a handful of addresses -- 12 us; a shuffle reduction per probe 13.7 us).
+//      tau = the float of P << 16: at most 2^-7 (relative) below the element of that rank;
+//   3. the sample logits >= tau go out as (logit, column) pairs, one flat list per row (slots from a block-wide
+//      exclusive scan of the per-thread counts: no atomics) -- group 0 of the final selection.  Phase B never
+//      looks at the sample again.
+constexpr int TAU_PER = 16;        // maxima per thread held in registers: rows of <= 4096 maxima in one sweep
+constexpr int TAU_PRE = 16;        // float4 of dense sample logits per thread requested before the search
+struct TauP {
+    const float* gmax; int64_t ld_g; int n_g;                    // group maxima [B][ld_g], n_g per row
+    const float* samp; int64_t ld_s; int n_s;                    // dense sample logits [B][ld_s], n_s per row (% 32 == 0)
+    const int* samp_list; int col_lo;                            // column of sample element q = col_lo + list[q >> 5] * 32 + (q & 31)
+    const int32_t* seed_row_ptr; int k;
+    float* tau; uint2* out_pairs; int64_t pairs_stride; int* out_cnt;
+    long long* dbg;
+};
+__global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
+{
+    __shared__ unsigned wcnt[2][4][3];
+    __shared__ unsigned wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.x;
+#ifdef DAE_EXPERIMENTS         // stage stamps of rows 0 and 100 (DAE_DBG_TAU=1 prints them every 50 launches)
+#define TSTAMP(i) if (p.dbg && tid == 0 && (row == 0 || row == 100)) p.dbg[(row ? 8 : 0) + (i)] = __builtin_readcyclecounter();
+#else
+#define TSTAMP(i)
+#endif
+    TSTAMP(0)
+    const float* g = p.gmax + (size_t)row * p.ld_g;
+    const int n = p.n_g;
+    const unsigned ns = p.seed_row_ptr ? (unsigned)(p.seed_row_ptr[row + 1] - p.seed_row_ptr[row]) : 0u;
+    const unsigned need = (unsigned)p.k + ns;
+    // ---- 1. requests: the group maxima first (the search needs them), then the first TAU_PRE float4 per thread of
+    // the dense sample row, which stay in flight under the search ------------------------------------------------
+    const bool one_sweep = n <= 256 * TAU_PER;
+    float graw[TAU_PER];
+#pragma unroll
+    for (int u = 0; u < TAU_PER; ++u) {
+        const int i = u * 256 + tid;
+        graw[u] = (one_sweep && i < n) ? g[i] : -__builtin_inff();
+    }
+    const float4* srow = reinterpret_cast<const float4*>(p.samp + (size_t)row * p.ld_s);
+    const int n4 = p.n_s >> 2;
+    float4 zpre[TAU_PRE];
+#pragma unroll
+    for (int u = 0; u < TAU_PRE; ++u) {
+        const int f = u * 256 + tid;
+        zpre[u] = srow[f < n4 ? f : 0];
+    }
+    // tiles of the preloaded part (one id per 8 float4) -> LDS: consumed only where something passes
+    __shared__ int ltile[TAU_PRE * 256 / 8];
+    for (int i = tid; i < TAU_PRE * 256 / 8; i += 256) ltile[i] = p.samp_list[i < (n4 + 7) / 8 ? i : 0];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2. tau -------------------------------------------------------------------------------------------------
+    unsigned kreg[TAU_PER];
+#pragma unroll
+    for (int u = 0; u < TAU_PER; ++u) kreg[u] = dae_okey(graw[u]);     // -inf -> NEG_INF key: never counted
+    __builtin_amdgcn_sched_barrier(0);                           // keep every request above ahead of the search
+    // counts of keys >= each of 3 probes over the row (block-uniform results); absent / -inf keys never count
+    auto count3 = [&](unsigned q0, unsigned q1, unsigned q2, int it, unsigned (&c)[3]) {
+        unsigned a0 = 0, a1 = 0, a2 = 0;
+        if (one_sweep) {
+            // all compare masks of a probe first, then their popcounts: a VALU compare -> SALU popcount pair stalls
+            // the (only) wave of the SIMD for the VALU -> SALU hand-over; interleaved pair by pair a step cost 2 000 cycles
+            unsigned long long m[TAU_PER];
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) m[u] = __ballot(kreg[u] >= q0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) a0 += (unsigned)__popcll(m[u]);
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) m[u] = __ballot(kreg[u] >= q1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) a1 += (unsigned)__popcll(m[u]);
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) m[u] = __ballot(kreg[u] >= q2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < TAU_PER; ++u) a2 += (unsigned)__popcll(m[u]);
+        } else {
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const unsigned key = i0 + tid < n ? dae_okey(g[i0 + tid]) : 0u;
+                a0 += (unsigned)__popcll(__ballot(key >= q0));
+                a1 += (unsigned)__popcll(__ballot(key >= q1));
+                a2 += (unsigned)__popcll(__ballot(key >= q2));
+            }
+        }
+        if (lane == 0) { wcnt[it & 1][wv][0] = a0; wcnt[it & 1][wv][1] = a1; wcnt[it & 1][wv][2] = a2; }
+        __syncthreads();                                         // slots alternate: one barrier per step is enough
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            c[e] = wcnt[it & 1][0][e] + wcnt[it & 1][1][e] + wcnt[it & 1][2][e] + wcnt[it & 1][3][e];
+    };
+    // prefixes below (NEG_INF >> 16) + 1 would count -inf / absent entries
+    const unsigned p_min = (DAE_KEY_NEG_INF >> 16) + 1u;
+    unsigned lo = p_min, hi = 0xFFFFu;                           // the answer lies in [lo, hi] if it exists
+    int it = 0;
+    unsigned c[3];
+    TSTAMP(1)
+    count3(lo << 16, lo << 16, lo << 16, it++, c);
+    TSTAMP(2)
+    const bool found = c[0] >= need;
+    if (found) {
+        while (lo < hi) {                                        // invariant: count(lo) >= need, count(hi + 1) < need
+            const unsigned span = hi - lo;                       // >= 1; three probes cut [lo + 1, hi] into four parts
+            const unsigned m1 = lo + (span + 3u) / 4u, m2 = lo + (2u * span + 3u) / 4u, m3 = lo + (3u * span + 3u) / 4u;
+            count3(m1 << 16, m2 << 16, m3 << 16, it++, c);       // lo < m1 <= m2 <= m3 <= hi
+            if (c[2] >= need) lo = m3;
+            else if (c[1] >= need) { lo = m2; hi = m3 - 1u; }
+            else if (c[0] >= need) { lo = m1; hi = m2 - 1u; }
+            else hi = m1 - 1u;
+        }
+    }
+    TSTAMP(3)
+    const float tv = found ? dae_okey_inv(lo << 16) : -__builtin_inff();
+    if (tid == 0) p.tau[row] = tv;
+    // ---- 3. the sample's survivors (never -inf: masked columns and pads are not candidates) ------------------------
+    auto passes = [&](float z) { return z >= tv && z > -__builtin_inff(); };
+    unsigned mine = 0;
+    unsigned live = 0;                                           // bit u: some lane of this wave has a survivor in zpre[u]
+#pragma unroll
+    for (int u = 0; u < TAU_PRE; ++u) {
+        const float mx = fmaxf(fmaxf(zpre[u].x, zpre[u].y), fmaxf(zpre[u].z, zpre[u].w));
+        if (__ballot(u * 256 + tid < n4 && passes(mx))) {        // wave-uniform: most groups hold nothing above tau
+            live |= 1u << u;
+            if (u * 256 + tid < n4)
+                mine += (passes(zpre[u].x) ? 1u : 0u) + (passes(zpre[u].y) ? 1u : 0u) + (passes(zpre[u].z) ? 1u : 0u) +
+                        (passes(zpre[u].w) ? 1u : 0u);
+        }
+    }
+    for (int f = TAU_PRE * 256 + tid; f < n4; f += 256) {       // rows longer than the preloaded part: read again
+        const float4 z = srow[f];
+        mine += (passes(z.x) ? 1u : 0u) + (passes(z.y) ? 1u : 0u) + (passes(z.z) ? 1u : 0u) + (passes(z.w) ? 1u : 0u);
+    }
+    TSTAMP(4)
+    unsigned incl = mine;                                        // block-wide exclusive scan of the counts
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned at = incl - mine;
+    for (int w = 0; w < wv; ++w) at += wsum[w];
+    if (tid == 255) p.out_cnt[row] = (int)(at + mine);
+    TSTAMP(5)
+    uint2* dst = p.out_pairs + (size_t)row * p.pairs_stride;
+    auto emit4 = [&](const float4 z, int f, int tile) {
+        const unsigned cb = (unsigned)(p.col_lo + tile * 32 + ((4 * f) & 31));
+        if (passes(z.x)) dst[at++] = make_uint2(__float_as_uint(z.x), cb);
+        if (passes(z.y)) dst[at++] = make_uint2(__float_as_uint(z.y), cb + 1u);
+        if (passes(z.z)) dst[at++] = make_uint2(__float_as_uint(z.z), cb + 2u);
+        if (passes(z.w)) dst[at++] = make_uint2(__float_as_uint(z.w), cb + 3u);
+    };
+#pragma unroll
+    for (int u = 0; u < TAU_PRE; ++u)
+        if (((live >> u) & 1u) && u * 256 + tid < n4) emit4(zpre[u], u * 256 + tid, ltile[(u * 256 + tid) >> 3]);
+    for (int f = TAU_PRE * 256 + tid; f < n4; f += 256) emit4(srow[f], f, p.samp_list[f >> 3]);
+    TSTAMP(6)
+#ifdef DAE_EXPERIMENTS
+    if (p.dbg && tid == 0 && row == 0) p.dbg[7] = it;
+#endif
+}
+
+int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
+{
+    if (B <= 0) return DAE_OK;
+    TauP q = p;
+#ifdef DAE_EXPERIMENTS
+    static const bool dbg = dae_exp_env("DAE_DBG_TAU") != nullptr;
+    static long long* dbuf = nullptr;
+    static int calls = 0;
+    if (dbg) { if (!dbuf) (void)hipMalloc(&dbuf, 16 * 8); q.dbg = dbuf; }
+#endif
+    hipLaunchKernelGGL(tau_select_kernel, dim3(B), dim3(256), 0, ctx->stream, q);
+    DAE_CHECK_LAUNCH(ctx, "tau_select_kernel");
+#ifdef DAE_EXPERIMENTS
+    if (dbg && (++calls % 50) == 0) {
+        long long h[16];
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemcpy(h, dbuf, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "TAU row0:");
+        for (int i = 1; i < 7; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
+        fprintf(stderr, " steps %lld | row100:", h[7]);
+        for (int i = 1; i < 7; ++i) fprintf(stderr, " %lld", h[8 + i] - h[8]);
+        fprintf(stderr, "\n");
+    }
+#endif
+    return DAE_OK;
+}
+
 template <typename Src>
 int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
 {
@@ -777,7 +976,7 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     //     thread, so a workgroup fits on a CU NEXT to a decode workgroup of another batch.  Measured
     //     (profiles/r01_notes.md): the co-resident decode launch slows down by about what the overlap
     //     gains, and the kernel alone is slower (re-reads its source), so it is not the default.
-    static const bool want_lean = getenv("DAE_TOPK_LEAN") != nullptr;
+    static const bool want_lean = dae_exp_env("DAE_TOPK_LEAN") != nullptr;
     aa.lean = want_lean ? 1 : 0;
     // a ranked range too wide for the LDS bitmap (> ~1 M columns) takes the bitmap-free mode instead of failing
     if ((((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) + (size_t)sort_n * 8 + 22 * 1024 > (size_t)160 * 1024) aa.lean = 1;
@@ -814,13 +1013,13 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     }
     // debug: DAE_TOPK_STOP=n stops the phase-A (tau-producing) kernel after stage n,
     // DAE_TOPK_STOP=-n the other launches (bisecting stage costs under rocprofv3)
-    static const int dbg_env = getenv("DAE_TOPK_STOP") ? atoi(getenv("DAE_TOPK_STOP")) : 0;
+    static const int dbg_env = dae_exp_env("DAE_TOPK_STOP") ? atoi(dae_exp_env("DAE_TOPK_STOP")) : 0;
     const int dbg_stop = dbg_env > 0 ? (a.out_tau ? dbg_env : 0) : (a.out_tau ? 0 : -dbg_env);
     // threads per row: 256 for rows known to be short (see topk_kernel): dense rows of <= 4096 columns (the
     // sample of a small vocabulary shard) and gathered shard lists.  Candidate lists (PairSrc) keep 1024: their
     // cost is walking the per-workgroup segments (one wave per segment), which 4 waves do slower than 16
     // (measured: 407 vs 354 us per step at --sim-world 8).  DAE_TOPK_THREADS=1024|256 forces one shape (A/B).
-    static const int nth_env = getenv("DAE_TOPK_THREADS") ? atoi(getenv("DAE_TOPK_THREADS")) : 0;
+    static const int nth_env = dae_exp_env("DAE_TOPK_THREADS") ? atoi(dae_exp_env("DAE_TOPK_THREADS")) : 0;
     const int bound = Src::kSegs ? 0 : src.max_keys();
     const bool small = nth_env ? nth_env == 256 : (!Src::kSegs && bound <= 4096);
     if (small)
@@ -832,6 +1031,16 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
 }
 
 }  // namespace
+
+int dae_launch_tau_select(dae_ctx* ctx, const float* gmax, int64_t ld_g, int n_g, const float* samp, int64_t ld_s,
+                          int n_s, const int* samp_list, int col_lo, int B, int k, const int32_t* seed_row_ptr,
+                          float* tau, uint2* out_pairs, int64_t pairs_stride, int* out_cnt)
+{
+    if ((n_s & 31) || (ld_s & 3) || (reinterpret_cast<uintptr_t>(samp) & 15))
+        return dae_fail(ctx, DAE_ERR_ARG, "sample rows must be whole tiles, 16-byte aligned");
+    TauP p{gmax, ld_g, n_g, samp, ld_s, n_s, samp_list, col_lo, seed_row_ptr, k, tau, out_pairs, pairs_stride, out_cnt, nullptr};
+    return launch_tau_select(ctx, p, B);
+}
 
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& s, const dae_topk_args& a)
 {

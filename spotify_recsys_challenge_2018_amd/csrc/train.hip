@@ -346,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 #undef GW_MMA
         // D[i][j]: hidden unit hc0 + NA * i_idx + a, i_idx = (reg & 3) + 8 (reg >> 2) + 4 hi; column
         // v0 + 2 j + b.  The NA `a` accumulators of one reg are NA consecutive hidden units.
-        if (p.dbg & 1) {
+        if (DAE_EXP_ON(p.dbg & 1)) {
             float keep = cs0 + cs1;
 #pragma unroll
             for (int a = 0; a < NA; ++a)
@@ -1229,14 +1229,14 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     const int Hp = dae_round_up(H, DAE_HPAD);
     t.dtype = ctx->train_dtype;
     {   // bf16 GEMMs with the 4-tile backward kernels: dL/dz itself is stored as bf16 (DAE_BWD_F32 / DAE_DZ_F32: A/B)
-        static const bool dz_f32 = getenv("DAE_BWD_F32") != nullptr || getenv("DAE_DZ_F32") != nullptr;
+        static const bool dz_f32 = dae_exp_env("DAE_BWD_F32") != nullptr || dae_exp_env("DAE_DZ_F32") != nullptr;
         t.dz16 = (t.dtype == DAE_DTYPE_BF16 && (H % 128) == 0 && !dz_f32) ? 1 : 0;
     }
     t.g = t.dtype == DAE_DTYPE_BF16 ? dae_row_geometry_bf16(B, Hp) : dae_row_geometry(B, Hp);
     t.G = Hp / DAE_KG; t.RB = t.g.R_TILE / 32;
     {   // hidden 256: K5 reads the row-major decoder and hidden activations directly (fp32, or rounded to bf16 in
         // registers) -- no per-step prepack
-        static const bool k5_packed = getenv("DAE_K5_PACKED") != nullptr;                 // A/B
+        static const bool k5_packed = dae_exp_env("DAE_K5_PACKED") != nullptr;                 // A/B
         t.rm = (H == 256 && t.g.R_TILE == 128 && t.g.waves == 4 && !k5_packed) ? 1 : 0;
     }
     t.Bpad64 = (B + 63) / 64 * 64;
@@ -1307,7 +1307,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         }
         p.dzT = t.dzT; p.ldT = t.Bpad64; p.h = t.hbuf; p.H = H; p.B = B; p.V = Vl; p.gW = gWd; p.gb = gb_dec;
         p.accumulate = 0;
-        static const int k6dbg = getenv("DAE_DBG_K6") ? atoi(getenv("DAE_DBG_K6")) : 0;
+        static const int k6dbg = dae_exp_env("DAE_DBG_K6") ? atoi(dae_exp_env("DAE_DBG_K6")) : 0;
         p.dbg = k6dbg;
         p.n_half = H / (32 * NA);
         int nb = (DAE_NUM_CU / p.n_half) / DAE_NUM_XCD * DAE_NUM_XCD;
@@ -1322,8 +1322,8 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         const dim3 grid(p.n_half * nb), blk(256);
         // two waves per SIMD on the shared h image: 241 us against 257 us with one (V = 170 000, B = H = 256); the
         // second wave covers the dz^T load latency and the gW stores of the first (DAE_K6_WAVES=4 for the A/B)
-        static const bool k6w8 = !(getenv("DAE_K6_WAVES") && atoi(getenv("DAE_K6_WAVES")) == 4);
-        static const bool bwd_f32 = getenv("DAE_BWD_F32") != nullptr;      // A/B: bf16 forward only
+        static const bool k6w8 = !(dae_exp_env("DAE_K6_WAVES") && atoi(dae_exp_env("DAE_K6_WAVES")) == 4);
+        static const bool bwd_f32 = dae_exp_env("DAE_BWD_F32") != nullptr;      // A/B: bf16 forward only
         if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32) {
             static const char attr16_key = 0;
             if (dae_first_use(ctx, &attr16_key)) {
@@ -1335,7 +1335,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8, true, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            static const bool k6_old = getenv("DAE_K6_ORIENT") && !strcmp(getenv("DAE_K6_ORIENT"), "hidden");   // A/B
+            static const bool k6_old = dae_exp_env("DAE_K6_ORIENT") && !strcmp(dae_exp_env("DAE_K6_ORIENT"), "hidden");   // A/B
             if (t.dz16 && !k6_old) {
                 const size_t lds_t = (size_t)(((B + 31) & ~31) >> 4) * 4 * 64 * sizeof(uint4);
                 static const char k6t_key = 0;
@@ -1351,7 +1351,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                 DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_kernel<4, 8>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
-            static const bool k6_old32 = getenv("DAE_K6_ORIENT") && !strcmp(getenv("DAE_K6_ORIENT"), "hidden");   // A/B
+            static const bool k6_old32 = dae_exp_env("DAE_K6_ORIENT") && !strcmp(dae_exp_env("DAE_K6_ORIENT"), "hidden");   // A/B
             if (!k6_old32) {
                 static const char attr8t_key = 0;
                 if (dae_first_use(ctx, &attr8t_key))
@@ -1375,7 +1375,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         const int total = p.n_half * p.n_rblk * t.n_chunk;
         int blocks = (total + 3) / 4;
         if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
-        static const bool bwd_f32_7 = getenv("DAE_BWD_F32") != nullptr;
+        static const bool bwd_f32_7 = dae_exp_env("DAE_BWD_F32") != nullptr;
         if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7 && t.dz16)
             hipLaunchKernelGGL((grad_hidden_kernel<4, true, true>), dim3(blocks), dim3(256), 0, st, p);
         else if (NA == 4 && t.dtype == DAE_DTYPE_BF16 && !bwd_f32_7)

@@ -30,10 +30,11 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("dtype", [_lib.DAE_DTYPE_F32, _lib.DAE_DTYPE_BF16])
-def test_four_shard_contexts_full_size_equal_unsharded(dtype):
+@pytest.mark.parametrize("dtype,world,B", [(_lib.DAE_DTYPE_F32, 4, 1024), (_lib.DAE_DTYPE_BF16, 4, 1024),
+                                           (_lib.DAE_DTYPE_F32, 8, 512)])
+def test_shard_contexts_full_size_equal_unsharded(dtype, world, B):
     import torch
-    V, nt, H, B, k, world = 170000, 140000, 256, 1024, 500, 4
+    V, nt, H, k = 170000, 140000, 256, 500
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
     pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
     rp, col, val = coo_to_csr(pos, ones, B, V)
@@ -50,7 +51,8 @@ def test_four_shard_contexts_full_size_equal_unsharded(dtype):
         c.prepack_decoder(d_Wd, d_bd, lo, hi, dtype=dtype)
         ctxs.append(c)
         stages.append(HipRankStages(c, d_We, d_be, nt, dtype))
-    assert all_shard_bounds(V, world)[-1][0] > nt          # the last shard holds artist columns only: empty lists
+    if world == 8:
+        assert all_shard_bounds(V, world)[-1][0] > nt      # the last shard holds artist columns only: empty lists
 
     def gather_for(rank, exchange):
         # stands in for the collective: this process holds every shard, so "receiving" a peer's list = computing it
