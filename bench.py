@@ -90,6 +90,15 @@ def _probe_tensorflow():
         return None if isinstance(e, ImportError) else "import failed: %r" % (e,)
 
 
+def _pmc_traffic(key, kernel):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes, only if they were taken on this kernel."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_decode.json"))).get(key, {})
+        return tj.get("hbm_bytes_per_launch") if tj.get("kernel") == kernel else None
+    except Exception:
+        return None
+
+
 def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k, V, n_steps, n_warm, idx_f32, peaks):
     """Extra row of the default run (BASELINE.json configs[4]): the same step with the decode GEMM on bf16 operands
     (v_mfma_f32_32x32x16_bf16, fp32 accumulate; encode, threshold and top-k stay fp32)."""
@@ -127,7 +136,7 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
                                                   for r in range(a32.shape[0])])), 4)
     row = {"value": round(B * n_steps / el, 1), "unit": "playlists/s", "ms_per_step": round(el / n_steps * 1e3, 4),
            "steps": n_steps, "dtype": "bf16 decode GEMM (fp32 accumulate), fp32 encode / threshold / top-k",
-           "roofline": {"kernel": ctxs[0].profile_kernel(),
+           "roofline": {"kernel": ctxs[0].profile_kernel(), "traffic": _pmc_traffic("bf16", ctxs[0].profile_kernel()),
                         "bound": "hbm" if t_hbm > t_mfma else "mfma",
                         "mfma": {"achieved": round(tf_, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(tf_ / PEAK_BF16_TFLOPS, 4)},
@@ -361,7 +370,7 @@ def main():
     flop_per_launch = 2.0 * B * H * dom_tiles * 32
     kern_avg_ms = kern_ms / max(kern_n, 1)
     achieved_tflops = flop_per_launch / (kern_avg_ms * 1e-3) / 1e12 if kern_avg_ms > 0 else 0.0
-    traffic = None
+    traffic, pmc_mfma = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
     if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 256 and not sim:
         try:
@@ -369,6 +378,7 @@ def main():
             # PMC passes are separate rocprofv3 runs (scripts/gpu_pmc_traffic.sh); the figure is quoted only when it
             # was collected for the kernel this run timed
             traffic = tj.get("hbm_bytes_per_launch") if tj.get("kernel") == ctx.profile_kernel() else None
+            pmc_mfma = tj.get("mfma") if tj.get("kernel") == ctx.profile_kernel() else None
         except Exception:
             traffic = None
     peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -396,6 +406,9 @@ def main():
                     "traffic": traffic, "flop_per_launch": flop_per_launch, "bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(kern_avg_ms, 4), "launches": kern_n}
 
+    if pmc_mfma:
+        roofline["pmc"] = dict(pmc_mfma, note="rocprofv3 --pmc pass of the same kernel (profiles/traffic_decode.json): "
+                               "matrix-pipe busy cycles over the 1024 SIMDs / kernel cycles")
     # the same kernel alone on the GPU (one stream, nothing overlapping it), after the timed region
     if n_str > 1:
         torch.cuda.synchronize()

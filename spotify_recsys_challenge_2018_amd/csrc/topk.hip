@@ -570,119 +570,74 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
     }
 
     if (DAE_EXP_ON(dbg_stop == 4)) return;
-    // ---- 4b. k <= 512: get down to <= 512 keys so that the cheap ordering stage applies.  If more
-    // than 512 were collected, cut at the k-th key with one more histogram over the collected keys
-    // (one per thread).
-    u64 cut_final = lo;
-    if (sort_n == 1024 && k_eff > 0) {
-        if (s_cnt <= 512u) {
-            sort_n = 512;
-        } else {
-            const unsigned c = s_cnt < 1024u ? s_cnt : 1024u;
-            constexpr int PER = 1024 / NTH;                      // collected keys per thread (slot e * NTH + tid)
-            u64 mine[PER];
-#pragma unroll
-            for (int e = 0; e < PER; ++e) mine[e] = (unsigned)(e * NTH + tid) < c ? skey[e * NTH + tid] : 0ull;
-            // float keys are log-spaced, so one linear histogram over [cut, max] can leave the k-th
-            // key in a fat bin: re-bin inside that bin until what is kept fits (<= 1024 keys in registers,
-            // so every pass is a handful of barriers)
-            u64 rlo = lo, rhi = s_max, cut2 = lo;
-            unsigned rabove = 0, keep = c;
-            for (int it = 0; it < 6 && keep > 512u; ++it) {
-                const u64 range = rhi - rlo;
-                int shift = 64 - 11 - __clzll(range | 1ull);
-                if (shift < 0) shift = 0;
-                for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < PER; ++e)
-                    if (mine[e] != 0ull && mine[e] >= rlo && mine[e] <= rhi)
-                        atomicAdd(&hist[(unsigned)((mine[e] - rlo) >> shift)], 1u);
-                __syncthreads();
-                find_bin<NTH>(hist, wave_tot, tid, k_eff - rabove, &s_bin, &s_above);
-                const unsigned bcnt = hist[s_bin];
-                cut2 = rlo + ((u64)(unsigned)s_bin << shift);
-                keep = rabove + s_above + bcnt;                  // keys >= cut2
-                u64 nhi = cut2 + ((1ull << shift) - 1ull);
-                if (nhi > rhi) nhi = rhi;
-                rabove += s_above;
-                rlo = cut2; rhi = nhi;
-                __syncthreads();
-            }
-            if (keep <= 512u) {
-                if (tid == 0) s_cnt = 0;
-                __syncthreads();                                 // all old skey reads are done (mine[] holds them)
-                for (int i = tid; i < 512; i += TK_THREADS) skey[i] = 0ull;
-                __syncthreads();
-#pragma unroll
-                for (int e = 0; e < PER; ++e) {
-                    const bool v = mine[e] != 0ull && mine[e] >= cut2;
-                    const u64 bal = __ballot(v);
-                    if (bal) {
-                        const int leader = __ffsll((long long)bal) - 1;
-                        unsigned base = 0;
-                        if (lane == leader) base = atomicAdd(&s_cnt, (unsigned)__popcll(bal));
-                        base = __shfl(base, leader);
-                        if (v) skey[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine[e];
-                    }
-                }
-                __syncthreads();
-                sort_n = 512;
-                cut_final = cut2;
-            }
-        }
-        if (sort_n == 512 && a.out_cnt && k_eff == (unsigned)k) {
-            // threshold mode (phase A): >= k keys are >= cut_final, so its logit is a valid lower
-            // bound of the k-th largest logit -- all phase B needs; survivors go out unsorted.
-            const unsigned c2 = s_cnt;
-            for (unsigned i = (unsigned)tid; i < c2; i += TK_THREADS) {
-                const u64 ck = skey[i];
-                a.out_pairs[(size_t)row * a.pairs_stride + i] =
-                    make_uint2(__float_as_uint(dae_okey_inv((unsigned)(ck >> 32))),
-                               ~(unsigned)(ck & 0xFFFFFFFFull));
-            }
-            if (tid == 0) {
-                a.out_cnt[row] = (int)c2;
-                a.out_tau[row] = dae_okey_inv((unsigned)(cut_final >> 32));
-            }
-            return;
-        }
-    }
-
-    if (DAE_EXP_ON(dbg_stop == 99) && tid == 0)
-        printf("SLOWPATH row %d m %u k_eff %u s_cnt %u sort_n %d narrowed %d tau_mode %d\n", row, m, k_eff,
-               s_cnt, sort_n, (int)narrowed, a.out_cnt ? 1 : 0);
+    // ---- 5a. k <= 512 (at most 1024 keys were collected): order by HISTOGRAM RANK.  The output position of a key is
+    // the number of keys above it = (keys in higher bins) + (keys of its own bin above it): a 2048-bin histogram over
+    // the live key range, a suffix scan over the bins, the keys dropped bin by bin into a second buffer, and a count
+    // over the (few) keys that share the bin.  ~6 barriers and one LDS atomic per key; it takes whatever was
+    // collected, so no separate "refine to <= 512 keys" stage exists (that stage + a 512-key network cost 3.9 + 13.9 us
+    // of the final launch, rank-by-counting over 512 keys 3.9 + 5.7 us; profiles/r02_notes.md).
     if (DAE_EXP_ON(dbg_stop == 5)) return;
-    if (NTH >= 512 && sort_n == 512) {
-        // <= 512 unique keys (0 = empty slot): the position of a key in the output IS the number of keys above it.
-        // Thread (key, part) counts over its part of the buffer with 16-byte LDS reads at a wave-uniform address (a
-        // broadcast: one LDS cycle per wave) -- 128 reads + 256 compares per thread with 1024 threads -- instead of
-        // the 45-stage bitonic network (13.9 us of shuffles and 2-barrier LDS stages, profiles/r01_notes.md).
-        constexpr int PARTS = NTH / 512;
-        const int me = tid & 511, part = tid >> 9;
-        const u64 kr = skey[me];
-        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(skey) + part * (256 / PARTS);
-        unsigned above = 0;
-#pragma unroll 8
-        for (int m = 0; m < 256 / PARTS; ++m) {
-            const ulonglong2 v = s2[m];
-            above += (v.x > kr ? 1u : 0u) + (v.y > kr ? 1u : 0u);
+    if (sort_n == 1024) {
+        constexpr int PER = 1024 / NTH;                          // collected keys per thread (slot e * NTH + tid)
+        constexpr int BPT = TK_BINS / NTH;
+        const unsigned c = s_cnt < 1024u ? s_cnt : 1024u;
+        u64 mine[PER];
+        unsigned mbin[PER], mpos[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) mine[e] = (unsigned)(e * NTH + tid) < c ? skey[e * NTH + tid] : 0ull;
+        const u64 rlo = lo, rhi = s_max;                         // every collected key lies in [lo, s_max]
+        int shift = 64 - 11 - __clzll((rhi - rlo) | 1ull);
+        if (shift < 0) shift = 0;
+        for (int b2 = tid; b2 < TK_BINS; b2 += TK_THREADS) hist[b2] = 0;
+        __syncthreads();                                         // also: every skey read above is done
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            mbin[e] = mine[e] != 0ull ? (unsigned)((mine[e] - rlo) >> shift) : 0u;
+            mpos[e] = mine[e] != 0ull ? atomicAdd(&hist[mbin[e]], 1u) : 0u;
         }
-        if (PARTS > 1) {
-            __syncthreads();                                     // hist is free after the narrowing stages
-            if (part) hist[me] = above;
+        __syncthreads();
+        // above[b] = keys in bins > b.  Thread t owns the BPT bins from 2047 - BPT t downwards.
+        unsigned* above = reinterpret_cast<unsigned*>(skey);     // 2048 x 4 B = the sort buffer's 1024 x 8 B
+        u64* sorted = keys;                                      // key cache region: >= 1024 keys (launch_topk)
+        {
+            const int top = TK_BINS - 1 - BPT * tid;
+            unsigned cb[BPT], own = 0;
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) { cb[e] = hist[top - e]; own += cb[e]; }
+            unsigned v = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned o = __shfl_up(v, d);
+                if (lane >= d) v += o;
+            }
+            if (lane == 63) wave_tot[tid >> 6] = v;
             __syncthreads();
-            if (!part) above += hist[me];
+            unsigned run = v - own;
+            for (int w = 0; w < (tid >> 6); ++w) run += wave_tot[w];
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) { above[top - e] = run; run += cb[e]; }
         }
-        if (!part && kr != 0ull && above < k_eff) {
-            const float z = dae_okey_inv((unsigned)(kr >> 32));
-            const int colv = (int)(~(unsigned)(kr & 0xFFFFFFFFull));
-            const size_t o = (size_t)row * k + above;
-            if (a.out_idx) a.out_idx[o] = colv;
-            if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
-            if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + above] =
-                make_uint2(__float_as_uint(z), (unsigned)colv);
-            if (a.out_tau && above == (unsigned)k - 1) a.out_tau[row] = z;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (mine[e] != 0ull) sorted[above[mbin[e]] + mpos[e]] = mine[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (mine[e] == 0ull) continue;
+            const unsigned base = above[mbin[e]], nb = hist[mbin[e]];
+            unsigned rank = base;
+            for (unsigned i = 0; i < nb; ++i) rank += sorted[base + i] > mine[e] ? 1u : 0u;
+            if (rank < k_eff) {
+                const float z = dae_okey_inv((unsigned)(mine[e] >> 32));
+                const int colv = (int)(~(unsigned)(mine[e] & 0xFFFFFFFFull));
+                const size_t o = (size_t)row * k + rank;
+                if (a.out_idx) a.out_idx[o] = colv;
+                if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
+                if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + rank] =
+                    make_uint2(__float_as_uint(z), (unsigned)colv);
+                if (a.out_tau && rank == (unsigned)k - 1) a.out_tau[row] = z;
+            }
         }
     } else
     // Hybrid bitonic sort, descending.  Thread t holds elements t, t + NTH, ... (E = sort_n / NTH of them,
@@ -997,6 +952,7 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
         // with many rows of few keys (large batches, vocabulary shards) two workgroups then share a CU.
         const size_t room = lds_total - lds_static - bm_bytes - (size_t)sort_n * 8;
         size_t want = (size_t)(src.max_keys() > 0 ? src.max_keys() : 8192) * 8;
+        if (want < 1024 * 8) want = 1024 * 8;                   // the ordering stage's second buffer (1024 keys)
         if (want > room) want = room;
         key_cap = (int)(want / 8);
         dyn = bm_bytes + (size_t)sort_n * 8 + want;
