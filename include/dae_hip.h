@@ -102,6 +102,14 @@ int dae_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, 
                    int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                    int32_t* status);
 
+/* The seed lists of a scoring call whose seeds are the playlist's OWN tracks -- what both reference drivers pass
+ * (main_challenge.py:76-88 `seed` = the track ids x_positions feeds; main_train.py:64-89 `test_seed` likewise): the
+ * columns < n_tracks of every row of the input CSR, as a CSR (seed_row_ptr [B+1], seed_col with room for
+ * row_ptr[B] entries; sorted and unique per row because the input rows are).  Saves the host the list handling and
+ * two uploads per batch.  B <= 16384. */
+int dae_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
+                       int32_t* seed_row_ptr, int32_t* seed_col);
+
 /* h[r,:] = hidden_dropout( sigmoid( sum_c (x[r,c]/(s_r+1e-10)) * W_enc[c,:] + b_enc ) )
  *   x      = input_dropout(CSR row r), s_r = sum of surviving weights.
  *   ikp/kp = input / hidden keep probabilities (1.0 = identity, the inference setting);
@@ -260,6 +268,24 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
  * x_count / (u + x_count + 1e-10)), computed by the caller from the feed. */
 int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,
                    const float* w_title, const float* w_playlist, int B, int ncols);
+
+/* The same mix WITHOUT the two [B, V] score matrices (what `--challenge` runs for titled batches, main_challenge.py:80-90
+ * with DAE_title.y_pred of DAEs.py:176-181):
+ *
+ * dae_decode_mix_term (on the DAE's context): outT[c * ldT + r] = w_playlist[r] * sigmoid(h[r,:] . W_dec[c,:] + b_dec[c])
+ *   for the prepacked columns c < n_cols (pass n_tracks: only track columns are ranked) -- the second term of
+ *   DAEs.py:180, stored TRANSPOSED ([column][row], ldT >= B) so that both sides touch whole cache lines.  Whole
+ *   32-column tiles are written: outT needs room for n_cols rounded up to a multiple of 32 (but never past the image).
+ * dae_set_score_mix (on the title scorer's context, whose prepacked "decoder" is Output_W^T / Output_b): until
+ *   cleared with (NULL, 0, 0, NULL), dae_decode_topk on this context ranks
+ *       y[r, c] = sigmoid(feat[r,:] . Output_W[:, c] + Output_b[c]) * w_title[r] + mixT[c * ld + r]
+ *   instead of the logit -- same operations and order as dae_mix_scores, so the result is bit-identical to
+ *   dae_mix_scores + dae_topk_dense(DAE_OUT_LOGIT) -- through the fused threshold path (sample tiles -> tau -> filter
+ *   -> top-k); out_score holds y whatever out_kind says.  mixT ([n_cols][ld], columns past n_cols count as 0) and
+ *   w_title are caller-owned device arrays. */
+int dae_decode_mix_term(dae_ctx* ctx, const float* h, int B, int H, int dtype, const float* row_scale, int n_cols,
+                        float* outT, int64_t ldT);
+int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, const float* w_title);
 
 /* Training of the title variables (main_train.py:214-221 feeds the playlist as x AND y, titles_use = 1; the DAE
  * arrays are constants, DAEs.py:165-171).  The caller runs the forward pieces -- dae_encode (dropout on) +

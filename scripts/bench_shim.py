@@ -42,6 +42,29 @@ def main():
         dt = time.perf_counter() - t0
         print("model.recommend, feed -> top-500 on the host, device_csr=%s: %.0f playlists/s (%.2f ms per batch of %d)"
               % (dev_csr, n / dt, dt / (n / B) * 1e3, B))
+    # the drivers' loop: batches streamed through recommend_iter (upload / launch of batch n + 1 before the fetch of
+    # batch n), seeds cut out of the input on the device, indices only -- what main.py --challenge runs
+    from spotify_recsys_challenge_2018_amd.models.DAEs import SEEDS_FROM_INPUT
+    m.device_csr = True
+    for label, seeds_of, scores in (("seed lists from the host, idx + score", lambda s_: s_, True),
+                                    ("seeds = input tracks (device), idx only", lambda s_: SEEDS_FROM_INPUT, False)):
+        def feeds(reps):
+            for _ in range(reps):
+                for p_, o_, s_ in batches:
+                    yield p_, o_, seeds_of(s_), B
+        for _ in m.recommend_iter(feeds(1), k=500, want_scores=scores):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _idx, _sc in m.recommend_iter(feeds(5), k=500, want_scores=scores):
+            n += B
+        dt = time.perf_counter() - t0
+        print("model.recommend_iter (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (label, n / dt, dt / (n / B) * 1e3, B))
+    # same answers either way
+    a = m.recommend(batches[0][0], batches[0][1], batches[0][2], k=500)
+    b = next(iter(m.recommend_iter([(batches[0][0], batches[0][1], SEEDS_FROM_INPUT, B)], k=500)))
+    print("recommend_iter(SEEDS_FROM_INPUT) == recommend(seed lists):", bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Title path at the reference's shapes ([TITLE] batch = 150, filter sizes 3/5/7/9 x 100, char_emb 50) over the
-170 000-item vocabulary: mixed (unfused) scoring through DAE_title.recommend and one --title training step."""
+170 000-item vocabulary: mixed scoring through DAE_title.recommend (fused: dae_decode_mix_term + dae_set_score_mix),
+the plain DAE path on the same batch, and one --title training step."""
 import os
 import pickle
 import sys
@@ -40,7 +41,38 @@ def main():
     for _ in range(n):
         m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use)
     dt = (time.perf_counter() - t0) / n
-    print("DAE_title.recommend (mixed, unfused, host feed -> top-500): %.2f ms per batch of %d = %.0f playlists/s" % (dt * 1e3, B, B / dt))
+    print("DAE_title.recommend (mixed, fused: no [B,V] matrices; host feed -> top-500): %.2f ms per batch of %d = %.0f playlists/s" % (dt * 1e3, B, B / dt))
+    i32, _ = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use)
+    for _ in range(2):
+        m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="bf16")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        i16, _ = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="bf16")
+    d16 = (time.perf_counter() - t0) / n
+    ov = np.mean([len(set(i32[r].tolist()) & set(i16[r].tolist())) / 500.0 for r in range(B)])
+    print("same, both GEMMs on bf16 operands: %.2f ms = %.0f playlists/s; top-500 overlap with fp32 %.4f" % (d16 * 1e3, B / d16, ov))
+    from spotify_recsys_challenge_2018_amd.models.DAEs import SEEDS_FROM_INPUT
+    for label, dt_, feed in (("titled fp32", "f32", (pos, ones, SEEDS_FROM_INPUT, B, titles, use)),
+                             ("titled bf16", "bf16", (pos, ones, SEEDS_FROM_INPUT, B, titles, use)),
+                             ("plain fp32", "f32", (pos, ones, SEEDS_FROM_INPUT, B))):
+        for _ in m.recommend_iter([feed] * 3, k=500, dtype=dt_, want_scores=False):
+            pass
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in m.recommend_iter([feed] * 40, k=500, dtype=dt_, want_scores=False):
+            pass
+        ds = (time.perf_counter() - t0) / 40
+        print("recommend_iter, %s (the drivers' loop: streamed batches, seeds from the input, idx only): %.3f ms per batch of %d = %.0f playlists/s"
+              % (label, ds * 1e3, B, B / ds))
+    for _ in range(2):
+        m.recommend(pos, ones, seeds, k=500)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        m.recommend(pos, ones, seeds, k=500)
+    dp = (time.perf_counter() - t0) / n
+    print("plain DAE.recommend, same batch and host feed: %.2f ms = %.0f playlists/s; titled / plain = %.2fx" % (dp * 1e3, B / dp, dt / dp))
+    # device time only (feeds resident): the mixed path's launches
+    rp_ = m._upload_csr(pos, ones)
+    torch.cuda.synchronize()
     yo = np.ones(len(pos), np.float32)
     for _ in range(2):
         m.train_step(pos, yo, pos, yo, 0.8, 0.01, titles=titles, title_keep_prob=0.8)

@@ -15,10 +15,10 @@ DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_last_plan",
-    "dae_coo_to_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
+    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate",
 ]
@@ -60,6 +60,7 @@ def load():
     lib.dae_profile_kernel.restype = ctypes.c_char_p
     lib.dae_last_plan.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.dae_coo_to_csr.argtypes = [vp, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, vp, vp]
+    lib.dae_seeds_from_csr.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
@@ -80,6 +81,8 @@ def load():
     lib.dae_title_features.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(ctypes.c_int32),
                                        c_int, c_int, c_f, c_u32, vp, c_i64, vp, vp]
     lib.dae_mix_scores.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, c_int, c_int]
+    lib.dae_decode_mix_term.argtypes = [vp, vp, c_int, c_int, c_int, vp, c_int, vp, c_i64]
+    lib.dae_set_score_mix.argtypes = [vp, vp, c_i64, c_int, vp]
     lib.dae_row_sums.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp]
     lib.dae_title_loss_backward.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, c_int, c_int, c_int,
                                             vp, c_int, vp, vp, vp, vp, vp]
@@ -150,6 +153,15 @@ class Context:
                                            int(n_cols), _ptr(rp), _ptr(col), _ptr(val), _ptr(status)))
         return rp, col, val, status
 
+    def seeds_from_csr(self, row_ptr, col, n_tracks):
+        """Seed CSR = the track columns of the input CSR (seeds are the playlist's own tracks).  -> (seed_row_ptr, seed_col)."""
+        import torch
+        B = row_ptr.numel() - 1
+        srp = torch.empty(B + 1, dtype=torch.int32, device=row_ptr.device)
+        sc = torch.empty(max(int(col.numel()), 1), dtype=torch.int32, device=row_ptr.device)
+        self.check(self.lib.dae_seeds_from_csr(self.h, _ptr(row_ptr), _ptr(col), B, int(n_tracks), _ptr(srp), _ptr(sc)))
+        return srp, sc
+
     def set_train_dtype(self, dtype):
         """Arithmetic of the training forward GEMM: DAE_DTYPE_F32 (default) or DAE_DTYPE_BF16."""
         self.check(self.lib.dae_set_train_dtype(self.h, int(dtype)))
@@ -210,6 +222,17 @@ class Context:
                                            int(ncols), int(col_base), _ptr(seed_row_ptr),
                                            _ptr(seed_col), int(k), int(out_kind),
                                            _ptr(out_score), _ptr(out_idx)))
+
+    def decode_mix_term(self, h, row_scale, n_cols, outT, dtype=DAE_DTYPE_F32):
+        """outT[c, r] = row_scale[r] * sigmoid(logit[r, c]) for the prepacked columns c < n_cols (DAEs.py:180, DAE term)."""
+        B, H = h.shape
+        self.check(self.lib.dae_decode_mix_term(self.h, _ptr(h), B, H, int(dtype), _ptr(row_scale), int(n_cols),
+                                                _ptr(outT), int(outT.stride(0))))
+
+    def set_score_mix(self, mixT=None, w_title=None):
+        """dae_decode_topk on this context ranks sigmoid(.) * w_title[r] + mixT[c, r] until cleared (no arguments)."""
+        self.check(self.lib.dae_set_score_mix(self.h, _ptr(mixT), int(mixT.stride(0)) if mixT is not None else 0,
+                                              int(mixT.shape[0]) if mixT is not None else 0, _ptr(w_title)))
 
     def topk_merge(self, cand_logit, cand_idx, out_score, out_idx, out_kind=DAE_OUT_SCORE):
         G, B, k = cand_logit.shape

@@ -206,6 +206,15 @@ int dae_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, 
                                  status);
 }
 
+int dae_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
+                       int32_t* seed_row_ptr, int32_t* seed_col)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !col || !seed_row_ptr || !seed_col) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0) return DAE_OK;
+    return dae_launch_seeds_from_csr(ctx, row_ptr, col, B, n_tracks, seed_row_ptr, seed_col);
+}
+
 int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
                const float* W_enc, const float* b_enc, int V, int H, int B,
                float ikp, float kp, uint32_t seed, float* h_out)
@@ -311,7 +320,9 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     // one maximum per (workgroup of the row group, round of sample tiles, position in the tile)
     const int n_ws_a = g.nb_rg * g.waves;
     const int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
-    if (fused) {
+    const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
+    if (mixed) out_kind = DAE_OUT_LOGIT;                   // ... which is a probability already: it goes out as it is
+    if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
         if (rc) return rc;
         gmax = static_cast<float*>(ctx->gmax.p);
@@ -343,7 +354,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     if (rc) return rc;
 
     // phase B: everything else through the threshold filter
-    const int cap = dae_filter_block_tiles(g, n_other, dtype, pk->Hp) * 32;     // worst case: everything passes
+    const int cap = dae_filter_block_tiles(g, n_other, dtype, pk->Hp, mixed) * 32;     // worst case: everything passes
     rc = dae_reserve(ctx, ctx->cand, (size_t)g.nb_rg * g.Bpad * cap * sizeof(uint2));
     if (rc) return rc;
     rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
@@ -495,6 +506,34 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
     if (rc) return rc;
     return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
                             out_score, out_idx, dtype);
+}
+
+int dae_decode_mix_term(dae_ctx* ctx, const float* h, int B, int H, int dtype, const float* row_scale, int n_cols,
+                        float* outT, int64_t ldT)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!h || !row_scale || !outT) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
+    const dae_packed* pk = packed_for(ctx, dtype, H);
+    if (!pk) return DAE_ERR_STATE;
+    if (ldT < B) return dae_fail(ctx, DAE_ERR_ARG, "ldT=%lld < %d rows", (long long)ldT, B);
+    if (B <= 0) return DAE_OK;
+    int n_loc = n_cols - pk->col_lo;                       // columns of the image below the global bound
+    if (n_loc > pk->col_hi - pk->col_lo) n_loc = pk->col_hi - pk->col_lo;
+    if (n_loc <= 0) return DAE_OK;
+    const dae_rowgeom g = geom_for(dtype, B, pk->Hp);
+    int rc = pack_hidden(ctx, dtype, h, B, H, g);
+    if (rc) return rc;
+    dae_tileset ts{(n_loc + 31) / 32, 1, 0, static_cast<const int*>(pk->ident.p)};
+    return dae_launch_decode_scaled_T(ctx, g, B, ts, row_scale, outT, ldT, dtype);
+}
+
+int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, const float* w_title)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if ((mixT == nullptr) != (w_title == nullptr)) return dae_fail(ctx, DAE_ERR_ARG, "mixT and w_title go together");
+    ctx->mixT = mixT; ctx->mix_ld = ld; ctx->mix_w = w_title; ctx->mix_ncols = mixT ? n_cols : 0;
+    return DAE_OK;
 }
 
 int dae_topk_dense(dae_ctx* ctx, const float* logits, int64_t ld, int B, int ncols, int col_base,

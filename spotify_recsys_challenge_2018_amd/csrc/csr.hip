@@ -297,7 +297,68 @@ __global__ __launch_bounds__(256) void csr_compact_sum_kernel(const int* __restr
     for (int s2 = tid; s2 < m; s2 += 256) { col[o + s2] = k_col[b + s2]; val[o + s2] = k_val[b + s2]; }
 }
 
+// The seed lists of a scoring call when the seeds ARE the playlist's own tracks (main_challenge.py:76-88: `seed` is
+// playlists[i][0], the ids x_positions feeds; main_train.py:66-89 likewise): the track columns (< n_tracks) of every
+// CSR row, as their own CSR.  Columns ascend within a row, so a row's tracks are its first entries: one binary search
+// per row, a block scan, a copy.  One workgroup (rows <= 16384: the scoring path works in slabs of 4096).
+constexpr int SEED_MAX_ROWS = 16384;
+__global__ __launch_bounds__(1024) void seeds_from_csr_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ col, int B, int n_tracks,
+                                                              int32_t* __restrict__ seed_row_ptr,
+                                                              int32_t* __restrict__ seed_col)
+{
+    extern __shared__ int s_off[];                                // [B + 1]
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int carry = 0;
+    for (int r0 = 0; r0 < B; r0 += 1024) {
+        const int r = r0 + tid;
+        int cnt = 0;
+        if (r < B) {
+            int lo = row_ptr[r], hi = row_ptr[r + 1];
+            const int beg = lo;
+            while (lo < hi) {                                     // first entry with col >= n_tracks
+                const int mid = (lo + hi) >> 1;
+                if (col[mid] < n_tracks) lo = mid + 1; else hi = mid;
+            }
+            cnt = lo - beg;
+        }
+        int v = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v += o;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wv] = v;
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wv; ++w) pre += wsum[w];
+        if (r < B) s_off[r] = pre + v - cnt;
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];
+        carry += tot;
+    }
+    if (tid == 0) s_off[B] = carry;
+    __syncthreads();
+    for (int r = tid; r <= B; r += 1024) seed_row_ptr[r] = s_off[r];
+    for (int r = wv; r < B; r += 16) {
+        const int n = s_off[r + 1] - s_off[r], src = row_ptr[r], dst = s_off[r];
+        for (int i = lane; i < n; i += 64) seed_col[dst + i] = col[src + i];
+    }
+}
+
 }  // namespace
+
+int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
+                              int32_t* seed_row_ptr, int32_t* seed_col)
+{
+    if (B > SEED_MAX_ROWS) return dae_fail(ctx, DAE_ERR_ARG, "seeds_from_csr: %d rows (max %d)", B, SEED_MAX_ROWS);
+    hipLaunchKernelGGL(seeds_from_csr_kernel, dim3(1), dim3(1024), (size_t)(B + 1) * sizeof(int), ctx->stream, row_ptr,
+                       col, B, n_tracks, seed_row_ptr, seed_col);
+    DAE_CHECK_LAUNCH(ctx, "seeds_from_csr_kernel");
+    return DAE_OK;
+}
 
 int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,

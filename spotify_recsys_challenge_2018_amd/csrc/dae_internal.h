@@ -73,6 +73,7 @@ struct dae_ctx {
     dae_buf dense_tmp;         // unfused fallback logits
     dae_buf train_a, train_b, train_c, train_d;
     float* arm_m = nullptr; float* arm_v = nullptr; float arm_alpha = 0.f, arm_b1 = 0.f, arm_b2 = 0.f, arm_eps = 0.f;  // dae_arm_decoder_adam
+    const float* mixT = nullptr; int64_t mix_ld = 0; const float* mix_w = nullptr; int mix_ncols = 0;   // dae_set_score_mix (caller-owned)
     hipEvent_t gate_wait = nullptr, gate_record = nullptr;   // dae_set_decode_gate (caller-owned events)
     int enc_grad_prezeroed = 0;        // untied gW_enc is all-zero on entry (dae_adam_rows_apply re-zeroes what it reads)
     int adam_t = 0; float adam_b1 = 0.f, adam_b2 = 0.f, adam_b1p = 1.f, adam_b2p = 1.f;   // running beta powers of dae_adam_alpha
@@ -214,7 +215,7 @@ int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, 
                            int col_lo, int col_hi);
 int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
 // (re)build pk.order for `nrank` rankable columns; the first n_samp entries are the threshold sample
-int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp);
+int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp, bool mixed = false);
 int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, int S);
 
 struct dae_tileset {        // which wave tiles a decode launch walks
@@ -234,6 +235,9 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
                                  int cap, int dtype = DAE_DTYPE_F32);
+
+int dae_launch_decode_scaled_T(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, const float* row_scale,
+                               float* outT, int64_t ldT, int dtype = DAE_DTYPE_F32);
 
 // training forward: all tiles; the epilogue takes every element as a negative (target 0), writes dL/dz
 // TRANSPOSED ([ncols, ldT]: what both backward GEMMs read) and one loss partial per workgroup
@@ -285,6 +289,9 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
 int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                           int32_t* status);
+
+int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
+                              int32_t* seed_row_ptr, int32_t* seed_col);
 
 // title.hip
 int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,

@@ -22,6 +22,8 @@
 //   * blockIdx -> (row group, slot) is XCD-aware: the workgroups that walk the SAME column tiles
 //     for different row groups sit on the same XCD (blockIdx % 8), so the second..n-th read of a
 //     W tile hits that XCD's L2 instead of HBM.
+#include <climits>
+
 #include "dae_internal.h"
 
 namespace {
@@ -73,6 +75,12 @@ struct DecP {
     float* gmax; int64_t ld_gmax;
     // filter epilogue
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
+    // title mix (models/DAEs.py:180 of the reference: y = title_score * w_title + dae_score * w_playlist):
+    //   DAE side, EPI_DENSE: outT[column * ld_outT + row] = sigmoid(z) * row_scale[row] -- the second term, transposed
+    //   title side, EPI_GMAX / EPI_FILTER: every value becomes sigmoid(z) * mix_w[row] + mixT[column * mix_ld + row]
+    //   before it is stored / compared, i.e. the launch ranks the MIXED score; no [B, V] matrix of either scorer exists
+    float* outT; int64_t ld_outT; const float* row_scale;
+    const float* mixT; int64_t mix_ld; const float* mix_w; int mix_ncols;   // mixT holds global columns [0, mix_ncols)
     // loss epilogue
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
     int dz16;                      // dzT holds bf16 (the bf16 backward GEMMs read it as such)
@@ -235,6 +243,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         for (int qd = 0; qd < 4; ++qd)
             bq[qd] = DT == DT_BF16 ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bp + 8 * qd);
 
+        // title mix: the other scorer's term of this tile's elements, requested now, consumed in the epilogue
+        float mixv[(EPI == EPI_GMAX || EPI == EPI_FILTER) ? RB : 1][16];
+        if ((EPI == EPI_GMAX || EPI == EPI_FILTER) && p.mixT) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lc = t * 32 + 4 * hi + (e & 3) + 8 * (e >> 2);
+                    mixv[rb][e] = (row < p.B && lc < p.ncols && p.col_lo + lc < p.mix_ncols)
+                                      ? p.mixT[(size_t)(p.col_lo + lc) * p.mix_ld + row] : 0.0f;
+                }
+            }
+        }
+
         f32x16 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -326,7 +349,46 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
         const int tcol0 = t * 32 + 4 * hi;                // local column of reg 0 in the image
 
-        if (EPI == EPI_DENSE || EPI == EPI_GMAX) {
+        if ((EPI == EPI_GMAX || EPI == EPI_FILTER) && p.mixT) {
+            // the accumulators become the mixed scores (same operations, same order as mix_scores_kernel of the
+            // unfused path: title * w_title + dae * w_playlist, no contraction); the bias is consumed here
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                const float wt = row < p.B ? p.mix_w[row] : 0.0f;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ts = dae_sigmoidf(acc[rb][4 * qd + e] + zb[e]) * wt;
+                        acc[rb][4 * qd + e] = ts + mixv[rb][4 * qd + e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) bq[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+        if (EPI == EPI_DENSE && p.outT) {
+            // DAE term of the title mix, transposed: a store instruction writes 32 consecutive rows of one column
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                if (row >= p.B) continue;
+                const float sc = p.row_scale[row];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lc = tcol0 + 8 * qd + e;
+                        if (lc < p.ncols)
+                            p.outT[(size_t)(p.col_lo + lc) * p.ld_outT + row] = dae_sigmoidf(acc[rb][4 * qd + e] + zb[e]) * sc;
+                    }
+                }
+            }
+        } else if (EPI == EPI_DENSE || EPI == EPI_GMAX) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
@@ -1437,16 +1499,17 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     p.col_lo = pk.col_lo;
     p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg; p.Bpad = g.Bpad;
     p.ts = ts;
+    p.mixT = ctx->mixT; p.mix_ld = ctx->mix_ld; p.mix_w = ctx->mix_w; p.mix_ncols = ctx->mix_ncols;      // dae_set_score_mix (GMAX / FILTER epilogues)
     return DAE_OK;
 }
 
 }  // namespace
 
 // most tiles one workgroup of the filter launch can walk (sizes its private candidate lists)
-int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp)
+int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp, bool mixed)
 {
     const int n_ws = g.nb_rg * g.waves;
-    if (bf16_fast_filter(g, dtype, Hp / 16)) {
+    if (bf16_fast_filter(g, dtype, Hp / 16) && !mixed) {
         const bool pair = g.R_TILE != 256 && bf16_pair_variant();
         const int nt = pair ? 2 : 1;
         const int nw = (g.R_TILE == 256 || pair) ? 4 : 8;
@@ -1645,6 +1708,18 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
                                   : launch_decode_rb_bf16<EPI_DENSE>(ctx, g, p);
 }
 
+// DAE term of the title mix: outT[c * ldT + r] = sigmoid(logit[r, c]) * row_scale[r] for the first n_items tiles
+int dae_launch_decode_scaled_T(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, const float* row_scale,
+                               float* outT, int64_t ldT, int dtype)
+{
+    DecP p;
+    int rc = fill_common(ctx, g, B, ts, p, dtype);
+    if (rc) return rc;
+    p.mixT = nullptr;
+    p.outT = outT; p.ld_outT = ldT; p.row_scale = row_scale; p.mask_from_col = INT_MAX;
+    return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_DENSE>(ctx, g, p) : launch_decode_rb_bf16<EPI_DENSE>(ctx, g, p);
+}
+
 // K5 from the row-major decoder (fp32, hidden = 256, 128-row groups); returns DAE_ERR_STATE when the shape does not apply
 int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, int V, int H, const float* W,
                                     const float* bias, const float* h, float inv_n_batch, float* dzT, int64_t ldT,
@@ -1703,7 +1778,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
     static const bool f32_generic = dae_exp_env("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body
-    if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && g.waves == 4 && !f32_generic) {
+    if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && g.waves == 4 && !f32_generic && !p.mixT) {
         const size_t lds = (size_t)4 * 64 * 32 * sizeof(float4) + 128 * sizeof(int) + 128 * sizeof(float);
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {
@@ -1721,7 +1796,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
         DAE_CHECK_LAUNCH(ctx, "decode_f32_h256_filter_kernel");
         return DAE_OK;
     }
-    if (bf16_fast_filter(g, dtype, p.G)) {
+    if (bf16_fast_filter(g, dtype, p.G) && !p.mixT) {
         const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * (sizeof(int) + sizeof(float));
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {

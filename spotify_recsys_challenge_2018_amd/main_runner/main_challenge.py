@@ -122,24 +122,50 @@ def run(conf, model=None):
         log_write(conf, 'title model: batches partitioned over %d ranks' % world)
 
     cands = []                  # (position in the file, [pid, uris...]) of the rows THIS rank holds results for
-    n_seen, n_batches = 0, 0
-    while True:
-        x_positions, seed, titles, titles_exist, pid, x_ones = reader.next_batch()
-        mine = sharded or world == 1 or n_batches % world == rank
-        if mine and use_titles:
-            idx, _score = model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed), titles=titles,
-                                          titles_use=[t[0] for t in titles_exist])
-        elif mine:
-            idx, _score = model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed))
-        if mine and not (sharded and exchange == 'allgather' and rank != 0):   # all-gather: rank 0 formats and writes
-            r0, _r1 = model.owned_rows() if sharded else (0, len(seed))
-            for j in range(len(idx)):                       # rows r0 .. of the batch (all of them unless alltoall)
-                i = r0 + j
-                cands.append((n_seen + i, [pid[i]] + cand_to_uris(idx[j], reader.id2uri)))
-        n_seen += len(seed)
-        n_batches += 1
-        if reader.ch_idx == 0:
-            break
+    # The challenge seeds ARE the playlist's tracks (reader: seed = playlists[i][0], the ids x_positions feeds), so the
+    # model cuts the seed lists out of the input on the device; batches are streamed through recommend_iter (upload and
+    # launch of batch n + 1 before the results of batch n are fetched).
+    from ..models.DAEs import SEEDS_FROM_INPUT
+    meta = []                   # per submitted batch: (first position in the file, pids, rows in the batch)
+
+    def feeds():
+        n_seen, n_batches = 0, 0
+        while True:
+            x_positions, seed, titles, titles_exist, pid, x_ones = reader.next_batch()
+            mine = sharded or world == 1 or n_batches % world == rank
+            if mine:
+                meta.append((n_seen, pid, len(seed)))
+                yield x_positions, x_ones, seed, titles, titles_exist
+            n_seen += len(seed)
+            n_batches += 1
+            if reader.ch_idx == 0:
+                break
+
+    def results():
+        if use_titles and hasattr(model, 'recommend_iter'):
+            stream = ((xp, xo, SEEDS_FROM_INPUT, len(seed), t, [e[0] for e in te]) for xp, xo, seed, t, te in feeds())
+            for idx, _score in model.recommend_iter(stream, k=500, want_scores=False):
+                yield idx
+        elif use_titles:
+            for x_positions, x_ones, seed, titles, titles_exist in feeds():
+                yield model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed), titles=titles,
+                                      titles_use=[t[0] for t in titles_exist])[0]
+        elif hasattr(model, 'recommend_iter'):
+            stream = ((xp, xo, SEEDS_FROM_INPUT, len(seed)) for xp, xo, seed, _t, _e in feeds())
+            for idx, _score in model.recommend_iter(stream, k=500, want_scores=False):
+                yield idx
+        else:                   # a model object without the streaming entry point (tests)
+            for x_positions, x_ones, seed, _t, _e in feeds():
+                yield model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed))[0]
+
+    for b_no, idx in enumerate(results()):
+        first, pid, n_in_batch = meta[b_no]
+        if sharded and exchange == 'allgather' and rank != 0:        # all-gather: rank 0 formats and writes
+            continue
+        r0, _r1 = model.owned_rows() if sharded else (0, n_in_batch)
+        for j in range(len(idx)):                           # rows r0 .. of the batch (all of them unless alltoall)
+            i = r0 + j
+            cands.append((first + i, [pid[i]] + cand_to_uris(idx[j], reader.id2uri)))
 
     if world > 1:
         import torch.distributed as dist

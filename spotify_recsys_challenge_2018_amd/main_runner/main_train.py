@@ -32,24 +32,61 @@ def eval(reader_test, conf, model):
     """Mean r-precision over one test split (main_train.py:48-100): seed tracks only, both
     keep-probs 1.0, rank the track columns, drop the seeds, top 500."""
     total, count = 0.0, len(reader_test.playlists)
-    while True:
-        x_positions, test_seed, test_answer, titles, x_ones = reader_test.next_batch_test()
+    answers = []
+
+    def feeds():
+        while True:
+            x_positions, test_seed, test_answer, titles, x_ones = reader_test.next_batch_test()
+            answers.append(test_answer)
+            yield x_positions, x_ones, test_seed, titles
+            if reader_test.test_idx == 0:
+                break
+
+    def results():
         if conf.mode == 'title':                                   # main_train.py:69-79: titles_use = 1 everywhere
             # ... for rows that HAVE a title (every row of a file this repo's or the reference's generator
             # writes).  A 5-field row (the snapshot reader's layout) carries none: mixing in the score of an
             # all-padding title would rank a 0-seed row on noise, so such rows take titles_use = 0.
             pad = [-1] * conf.strmaxlen
-            use = np.array([0.0 if t is None else 1.0 for t in titles], np.float32)
-            titles = [t if t is not None else pad for t in titles]
-            idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed), titles=titles,
-                                     titles_use=use)
+            from ..models.DAEs import SEEDS_FROM_INPUT
+
+            def titled():
+                for x_positions, x_ones, test_seed, titles in feeds():
+                    use = np.array([0.0 if t is None else 1.0 for t in titles], np.float32)
+                    yield (x_positions, x_ones, SEEDS_FROM_INPUT, len(test_seed),
+                           [t if t is not None else pad for t in titles], use)
+            for idx, _score in model.recommend_iter(titled(), k=500, want_scores=False):
+                yield idx
+        elif hasattr(model, 'recommend_iter'):
+            # the evaluation seeds are the seed tracks the reader feeds (main_train.py:64-68): cut out of the input on
+            # the device; batches streamed (upload / launch of batch n + 1 before the fetch of batch n)
+            from ..models.DAEs import SEEDS_FROM_INPUT
+            stream = ((xp, xo, SEEDS_FROM_INPUT, len(seed)) for xp, xo, seed, _t in feeds())
+            for idx, _score in model.recommend_iter(stream, k=500, want_scores=False):
+                yield idx
         else:
-            idx, _ = model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))
-        for i in range(len(test_seed)):
-            total += met.eval_topk(idx[i], test_answer[i])
-        if reader_test.test_idx == 0:
-            break
+            for x_positions, x_ones, test_seed, _t in feeds():
+                yield model.recommend(x_positions, x_ones, test_seed, k=500, n_rows=len(test_seed))[0]
+
+    for b_no, idx in enumerate(results()):
+        for i in range(len(idx)):
+            total += met.eval_topk(idx[i], answers[b_no][i])
     return total / max(count, 1)
+
+
+def _eval_splits(readers_test, conf, model, rank, world):
+    """r-precision of every test split.  Under torch.distributed.run the splits are dealt round-robin to the ranks
+    (every rank holds a full, freshly synchronised replica for inference) and the values meet in one all-reduce, so
+    the evaluation of an epoch costs 1/world of what every-rank-evaluates-everything did."""
+    names = list(readers_test)
+    vals = [eval(readers_test[n], conf, model) if i % world == rank else 0.0 for i, n in enumerate(names)]
+    if world > 1 and names:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(vals, dtype=torch.float64, device=torch.device("cuda", conf.device_index))
+        dist.all_reduce(t)
+        vals = t.tolist()
+    return dict(zip(names, vals))
 
 
 def _init_distributed(conf):
@@ -120,9 +157,8 @@ def run(conf, only_testmode):
 
     if only_testmode:                                               # main_train.py:181-191
         log_write(conf, '<<only test mode>>')
-        out = {}
-        for seed_num, reader_test in readers_test.items():
-            out[seed_num] = eval(reader_test, conf, model)
+        out = _eval_splits(readers_test, conf, model, rank, world)
+        for seed_num in readers_test:
             log_write(conf, "seed num: %s rprecision: %f" % (seed_num, out[seed_num]))
         return out
 
@@ -142,9 +178,9 @@ def run(conf, only_testmode):
                 x_pos, x_val = trk_positions, trk_val
             else:
                 x_pos, x_val = art_positions, art_val
-            # single GPU: the cost stays on the device (a 0-dim tensor, summed there and fetched once per epoch)
-            # so the reader builds the next batch while this step runs; the sharded path returns a float
-            kw = {} if world > 1 else {"fetch_cost": False}
+            # the cost stays on the device (a 0-dim tensor, summed there and fetched once per epoch) so the reader
+            # builds the next batch while this step runs -- single GPU and vocabulary-sharded alike
+            kw = {"fetch_cost": False}
             l = model.train_step(x_pos, x_val, y_positions, np.ones(len(y_positions), np.float32),
                                  conf.kp, input_kp, **kw)
         loss = loss + l
@@ -157,13 +193,13 @@ def run(conf, only_testmode):
             log_write(conf, "epoch " + str(epoch))
             log_write(conf, "training loss: " + str(loss / it))
             cur_eval = 0.0
-            for seed_num, reader_test in readers_test.items():
-                rprec = eval(reader_test, conf, model)
-                log_write(conf, "seed num: %s rprecision: %f" % (seed_num, rprec))
+            model.sync_params()            # collective when sharded: every rank refreshes its replica first
+            rprecs = _eval_splits(readers_test, conf, model, rank, world)
+            for seed_num in readers_test:
+                log_write(conf, "seed num: %s rprecision: %f" % (seed_num, rprecs[seed_num]))
                 if seed_num in conf.update_seed:
-                    cur_eval += rprec
+                    cur_eval += rprecs[seed_num]
             history.append((epoch, loss / it, cur_eval))
-            model.sync_params()            # collective when sharded: every rank, before rank 0 saves
             if cur_eval >= max_eval:                                # :243-249
                 if rank == 0:
                     if conf.mode == 'title':

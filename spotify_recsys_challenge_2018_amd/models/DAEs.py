@@ -42,6 +42,9 @@ class _Fetch:
         return "<fetch %s>" % self.name
 
 
+SEEDS_FROM_INPUT = "input"      # recommend(seeds=SEEDS_FROM_INPUT): the seeds are the track columns of the input feed
+
+
 def coo_to_csr(positions, values, n_rows, n_cols=None):
     """DAEs.py:33-35 semantics for the kernels: the reference scatters COO (row, col) -> value
     into a dense matrix by ASSIGNMENT with validate_indices=False, so duplicates are the norm and
@@ -341,13 +344,12 @@ class DAE_tied:
         self._flush_rows_adam()
         if self._sharded is None or not self._params_stale:
             return
-        import torch
-        enc_W, dec_W, enc_b, dec_b = self._sharded.gather_params()
-        self.weights["encoder_h"].copy_(torch.from_numpy(enc_W))
+        enc_W, dec_W, enc_b, dec_b = self._sharded.gather_params(as_numpy=False)     # stays on the device
+        self.weights["encoder_h"].copy_(enc_W)
         if not self.tied:
-            self.weights["decoder_h"].copy_(torch.from_numpy(dec_W))
-        self.biases["encoder_b"].copy_(torch.from_numpy(enc_b))
-        self.biases["decoder_b"].copy_(torch.from_numpy(dec_b))
+            self.weights["decoder_h"].copy_(dec_W)
+        self.biases["encoder_b"].copy_(enc_b)
+        self.biases["decoder_b"].copy_(dec_b)
         self._params_stale = False
         self._mark_dirty()
 
@@ -386,38 +388,107 @@ class DAE_tied:
         self._check_feed()
         return res
 
+    def _dtype_of(self, dtype):
+        return self.decode_dtype if dtype is None else (
+            _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
+
+    def _seed_csr_dev(self, seeds, csr, side_stream=False):
+        """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
+        SEEDS_FROM_INPUT: the seeds are the playlist's own tracks -- what both reference drivers pass -- and are cut
+        out of the input CSR on the device (dae_seeds_from_csr): no per-row list handling, no uploads."""
+        import torch
+        if isinstance(seeds, str):
+            if seeds != SEEDS_FROM_INPUT:
+                raise ValueError("seeds: a list of per-row id lists, or SEEDS_FROM_INPUT")
+            return self.ctx.seeds_from_csr(csr[0], csr[1], self.n_tracks)
+        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
+        if sc.size == 0:
+            sc = np.zeros(1, np.int32)
+        return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
+
+    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None):
+        """Enqueue one batch of the fused scoring path; nothing is fetched.  -> (score, idx, done event)."""
+        import torch
+        dev = self.weights["encoder_h"].device
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream)
+        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
+        self.ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
+                            self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
+        ev = torch.cuda.current_stream(self.device_index).record_event()
+        return score, idx, ev
+
     def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None):
         """Fused scoring path: encode -> decode -> top-k (track columns, seeds removed).
         Equivalent of main_challenge.py:80-90 / main_train.py:66-89 without the dense matrix.
         Returns (idx [n_rows,k] int32 with -1 padding, score [n_rows,k] float32)."""
         import torch
-        dtype = self.decode_dtype if dtype is None else (
-            _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
+        dtype = self._dtype_of(dtype)
         sh = self._score_shard
         self._ensure_packed(dtype, None if sh is None else sh["cols"])
         self.ctx.bind_stream()
-        dev = self.weights["encoder_h"].device
-        rp, c, v = self._upload_csr(x_positions, x_ones)
-        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
-        if sc.size == 0:
-            sc = np.zeros(1, np.int32)
-        d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
         n_rows = self.n_batch if n_rows is None else n_rows
         if sh is not None:
             # vocabulary-sharded: local top-k over this rank's columns, one exchange, merge (sharding.ShardedRanker)
-            score, idx = self._shard_ranker(dtype).rank_batch((rp, c, v, d_srp, d_sc), k)
+            csr = self._upload_csr(x_positions, x_ones)
+            d_srp, d_sc = self._seed_csr_dev(seeds, csr)
+            score, idx = self._shard_ranker(dtype).rank_batch((csr[0], csr[1], csr[2], d_srp, d_sc), k)
             r0, r1 = self.owned_rows()
             n_own = max(0, min(r1, n_rows) - r0)
             res = idx[:n_own].cpu().numpy(), score[:n_own].cpu().numpy()
             self._check_feed()
             return res
-        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
-        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
-        self.ctx.score_topk(rp, c, v, self.weights["encoder_h"], self.biases["encoder_b"],
-                            self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
+        score, idx, _ev = self._submit(x_positions, x_ones, seeds, k, dtype, side_stream=False)
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
         self._check_feed()
         return res
+
+    def recommend_iter(self, feeds, k=500, dtype=None, want_scores=True):
+        """`recommend` over a stream of batches with the host and the device overlapped (the loop of
+        main_challenge.py:72-93 / main_train.py:62-96): `feeds` yields (x_positions, x_ones, seeds, n_rows); the
+        (DAE_title: + titles, titles_use) and the
+        generator yields (idx [n_rows,k], score [n_rows,k] or None) in order.  Batch n + 1 is uploaded (copy stream)
+        and enqueued BEFORE the results of batch n are fetched, and the fetch (a blocking copy to pageable memory) runs
+        on its own stream behind batch n's event, so it never waits for batch n + 1; the reader builds batch n + 2 while
+        the device scores.  Same results as calling `recommend` per batch."""
+        import torch
+        if self._score_shard is not None:
+            for x_positions, x_ones, seeds, n_rows in feeds:         # the exchange is a collective: no run-ahead
+                idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
+                yield idx, (score if want_scores else None)
+            return
+        dtype = self._dtype_of(dtype)
+        self._ensure_packed(dtype)
+        if getattr(self, "title_model", None) is not None:
+            self.title_model._ensure_packed(dtype)
+        self.ctx.bind_stream()
+        fs = self.__dict__.get("_fetch_stream")
+        if fs is None:
+            fs = self._fetch_stream = torch.cuda.Stream(device=self.weights["encoder_h"].device)
+
+        def fetch(ticket):
+            score, idx, ev, n_rows = ticket
+            fs.wait_event(ev)
+            with torch.cuda.stream(fs):
+                idx.record_stream(fs)
+                i_h = idx[:n_rows].cpu().numpy()
+                s_h = None
+                if want_scores:
+                    score.record_stream(fs)
+                    s_h = score[:n_rows].cpu().numpy()
+            return i_h, s_h
+        pending = None
+        for feed in feeds:
+            x_positions, x_ones, seeds, n_rows = feed[:4]
+            score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
+            ticket = (score, idx, ev, self.n_batch if n_rows is None else n_rows)
+            if pending is not None:
+                yield fetch(pending)
+            pending = ticket
+        if pending is not None:
+            yield fetch(pending)
+        self._check_feed()
 
     # -- training -----------------------------------------------------------------------------------
     def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, fetch_cost=True):
@@ -431,8 +502,9 @@ class DAE_tied:
             x = self._upload_csr(x_positions, x_ones)
             y = self._upload_csr(y_positions, y_ones)
             self._params_stale = True
-            cost = self._sharded.train_step(x, y, keep_prob, input_keep_prob)
-            self._check_feed()
+            cost = self._sharded.train_step(x, y, keep_prob, input_keep_prob, fetch_cost=fetch_cost)
+            if fetch_cost:
+                self._check_feed()
             return cost
         dev = self.weights["encoder_h"].device
         if self._adam is None:
@@ -593,22 +665,39 @@ class DAE_title(DAE):
         rows = np.repeat(np.arange(self.n_batch), np.diff(rp))
         return np.bincount(rows, weights=v.astype(np.float64), minlength=self.n_batch).astype(np.float32)
 
-    def mixed_scores(self, x_positions, x_ones, titles, titles_use, input_keep_prob=1.0, title_keep_prob=1.0,
-                     seed=0):
-        """sess.run(model.y_pred, ...) of the title graph: dense mixed scores [n_batch, n_input] (CUDA tensor)."""
+    def _mix_weights(self, csr, titles_use, input_keep_prob=1.0, seed=0, side_stream=False):
+        """DAEs.py:159-162 on the device: x_count = row_sum(x) * input_keep_prob; w_title = u / (u + x_count + 1e-10),
+        w_playlist = x_count / (same) -- fp32 operations in the reference's order.  -> (w_title, w_playlist) [n_batch]."""
         import torch
-        self._ensure_packed()
-        h = self.encode(x_positions, x_ones, 1.0, input_keep_prob, seed)
-        y = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=h.device)
-        self.ctx.decode_dense(h, y, apply_sigmoid=True)
-        ts = self.title_model.score(titles, self.n_batch, title_keep_prob, seed)
+        rp, c, v = csr
+        dev = rp.device
+        s = torch.empty(self.n_batch, dtype=torch.float32, device=dev)
+        P = _lib._ptr
+        self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(rp), P(c), P(v), self.n_batch, float(input_keep_prob),
+                                                 int(seed), P(s)))
         u = np.zeros(self.n_batch, np.float32)
         tu = np.asarray(titles_use, np.float32).reshape(-1)
         u[:len(tu)] = tu[:self.n_batch]
-        x_count = self._row_sums(x_positions, x_ones) * np.float32(input_keep_prob)
-        deno = u + x_count + np.float32(1e-10)
-        w_t = self._to_dev((u / deno).astype(np.float32), torch.float32)
-        w_p = self._to_dev((x_count / deno).astype(np.float32), torch.float32)
+        u = self._to_dev(u, torch.float32, side_stream)
+        x_count = s * float(np.float32(input_keep_prob))
+        deno = u + x_count + 1e-10
+        return (u / deno).contiguous(), (x_count / deno).contiguous()
+
+    def mixed_scores(self, x_positions, x_ones, titles, titles_use, input_keep_prob=1.0, title_keep_prob=1.0,
+                     seed=0):
+        """sess.run(model.y_pred, ...) of the title graph: dense mixed scores [n_batch, n_input] (CUDA tensor).  The
+        dense fetch of the protocol; `recommend` never builds these matrices."""
+        import torch
+        self._ensure_packed()
+        self.ctx.bind_stream()
+        csr = self._upload_csr(x_positions, x_ones)
+        h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32, device=self.weights["encoder_h"].device)
+        self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h,
+                        ikp=input_keep_prob, kp=1.0, seed=seed)
+        y = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=h.device)
+        self.ctx.decode_dense(h, y, apply_sigmoid=True)
+        ts = self.title_model.score(titles, self.n_batch, title_keep_prob, seed)
+        w_t, w_p = self._mix_weights(csr, titles_use, input_keep_prob, seed)
         self.ctx.bind_stream()
         P = _lib._ptr
         self.ctx.check(self.ctx.lib.dae_mix_scores(self.ctx.h, P(ts), int(ts.stride(0)), P(y), int(y.stride(0)),
@@ -660,23 +749,52 @@ class DAE_title(DAE):
         self._check_feed()
         return cost
 
+    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None):
+        """One batch enqueued, nothing fetched.  Without titles in use the mix reduces to the plain DAE (w_playlist is
+        exactly 1.0f, App. B.6): the fused path of the base class.  With titles: the DAE term of the track columns
+        goes to a transposed scratch (dae_decode_mix_term) and the title scorer's context runs the fused threshold
+        path on sigmoid(z_title) * w_title + that term (dae_set_score_mix) -- no [batch, n_input] matrix of either."""
+        if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
+            return DAE._submit(self, x_positions, x_ones, seeds, k, dtype, side_stream)
+        import torch
+        tm = self.title_model
+        tm.ctx.bind_stream()
+        dev = self.weights["encoder_h"].device
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream)
+        h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32, device=dev)
+        self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h)
+        w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream)
+        nt32 = min((self.n_tracks + 31) // 32 * 32, self.n_input)
+        y1T = torch.empty((nt32, self.n_batch), dtype=torch.float32, device=dev)
+        self.ctx.decode_mix_term(h, w_p, self.n_tracks, y1T, dtype=dtype)
+        feat = tm.features(titles, self.n_batch, side_stream_of=self if side_stream else None)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream)
+        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
+        tm.ctx.set_score_mix(y1T, w_t)
+        try:
+            tm.ctx.decode_topk(feat, self.n_tracks, d_srp, d_sc, k, score, idx, out_kind=_lib.DAE_OUT_LOGIT, dtype=dtype)
+        finally:
+            tm.ctx.set_score_mix()
+        ev = torch.cuda.current_stream(self.device_index).record_event()
+        return score, idx, ev
+
     def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None, titles=None, titles_use=None):
+        """Top-k of the MIXED score (DAEs.py:176-181 + main_challenge.py:26-41) without either [batch, n_input] matrix
+        (see `_submit`).  Same operations in the same order as `mixed_scores` + dae_topk_dense, hence the same bits
+        (fp32).  dtype "bf16" (or [BASE] decode_dtype = bf16) runs BOTH vocabulary-wide GEMMs -- the DAE decoder and
+        the title scorer's output layer -- on bf16 operands with fp32 accumulate; encode, title features, sigmoids,
+        the mix, the threshold and the ranking stay fp32."""
         if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
             return DAE.recommend(self, x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
-        import torch
         if self._score_shard is not None:
             raise _lib.DaeError("title-mixed batches are not vocabulary-sharded: run --challenge with titles on one "
                                 "GPU per process group (playlist partitioning), or without the title variables")
-        y = self.mixed_scores(x_positions, x_ones, titles, titles_use)
-        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
-        if sc.size == 0:
-            sc = np.zeros(1, np.int32)
-        d_srp, d_sc = self._to_dev(srp, torch.int32), self._to_dev(sc, torch.int32)
-        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=y.device)
-        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=y.device)
+        dtype = self._dtype_of(dtype)
+        self._ensure_packed(dtype)
+        self.title_model._ensure_packed(dtype)
         self.ctx.bind_stream()
-        # the mixed values are probabilities already: rank them as they are (no sigmoid on the way out)
-        self.ctx.topk_dense(y, self.n_tracks, 0, d_srp, d_sc, k, score, idx, out_kind=_lib.DAE_OUT_LOGIT)
+        score, idx, _ev = self._submit(x_positions, x_ones, seeds, k, dtype, False, titles, titles_use)
         n_rows = self.n_batch if n_rows is None else n_rows
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
         self._check_feed()

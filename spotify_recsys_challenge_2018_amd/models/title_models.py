@@ -63,18 +63,26 @@ class Char_CNN:
         return n + ["Output_W", "Output_b"]
 
     def _host_init(self):
-        """xavier_initializer(uniform=False) for every variable, biases included (Char_CNN.py:19, :44-46, :68-70)."""
+        """tf.contrib.layers.xavier_initializer(uniform=False) for every variable, biases included (Char_CNN.py:19,
+        :44-46, :68-70): a normal of stddev sqrt(2 / (fan_in + fan_out)) TRUNCATED at two standard deviations
+        (TF redraws the samples outside; the stddev is that of the untruncated normal).  For a rank-1 variable TF
+        takes fan_in = fan_out = its length: stddev sqrt(1 / n)."""
         rng = np.random.default_rng(self.init_seed)
 
         def xn(shape, fan_in, fan_out):
-            return (rng.standard_normal(shape) * np.sqrt(2.0 / (fan_in + fan_out))).astype(np.float32)
+            x = rng.standard_normal(shape)
+            bad = np.abs(x) > 2.0
+            while bad.any():                                     # truncated normal: redraw the tails
+                x[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(x) > 2.0
+            return (x * np.sqrt(2.0 / (fan_in + fan_out))).astype(np.float32)
         E, F, V = self.embedding, self.filter_num, self.output_dim
         p = {"char_embedding": xn((self.char_size, E), self.char_size, E)}
         for i, fs in enumerate(self.filter_sizes):
             p["Conv_W%d" % i] = xn((fs, E, 1, F), fs * E, fs * E * F)
-            p["Conv_b%d" % i] = xn((F,), F, 1)
+            p["Conv_b%d" % i] = xn((F,), F, F)
         p["Output_W"] = xn((self.n_feat, V), self.n_feat, V)
-        p["Output_b"] = xn((V,), V, 1)
+        p["Output_b"] = xn((V,), V, V)
         return p
 
     def fit(self, params=None):
@@ -134,19 +142,21 @@ class Char_CNN:
             self.set_params(pickle.load(f))
 
     # -- forward ----------------------------------------------------------------------------------------
-    def _titles_dev(self, titles, n_rows):
+    def _titles_dev(self, titles, n_rows, side_stream_of=None):
         import torch
         t = np.full((n_rows, self.input_len), -1, np.int32)
         src = np.asarray(titles, np.int64).reshape(-1, self.input_len) if len(titles) else np.zeros((0, self.input_len))
         t[:len(src)] = src[:n_rows]
+        if side_stream_of is not None:                 # streamed scoring: upload on the model's copy stream
+            return side_stream_of._to_dev(t, torch.int32, side_stream=True)
         return torch.from_numpy(t).to(torch.device("cuda", self.device_index))
 
-    def features(self, titles, n_rows, keep_prob=1.0, seed=0, keep_for_backward=False):
+    def features(self, titles, n_rows, keep_prob=1.0, seed=0, keep_for_backward=False, side_stream_of=None):
         """Char_CNN.py:23-63 -> feat [n_rows, ld] (CUDA); with keep_for_backward also (argmax, raw)."""
         import torch
         self.ctx.bind_stream()
         dev = self.p["conv_w"].device
-        d_t = self._titles_dev(titles, n_rows)
+        d_t = self._titles_dev(titles, n_rows, side_stream_of)
         feat = torch.empty((n_rows, self.ld), dtype=torch.float32, device=dev)
         arg = torch.empty((n_rows, self.n_feat), dtype=torch.int32, device=dev) if keep_for_backward else None
         raw = torch.empty((n_rows, self.n_feat), dtype=torch.float32, device=dev) if keep_for_backward else None
@@ -157,11 +167,14 @@ class Char_CNN:
             float(keep_prob), int(seed), P(feat), self.ld, P(arg), P(raw)))
         return (feat, d_t, arg, raw) if keep_for_backward else feat
 
-    def _ensure_packed(self):
+    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
         if self._packed_dirty:
-            self.ctx.bind_stream()
-            self.ctx.prepack_decoder(self.p["Output_WT"], self.p["Output_b"], 0, self.output_dim, _lib.DAE_DTYPE_F32)
+            self._packed = set()
             self._packed_dirty = False
+        if dtype not in self.__dict__.setdefault("_packed", set()):
+            self.ctx.bind_stream()
+            self.ctx.prepack_decoder(self.p["Output_WT"], self.p["Output_b"], 0, self.output_dim, dtype)
+            self._packed.add(dtype)
 
     def score(self, titles, n_rows, keep_prob=1.0, seed=0):
         """`model_title.output`: sigmoid(features . Output_W + Output_b) as a dense [n_rows, n_output] CUDA tensor."""

@@ -253,9 +253,10 @@ class ShardedTrainer:
             import torch.distributed as dist
             dist.all_reduce(t, group=self.group)
 
-    def train_step(self, x_csr, y_csr, keep_prob, input_keep_prob):
+    def train_step(self, x_csr, y_csr, keep_prob, input_keep_prob, fetch_cost=True):
         """x_csr / y_csr: (row_ptr, col, val) device tensors of the WHOLE batch with global column
-        ids (models.DAEs.coo_to_csr).  Returns the global cost (float)."""
+        ids (models.DAEs.coo_to_csr).  Returns the global cost: a float, or with fetch_cost=False a 0-dim tensor
+        on the trainer's device (no host synchronisation in the step: the reader builds the next batch meanwhile)."""
         st, g = self.stages, self.grads
         seed = int(self._rng.randint(0, 2 ** 31 - 1))
         st.encode(x_csr, self.W_enc, self.lo, self.hi, input_keep_prob, seed, self.pre)
@@ -273,11 +274,12 @@ class ShardedTrainer:
         for n, p in self.params.items():
             m, v = self.moments[n]
             st.adam(p, m, v, g[n], self.lr, self.step)
-        return float(self.cost.item())
+        return float(self.cost.item()) if fetch_cost else self.cost[0].clone()
 
-    def gather_params(self):
+    def gather_params(self, as_numpy=True):
         """The full d_params list [W_enc, W_dec, b_enc, b_dec] (DAEs.py:61/:138) on every rank:
-        all-gather of the row shards (padded to the largest shard, then trimmed)."""
+        all-gather of the row shards (padded to the largest shard, then trimmed).  as_numpy=False keeps the
+        gathered tensors on the trainer's device (the model copies them straight into its replica)."""
         import torch
         if self.world == 1:
             full = {n: p for n, p in self.params.items()}
@@ -296,6 +298,8 @@ class ShardedTrainer:
                 dist.all_gather_into_tensor(out, pad, group=self.group)
                 out = out.view((self.world, rows) + tuple(p.shape[1:]))
                 full[n] = torch.cat([out[r, :hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
+        if not as_numpy:
+            return [full["W_enc"], full["W_enc"] if self.tied else full["W_dec"], full["b_enc"], full["b_dec"]]
         W_enc = full["W_enc"].cpu().numpy()
         W_dec = W_enc if self.tied else full["W_dec"].cpu().numpy()
         return [W_enc, W_dec, full["b_enc"].cpu().numpy(), full["b_dec"].cpu().numpy()]
