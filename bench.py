@@ -570,7 +570,7 @@ def main():
                                      "same_indices_as_alltoall": agree,
                                      "note": "same shards, the per-shard lists all-gathered and ALL rows merged on "
                                              "every rank"}
-        exchange = "alltoall"
+        exchange[0] = "alltoall"
 
     # ---- the same job with the PLAYLISTS partitioned over the ranks instead of the vocabulary -------------
     # Not the headline (BASELINE.json configs[2] names the vocabulary shard): every rank holds the whole
@@ -611,7 +611,11 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el_r = float(t.item())
-        # same rows, same model: the two partitionings must agree bit for bit
+        # same rows, same model: the two partitionings must agree bit for bit (the shard images first: the timed loop
+        # above ran on the whole decoder)
+        for c in ctxs:
+            c.prepack_decoder(d_Wd_full, d_bd, col_lo, col_hi, dtype=DT)
+        torch.cuda.synchronize()
         step(); step()
         torch.cuda.synchronize()
         got = last[0] if exchange[0] == "alltoall" else (last[0][0][r0:r0 + bpg], last[0][1][r0:r0 + bpg])
@@ -622,8 +626,6 @@ def main():
                                    "note": "NOT the headline: playlists partitioned over the ranks, whole decoder on "
                                            "every GPU, no collective; the headline shards the vocabulary as "
                                            "BASELINE.json configs[2] names it"}
-        for c in ctxs:
-            c.prepack_decoder(d_Wd_full, d_bd, col_lo, col_hi, dtype=DT)
         del d_Wd_full
 
     # ---- own row: decode ONLY the track columns --------------------------------

@@ -319,7 +319,11 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     float* gmax = nullptr;
     // one maximum per (workgroup of the row group, round of sample tiles, position in the tile)
     const int n_ws_a = g.nb_rg * g.waves;
-    const int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
+    int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
+    // ... unless that leaves too few maxima for the rank tau needs (k + seeds): small samples -- vocabulary shards,
+    // large batches -- keep one value per wave slot and position, i.e. every sample element
+    const int gmax_per_wave = ld_g < 4 * (int64_t)k ? 1 : 0;
+    if (gmax_per_wave) ld_g *= g.waves;
     const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
     if (mixed) out_kind = DAE_OUT_LOGIT;                   // ... which is a probability already: it goes out as it is
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
@@ -328,7 +332,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
         gmax = static_cast<float*>(ctx->gmax.p);
     }
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
-    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype, gmax, ld_g);
+    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype, gmax, ld_g, gmax_per_wave);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 

@@ -230,7 +230,7 @@ struct dae_tileset {        // which wave tiles a decode launch walks
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
                                 int fill_pad, int dtype = DAE_DTYPE_F32, float* gmax = nullptr,
-                                int64_t ld_gmax = 0);
+                                int64_t ld_gmax = 0, int gmax_per_wave = 0);
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,

@@ -73,6 +73,7 @@ struct DecP {
     // = popularity ranks the winners are packed into the first tiles, and a group then holds at most one of them
     // (maxima over neighbouring columns would lose 7 of 8: measured, 4 000 instead of 600 survivors per row).
     float* gmax; int64_t ld_gmax;
+    int gmax_per_wave;             // small samples (vocabulary shards): no cross-wave maximum, slot = (round * n_ws + wave * nb_rg + bir)
     // filter epilogue
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
     // title mix (models/DAEs.py:180 of the reference: y = title_score * w_title + dae_score * w_playlist):
@@ -193,6 +194,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     // (quad, half, playlist) takes the maximum over the waves and stores 4 maxima of its playlist's row
     auto gmax_round = [&](bool has, int round, const f32x16* accv, const float4* bqv, int tcol0v) {
         float4* xl = reinterpret_cast<float4*>(lcnt + R_TILE);
+        if (p.gmax_per_wave) {
+            // a sample too small for groups of NW (a vocabulary shard: 61 tiles for 64 wave slots): every element is
+            // its own "group" -- the wave stores its masked logits, -inf where it had no tile this round
+            const size_t slot = ((size_t)round * p.nb_rg * NW + (size_t)wave * p.nb_rg + bir) * 32;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                if (row >= p.B) continue;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float4 v = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+                    if (has) {
+                        const int lc = tcol0v + 8 * qd;
+                        float z[4] = {accv[rb][4 * qd + 0] + bqv[qd].x, accv[rb][4 * qd + 1] + bqv[qd].y,
+                                      accv[rb][4 * qd + 2] + bqv[qd].z, accv[rb][4 * qd + 3] + bqv[qd].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (p.col_lo + lc + e >= p.mask_from_col || lc + e >= p.ncols) z[e] = -__builtin_inff();
+                        v = make_float4(z[0], z[1], z[2], z[3]);
+                    }
+                    *reinterpret_cast<float4*>(p.gmax + (size_t)row * p.ld_gmax + slot + 4 * hi + 8 * qd) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             __syncthreads();                                     // the previous row block's slots were read
@@ -1690,13 +1716,13 @@ int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowg
 
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad, int dtype, float* gmax, int64_t ld_gmax)
+                                int fill_pad, int dtype, float* gmax, int64_t ld_gmax, int gmax_per_wave)
 {
     DecP p;
     int rc = fill_common(ctx, g, B, ts, p, dtype);
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
-    p.gmax = gmax; p.ld_gmax = ld_gmax;
+    p.gmax = gmax; p.ld_gmax = ld_gmax; p.gmax_per_wave = gmax_per_wave;
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;

@@ -726,7 +726,6 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
 //   3. the sample logits >= tau go out as (logit, column) pairs, one flat list per row (slots from a block-wide
 //      exclusive scan of the per-thread counts: no atomics) -- group 0 of the final selection.  Phase B never
 //      looks at the sample again.
-constexpr int TAU_PER = 16;        // maxima per thread held in registers: rows of <= 4096 maxima in one sweep
 constexpr int TAU_PRE = 16;        // float4 of dense sample logits per thread requested before the search
 struct TauP {
     const float* gmax; int64_t ld_g; int n_g;                    // group maxima [B][ld_g], n_g per row
@@ -736,6 +735,7 @@ struct TauP {
     float* tau; uint2* out_pairs; int64_t pairs_stride; int* out_cnt;
     long long* dbg;
 };
+template <int TAU_PER>               // maxima per thread held in registers: rows of <= 256 * TAU_PER maxima in one sweep
 __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
 {
     __shared__ unsigned wcnt[2][4][3];
@@ -897,7 +897,10 @@ int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
     static int calls = 0;
     if (dbg) { if (!dbuf) (void)hipMalloc(&dbuf, 16 * 8); q.dbg = dbuf; }
 #endif
-    hipLaunchKernelGGL(tau_select_kernel, dim3(B), dim3(256), 0, ctx->stream, q);
+    if (p.n_g <= 256 * 16)
+        hipLaunchKernelGGL(tau_select_kernel<16>, dim3(B), dim3(256), 0, ctx->stream, q);
+    else
+        hipLaunchKernelGGL(tau_select_kernel<64>, dim3(B), dim3(256), 0, ctx->stream, q);
     DAE_CHECK_LAUNCH(ctx, "tau_select_kernel");
 #ifdef DAE_EXPERIMENTS
     if (dbg && (++calls % 50) == 0) {
