@@ -73,6 +73,7 @@ struct DecP {
     // = popularity ranks the winners are packed into the first tiles, and a group then holds at most one of them
     // (maxima over neighbouring columns would lose 7 of 8: measured, 4 000 instead of 600 survivors per row).
     float* gmax; int64_t ld_gmax;
+    long long* stamps;             // experiments build: stage stamps of workgroup 0 / wave 0 (DAE_DBG_A)
     int gmax_per_wave;             // small samples (vocabulary shards): no cross-wave maximum, slot = (round * n_ws + wave * nb_rg + bir)
     // filter epilogue
     const float* tau; int n_valid_col; uint2* cand; int* cand_cnt; int cap;
@@ -91,6 +92,12 @@ __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
 {
     return ts.list[i];          // always a list (the identity for "all tiles"): no branch around a load
 }
+
+#ifdef DAE_EXPERIMENTS
+#define ASTAMP(i) if (EPI == EPI_GMAX && p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_readcyclecounter();
+#else
+#define ASTAMP(i)
+#endif
 
 // GT > 0: hidden size known at compile time (G = GT groups of 8 k) -> the k loop is fully
 // unrolled, so no loop header sits between the register-ring loads and their use (hipcc drains
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     const int rg = rem / DAE_NUM_XCD;
     const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
 
+    ASTAMP(0)
     // ---- hidden tile of this row group -> LDS, once ------------------------------------------
     const int n_h4 = RB * 64 * G;
     {
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
     }
 
+    ASTAMP(1)
     float loss_acc = 0.0f;
     // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
     // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
@@ -248,6 +257,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                 if (row < p.B)
                     *reinterpret_cast<float4*>(p.gmax + (size_t)row * p.ld_gmax +
                                                ((size_t)round * p.nb_rg + bir) * 32 + (sl >> 5) * 4) = m;
+            }
+            // the dense sample rows of this row block, from the same slots: thread (tile w, playlist jj, half) writes 64
+            // contiguous bytes, a wave 32 whole 128-byte rows -- the accumulator layout itself would store 16-byte
+            // pieces of 64 different rows per instruction (4.9 us of the launch, measured with stage stamps)
+            for (int t2 = tid; t2 < NW * 64; t2 += NW * 64) {
+                const int w = t2 >> 6, jj = (t2 & 63) >> 1, half = t2 & 1;
+                const int item_w = w * p.nb_rg + bir + round * (p.nb_rg * NW);
+                const int row = rg * R_TILE + rb * 32 + jj;
+                if (item_w < p.ts.n_items && row < p.B) {
+                    float* orow = p.out + (size_t)row * p.ld + (size_t)item_w * 32 + half * 16;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        *reinterpret_cast<float4*>(orow + 4 * q4) = xl[w * 256 + (half * 4 + q4) * 32 + jj];
+                }
             }
         }
     };
@@ -370,6 +393,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
         }
 #undef DAE_STEP
 
+        ASTAMP(2)
         // ---- epilogue -----------------------------------------------------------------------
         // lane holds, for playlist j of row block rb, the columns
         //   v_local(reg) = (reg & 3) + 8 * (reg >> 2) + 4 * hi          (reg = 0..15)
@@ -414,7 +438,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                     }
                 }
             }
-        } else if (EPI == EPI_DENSE || EPI == EPI_GMAX) {
+        } else if (EPI == EPI_DENSE || (EPI == EPI_GMAX && p.gmax_per_wave)) {
+            // (EPI_GMAX with the cross-wave exchange stores its dense rows from LDS, inside gmax_round)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
@@ -446,7 +471,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
                     }
                 }
             }
+            ASTAMP(3)
             if (EPI == EPI_GMAX) gmax_round(true, (item - item0) / n_ws, acc, bq, tcol0);
+            ASTAMP(4)
+        } else if (EPI == EPI_GMAX) {
+            ASTAMP(3)
+            gmax_round(true, (item - item0) / n_ws, acc, bq, tcol0);      // maxima AND the dense rows, through LDS
+            ASTAMP(4)
         } else if (EPI == EPI_LOSS) {
             // Every element is treated as a NEGATIVE (target 0) here; the few positives of the batch (~100
             // of 170 000 columns per row) are redone from their own dot products by loss_fixup_kernel
@@ -1723,6 +1754,21 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
     p.gmax = gmax; p.ld_gmax = ld_gmax; p.gmax_per_wave = gmax_per_wave;
+#ifdef DAE_EXPERIMENTS
+    static const bool dbgA = dae_exp_env("DAE_DBG_A") != nullptr;
+    static long long* abuf = nullptr;
+    static int acalls = 0;
+    if (dbgA && gmax) {
+        if (!abuf) (void)hipMalloc(&abuf, 8 * 8);
+        p.stamps = abuf;
+        if ((++acalls % 50) == 0) {
+            long long h[8];
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, abuf, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "PHASE_A wg0: fill %lld  prologue+kloop %lld  dense epi %lld  gmax %lld\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3]);
+        }
+    }
+#endif
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
