@@ -75,7 +75,7 @@ struct PairSrc {
     static constexpr int kSegs = TK_MAX_SEG;
     static constexpr bool kFixedSlots = false;
     dae_pair_group g0, g1;
-    int max_keys() const { return 8192; }                 // typical rows are far below; larger rows re-read
+    int max_keys() const { return 2048; }                 // typical rows are far below; larger rows re-read
     __device__ __forceinline__ int seg_count(const dae_pair_group& g, int seg, int row) const
     {
         return g.cnt ? g.cnt[(size_t)seg * g.cnt_seg_stride + row] : g.fixed_cnt;
