@@ -980,7 +980,10 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     // (measured: 407 vs 354 us per step at --sim-world 8).  DAE_TOPK_THREADS=1024|256 forces one shape (A/B).
     static const int nth_env = dae_exp_env("DAE_TOPK_THREADS") ? atoi(dae_exp_env("DAE_TOPK_THREADS")) : 0;
     const int bound = Src::kSegs ? 0 : src.max_keys();
-    const bool small = nth_env ? nth_env == 256 : (!Src::kSegs && bound <= 4096);
+    // ... and candidate lists when the launch has many rows (>= 4 per CU: large batches, vocabulary shards): a row then
+    // holds few candidates, four 256-thread workgroups share a CU, and the per-row fixed cost is what counts
+    // (--sim-world 8, 2048 rows: step 322 -> 284 us; at 256 rows 256 threads lose: 22 vs 14 us)
+    const bool small = nth_env ? nth_env == 256 : ((!Src::kSegs && bound <= 4096) || (Src::kSegs && a.B >= 1024));
     if (small)
         hipLaunchKernelGGL((topk_kernel<Src, 256>), dim3(a.B), dim3(256), dyn, ctx->stream, src, aa, key_cap, dbg_stop);
     else
