@@ -379,7 +379,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), sample_cnt, 0, pstride, 0, 1, 0};
     dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
-    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr; ta.out_cnt = nullptr;
+    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
     ta.out_score = out_score; ta.out_idx = out_idx;
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
 }

@@ -330,10 +330,7 @@ struct dae_topk_args {
     float* out_score; int32_t* out_idx;   // [B,k]  (may be null)
     uint2* out_pairs;                     // [B,k] (logit bits, idx) (may be null)
     float* out_tau;                       // [B] k-th logit or -inf (may be null)
-    // threshold mode (phase A of the fused path): when out_cnt is set the kernel may stop before
-    // the sort and emit the <= 512 surviving pairs UNSORTED at out_pairs[row*pairs_stride + i],
-    // their number in out_cnt[row], and any valid lower bound of the k-th logit in out_tau.
-    int* out_cnt; int pairs_stride;
+    int pairs_stride;             // row stride of out_pairs
     int lean, sort_cap;           // set by the launcher (topk.hip): LDS mode, sort buffer keys
 };
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);

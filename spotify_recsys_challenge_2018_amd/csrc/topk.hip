@@ -14,13 +14,15 @@
 //      chosen from the live range [lo, hi], parallel suffix scan to find the bin holding the
 //      k-th key, shrink [lo, hi] to that bin; stop as soon as the keys >= lo fit the sort buffer
 //      (keys are unique, so no tie handling exists anywhere);
-//   4. collect those keys, sort them descending (bitonic: wave shuffles + 10 LDS stages), emit k.
+//   4. collect those keys; k <= 512: order them by HISTOGRAM RANK (position = keys in higher bins + keys of the
+//      own bin above; one LDS atomic per key, a suffix scan, a count inside the bin); k > 512: hybrid bitonic sort
+//      (wave shuffles + LDS stages); emit k.
 // Rows whose elements do not fit the LDS key buffer (dae_topk_dense over a whole vocabulary row)
 // run the same steps with step 3 re-reading the source instead of LDS.
 //
 // Element sources:
-//   dense : a row of logits (phase-A sample buffer of the fused path, dae_topk_dense)
-//   pairs : segments of (logit, column) pairs (phase-B candidate lists)
+//   dense : a row of logits (dae_topk_dense; small problems of the fused path)
+//   pairs : segments of (logit, column) pairs (the sample's survivors from tau_select_kernel + phase-B candidate lists)
 //   soa   : [G, B, k] shard lists gathered by RCCL (K4 merge)
 #include "dae_internal.h"
 
@@ -707,7 +709,6 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + i] = make_uint2(__float_as_uint(-__builtin_inff()), 0xFFFFFFFFu);
     }
     if (a.out_tau && tid == 0 && k_eff < (unsigned)k) a.out_tau[row] = -__builtin_inff();
-    if (a.out_cnt && tid == 0) a.out_cnt[row] = k;
 }
 
 // ---- tau of the fused path from the sample's group maxima, and the sample's survivors ---------------------------
