@@ -292,15 +292,16 @@ def main():
         with torch.cuda.stream(st):
             c.bind_stream()
     gate_events = []
-    if n_str == 2 and (args.gate == 1 or (args.gate < 0 and args.dtype == "f32")):
-        # the two contexts' dominant launches alternate instead of queueing behind each other (dae_set_decode_gate)
+    if n_str >= 2 and (args.gate == 1 or (args.gate < 0 and args.dtype == "f32")):
+        # the contexts' dominant launches take turns instead of queueing behind each other (dae_set_decode_gate):
+        # context i waits for the event context i - 1 records after its own launch (a ring)
         for st in streams:
             ev = torch.cuda.Event()
             ev.record(st)                    # materialises the hipEvent_t
             gate_events.append(ev)
         torch.cuda.synchronize()
         for i, c in enumerate(ctxs):
-            c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[1 - i].cuda_event),
+            c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),
                                               ctypes.c_void_p(gate_events[i].cuda_event)))
     step_no = [0]
     exchange = [args.exchange]
@@ -750,7 +751,7 @@ def main():
                                            args.steps, args.warmup, idx_f32, (PEAK_BF16_TFLOPS, PEAK_HBM_GBS))
             if gate_events:
                 for i, c in enumerate(ctxs):
-                    c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[1 - i].cuda_event),
+                    c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),
                                                       ctypes.c_void_p(gate_events[i].cuda_event)))
         except Exception as e:                              # the row is an extra: never lose the headline over it
             out["bf16_decode"] = {"error": repr(e)}
