@@ -346,6 +346,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0         # host time to issue the K steps (== elapsed when the host is the limit)
     torch.cuda.synchronize()
     if sharded:
         dist.barrier()
@@ -533,7 +534,8 @@ def main():
                                    "vocab column shard x%d + RCCL %s of the per-shard top-%d" % (
                                        world, "all-to-all (each rank merges the %d rows it owns)" % (B // world)
                                        if args.exchange == "alltoall" else "all-gather (each rank merges all rows)", k)),
-                   "plan": plan, "streams": n_str, "decode_gate": bool(gate_events), "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
+                   "plan": plan, "streams": n_str, "decode_gate": bool(gate_events),
+                   "host_issue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,
     }

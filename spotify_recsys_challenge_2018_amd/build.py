@@ -13,6 +13,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 if os.environ.get("DAE_EXPERIMENTS"):          # A/B switches and stage early-outs (csrc/dae_internal.h); never the default
     FLAGS.append("-DDAE_EXPERIMENTS")
+FLAGS += os.environ.get("DAE_EXTRA_FLAGS", "").split()        # e.g. -DDAE_SMALL_PRIO=0 for an A/B build
 
 
 def _deps_mtime():

@@ -753,8 +753,10 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
     const int n = p.n_g;
     const unsigned ns = p.seed_row_ptr ? (unsigned)(p.seed_row_ptr[row + 1] - p.seed_row_ptr[row]) : 0u;
     const unsigned need = (unsigned)p.k + ns;
-    // ---- 1. requests: the group maxima first (the search needs them), then the first TAU_PRE float4 per thread of
-    // the dense sample row, which stay in flight under the search ------------------------------------------------
+    // ---- 1. requests: the group maxima ALONE first -- the search needs them and 256 rows asking for their 62 KB of
+    // dense logits at the same moment put every row's maxima behind everybody's dense lines (maxima arrived after
+    // 8.3 k cycles).  The dense row (TAU_PRE float4 per thread, kept in registers) is requested once the maxima are
+    // here and stays in flight under the search.
     const bool one_sweep = n <= 256 * TAU_PER;
     float graw[TAU_PER];
 #pragma unroll
@@ -762,6 +764,11 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
         const int i = u * 256 + tid;
         graw[u] = (one_sweep && i < n) ? g[i] : -__builtin_inff();
     }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned kreg[TAU_PER];
+#pragma unroll
+    for (int u = 0; u < TAU_PER; ++u) kreg[u] = dae_okey(graw[u]);     // -inf -> NEG_INF key: never counted
+    __builtin_amdgcn_sched_barrier(0);
     const float4* srow = reinterpret_cast<const float4*>(p.samp + (size_t)row * p.ld_s);
     const int n4 = p.n_s >> 2;
     float4 zpre[TAU_PRE];
@@ -773,12 +780,8 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
     // tiles of the preloaded part (one id per 8 float4) -> LDS: consumed only where something passes
     __shared__ int ltile[TAU_PRE * 256 / 8];
     for (int i = tid; i < TAU_PRE * 256 / 8; i += 256) ltile[i] = p.samp_list[i < (n4 + 7) / 8 ? i : 0];
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- 2. tau -------------------------------------------------------------------------------------------------
-    unsigned kreg[TAU_PER];
-#pragma unroll
-    for (int u = 0; u < TAU_PER; ++u) kreg[u] = dae_okey(graw[u]);     // -inf -> NEG_INF key: never counted
     __builtin_amdgcn_sched_barrier(0);                           // keep every request above ahead of the search
+    // ---- 2. tau -------------------------------------------------------------------------------------------------
     // counts of keys >= each of 3 probes over the row (block-uniform results); absent / -inf keys never count
     auto count3 = [&](unsigned q0, unsigned q1, unsigned q2, int it, unsigned (&c)[3]) {
         unsigned a0 = 0, a1 = 0, a2 = 0;
@@ -815,26 +818,25 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
         for (int e = 0; e < 3; ++e)
             c[e] = wcnt[it & 1][0][e] + wcnt[it & 1][1][e] + wcnt[it & 1][2][e] + wcnt[it & 1][3][e];
     };
-    // prefixes below (NEG_INF >> 16) + 1 would count -inf / absent entries
+    // prefixes below (NEG_INF >> 16) + 1 would count -inf / absent entries.  The search runs over [p_min - 1, 0xFFFF]:
+    // p_min - 1 stands for "fewer than `need` maxima exist" (count taken as >= need by convention, never probed --
+    // every probe is > lo), so no separate existence pass is needed.
     const unsigned p_min = (DAE_KEY_NEG_INF >> 16) + 1u;
-    unsigned lo = p_min, hi = 0xFFFFu;                           // the answer lies in [lo, hi] if it exists
+    unsigned lo = p_min - 1u, hi = 0xFFFFu;                      // the answer lies in [lo, hi]
     int it = 0;
     unsigned c[3];
     TSTAMP(1)
-    count3(lo << 16, lo << 16, lo << 16, it++, c);
     TSTAMP(2)
-    const bool found = c[0] >= need;
-    if (found) {
-        while (lo < hi) {                                        // invariant: count(lo) >= need, count(hi + 1) < need
-            const unsigned span = hi - lo;                       // >= 1; three probes cut [lo + 1, hi] into four parts
-            const unsigned m1 = lo + (span + 3u) / 4u, m2 = lo + (2u * span + 3u) / 4u, m3 = lo + (3u * span + 3u) / 4u;
-            count3(m1 << 16, m2 << 16, m3 << 16, it++, c);       // lo < m1 <= m2 <= m3 <= hi
-            if (c[2] >= need) lo = m3;
-            else if (c[1] >= need) { lo = m2; hi = m3 - 1u; }
-            else if (c[0] >= need) { lo = m1; hi = m2 - 1u; }
-            else hi = m1 - 1u;
-        }
+    while (lo < hi) {                                            // invariant: count(lo) >= need, count(hi + 1) < need
+        const unsigned span = hi - lo;                           // >= 1; three probes cut [lo + 1, hi] into four parts
+        const unsigned m1 = lo + (span + 3u) / 4u, m2 = lo + (2u * span + 3u) / 4u, m3 = lo + (3u * span + 3u) / 4u;
+        count3(m1 << 16, m2 << 16, m3 << 16, it++, c);           // lo < m1 <= m2 <= m3 <= hi
+        if (c[2] >= need) lo = m3;
+        else if (c[1] >= need) { lo = m2; hi = m3 - 1u; }
+        else if (c[0] >= need) { lo = m1; hi = m2 - 1u; }
+        else hi = m1 - 1u;
     }
+    const bool found = lo >= p_min;
     TSTAMP(3)
     const float tv = found ? dae_okey_inv(lo << 16) : -__builtin_inff();
     if (tid == 0) p.tau[row] = tv;
