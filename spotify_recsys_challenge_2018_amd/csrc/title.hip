@@ -11,6 +11,7 @@
 
 namespace {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int T_MAX_SIZES = 8;
 constexpr int T_MAX_LEN = 64;
 constexpr int T_MAX_EMB = 128;
@@ -133,6 +134,103 @@ __global__ __launch_bounds__(NW * 64) void title_features_wave_kernel(const Titl
             if (pos < P && (pos == 0 || a > best)) { best = a; arg = pos; }
         }
         if (live) {
+            const int fi = i * p.F + f;
+            if (p.argmax) p.argmax[(size_t)row * nf + fi] = arg;
+            if (p.feat_raw) p.feat_raw[(size_t)row * nf + fi] = best;
+            float v = best;
+            if (p.kp < 1.0f) v = (v / p.kp) * floorf(p.kp + dae_uniform(p.seed, 2U, (uint32_t)row, (uint32_t)fi));
+            p.feat[(size_t)row * p.ld + fi] = v;
+        }
+    }
+    for (int fi = nf + tid; fi < p.ld; fi += NW * 64) p.feat[(size_t)row * p.ld + fi] = 0.0f;
+}
+
+// The same features on the matrix cores: for one filter size the convolution of a title is the product
+// X[pos][q] . W[q][f] with X[pos][q] = xs[pos * E + q] (the overlapping windows ARE the rows of the LDS image), q < fs * E.
+// v_mfma_f32_32x32x2_f32 accumulates its two k values as the fmaf chain does (one rounding per product, ascending k:
+// DESIGN.md section 2), so with the accumulators preset to the filter's bias the 32 x 32 block of (position, filter)
+// sums equals the chains of the two kernels above bit for bit.  One wave = one (filter size, block of 32 filters);
+// a workgroup's 8 waves take the tasks from both ends of the (size-major) list so that a wave with a long kernel
+// also gets a short one.  A operand: one LDS word per lane (the stride E = 50 puts the 32 positions on 32 different
+// even banks, the second k value on the odd ones); B operand: one coalesced 128-byte row piece of W per k value, 16
+// k-steps requested ahead.  105 -> ~15 us at the reference's shapes (150 titles x 25 characters, 3/5/7/9 x 100).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void title_features_mfma_kernel(const TitleP p, int lpad)
+{
+    extern __shared__ float xs[];                     // [lpad][E], rows >= L are zero
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < lpad * p.E; i += NW * 64) {
+        const int pos = i / p.E, c = i - pos * p.E;
+        float v = 0.0f;
+        if (pos < p.L) {
+            const int t = p.titles[(size_t)row * p.L + pos];
+            if (t >= 0 && t < p.n_char) v = p.emb[(size_t)t * p.E + c];
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int nf = p.n_sizes * p.F;
+    const int fblocks = (p.F + 31) >> 5;
+    const int n_tasks = p.n_sizes * fblocks;
+    for (int r = 0;; ++r) {
+        if (r * NW + wave >= n_tasks) break;          // r * NW + wave tasks are taken before this one: the ends never cross
+        const int fwd = (r >> 1) * NW + wave;
+        const int task = (r & 1) ? n_tasks - 1 - fwd : fwd;
+        const int i = task / fblocks, fb = task - i * fblocks;
+        const int fs = p.fs[i];
+        const int P = p.L - fs + 1;                   // 1 .. 32 (checked by the launcher)
+        const int f = fb * 32 + j;
+        const bool live = f < p.F;
+        const int fc = live ? f : p.F - 1;
+        const float* W = p.conv_w + p.w_off[i] + fc + (size_t)hi * p.F;        // k = 2 s + hi
+        const float* xa = xs + j * p.E + hi;
+        const float b = p.conv_b[i * p.F + fc];
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = b;
+        const int S = (fs * p.E) >> 1;                // k-steps of two
+        constexpr int QB = 8;
+        float w0[QB], w1[QB];
+        const size_t kstride = (size_t)2 * p.F;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            w0[u] = W[(size_t)(u < S ? u : S - 1) * kstride];
+            w1[u] = W[(size_t)(QB + u < S ? QB + u : S - 1) * kstride];
+        }
+        for (int s0 = 0; s0 < S; s0 += QB) {
+            float wn[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int sn = s0 + 2 * QB + u;
+                wn[u] = W[(size_t)(sn < S ? sn : S - 1) * kstride];
+            }
+            float xq[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) xq[u] = xa[2 * (s0 + u < S ? s0 + u : S - 1)];
+#pragma unroll
+            for (int u = 0; u < QB; ++u)
+                if (s0 + u < S)                       // wave-uniform
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xq[u], w0[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < QB; ++u) { w0[u] = w1[u]; w1[u] = wn[u]; }
+        }
+        // accumulator e of lane (j, hi): position 8 (e / 4) + 4 hi + e % 4, filter j.  ReLU, then the FIRST maximum over
+        // the positions in ascending order (the chain kernels' rule): per lane first, then across the two halves
+        float best = 0.0f;
+        int arg = 0;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int pos = 8 * (e >> 2) + 4 * hi + (e & 3);
+            const float a = acc[e] > 0.0f ? acc[e] : 0.0f;
+            if (pos < P && (!any || a > best)) { best = a; arg = pos; any = true; }
+        }
+        const float ob = __shfl_xor(best, 32);
+        const int oa = __shfl_xor(arg, 32);
+        const bool oany = __shfl_xor((int)any, 32) != 0;
+        if (oany && (!any || ob > best || (ob == best && oa < arg))) { best = ob; arg = oa; }
+        if (live && hi == 0) {
             const int fi = i * p.F + f;
             if (p.argmax) p.argmax[(size_t)row * nf + fi] = arg;
             if (p.feat_raw) p.feat_raw[(size_t)row * nf + fi] = best;
@@ -429,6 +527,17 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
     for (int i = 0; i < n_sizes; ++i) { fs_min = p.fs[i] < fs_min ? p.fs[i] : fs_min; fs_max = p.fs[i] > fs_max ? p.fs[i] : fs_max; }
     const int p_max = L - fs_min + 1;                 // most window positions of any size
     static const bool generic = dae_exp_env("DAE_TITLE_GENERIC") != nullptr;          // A/B against the first kernel
+    bool even_k = true;
+    for (int i = 0; i < n_sizes; ++i) even_k = even_k && ((p.fs[i] * E) % 2 == 0);
+    static const bool no_mfma = dae_exp_env("DAE_TITLE_WAVE") != nullptr;              // A/B against the fmaf-chain kernel
+    if (p_max >= 1 && p_max <= 32 && fs_max <= L && even_k && !generic && !no_mfma) {
+        // positions 0 .. 31 are computed for every size: rows up to 31 + fs_max - 1 of the LDS image are read
+        const int lpad = 32 + fs_max;
+        const size_t lds = (size_t)lpad * E * sizeof(float);
+        hipLaunchKernelGGL((title_features_mfma_kernel<8>), dim3(B), dim3(512), lds, ctx->stream, p, lpad);
+        DAE_CHECK_LAUNCH(ctx, "title_features_mfma_kernel");
+        return DAE_OK;
+    }
     if (p_max >= 1 && p_max <= 32 && fs_max <= L && !generic) {
         // positions up to PMAX - 1 + fs_max - 1 are read: pad the LDS image with zero rows
         const int pm = p_max <= 24 ? 24 : 32;

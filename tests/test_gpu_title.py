@@ -60,6 +60,57 @@ def test_features_and_title_scores_match_numpy():
     assert sorted(back) == sorted(host) and all(np.array_equal(back[k], host[k]) for k in host)
 
 
+def _fma32(a, b, c):
+    """fmaf(a, b, c) for float32 arrays, exactly: the product is exact in float64 (24 + 24 bits); the sum is rounded
+    to ODD in float64 (TwoSum gives its error), so the final rounding to float32 is the single rounding of the exact
+    a * b + c (Boldo & Melquiond: 53 >= 2 * 24 + 2)."""
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c = c.astype(np.float64)
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)                    # p + c == s + err exactly
+    bits = s.view(np.int64)
+    inexact = err != 0.0
+    # the exact sum lies between s and its neighbour in the direction of err: of the two, take the one with an odd
+    # last bit.  s is even here -> step one ulp towards err (same sign as s: magnitude up, else magnitude down).
+    step = np.where((err > 0) == (s > 0), 1, -1).astype(np.int64)
+    adj = np.where(inexact & ((bits & 1) == 0) & (s != 0.0), bits + step, bits)
+    return adj.view(np.float64).astype(np.float32)
+
+
+def test_features_are_the_fmaf_chain_bit_for_bit():
+    """csrc/title.hip computes the convolutions with v_mfma_f32_32x32x2_f32, accumulators preset to the bias: the same
+    chain acc = fmaf(x[q], W[q][f], acc), q ascending, as the scalar kernels -- same bits, same
+    first-maximum position."""
+    conf = Conf()
+    m = get_model(conf)
+    host = tn.make_params(41, 50, FS, 100, conf.n_output, seed=5)
+    m.fit(host)
+    B = 6
+    titles = _titles(B, seed=2)
+    titles[1, :] = np.arange(25) % 41                                # a full-length title
+    feat, _d, arg, raw = m.features(titles, B, keep_for_backward=True)
+    feat, arg, raw = feat.cpu().numpy(), arg.cpu().numpy(), raw.cpu().numpy()
+    E = host["char_embedding"].astype(np.float32)
+    x = np.zeros((B, 25, 50), np.float32)
+    ok = titles >= 0
+    x[ok] = E[titles[ok]]
+    for i, fs in enumerate(FS):
+        W = host["Conv_W%d" % i].astype(np.float32)[:, :, 0, :].reshape(fs * 50, 100)      # [q][f]
+        b = host["Conv_b%d" % i].astype(np.float32)
+        P = 25 - fs + 1
+        win = np.stack([x[:, p:p + fs, :].reshape(B, fs * 50) for p in range(P)], axis=1)   # [B, P, q]
+        acc = np.broadcast_to(b, (B, P, 100)).astype(np.float32).copy()
+        for q in range(fs * 50):
+            acc = _fma32(win[:, :, q:q + 1], W[q][None, None, :], acc)
+        conv = np.maximum(acc, np.float32(0.0))
+        want, want_arg = conv.max(axis=1), conv.argmax(axis=1)                              # argmax: first maximum
+        got = raw[:, i * 100:(i + 1) * 100]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "size %d" % fs
+        assert np.array_equal(arg[:, i * 100:(i + 1) * 100], want_arg), "size %d" % fs
+        assert np.array_equal(feat[:, i * 100:(i + 1) * 100], got)
+
+
 def test_mix_equals_numpy_and_reduces_to_the_plain_dae_without_titles(tmp_path):
     conf = Conf()
     W_enc, b_enc, W_dec, b_dec = make_weights(conf.n_input, conf.hidden, seed=1, bias="zipf", n_tracks=conf.n_tracks)
