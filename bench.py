@@ -411,6 +411,36 @@ def main():
     if pmc_mfma:
         roofline["pmc"] = dict(pmc_mfma, note="rocprofv3 --pmc pass of the same kernel (profiles/traffic_decode.json): "
                                "matrix-pipe busy cycles over the 1024 SIMDs / kernel cycles")
+    # ---- the engine clock the chip sustains under this load (outside the timed region) -----------------------------
+    # The MFMA peaks of MI355X_MICROARCH.md are quoted at the 2.4 GHz maximum engine clock; the chip clocks to its
+    # power budget, so the roof the matrix cores can reach under a sustained launch is peak x clock / 2.4.  One wave on
+    # its own stream reads the shader-cycle counter and the constant-rate wall clock 50 us apart (dae_clock_probe)
+    # while the same step loop keeps running; `frac` above stays the fraction of the nominal peak.
+    try:
+        probe_stream = torch.cuda.Stream(device=dev)
+        n_probe = 24
+        probes = torch.zeros((n_probe, 2), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(16):
+            step()
+        khz = 0
+        for i in range(n_probe):
+            for _ in range(4):
+                step()
+            khz = ctx.clock_probe(probes[i], stream=probe_stream, window_us=50)
+        torch.cuda.synchronize()
+        pr = probes.cpu().numpy().astype(np.float64)
+        ghz = pr[:, 0] / np.maximum(pr[:, 1], 1.0) * khz / 1e6
+        nominal = 2.4
+        roofline["sustained_clock"] = {
+            "ghz_mean": round(float(ghz.mean()), 3), "ghz_min": round(float(ghz.min()), 3), "ghz_max": round(float(ghz.max()), 3),
+            "samples": n_probe, "window_us": 50, "nominal_ghz": nominal,
+            "peak_at_clock": round(peak_tf * float(ghz.mean()) / nominal, 1),
+            "mfma_frac_at_clock": round(achieved_tflops / (peak_tf * float(ghz.mean()) / nominal), 4),
+            "note": "shader cycles / wall-clock ticks of one probe wave (s_memtime / s_memrealtime) sampled while the step "
+                    "loop runs; the MFMA peak scales with this clock, `frac` is still against the nominal peak"}
+    except Exception as e:                      # the probe is a report, never a reason to lose the line
+        roofline["sustained_clock"] = {"error": str(e)[:200]}
     # the same kernel alone on the GPU (one stream, nothing overlapping it), after the timed region
     if n_str > 1:
         torch.cuda.synchronize()

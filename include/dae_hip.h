@@ -74,6 +74,13 @@ int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches);
 /* Symbol (as rocprofv3's kernel trace prints it) of the kernel the last event pair bracketed; "" before the first. */
 const char* dae_profile_kernel(const dae_ctx* ctx);
 
+/* Engine clock actually sustained while other work runs (the chip clocks to its power budget: the fp32 matrix-core
+ * roof moves with it).  Enqueues ONE wave on `hip_stream` (any stream; NULL = the ctx stream) that reads the shader
+ * cycle counter (s_memtime) and the constant-rate wall clock (s_memrealtime) `window_us` apart and stores
+ * {shader cycles, wall-clock ticks} in out2_dev (device, 2 x uint64).  wall_khz_out (host, may be NULL) receives the
+ * wall clock's rate (hipDeviceAttributeWallClockRate).  GHz = cycles / ticks * wall_khz / 1e6. */
+int dae_clock_probe(dae_ctx* ctx, void* hip_stream, int window_us, uint64_t* out2_dev, int* wall_khz_out);
+
 /* Geometry of the last dae_decode_topk issued from the calling thread, for roofline accounting:
  * {R_TILE, n_row_groups, blocks_per_row_group, sample_stride S, n_sample_tiles (phase A),
  *  n_filter_tiles (phase B), fused(0/1), n_tiles}.  A tile is 32 vocabulary columns. */

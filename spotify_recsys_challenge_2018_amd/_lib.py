@@ -14,7 +14,7 @@ DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
 # every symbol include/dae_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
-    "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_last_plan",
+    "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
     "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
@@ -58,6 +58,7 @@ def load():
     lib.dae_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]
     lib.dae_profile_kernel.argtypes = [vp]
     lib.dae_profile_kernel.restype = ctypes.c_char_p
+    lib.dae_clock_probe.argtypes = [vp, vp, c_int, vp, ctypes.POINTER(c_int)]
     lib.dae_last_plan.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     lib.dae_coo_to_csr.argtypes = [vp, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, vp, vp]
     lib.dae_seeds_from_csr.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
@@ -251,6 +252,14 @@ class Context:
     def profile_kernel(self):
         """Symbol of the kernel the last profiled launch ran (what rocprofv3's kernel trace calls it)."""
         return self.lib.dae_profile_kernel(self.h).decode()
+
+    def clock_probe(self, out2, stream=None, window_us=50):
+        """Enqueue the one-wave clock sampler (`out2`: CUDA int64/uint64 tensor of 2); returns the wall clock's kHz.
+        GHz = out2[0] / out2[1] * kHz / 1e6 once the stream has run it."""
+        khz = ctypes.c_int()
+        self.check(self.lib.dae_clock_probe(self.h, ctypes.c_void_p(stream.cuda_stream) if stream is not None else None,
+                                            int(window_us), _ptr(out2), ctypes.byref(khz)))
+        return khz.value
 
     def last_plan(self):
         arr = (ctypes.c_int32 * 8)()

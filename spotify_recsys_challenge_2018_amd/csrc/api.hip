@@ -183,6 +183,38 @@ int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches)
 
 const char* dae_profile_kernel(const dae_ctx* ctx) { return ctx ? ctx->prof_kernel.c_str() : ""; }
 
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(16);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+}  // namespace
+
+int dae_clock_probe(dae_ctx* ctx, void* hip_stream, int window_us, uint64_t* out2_dev, int* wall_khz_out)
+{
+    if (!ctx || !out2_dev || window_us < 1 || window_us > 1000000) return dae_fail(ctx, DAE_ERR_ARG, "dae_clock_probe: bad arguments");
+    int khz = 0;
+    DAE_HIP_CHECK(ctx, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (khz <= 0) return dae_fail(ctx, DAE_ERR_STATE, "dae_clock_probe: no wall clock rate");
+    if (wall_khz_out) *wall_khz_out = khz;
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->stream;
+    const unsigned long long ticks = (unsigned long long)window_us * (unsigned long long)khz / 1000ull;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(out2_dev), ticks);
+    DAE_CHECK_LAUNCH(ctx, "clock_probe_kernel");
+    return DAE_OK;
+}
+
 /* geometry of the last dae_decode_topk on this thread:
  * {R_TILE, n_rg, nb_rg, S, n_sample_tiles, n_filter_tiles, fused(0/1), ntiles} */
 int dae_last_plan(int32_t out[8])
