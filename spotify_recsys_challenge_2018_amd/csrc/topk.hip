@@ -890,6 +890,106 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
 #endif
 }
 
+// The same for launches of MANY SHORT rows (vocabulary shards, where every rank scores the whole global batch over its
+// slice of the columns: 2048 rows x 1952 sample logits at 8 ranks): one WAVE per row, four rows per workgroup.  The
+// maxima (<= 64 * KPL) and the dense sample (<= 64 * PRE float4) of a row sit in the registers of its wave; a search
+// step is 3 x KPL compare masks and their s_bcnt1 -- the counts are wave-uniform scalars, so there is no LDS, no
+// barrier and no other wave to wait for; the survivors' slots come from one wave scan.  Same tau, same survivor set
+// (list order differs: the final selection does not depend on it).
+template <int KPL, int PRE>
+__global__ __launch_bounds__(256) void tau_select_wave_kernel(const TauP p, const int B)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (row >= B) return;                                        // wave-uniform
+    const float* g = p.gmax + (size_t)row * p.ld_g;
+    const int n = p.n_g;
+    const unsigned ns = p.seed_row_ptr ? (unsigned)(p.seed_row_ptr[row + 1] - p.seed_row_ptr[row]) : 0u;
+    const unsigned need = (unsigned)p.k + ns;
+    float graw[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) {
+        const int i = u * 64 + lane;
+        graw[u] = i < n ? g[i] : -__builtin_inff();
+    }
+    const float4* srow = reinterpret_cast<const float4*>(p.samp + (size_t)row * p.ld_s);
+    const int n4 = p.n_s >> 2;
+    float4 zpre[PRE];
+    int tl[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int f = u * 64 + lane;
+        zpre[u] = srow[f < n4 ? f : 0];
+        tl[u] = p.samp_list[(f < n4 ? f : 0) >> 3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned kreg[KPL];
+#pragma unroll
+    for (int u = 0; u < KPL; ++u) kreg[u] = dae_okey(graw[u]);
+    auto count3 = [&](unsigned q0, unsigned q1, unsigned q2, unsigned (&c)[3]) {
+        unsigned long long m[KPL];
+        unsigned a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) m[u] = __ballot(kreg[u] >= q0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) a0 += (unsigned)__popcll(m[u]);
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) m[u] = __ballot(kreg[u] >= q1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) a1 += (unsigned)__popcll(m[u]);
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) m[u] = __ballot(kreg[u] >= q2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) a2 += (unsigned)__popcll(m[u]);
+        c[0] = a0; c[1] = a1; c[2] = a2;
+    };
+    const unsigned p_min = (DAE_KEY_NEG_INF >> 16) + 1u;         // see tau_select_kernel: [p_min - 1, 0xFFFF], sentinel lo
+    unsigned lo = p_min - 1u, hi = 0xFFFFu;
+    unsigned c[3];
+    while (lo < hi) {
+        const unsigned span = hi - lo;
+        const unsigned m1 = lo + (span + 3u) / 4u, m2 = lo + (2u * span + 3u) / 4u, m3 = lo + (3u * span + 3u) / 4u;
+        count3(m1 << 16, m2 << 16, m3 << 16, c);
+        if (c[2] >= need) lo = m3;
+        else if (c[1] >= need) { lo = m2; hi = m3 - 1u; }
+        else if (c[0] >= need) { lo = m1; hi = m2 - 1u; }
+        else hi = m1 - 1u;
+    }
+    const float tv = lo >= p_min ? dae_okey_inv(lo << 16) : -__builtin_inff();
+    if (lane == 0) p.tau[row] = tv;
+    auto passes = [&](float z) { return z >= tv && z > -__builtin_inff(); };
+    unsigned mine = 0;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u)
+        if (u * 64 + lane < n4)
+            mine += (passes(zpre[u].x) ? 1u : 0u) + (passes(zpre[u].y) ? 1u : 0u) + (passes(zpre[u].z) ? 1u : 0u) +
+                    (passes(zpre[u].w) ? 1u : 0u);
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    unsigned at = incl - mine;
+    if (lane == 63) p.out_cnt[row] = (int)incl;
+    uint2* dst = p.out_pairs + (size_t)row * p.pairs_stride;
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int f = u * 64 + lane;
+        if (f < n4) {
+            const unsigned cb = (unsigned)(p.col_lo + tl[u] * 32 + ((4 * f) & 31));
+            const float4 z = zpre[u];
+            if (passes(z.x)) dst[at++] = make_uint2(__float_as_uint(z.x), cb);
+            if (passes(z.y)) dst[at++] = make_uint2(__float_as_uint(z.y), cb + 1u);
+            if (passes(z.z)) dst[at++] = make_uint2(__float_as_uint(z.z), cb + 2u);
+            if (passes(z.w)) dst[at++] = make_uint2(__float_as_uint(z.w), cb + 3u);
+        }
+    }
+}
+
 int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
 {
     if (B <= 0) return DAE_OK;
@@ -900,6 +1000,15 @@ int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
     static int calls = 0;
     if (dbg) { if (!dbuf) (void)hipMalloc(&dbuf, 16 * 8); q.dbg = dbuf; }
 #endif
+    // many short rows (>= 4 per CU, <= 2048 maxima and sample logits each: the 8-rank shard of the global batch): a wave
+    // per row, everything in registers, no barriers -- 30.1 -> 22.3 us for 2048 rows.  Longer rows lose (4096 maxima per
+    // wave = 64 key registers and 128 mask SGPRs per probe: 37 vs 18.6 us at 4 ranks) and keep the workgroup kernel.
+    static const bool no_wave = dae_exp_env("DAE_TAU_NO_WAVE") != nullptr;            // A/B against the workgroup-per-row kernel
+    if (B >= 1024 && p.n_g <= 64 * 32 && (p.n_s >> 2) <= 64 * 8 && !no_wave) {
+        hipLaunchKernelGGL((tau_select_wave_kernel<32, 8>), dim3((B + 3) / 4), dim3(256), 0, ctx->stream, q, B);
+        DAE_CHECK_LAUNCH(ctx, "tau_select_wave_kernel");
+        return DAE_OK;
+    }
     if (p.n_g <= 256 * 16)
         hipLaunchKernelGGL(tau_select_kernel<16>, dim3(B), dim3(256), 0, ctx->stream, q);
     else
