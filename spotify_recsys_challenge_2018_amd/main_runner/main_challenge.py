@@ -58,6 +58,34 @@ def cand_to_uris(cand_idx, id2uri):
     return ['spotify:track:' + id2uri[str(int(i))] for i in cand_idx if i >= 0]
 
 
+class UriTable:
+    """The same mapping for whole batches: the 'spotify:track:<uri>' string of every track id built ONCE (an object
+    array), a batch of ranked ids turned into rows by one fancy index.  The per-id str() / dict lookup / concatenation of
+    `cand_to_uris` was 42 % of a full-size --challenge run (scripts/bench_challenge.py), and because every occurrence of
+    a track is now the same str object, pickle writes it once and refers back to it (the result file loads to equal
+    lists)."""
+
+    def __init__(self, id2uri, n_tracks):
+        import numpy as np
+        self.table = np.empty(n_tracks, dtype=object)
+        self.missing = np.zeros(n_tracks, dtype=bool)
+        for i in range(n_tracks):
+            u = id2uri.get(str(i))
+            self.missing[i] = u is None
+            self.table[i] = None if u is None else 'spotify:track:' + u
+        self.any_missing = bool(self.missing.any())
+
+    def rows(self, idx):
+        """idx [rows, k] ranked ids (-1 = padding of a short list) -> list of lists of URI strings."""
+        import numpy as np
+        idx = np.asarray(idx)
+        if self.any_missing and idx.size and self.missing[idx[idx >= 0]].any():
+            raise KeyError("a ranked track id has no entry in id2uri")
+        if idx.size and idx.min() >= 0:
+            return self.table[idx].tolist()
+        return [self.table[r[r >= 0]].tolist() for r in idx]
+
+
 def run(conf, model=None):
     """`model`: None -> built from conf (DAE / DAE_title on the GPU); tests pass their own object with the same
     `recommend` / `shard_scoring` / `owned_rows` protocol."""
@@ -158,14 +186,15 @@ def run(conf, model=None):
             for x_positions, x_ones, seed, _t, _e in feeds():
                 yield model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed))[0]
 
+    uris = UriTable(reader.id2uri, reader.num_tracks)
     for b_no, idx in enumerate(results()):
         first, pid, n_in_batch = meta[b_no]
         if sharded and exchange == 'allgather' and rank != 0:        # all-gather: rank 0 formats and writes
             continue
         r0, _r1 = model.owned_rows() if sharded else (0, n_in_batch)
-        for j in range(len(idx)):                           # rows r0 .. of the batch (all of them unless alltoall)
+        for j, row in enumerate(uris.rows(idx)):            # rows r0 .. of the batch (all of them unless alltoall)
             i = r0 + j
-            cands.append((first + i, [pid[i]] + cand_to_uris(idx[j], reader.id2uri)))
+            cands.append((first + i, [pid[i]] + row))
 
     if world > 1:
         import torch.distributed as dist

@@ -132,3 +132,23 @@ def test_missing_title_variables_need_an_explicit_opt_in(tmp_path):
     conf = _conf(str(tmp_path), None, 5)
     with pytest.raises(FileNotFoundError, match="allow_no_title"):
         main_challenge.run(conf)              # model=None -> the product path; stops before any device work
+
+
+def test_uri_table_equals_the_per_row_mapping():
+    """The batched id -> URI mapping (one fancy index per batch) gives the rows main_challenge.py:37-41 builds one id at
+    a time, including short lists padded with -1; the result pickle loads to the same lists."""
+    import io
+    from spotify_recsys_challenge_2018_amd.main_runner.main_challenge import UriTable, cand_to_uris
+    rng = np.random.default_rng(0)
+    nt = 300
+    id2uri = {str(i): "u%05d" % (7 * i) for i in range(nt)}
+    t = UriTable(id2uri, nt)
+    full = rng.integers(0, nt, (9, 40))
+    assert t.rows(full) == [cand_to_uris(r, id2uri) for r in full]
+    short = full.copy(); short[2, 25:] = -1; short[5, :] = -1
+    assert t.rows(short) == [cand_to_uris(r, id2uri) for r in short]
+    assert t.rows(np.zeros((0, 40), np.int32)) == []
+    rows = [[11] + r for r in t.rows(full)]
+    assert pickle.loads(pickle.dumps(rows)) == [[11] + cand_to_uris(r, id2uri) for r in full]
+    with pytest.raises(KeyError):
+        UriTable({"0": "a"}, 2).rows(np.array([[1]]))
