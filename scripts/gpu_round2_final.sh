@@ -1,7 +1,7 @@
 # the measurements DESIGN.md section 5 quotes for round 2 (one gpurun call); outputs under gpurun_out/r02f_*
 cd $GRAFT_REPO_ROOT
 o=gpurun_out
-python bench.py > $o/r02f_bench_default.json 2> $o/r02f_bench_default.err
+t0=$(date +%s.%N); python bench.py > $o/r02f_bench_default.json 2> $o/r02f_bench_default.err; echo "default bench.py wall $(( $(date +%s) - ${t0%.*} )) s"
 python bench.py --dtype bf16 --no-train-row > $o/r02f_bench_bf16.json 2>/dev/null
 python bench.py --batch-per-gpu 1024 --no-train-row --no-cpu-baseline > $o/r02f_bench_b1024.json 2>/dev/null
 python bench.py --streams 1 --no-train-row --no-cpu-baseline --no-bf16-row > $o/r02f_bench_1stream.json 2>/dev/null
@@ -27,3 +27,4 @@ except Exception as e:
 PY
 done
 tail -3 $o/r02f_shim.log; tail -6 $o/r02f_title.log; tail -2 $o/r02f_epoch.log $o/r02f_epoch_bf16.log; tail -5 $o/r02f_bench_gloo2.err
+python scripts/bench_challenge.py > $o/r02f_challenge.log 2>&1; tail -1 $o/r02f_challenge.log

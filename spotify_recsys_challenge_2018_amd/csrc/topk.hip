@@ -1011,6 +1011,8 @@ int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
     }
     if (p.n_g <= 256 * 16)
         hipLaunchKernelGGL(tau_select_kernel<16>, dim3(B), dim3(256), 0, ctx->stream, q);
+    else if (p.n_g <= 256 * 32)        // batch 1024 on one GPU: 5 120 maxima per row -- half the compares of the 64-key shape
+        hipLaunchKernelGGL(tau_select_kernel<32>, dim3(B), dim3(256), 0, ctx->stream, q);
     else
         hipLaunchKernelGGL(tau_select_kernel<64>, dim3(B), dim3(256), 0, ctx->stream, q);
     DAE_CHECK_LAUNCH(ctx, "tau_select_kernel");
