@@ -52,9 +52,10 @@ def parse():
     ap.add_argument("--bias", default="zipf", choices=["zipf", "zeros"])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="decode arithmetic: f32 = bit-exact headline path, bf16 = BASELINE configs[4]")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: each has its own library context and HIP stream, so the "
-                         "latency-bound kernels of one batch overlap the MFMA-bound decode of the other")
+                         "latency-bound kernels of one batch overlap the decode of the other.  Default: 2 for f32 (a third "
+                         "only stretches the fp32 MFMA launches), 3 for bf16 (short launches that leave the CUs room)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--sim-world", type=int, default=0,
@@ -254,7 +255,7 @@ def main():
     d_rp, d_col, d_val = up(rp, torch.int32), up(col, torch.int32), up(val, torch.float32)
     d_srp, d_sc = up(srp, torch.int32), up(sc if sc.size else np.zeros(1, np.int32), torch.int32)
     col_lo, col_hi = shard_bounds(V, sim, args.sim_rank) if sim else shard_bounds(V, world, rank)
-    n_str = max(1, args.streams)
+    n_str = args.streams if args.streams > 0 else (3 if args.dtype == "bf16" else 2)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     ctx = ctxs[0]
@@ -761,26 +762,35 @@ def main():
             idx_f32 = outs[0][1].clone()
             for c in ctxs:                                  # the bf16 launch runs ungated (two share a CU)
                 c.check(c.lib.dae_set_decode_gate(c.h, None, None))
+            # three batches in flight for this row (what `--dtype bf16` runs by default): one more context + stream
+            ctxs_b, streams_b = list(ctxs), list(streams)
+            while len(ctxs_b) < 3:
+                c3, s3 = _lib.Context(local_rank), torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(s3):
+                    c3.bind_stream()
+                ctxs_b.append(c3); streams_b.append(s3)
+            n_b = len(ctxs_b)
 
             def prepack_all(dt):
-                for c in ctxs:
+                for c in ctxs_b:
                     c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
                 torch.cuda.synchronize()
 
             def factory(dt):
                 o16 = [(torch.empty((B, k), dtype=torch.float32, device=dev),
-                        torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+                        torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_b)]
                 cnt = [0]
 
                 def st():
-                    s_ = cnt[0] % n_str
+                    s_ = cnt[0] % n_b
                     cnt[0] += 1
-                    with torch.cuda.stream(streams[s_]):
-                        ctxs[s_].score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, o16[s_][0],
-                                            o16[s_][1], dtype=dt)
+                    with torch.cuda.stream(streams_b[s_]):
+                        ctxs_b[s_].score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, o16[s_][0],
+                                              o16[s_][1], dtype=dt)
                 return o16, st
-            out["bf16_decode"] = _bf16_row(torch, _lib, met, ctxs, streams, factory, prepack_all, B, H, k, V,
+            out["bf16_decode"] = _bf16_row(torch, _lib, met, ctxs_b, streams_b, factory, prepack_all, B, H, k, V,
                                            args.steps, args.warmup, idx_f32, (PEAK_BF16_TFLOPS, PEAK_HBM_GBS))
+            out["bf16_decode"]["streams"] = n_b
             if gate_events:
                 for i, c in enumerate(ctxs):
                     c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),

@@ -363,8 +363,17 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
         if (rc) return rc;
         gmax = static_cast<float*>(ctx->gmax.p);
     }
+    // bf16: the filter launch decodes the sample tiles AGAIN instead of phase A storing their dense logits for the
+    // threshold kernel to scan: 483 more tiles cost its matrix cores 1.5 us, the 15.8 MB dense buffer (written by phase
+    // A through LDS, read back by the threshold kernel, its survivors compacted there) costs more.  Phase A then leaves
+    // the group maxima only, the threshold kernel emits no survivors, and every candidate comes from the filter launch.
+    // (fp32 keeps the buffer: the same tiles are 13.6 us of its matrix time.)
+    static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
+    const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && !gmax_per_wave && !mixed && !no_whole;
+    if (whole_b) g_plan.n_other = ntiles;
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
-    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, sample, ld_s, 1, dtype, gmax, ld_g, gmax_per_wave);
+    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, whole_b ? nullptr : sample, ld_s, 1, dtype, gmax, ld_g,
+                                     gmax_per_wave);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
@@ -384,18 +393,20 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = dae_reserve(ctx, ctx->sample_top, ((size_t)g.Bpad * pstride) * sizeof(uint2) + (size_t)g.Bpad * sizeof(int));
     if (rc) return rc;
     int* sample_cnt = reinterpret_cast<int*>(static_cast<uint2*>(ctx->sample_top.p) + (size_t)g.Bpad * pstride);
-    rc = dae_launch_tau_select(ctx, gmax, ld_g, (int)ld_g, sample, ld_s, (int)ld_s, order, pk->col_lo, B, k,
+    rc = dae_launch_tau_select(ctx, gmax, ld_g, (int)ld_g, whole_b ? gmax : sample, whole_b ? 0 : ld_s,
+                               whole_b ? 0 : (int)ld_s, order, pk->col_lo, B, k,
                                seed_row_ptr, static_cast<float*>(ctx->tau.p), static_cast<uint2*>(ctx->sample_top.p),
                                pstride, sample_cnt);
     if (rc) return rc;
 
     // phase B: everything else through the threshold filter
-    const int cap = dae_filter_block_tiles(g, n_other, dtype, pk->Hp, mixed) * 32;     // worst case: everything passes
+    const int n_filter = whole_b ? ntiles : n_other;
+    const int cap = dae_filter_block_tiles(g, n_filter, dtype, pk->Hp, mixed) * 32;    // worst case: everything passes
     rc = dae_reserve(ctx, ctx->cand, (size_t)g.nb_rg * g.Bpad * cap * sizeof(uint2));
     if (rc) return rc;
     rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
     if (rc) return rc;
-    dae_tileset tsB{n_other, S, 3, order + n_samp};
+    dae_tileset tsB{n_filter, S, 3, whole_b ? order : order + n_samp};
     // dae_set_decode_gate: the dominant launch takes every CU, so two of them in flight on two streams only queue
     // behind each other; the gate makes this one wait for the other context's and announces its own end
     if (ctx->gate_wait) DAE_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gate_wait, 0));

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
             // the dense sample rows of this row block, from the same slots: thread (tile w, playlist jj, half) writes 64
             // contiguous bytes, a wave 32 whole 128-byte rows -- the accumulator layout itself would store 16-byte
             // pieces of 64 different rows per instruction (4.9 us of the launch, measured with stage stamps)
-            for (int t2 = tid; t2 < NW * 64; t2 += NW * 64) {
+            for (int t2 = tid; t2 < NW * 64 && p.out; t2 += NW * 64) {   // p.out == null: the launch leaves maxima only
                 const int w = t2 >> 6, jj = (t2 & 63) >> 1, half = t2 & 1;
                 const int item_w = w * p.nb_rg + bir + round * (p.nb_rg * NW);
                 const int row = rg * R_TILE + rb * 32 + jj;
@@ -1754,6 +1754,7 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
     p.gmax = gmax; p.ld_gmax = ld_gmax; p.gmax_per_wave = gmax_per_wave;
+    if (!out && (!gmax || gmax_per_wave)) return dae_fail(ctx, DAE_ERR_ARG, "dense decode without an output");
 #ifdef DAE_EXPERIMENTS
     static const bool dbgA = dae_exp_env("DAE_DBG_A") != nullptr;
     static long long* abuf = nullptr;
@@ -1770,7 +1771,7 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     }
 #endif
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
-    p.fill_pad = (fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
+    p.fill_pad = (out && fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
     if (gmax) {
         if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "group maxima need 4-wave workgroups");
