@@ -121,6 +121,16 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
         a, b = c.profile_read()
         kms += a; kn += b
         c.profile_enable(False)
+    # the same launch with nothing else in flight (the timed region overlaps len(ctxs) batches, which stretches every
+    # launch's event pair but raises throughput)
+    iso_outs, iso_step = step_fn_factory(_lib.DAE_DTYPE_BF16, only=0)
+    ctxs[0].profile_enable(True)
+    for _ in range(10):
+        iso_step()
+    torch.cuda.synchronize()
+    iso_ms, iso_n = ctxs[0].profile_read()
+    ctxs[0].profile_enable(False)
+    iso_avg = iso_ms / max(iso_n, 1)
     plan = ctxs[0].last_plan()
     tiles = plan["n_filter_tiles"] if plan["fused"] else plan["n_tiles"]
     flop = 2.0 * B * H * tiles * 32
@@ -145,6 +155,10 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
                                 "frac": round(gbs / PEAK_HBM_GBS, 4)},
                         "flop_per_launch": flop, "bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg, 4),
                         "launches": kn,
+                        "isolated": {"avg_launch_ms": round(iso_avg, 4),
+                                     "hbm_frac": round(alg_bytes / (iso_avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if iso_avg > 0 else None,
+                                     "mfma_frac": round(flop / (iso_avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if iso_avg > 0 else None,
+                                     "note": "same launch with no other batch in flight"},
                         "note": "%.1f us of matrix time at the bf16 peak, %.1f us to stream the launch's bytes at the "
                                 "HBM peak: the binding roof is the larger" % (t_mfma * 1e6, t_hbm * 1e6)},
            "r_precision_vs_fp32_lists": rprec,
@@ -776,13 +790,13 @@ def main():
                     c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
                 torch.cuda.synchronize()
 
-            def factory(dt):
+            def factory(dt, only=None):
                 o16 = [(torch.empty((B, k), dtype=torch.float32, device=dev),
                         torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_b)]
                 cnt = [0]
 
                 def st():
-                    s_ = cnt[0] % n_b
+                    s_ = cnt[0] % n_b if only is None else only
                     cnt[0] += 1
                     with torch.cuda.stream(streams_b[s_]):
                         ctxs_b[s_].score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, o16[s_][0],
