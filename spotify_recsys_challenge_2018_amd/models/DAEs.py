@@ -229,7 +229,7 @@ class DAE_tied:
         t.record_stream(cur)
         return t
 
-    def _upload_csr(self, positions, values, side_stream=False):
+    def _upload_csr(self, positions, values, side_stream=False, ctx=None):
         """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
         and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
         restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
@@ -243,9 +243,11 @@ class DAE_tied:
                 pos = np.zeros((0, 2), np.int64)
             d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
             d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
-            rp, c, v, status = self.ctx.coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
+            rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
             pending = (self._csr_status or []) + [status]      # checked lazily (no sync on the scoring path)
             if len(pending) > 64:                               # un-fetched training steps: fold on the device
+                if self.__dict__.get("_lane2") is not None:     # flags of the other scoring lane: written on its stream
+                    torch.cuda.current_stream(self.device_index).wait_stream(self._lane2["stream"])
                 pending = [torch.cat(pending).max().reshape(1)]
             self._csr_status = pending
             return rp, c, v
@@ -268,9 +270,10 @@ class DAE_tied:
     check_feed = _check_feed
 
     def _mark_dirty(self):
-        """The packed decoder images of the context no longer hold the current weights."""
+        """The packed decoder images of the context(s) no longer hold the current weights."""
         self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
         self._packed_cols = {}
+        self._weights_gen = self.__dict__.get("_weights_gen", 0) + 1
 
     # -- multi-GPU scoring (SURVEY.md 8e; BASELINE.json configs[2]): vocabulary columns sharded over the ranks ----
     def shard_scoring(self, rank, world, group=None, exchange="allgather"):
@@ -392,7 +395,7 @@ class DAE_tied:
         return self.decode_dtype if dtype is None else (
             _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
 
-    def _seed_csr_dev(self, seeds, csr, side_stream=False):
+    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None):
         """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
         SEEDS_FROM_INPUT: the seeds are the playlist's own tracks -- what both reference drivers pass -- and are cut
         out of the input CSR on the device (dae_seeds_from_csr): no per-row list handling, no uploads."""
@@ -400,22 +403,24 @@ class DAE_tied:
         if isinstance(seeds, str):
             if seeds != SEEDS_FROM_INPUT:
                 raise ValueError("seeds: a list of per-row id lists, or SEEDS_FROM_INPUT")
-            return self.ctx.seeds_from_csr(csr[0], csr[1], self.n_tracks)
+            return (ctx or self.ctx).seeds_from_csr(csr[0], csr[1], self.n_tracks)
         srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
         return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
 
-    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None):
-        """Enqueue one batch of the fused scoring path; nothing is fetched.  -> (score, idx, done event)."""
+    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None):
+        """Enqueue one batch of the fused scoring path on the current stream; nothing is fetched.
+        -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's)."""
         import torch
+        ctx = ctx or self.ctx
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream)
-        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx)
         score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
         idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
-        self.ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
-                            self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
+        ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
+                       self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
@@ -478,17 +483,61 @@ class DAE_tied:
                     score.record_stream(fs)
                     s_h = score[:n_rows].cpu().numpy()
             return i_h, s_h
-        pending = None
-        for feed in feeds:
-            x_positions, x_ones, seeds, n_rows = feed[:4]
-            score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
-            ticket = (score, idx, ev, self.n_batch if n_rows is None else n_rows)
-            if pending is not None:
-                yield fetch(pending)
-            pending = ticket
-        if pending is not None:
-            yield fetch(pending)
+        lanes = self._scoring_lanes(dtype)              # [(context, stream)]: one, or two that take the batches in turn
+        pending = []
+        try:
+            for n_feed, feed in enumerate(feeds):
+                x_positions, x_ones, seeds, n_rows = feed[:4]
+                ctx, stream = lanes[n_feed % len(lanes)]
+                if stream is None:
+                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
+                else:
+                    with torch.cuda.stream(stream):
+                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx)
+                pending.append((score, idx, ev, self.n_batch if n_rows is None else n_rows))
+                if len(pending) > len(lanes):              # one batch per lane stays in flight behind the fetch
+                    yield fetch(pending.pop(0))
+            while pending:
+                yield fetch(pending.pop(0))
+        finally:
+            if len(lanes) > 1:
+                torch.cuda.current_stream(self.device_index).wait_stream(lanes[1][1])
+                for c, _s in lanes:                          # other entry points run ungated
+                    c.check(c.lib.dae_set_decode_gate(c.h, None, None))
         self._check_feed()
+
+    def _scoring_lanes(self, dtype):
+        """Contexts the streamed scoring loop alternates between.  The plain DAE runs TWO (what bench.py measures): the
+        second has its own HIP stream and its own packed decoder image, the dominant launches of the two take turns
+        (dae_set_decode_gate, fp32) and everything else of one batch overlaps the other batch's decode -- 0.30 ->
+        ~0.23 ms per batch through the drivers' loop.  A title model keeps one (its mix runs on two contexts already)."""
+        import torch
+        if type(self)._submit is not DAE._submit or not self.__dict__.get("two_lanes", True):
+            return [(self.ctx, None)]
+        st = self.__dict__.get("_lane2")
+        if st is None:
+            ctx2 = _lib.Context(self.device_index)
+            s2 = torch.cuda.Stream(device=self.weights["encoder_h"].device)
+            with torch.cuda.stream(s2):
+                ctx2.bind_stream()
+            ev = [torch.cuda.Event(), torch.cuda.Event()]
+            cur = torch.cuda.current_stream(self.device_index)
+            ev[0].record(cur); ev[1].record(s2)           # materialise the hipEvent_t handles
+            st = self._lane2 = {"ctx": ctx2, "stream": s2, "ev": ev, "packed": {}}
+        ctx2, s2 = st["ctx"], st["stream"]
+        gen = self.__dict__.get("_weights_gen", 0)
+        if st["packed"].get(dtype) != gen:                 # the second image follows the weights like the first
+            s2.wait_stream(torch.cuda.current_stream(self.device_index))
+            with torch.cuda.stream(s2):
+                ctx2.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0, self.n_input, dtype)
+            st["packed"][dtype] = gen
+        gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
+        e0, e1 = st["ev"]
+        import ctypes
+        P = lambda e: ctypes.c_void_p(e.cuda_event) if gate else None      # noqa: E731
+        self.ctx.check(self.ctx.lib.dae_set_decode_gate(self.ctx.h, P(e1), P(e0)))
+        ctx2.check(ctx2.lib.dae_set_decode_gate(ctx2.h, P(e0), P(e1)))
+        return [(self.ctx, None), (ctx2, s2)]
 
     # -- training -----------------------------------------------------------------------------------
     def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, fetch_cost=True):
