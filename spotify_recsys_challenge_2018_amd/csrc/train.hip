@@ -20,6 +20,20 @@
 
 namespace {
 
+// streamed-once 16-byte accesses (Adam state: every byte is read and written exactly once per step)
+typedef float nt4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_ld4(const float* a)
+{
+    const nt4_t t = __builtin_nontemporal_load(reinterpret_cast<const nt4_t*>(a));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_st4(float* a, const float4 x)
+{
+    const nt4_t t = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt4_t*>(a));
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int N> struct IntC { static constexpr int value = N; };
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -370,9 +384,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
                             const int reg = r4 + u;
                             const int v = v0 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi) + b;
                             const size_t o = (size_t)(v < p.V ? v : 0) * p.H + hc0 + 4 * j;
-                            pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o);
-                            mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o);
-                            vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o);
+                            pp[u] = nt_ld4(p.ad_p + o);
+                            mm[u] = nt_ld4(p.ad_m + o);
+                            vv[u] = nt_ld4(p.ad_v + o);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -389,9 +403,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
                             K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
 #undef K6_ADAM
                             if (v < p.V) {
-                                *reinterpret_cast<float4*>(p.ad_p + o) = pp[u];
-                                *reinterpret_cast<float4*>(p.ad_m + o) = mm[u];
-                                *reinterpret_cast<float4*>(p.ad_v + o) = vv[u];
+                                nt_st4(p.ad_p + o, pp[u]);
+                                nt_st4(p.ad_m + o, mm[u]);
+                                nt_st4(p.ad_v + o, vv[u]);
                             }
                         }
                     } else {
@@ -426,9 +440,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
                     for (int u = 0; u < 4; ++u) {
                         const int reg = r4 + u;
                         const size_t o = rbase + 4 * ((reg & 3) + 8 * (reg >> 2) + 4 * hi);
-                        pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o);
-                        mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o);
-                        vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o);
+                        pp[u] = nt_ld4(p.ad_p + o);
+                        mm[u] = nt_ld4(p.ad_m + o);
+                        vv[u] = nt_ld4(p.ad_v + o);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -443,9 +457,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
                         K6_ADAM(pp[u].x, mm[u].x, vv[u].x, g0) K6_ADAM(pp[u].y, mm[u].y, vv[u].y, g1)
                         K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
 #undef K6_ADAM
-                        *reinterpret_cast<float4*>(p.ad_p + o) = pp[u];
-                        *reinterpret_cast<float4*>(p.ad_m + o) = mm[u];
-                        *reinterpret_cast<float4*>(p.ad_v + o) = vv[u];
+                        nt_st4(p.ad_p + o, pp[u]);
+                        nt_st4(p.ad_m + o, mm[u]);
+                        nt_st4(p.ad_v + o, vv[u]);
                     }
                 }
             }
@@ -598,9 +612,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
                         const int v = v0 + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
                         ok[u] = v < p.V;
                         o[u] = (size_t)(ok[u] ? v : 0) * p.H + hc0 + 4 * n;
-                        pp[u] = *reinterpret_cast<const float4*>(p.ad_p + o[u]);
-                        mm[u] = *reinterpret_cast<const float4*>(p.ad_m + o[u]);
-                        vv[u] = *reinterpret_cast<const float4*>(p.ad_v + o[u]);
+                        pp[u] = nt_ld4(p.ad_p + o[u]);
+                        mm[u] = nt_ld4(p.ad_m + o[u]);
+                        vv[u] = nt_ld4(p.ad_v + o[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -614,9 +628,9 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
                         K6_ADAM(pp[u].z, mm[u].z, vv[u].z, g2) K6_ADAM(pp[u].w, mm[u].w, vv[u].w, g3)
 #undef K6_ADAM
                         if (ok[u]) {
-                            *reinterpret_cast<float4*>(p.ad_p + o[u]) = pp[u];
-                            *reinterpret_cast<float4*>(p.ad_m + o[u]) = mm[u];
-                            *reinterpret_cast<float4*>(p.ad_v + o[u]) = vv[u];
+                            nt_st4(p.ad_p + o[u], pp[u]);
+                            nt_st4(p.ad_m + o[u], mm[u]);
+                            nt_st4(p.ad_v + o[u], vv[u]);
                         }
                     }
                 }
@@ -1013,19 +1027,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         V.c = V.c + (G.c * G.c - V.c) * (1.0f - b2);                 \
         P.c = P.c - (M.c * lr_t) / (sqrtf(V.c) + eps);
     // two float4 groups per iteration: 8 independent 16-byte loads in flight per thread (HBM-bound: 7 passes
-    // over the tensor)
+    // over the tensor).  Every byte is touched once: nontemporal loads and stores keep the 7 streams out of each
+    // other's way in L2.
+    typedef float nt4 __attribute__((ext_vector_type(4)));
+    auto ld = [](const float4* a) {
+        const nt4 t = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(a));
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
+    auto st = [](float4* a, const float4 x) {
+        const nt4 t = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<nt4*>(a));
+    };
     const size_t stride = (size_t)gridDim.x * 256;
     size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (; o + stride < n4; o += 2 * stride) {
         const size_t o2 = o + stride;
-        float4 pa = p4[o], ma = m4[o], va = v4[o];
-        const float4 ga = g4[o];
-        float4 pb = p4[o2], mb = m4[o2], vb = v4[o2];
-        const float4 gb = g4[o2];
+        float4 pa = ld(p4 + o), ma = ld(m4 + o), va = ld(v4 + o);
+        const float4 ga = ld(g4 + o);
+        float4 pb = ld(p4 + o2), mb = ld(m4 + o2), vb = ld(v4 + o2);
+        const float4 gb = ld(g4 + o2);
         ADAM1(pa, ma, va, ga, x) ADAM1(pa, ma, va, ga, y) ADAM1(pa, ma, va, ga, z) ADAM1(pa, ma, va, ga, w)
         ADAM1(pb, mb, vb, gb, x) ADAM1(pb, mb, vb, gb, y) ADAM1(pb, mb, vb, gb, z) ADAM1(pb, mb, vb, gb, w)
-        p4[o] = pa; m4[o] = ma; v4[o] = va;
-        p4[o2] = pb; m4[o2] = mb; v4[o2] = vb;
+        st(p4 + o, pa); st(m4 + o, ma); st(v4 + o, va);
+        st(p4 + o2, pb); st(m4 + o2, mb); st(v4 + o2, vb);
     }
     for (; o < n4; o += stride) {
         float4 pp = p4[o], mm = m4[o], vv = v4[o];
