@@ -1,0 +1,21 @@
+# usage: bash scripts/gpu_ab_build.sh   (run on the GPU box: expects libdae_hip.so variants prebuilt as libdae_hip.so.<tag> in the package dir)
+# for each variant: kernel stats (1 stream, f32) + 2-stream throughput, f32 and bf16
+cd $GRAFT_REPO_ROOT
+pkg=spotify_recsys_challenge_2018_amd
+cp $pkg/libdae_hip.so /tmp/libdae_hip.so.orig
+for v in $pkg/libdae_hip.so.*; do
+  tag=${v##*.so.}
+  cp $v $pkg/libdae_hip.so
+  (cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ab_$tag; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$tag -o k -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-train-row --no-bf16-row --streams 1 --steps 150 > /dev/null 2>&1 < /dev/null)
+  f=$(find /tmp/ab_$tag -name "*kernel_stats.csv" | head -1)
+  python - "$f" $tag <<'PY'
+import csv, re, sys
+out = []
+for r in list(csv.DictReader(open(sys.argv[1])))[:5]:
+    n = re.sub(r"\(anonymous namespace\)::", "", r["Name"]); n = re.sub(r"\(.*", "", n).replace("void ", "")[:28]
+    out.append("%s %.1f" % (n, float(r["AverageNs"]) / 1e3))
+print("AB", sys.argv[2], "| ".join(out))
+PY
+  for dt in f32 bf16; do timeout 150 python bench.py --dtype $dt --no-cpu-baseline --no-train-row --no-bf16-row --steps 400 --warmup 40 2>/dev/null < /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('AB', '$tag', '$dt', d['value'], d['ms_per_step'])"; done
+done
+cp /tmp/libdae_hip.so.orig $pkg/libdae_hip.so
