@@ -16,7 +16,8 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 def main():
     import pickle
     import torch
-    nt, na, H, B = 140000, 30000, 256, 256
+    nt, na, H = 140000, 30000, 256
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256      # 150 = the reference's [CHALLENGE] / [TITLE] batch
     V = nt + na
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
     path = "/tmp/_shim_init.pkl"
@@ -46,6 +47,9 @@ def main():
     # batch n), seeds cut out of the input on the device, indices only -- what main.py --challenge runs
     from spotify_recsys_challenge_2018_amd.models.DAEs import SEEDS_FROM_INPUT
     m.device_csr = True
+    if "--alone" in sys.argv:                 # one feed per launch, one context: the loop before coalescing / two lanes
+        m.coalesce = 1
+        m.two_lanes = False
     for label, seeds_of, scores in (("seed lists from the host, idx + score", lambda s_: s_, True),
                                     ("seeds = input tracks (device), idx only", lambda s_: SEEDS_FROM_INPUT, False)):
         def feeds(reps):

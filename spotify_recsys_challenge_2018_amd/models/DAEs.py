@@ -229,7 +229,7 @@ class DAE_tied:
         t.record_stream(cur)
         return t
 
-    def _upload_csr(self, positions, values, side_stream=False, ctx=None):
+    def _upload_csr(self, positions, values, side_stream=False, ctx=None, n_rows=None):
         """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
         and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
         restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
@@ -243,7 +243,7 @@ class DAE_tied:
                 pos = np.zeros((0, 2), np.int64)
             d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
             d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
-            rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, self.n_batch, self.n_input)
+            rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, n_rows or self.n_batch, self.n_input)
             pending = (self._csr_status or []) + [status]      # checked lazily (no sync on the scoring path)
             if len(pending) > 64:                               # un-fetched training steps: fold on the device
                 if self.__dict__.get("_lane2") is not None:     # flags of the other scoring lane: written on its stream
@@ -251,7 +251,7 @@ class DAE_tied:
                 pending = [torch.cat(pending).max().reshape(1)]
             self._csr_status = pending
             return rp, c, v
-        rp, c, v = coo_to_csr(positions, values, self.n_batch, self.n_input)
+        rp, c, v = coo_to_csr(positions, values, n_rows or self.n_batch, self.n_input)
         if c.size == 0:          # keep valid device pointers for empty batches
             c = np.zeros(1, np.int32); v = np.zeros(1, np.float32)
         return self._to_dev(rp, torch.int32), self._to_dev(c, torch.int32), self._to_dev(v, torch.float32)
@@ -395,7 +395,7 @@ class DAE_tied:
         return self.decode_dtype if dtype is None else (
             _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
 
-    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None):
+    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None):
         """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
         SEEDS_FROM_INPUT: the seeds are the playlist's own tracks -- what both reference drivers pass -- and are cut
         out of the input CSR on the device (dae_seeds_from_csr): no per-row list handling, no uploads."""
@@ -404,21 +404,24 @@ class DAE_tied:
             if seeds != SEEDS_FROM_INPUT:
                 raise ValueError("seeds: a list of per-row id lists, or SEEDS_FROM_INPUT")
             return (ctx or self.ctx).seeds_from_csr(csr[0], csr[1], self.n_tracks)
-        srp, sc = seeds_to_csr(seeds, self.n_batch, self.n_tracks)
+        srp, sc = seeds_to_csr(seeds, n_rows or self.n_batch, self.n_tracks)
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
         return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
 
-    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None):
+    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
+                n_rows=None):
         """Enqueue one batch of the fused scoring path on the current stream; nothing is fetched.
-        -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's)."""
+        -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's); `n_rows`: rows of
+        this launch when it is not the model's batch (several feeds coalesced by recommend_iter)."""
         import torch
         ctx = ctx or self.ctx
+        nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx)
-        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx)
-        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
-        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb)
+        score = torch.empty((nb, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
         ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
                        self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
         ev = torch.cuda.current_stream(self.device_index).record_event()
@@ -484,27 +487,102 @@ class DAE_tied:
                     s_h = score[:n_rows].cpu().numpy()
             return i_h, s_h
         lanes = self._scoring_lanes(dtype)              # [(context, stream)]: one, or two that take the batches in turn
+        group = self._coalesce_count() if len(lanes) > 1 else 1
         pending = []
+
+        def launches():
+            """Feeds -> launches.  The plain DAE scores `group` consecutive feeds in ONE launch (rows of feed i become
+            rows i * n_batch ... of the launch): the reference's batch of 150 pads to 256 rows on its own (41 % of the
+            decode wasted) and leaves the per-launch costs to 150 playlists; 5 feeds make 750 rows of a 768-row launch.
+            Rows are scored independently, so every row gets the bits it gets alone."""
+            if group == 1:
+                for feed in feeds:
+                    yield feed, [self.n_batch if feed[3] is None else feed[3]], None
+                return
+            buf = []
+
+            def flush():
+                nb = self.n_batch
+                pos = [np.asarray(f[0], np.int64).reshape(-1, 2) + np.array([i * nb, 0], np.int64) for i, f in enumerate(buf)]
+                ones = [np.broadcast_to(np.asarray(f[1], np.float32).reshape(-1), (len(pp),)) for f, pp in zip(buf, pos)]
+                if all(isinstance(f[2], str) for f in buf):
+                    seeds = buf[0][2]
+                else:
+                    seeds = []
+                    for f, pp in zip(buf, pos):
+                        if isinstance(f[2], str):          # the playlist's own tracks, as lists
+                            own = [[] for _ in range(nb)]
+                            for r_, c_ in np.asarray(f[0], np.int64).reshape(-1, 2):
+                                if c_ < self.n_tracks:
+                                    own[int(r_)].append(int(c_))
+                            seeds += own
+                        else:
+                            seeds += list(f[2]) + [[] for _ in range(nb - len(f[2]))]
+                rows = [nb if f[3] is None else f[3] for f in buf]
+                feed = (np.concatenate(pos) if pos else np.zeros((0, 2), np.int64),
+                        np.concatenate(ones) if ones else np.zeros(0, np.float32), seeds, None)
+                return feed, rows, len(buf) * nb
+            for feed in feeds:
+                buf.append(feed)
+                if len(buf) == group:
+                    yield flush()
+                    buf = []
+            if buf:
+                yield flush()
+
+        def split(res, rows):
+            i_h, s_h = res
+            nb = self.n_batch
+            for i, n in enumerate(rows):
+                yield i_h[i * nb:i * nb + n], (None if s_h is None else s_h[i * nb:i * nb + n])
         try:
-            for n_feed, feed in enumerate(feeds):
-                x_positions, x_ones, seeds, n_rows = feed[:4]
-                ctx, stream = lanes[n_feed % len(lanes)]
-                if stream is None:
+            for n_launch, (feed, rows, n_total) in enumerate(launches()):
+                x_positions, x_ones, seeds = feed[:3]
+                ctx, stream = lanes[n_launch % len(lanes)]
+                if stream is None and n_total is None:      # one feed, the model's own context (also DAE_title's _submit)
                     score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
+                elif stream is None:
+                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, n_rows=n_total)
                 else:
                     with torch.cuda.stream(stream):
-                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx)
-                pending.append((score, idx, ev, self.n_batch if n_rows is None else n_rows))
-                if len(pending) > len(lanes):              # one batch per lane stays in flight behind the fetch
-                    yield fetch(pending.pop(0))
+                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, n_rows=n_total)
+                fetch_rows = rows[0] if n_total is None else n_total
+                pending.append(((score, idx, ev, fetch_rows), rows, n_total))
+                if len(pending) > len(lanes):              # one launch per lane stays in flight behind the fetch
+                    t, rws, nt_ = pending.pop(0)
+                    if nt_ is None:
+                        yield fetch(t)
+                    else:
+                        yield from split(fetch(t), rws)
             while pending:
-                yield fetch(pending.pop(0))
+                t, rws, nt_ = pending.pop(0)
+                if nt_ is None:
+                    yield fetch(t)
+                else:
+                    yield from split(fetch(t), rws)
         finally:
             if len(lanes) > 1:
                 torch.cuda.current_stream(self.device_index).wait_stream(lanes[1][1])
                 for c, _s in lanes:                          # other entry points run ungated
                     c.check(c.lib.dae_set_decode_gate(c.h, None, None))
         self._check_feed()
+
+    def _coalesce_count(self):
+        """Feeds per launch of the streamed loop: the count (<= 8, <= 1024 rows) that wastes the fewest padded rows of
+        the 128-row groups the decode works in; more feeds on a tie.  150 -> 5 (750 of 768 rows), 250 -> 4 (1000 of
+        1024), 256 -> 4, batches of >= 512 rows stay alone.  `model.coalesce = n` overrides."""
+        forced = self.__dict__.get("coalesce")
+        if forced:
+            return max(1, int(forced))
+        nb = self.n_batch
+        best, best_eff = 1, 0.0
+        for m in range(1, 9):
+            if m > 1 and m * nb > 1024:
+                break
+            eff = m * nb / float(-(-m * nb // 128) * 128)
+            if eff >= best_eff - 1e-9:
+                best, best_eff = m, max(eff, best_eff)
+        return best
 
     def _scoring_lanes(self, dtype):
         """Contexts the streamed scoring loop alternates between.  The plain DAE runs TWO (what bench.py measures): the

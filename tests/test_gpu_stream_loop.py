@@ -13,9 +13,11 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype):
-    nt, na, H, B, k = 20000, 4000, 256, 256, 500
+@pytest.mark.parametrize("dtype,B", [("f32", 256), ("bf16", 256), ("f32", 150), ("f32", 250)])
+def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
+    """7 feeds (short ones among them) through the streamed loop: coalesced 4 or 5 to a launch (256 / 250 -> 4, the
+    reference's challenge batch of 150 -> 5), launches alternating between two contexts."""
+    nt, na, H, k = 20000, 4000, 256, 500
     V = nt + na
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=2, bias="zipf", n_tracks=nt)
     path = str(tmp_path / "init.pkl")
@@ -28,6 +30,7 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype):
     m = DAE(C()); m.fit()
     batches = [make_playlists(B, nt, na, seed=10 + s) for s in range(7)]           # odd count: the lanes end unevenly
     rows = [B, B, 100, B, 1, B, 37]                                                # short last batches of a file
+    assert m._coalesce_count() == {256: 4, 250: 4, 150: 5}[B]
     want = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
     feeds = [(p, o, SEEDS_FROM_INPUT, n) for (p, o, _s), n in zip(batches, rows)]
     got = list(m.recommend_iter(feeds, k=k, dtype=dtype))
@@ -42,3 +45,9 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype):
     m.two_lanes = False
     got1 = list(m.recommend_iter(feeds[:3], k=k, dtype=dtype))
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got1, got2))
+    # explicit seed lists (and a mix of both kinds) through the coalesced launches
+    m.two_lanes = True
+    mixed = [(p, o, (s if i % 2 else SEEDS_FROM_INPUT), n) for i, ((p, o, s), n) in enumerate(zip(batches, rows))]
+    got3 = list(m.recommend_iter(mixed, k=k, dtype=dtype))
+    want3 = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got3, want3))
