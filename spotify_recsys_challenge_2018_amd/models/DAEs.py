@@ -487,7 +487,7 @@ class DAE_tied:
                     s_h = score[:n_rows].cpu().numpy()
             return i_h, s_h
         lanes = self._scoring_lanes(dtype)              # [(context, stream)]: one, or two that take the batches in turn
-        group = self._coalesce_count() if len(lanes) > 1 else 1
+        group = self._coalesce_count()
         pending = []
 
         def launches():
@@ -521,6 +521,16 @@ class DAE_tied:
                 rows = [nb if f[3] is None else f[3] for f in buf]
                 feed = (np.concatenate(pos) if pos else np.zeros((0, 2), np.int64),
                         np.concatenate(ones) if ones else np.zeros(0, np.float32), seeds, None)
+                if any(len(f) > 4 for f in buf):           # DAE_title feeds: titles / titles_use, one entry per row
+                    pad = [-1] * self.title_model.input_len
+                    titles, use = [], []
+                    for f in buf:
+                        t = [] if len(f) <= 4 or f[4] is None else [pad if x is None else x for x in f[4]]
+                        u = [] if len(f) <= 5 or f[5] is None else [float(x) for x in np.asarray(f[5]).reshape(-1)]
+                        u = (u + [0.0] * len(t))[:len(t)]
+                        titles += list(t)[:nb] + [pad] * (nb - min(len(t), nb))
+                        use += u[:nb] + [0.0] * (nb - min(len(u), nb))
+                    feed = feed + (titles, np.asarray(use, np.float32))
                 return feed, rows, len(buf) * nb
             for feed in feeds:
                 buf.append(feed)
@@ -542,7 +552,7 @@ class DAE_tied:
                 if stream is None and n_total is None:      # one feed, the model's own context (also DAE_title's _submit)
                     score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
                 elif stream is None:
-                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, n_rows=n_total)
+                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:], n_rows=n_total)
                 else:
                     with torch.cuda.stream(stream):
                         score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, n_rows=n_total)
@@ -792,19 +802,20 @@ class DAE_title(DAE):
         rows = np.repeat(np.arange(self.n_batch), np.diff(rp))
         return np.bincount(rows, weights=v.astype(np.float64), minlength=self.n_batch).astype(np.float32)
 
-    def _mix_weights(self, csr, titles_use, input_keep_prob=1.0, seed=0, side_stream=False):
+    def _mix_weights(self, csr, titles_use, input_keep_prob=1.0, seed=0, side_stream=False, n_rows=None):
         """DAEs.py:159-162 on the device: x_count = row_sum(x) * input_keep_prob; w_title = u / (u + x_count + 1e-10),
         w_playlist = x_count / (same) -- fp32 operations in the reference's order.  -> (w_title, w_playlist) [n_batch]."""
         import torch
         rp, c, v = csr
         dev = rp.device
-        s = torch.empty(self.n_batch, dtype=torch.float32, device=dev)
+        nb = n_rows or self.n_batch
+        s = torch.empty(nb, dtype=torch.float32, device=dev)
         P = _lib._ptr
-        self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(rp), P(c), P(v), self.n_batch, float(input_keep_prob),
+        self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(rp), P(c), P(v), nb, float(input_keep_prob),
                                                  int(seed), P(s)))
-        u = np.zeros(self.n_batch, np.float32)
+        u = np.zeros(nb, np.float32)
         tu = np.asarray(titles_use, np.float32).reshape(-1)
-        u[:len(tu)] = tu[:self.n_batch]
+        u[:len(tu)] = tu[:nb]
         u = self._to_dev(u, torch.float32, side_stream)
         x_count = s * float(np.float32(input_keep_prob))
         deno = u + x_count + 1e-10
@@ -876,28 +887,30 @@ class DAE_title(DAE):
         self._check_feed()
         return cost
 
-    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None):
-        """One batch enqueued, nothing fetched.  Without titles in use the mix reduces to the plain DAE (w_playlist is
+    def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
+                n_rows=None):
+        """One batch enqueued, nothing fetched (`n_rows`: rows of a launch that coalesces several feeds).  Without titles in use the mix reduces to the plain DAE (w_playlist is
         exactly 1.0f, App. B.6): the fused path of the base class.  With titles: the DAE term of the track columns
         goes to a transposed scratch (dae_decode_mix_term) and the title scorer's context runs the fused threshold
         path on sigmoid(z_title) * w_title + that term (dae_set_score_mix) -- no [batch, n_input] matrix of either."""
         if titles is None or titles_use is None or not np.any(np.asarray(titles_use)):
-            return DAE._submit(self, x_positions, x_ones, seeds, k, dtype, side_stream)
+            return DAE._submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, ctx=ctx, n_rows=n_rows)
         import torch
         tm = self.title_model
         tm.ctx.bind_stream()
+        nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream)
-        h = torch.empty((self.n_batch, self.n_hidden), dtype=torch.float32, device=dev)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
+        h = torch.empty((nb, self.n_hidden), dtype=torch.float32, device=dev)
         self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h)
-        w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream)
+        w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb)
         nt32 = min((self.n_tracks + 31) // 32 * 32, self.n_input)
-        y1T = torch.empty((nt32, self.n_batch), dtype=torch.float32, device=dev)
+        y1T = torch.empty((nt32, nb), dtype=torch.float32, device=dev)
         self.ctx.decode_mix_term(h, w_p, self.n_tracks, y1T, dtype=dtype)
-        feat = tm.features(titles, self.n_batch, side_stream_of=self if side_stream else None)
-        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream)
-        score = torch.empty((self.n_batch, k), dtype=torch.float32, device=dev)
-        idx = torch.empty((self.n_batch, k), dtype=torch.int32, device=dev)
+        feat = tm.features(titles, nb, side_stream_of=self if side_stream else None)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, n_rows=nb)
+        score = torch.empty((nb, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
         tm.ctx.set_score_mix(y1T, w_t)
         try:
             tm.ctx.decode_topk(feat, self.n_tracks, d_srp, d_sc, k, score, idx, out_kind=_lib.DAE_OUT_LOGIT, dtype=dtype)
