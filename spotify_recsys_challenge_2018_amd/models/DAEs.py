@@ -82,13 +82,14 @@ def seeds_to_csr(seeds, n_rows, n_tracks):
     """Per-row seed track lists (main_challenge.py:31-35 `cand.remove(i)`) -> CSR of sorted unique
     in-range track ids.  One lexsort over all rows (the per-row np.unique loop was the largest host cost
     of a scoring call)."""
-    lens = np.fromiter((len(seeds[i]) if i < len(seeds) else 0 for i in range(n_rows)), dtype=np.int64,
-                       count=n_rows)
+    import itertools
+    used = seeds[:n_rows] if len(seeds) > n_rows else seeds
+    lens = np.zeros(n_rows, dtype=np.int64)
+    lens[:len(used)] = np.fromiter(map(len, used), dtype=np.int64, count=len(used))
     total = int(lens.sum())
     if total == 0:
         return np.zeros(n_rows + 1, dtype=np.int32), np.zeros(0, dtype=np.int32)
-    flat = np.fromiter((int(t) for i in range(min(n_rows, len(seeds))) for t in seeds[i]), dtype=np.int64,
-                       count=total)
+    flat = np.fromiter(itertools.chain.from_iterable(used), dtype=np.int64, count=total)
     rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
     ok = (flat >= 0) & (flat < n_tracks)
     flat, rows = flat[ok], rows[ok]
@@ -98,8 +99,8 @@ def seeds_to_csr(seeds, n_rows, n_tracks):
     first[1:] = (rows[1:] != rows[:-1]) | (flat[1:] != flat[:-1])
     flat, rows = flat[first], rows[first]
     row_ptr = np.zeros(n_rows + 1, dtype=np.int64)
-    np.add.at(row_ptr, rows + 1, 1)
-    return np.cumsum(row_ptr).astype(np.int32), flat.astype(np.int32)
+    row_ptr[1:] = np.cumsum(np.bincount(rows, minlength=n_rows))
+    return row_ptr.astype(np.int32), flat.astype(np.int32)
 
 
 class DAE_tied:
