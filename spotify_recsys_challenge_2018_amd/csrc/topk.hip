@@ -590,14 +590,33 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         const u64 rlo = lo, rhi = s_max;                         // every collected key lies in [lo, s_max]
         int shift = 64 - 11 - __clzll((rhi - rlo) | 1ull);
         if (shift < 0) shift = 0;
+        // Bins are linear in the LOGIT, not in its bit pattern: the order-preserving key spends half of its range on
+        // magnitudes below 2^-126, so a row whose winners straddle zero (popular tracks at p ~ 0.5) had all of its keys
+        // in ~70 of the 2048 bit-pattern bins, and the same-bin loop below went quadratic (17 of the 40 us of a
+        // 1024-row launch).  Any monotone map of the key keeps the result: bins only have to respect the order.
+        const float zlo = dae_okey_inv((unsigned)(rlo >> 32)), zhi = dae_okey_inv((unsigned)(rhi >> 32));
+        const float zspan = zhi - zlo;
+        const bool lin = zspan > 1e-30f && zspan < 3.0e38f;      // finite, non-degenerate range; else the bit pattern
+        const float zscale = lin ? (float)(TK_BINS - 1) / zspan : 0.0f;
         for (int b2 = tid; b2 < TK_BINS; b2 += TK_THREADS) hist[b2] = 0;
         __syncthreads();                                         // also: every skey read above is done
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            mbin[e] = mine[e] != 0ull ? (unsigned)((mine[e] - rlo) >> shift) : 0u;
-            mpos[e] = mine[e] != 0ull ? atomicAdd(&hist[mbin[e]], 1u) : 0u;
+            unsigned bn = 0u;
+            if (mine[e] != 0ull) {
+                if (lin) {
+                    const float zz = dae_okey_inv((unsigned)(mine[e] >> 32));
+                    const float fb = fminf(fmaxf((zz - zlo) * zscale, 0.0f), (float)(TK_BINS - 1));
+                    bn = (unsigned)fb;
+                } else {
+                    bn = (unsigned)((mine[e] - rlo) >> shift);
+                }
+            }
+            mbin[e] = bn;
+            mpos[e] = mine[e] != 0ull ? atomicAdd(&hist[bn], 1u) : 0u;
         }
         __syncthreads();
+        if (DAE_EXP_ON(dbg_stop == 8)) { if (mpos[0] == 12345u) a.out_idx[0] = 1; return; }
         // above[b] = keys in bins > b.  Thread t owns the BPT bins from 2047 - BPT t downwards.
         unsigned* above = reinterpret_cast<unsigned*>(skey);     // 2048 x 4 B = the sort buffer's 1024 x 8 B
         u64* sorted = keys;                                      // key cache region: >= 1024 keys (launch_topk)
@@ -624,22 +643,36 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         for (int e = 0; e < PER; ++e)
             if (mine[e] != 0ull) sorted[above[mbin[e]] + mpos[e]] = mine[e];
         __syncthreads();
+        if (DAE_EXP_ON(dbg_stop == 6)) return;
+        unsigned rk[PER];
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
+            rk[e] = 0xFFFFFFFFu;
             if (mine[e] == 0ull) continue;
             const unsigned base = above[mbin[e]], nb = hist[mbin[e]];
             unsigned rank = base;
             for (unsigned i = 0; i < nb; ++i) rank += sorted[base + i] > mine[e] ? 1u : 0u;
-            if (rank < k_eff) {
-                const float z = dae_okey_inv((unsigned)(mine[e] >> 32));
-                const int colv = (int)(~(unsigned)(mine[e] & 0xFFFFFFFFull));
-                const size_t o = (size_t)row * k + rank;
-                if (a.out_idx) a.out_idx[o] = colv;
-                if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
-                if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + rank] =
-                    make_uint2(__float_as_uint(z), (unsigned)colv);
-                if (a.out_tau && rank == (unsigned)k - 1) a.out_tau[row] = z;
-            }
+            rk[e] = rank;
+        }
+        // the winners in rank order through LDS (the `above` table is dead now), then out in rank order: thread i writes
+        // position i, a wave 256 contiguous bytes.  Storing from the rank loop put every 4-byte value into a line of its
+        // own -- ~1000 partial-line writes per row, the larger half of this launch at 1024 rows.
+        if (DAE_EXP_ON(dbg_stop == 7)) { if (rk[0] == 12345u) a.out_idx[0] = 1; return; }
+        __syncthreads();
+        u64* fin = skey;
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (rk[e] < k_eff) fin[rk[e]] = mine[e];
+        __syncthreads();
+        for (unsigned i = tid; i < k_eff; i += NTH) {
+            const u64 key = fin[i];
+            const float z = dae_okey_inv((unsigned)(key >> 32));
+            const int colv = (int)(~(unsigned)(key & 0xFFFFFFFFull));
+            const size_t o = (size_t)row * k + i;
+            if (a.out_idx) a.out_idx[o] = colv;
+            if (a.out_score) a.out_score[o] = a.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
+            if (a.out_pairs) a.out_pairs[(size_t)row * a.pairs_stride + i] = make_uint2(__float_as_uint(z), (unsigned)colv);
+            if (a.out_tau && i == (unsigned)k - 1) a.out_tau[row] = z;
         }
     } else
     // Hybrid bitonic sort, descending.  Thread t holds elements t, t + NTH, ... (E = sort_n / NTH of them,
