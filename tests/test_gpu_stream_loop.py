@@ -51,3 +51,17 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
     got3 = list(m.recommend_iter(mixed, k=k, dtype=dtype))
     want3 = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got3, want3))
+
+
+def test_clock_probe_reads_a_plausible_engine_clock():
+    """dae_clock_probe (bench.py's `roofline.sustained_clock`): shader cycles over wall-clock ticks of one wave."""
+    import torch
+    ctx = _lib.Context(0)
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    khz = ctx.clock_probe(out, window_us=200)
+    torch.cuda.synchronize()
+    cyc, ticks = (int(v) for v in out.cpu())
+    assert khz > 0 and ticks >= 200 * khz // 1000 and cyc > 0
+    ghz = cyc / ticks * khz / 1e6
+    assert 0.1 < ghz < 3.0, ghz
+    ctx.close()
