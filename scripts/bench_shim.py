@@ -47,6 +47,7 @@ def main():
     # batch n), seeds cut out of the input on the device, indices only -- what main.py --challenge runs
     from spotify_recsys_challenge_2018_amd.models.DAEs import SEEDS_FROM_INPUT
     m.device_csr = True
+    it_dtype = "bf16" if "--bf16" in sys.argv else None      # decode GEMM of the streamed loop on bf16 operands
     if "--alone" in sys.argv:                 # one feed per launch, one context: the loop before coalescing / two lanes
         m.coalesce = 1
         m.two_lanes = False
@@ -56,15 +57,15 @@ def main():
             for _ in range(reps):
                 for p_, o_, s_ in batches:
                     yield p_, o_, seeds_of(s_), B
-        for _ in m.recommend_iter(feeds(1), k=500, want_scores=scores):
+        for _ in m.recommend_iter(feeds(1), k=500, want_scores=scores, dtype=it_dtype):
             pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
-        for _idx, _sc in m.recommend_iter(feeds(5), k=500, want_scores=scores):
+        for _idx, _sc in m.recommend_iter(feeds(5), k=500, want_scores=scores, dtype=it_dtype):
             n += B
         dt = time.perf_counter() - t0
-        print("model.recommend_iter (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (label, n / dt, dt / (n / B) * 1e3, B))
+        print("model.recommend_iter%s (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (" bf16" if it_dtype else "", label, n / dt, dt / (n / B) * 1e3, B))
     # same answers either way
     a = m.recommend(batches[0][0], batches[0][1], batches[0][2], k=500)
     b = next(iter(m.recommend_iter([(batches[0][0], batches[0][1], SEEDS_FROM_INPUT, B)], k=500)))
