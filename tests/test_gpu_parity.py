@@ -124,6 +124,37 @@ def test_topk_dense_bit_exact(ctx, n, k, B):
     _check_topk(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
 
 
+def test_topk_adversarial_value_distributions(ctx):
+    """The ordering histogram of the selection kernel bins the collected keys linearly in the logit: rows whose values
+    defeat one binning or the other -- straddling zero with tiny magnitudes, 60 orders of magnitude wide (the span
+    overflows: bit-pattern bins), constant, two far clusters (everything in one bin), denormals, -inf padding, one huge
+    outlier -- must still come out in the oracle's order, scores bit for bit (logit output)."""
+    import torch
+    rng = np.random.default_rng(7)
+    n, k = 3000, 500
+    rows = []
+    rows.append((rng.standard_normal(n) * 1e-38).astype(np.float32))                          # denormal-ish, both signs
+    rows.append((rng.standard_normal(n) * 10.0 ** rng.integers(-30, 30, n)).astype(np.float32))   # 60 decades
+    rows.append(np.full(n, -2.5, np.float32))                                                   # constant
+    r = np.where(rng.random(n) < 0.5, 1e4, -1e4).astype(np.float32) + rng.standard_normal(n).astype(np.float32) * 1e-3
+    rows.append(r.astype(np.float32))                                                           # two clusters
+    r = (rng.standard_normal(n) * 0.01).astype(np.float32); r[17] = 3.0e38; rows.append(r)      # one outlier stretches the span
+    r = rng.standard_normal(n).astype(np.float32); r[rng.random(n) < 0.9] = -np.inf; rows.append(r)   # < k finite values
+    r = np.concatenate([np.zeros(n // 2, np.float32), -np.zeros(n - n // 2, np.float32)]); rows.append(r)   # +0 / -0
+    r = (rng.standard_normal(n) * 0.5).astype(np.float32); r[::3] = r[0]; rows.append(r)        # straddling zero, heavy ties
+    z = np.stack(rows)
+    B = z.shape[0]
+    seeds = [list(rng.integers(0, n, size=rng.integers(0, 50))) for _ in range(B)]
+    srp, sc = seeds_to_csr(seeds, B, n)
+    for kk in (k, 1024, 3):
+        score = torch.empty((B, kk), dtype=torch.float32, device="cuda")
+        idx = torch.empty((B, kk), dtype=torch.int32, device="cuda")
+        ctx.topk_dense(_dev(z), n, 0, _dev(srp), _dev(sc if sc.size else np.zeros(1, np.int32)), kk, score, idx,
+                       out_kind=_lib.DAE_OUT_LOGIT)
+        sc_r, idx_r = oracle.topk(z, kk, srp, sc, out_kind=1)
+        _check_topk(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+
+
 def test_topk_all_equal_and_saturated(ctx):
     """All logits equal (tie order = ascending column) and sigmoid-saturated logits."""
     import torch
