@@ -457,10 +457,12 @@ class DAE_tied:
         """`recommend` over a stream of batches with the host and the device overlapped (the loop of
         main_challenge.py:72-93 / main_train.py:62-96): `feeds` yields (x_positions, x_ones, seeds, n_rows); the
         (DAE_title: + titles, titles_use) and the
-        generator yields (idx [n_rows,k], score [n_rows,k] or None) in order.  Batch n + 1 is uploaded (copy stream)
-        and enqueued BEFORE the results of batch n are fetched, and the fetch (a blocking copy to pageable memory) runs
-        on its own stream behind batch n's event, so it never waits for batch n + 1; the reader builds batch n + 2 while
-        the device scores.  Same results as calling `recommend` per batch."""
+        generator yields (idx [n_rows,k], score [n_rows,k] or None) in order, one pair per feed.  Consecutive feeds are
+        scored in ONE launch of up to 1024 rows (`_coalesce_count`: the reference's batches of 150 / 250 rows pad to 256
+        alone), the plain DAE alternates two library contexts (`_scoring_lanes`), launch n + 1 is uploaded (copy stream)
+        and enqueued BEFORE the results of launch n are fetched, and the fetch (a blocking copy to pageable memory) runs
+        on its own stream behind launch n's event; the reader builds the next feeds while the device scores.  Rows are
+        scored independently: every feed gets the bits `recommend` returns for it alone (tests/test_gpu_stream_loop.py)."""
         import torch
         if self._score_shard is not None:
             for x_positions, x_ones, seeds, n_rows in feeds:         # the exchange is a collective: no run-ahead
