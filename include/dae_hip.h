@@ -46,6 +46,16 @@ typedef struct dae_ctx dae_ctx;
 /* decode arithmetic */
 #define DAE_DTYPE_F32     0   /* v_mfma_f32_32x32x2_f32, exact fp32, bit-equal to oracle  */
 #define DAE_DTYPE_BF16    1   /* v_mfma_f32_32x32x16_bf16, fp32 accumulate (cfg 5)        */
+/* BASELINE.json north_star: the decode as a bf16 MFMA GEMM whose top-k lists are BIT-IDENTICAL to the fp32 path
+ * (indices and scores; main_challenge.py:26-36 ranks the fp32 y_pred).  The bf16 GEMM only FILTERS: with a rigorous
+ * per-column bound eps_c >= |z_fp32 - z_bf16| (bf16 rounding of both operands + both accumulations; computed by
+ * dae_prepack_decoder, readable through dae_exact_bounds), the threshold is taken from lower bounds z_bf16 - eps_c,
+ * every column with z_bf16 + eps_c >= threshold survives, and the survivors' logits are recomputed with the canonical
+ * fp32 fmaf chain before they are ranked.  Accepted by dae_prepack_decoder (bf16 image + bounds + a row-major fp32
+ * copy of the decoder rows), dae_score_topk and dae_decode_topk.  Precondition of the bound: hidden activations in
+ * [0, 1] (sigmoid outputs, DAEs.py:66-67) -- always true in dae_score_topk; a row passed to dae_decode_topk that
+ * violates it returns no recommendations (idx -1, score -inf).  Not available with dae_set_score_mix. */
+#define DAE_DTYPE_BF16_EXACT 2
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 
@@ -137,6 +147,11 @@ int dae_encode(dae_ctx* ctx,
  * lives in the ctx.  dtype selects the fp32 or bf16 packed image (both may be resident). */
 int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec,
                         int V, int H, int col_lo, int col_hi, int dtype);
+
+/* DAE_DTYPE_BF16_EXACT: copy the per-column bounds eps_c of the prepacked image (col_lo <= c < col_hi) to
+ * eps_out (device, col_hi - col_lo floats).  |fp32 logit - bf16 logit| <= eps_c for every hidden row in [0, 1]^H;
+ * DESIGN.md section 2b derives it, tests/test_gpu_exact.py checks it against measured differences. */
+int dae_exact_bounds(dae_ctx* ctx, float* eps_out);
 
 /* ---- decode (DAEs.py:73-77 tied / :141-145 untied) ---------------------------------------- */
 

@@ -9,13 +9,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
 
 DAE_OUT_SCORE, DAE_OUT_LOGIT = 0, 1
-DAE_DTYPE_F32, DAE_DTYPE_BF16 = 0, 1
+DAE_DTYPE_F32, DAE_DTYPE_BF16, DAE_DTYPE_BF16_EXACT = 0, 1, 2
 
 # every symbol include/dae_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
-    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_decode_dense", "dae_decode_topk",
+    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_exact_bounds", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
@@ -64,6 +64,7 @@ def load():
     lib.dae_seeds_from_csr.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
+    lib.dae_exact_bounds.argtypes = [vp, vp]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_score_topk.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp,
@@ -192,6 +193,10 @@ class Context:
             col_hi = V
         self.check(self.lib.dae_prepack_decoder(self.h, _ptr(W_dec), _ptr(b_dec), V, H,
                                                 int(col_lo), int(col_hi), int(dtype)))
+
+    def exact_bounds(self, eps_out):
+        """Per-column bounds |fp32 logit - bf16 logit| <= eps of the image prepacked with DAE_DTYPE_BF16_EXACT."""
+        self.check(self.lib.dae_exact_bounds(self.h, _ptr(eps_out)))
 
     def decode_dense(self, h, out, apply_sigmoid=True, dtype=DAE_DTYPE_F32):
         B, H = h.shape

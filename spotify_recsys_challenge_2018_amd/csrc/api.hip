@@ -77,8 +77,16 @@ dae_rowgeom geom_for(int dtype, int B, int Hp)
     return dtype == DAE_DTYPE_F32 ? dae_row_geometry(B, Hp) : dae_row_geometry_bf16(B, Hp);
 }
 
+bool known_dtype(int dtype) { return dtype == DAE_DTYPE_F32 || dtype == DAE_DTYPE_BF16 || dtype == DAE_DTYPE_BF16_EXACT; }
+
 int pack_hidden(dae_ctx* ctx, int dtype, const float* h, int B, int H, const dae_rowgeom& g)
 {
+    if (dtype == DAE_DTYPE_BF16_EXACT) {
+        // the bound behind the exact mode holds for hidden rows in [0, 1]: the packing pass flags the others
+        int rc = dae_reserve(ctx, ctx->row_bad, (size_t)g.Bpad * sizeof(int));
+        if (rc) return rc;
+        return dae_launch_pack_h_bf16(ctx, h, B, H, g, static_cast<int*>(ctx->row_bad.p));
+    }
     if (dtype == DAE_DTYPE_F32) {
         int rc = dae_launch_pack_h(ctx, h, B, H, g);          // rewrites the whole image incl. zero pads
         if (rc) return rc;
@@ -93,6 +101,9 @@ const dae_packed* packed_for(dae_ctx* ctx, int dtype, int H)
 {
     const dae_packed* pk = dtype == DAE_DTYPE_F32 ? &ctx->pk_f32 : &ctx->pk_bf16;
     if (!pk->valid) { dae_fail(ctx, DAE_ERR_STATE, "decoder weights not prepacked for dtype %d", dtype); return nullptr; }
+    if (dtype == DAE_DTYPE_BF16_EXACT && !pk->exact) {
+        dae_fail(ctx, DAE_ERR_STATE, "decoder weights not prepacked with DAE_DTYPE_BF16_EXACT"); return nullptr;
+    }
     if (pk->H != H) { dae_fail(ctx, DAE_ERR_ARG, "H=%d does not match prepacked H=%d", H, pk->H); return nullptr; }
     return pk;
 }
@@ -134,7 +145,8 @@ int dae_destroy(dae_ctx* ctx)
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
-                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp};
+                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
+                       &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -273,7 +285,19 @@ int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, in
         return dae_fail(ctx, DAE_ERR_ARG, "bad shape V=%d H=%d cols=[%d,%d)", V, H, col_lo, col_hi);
     if (dtype == DAE_DTYPE_F32) return dae_launch_prepack_f32(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
     if (dtype == DAE_DTYPE_BF16) return dae_launch_prepack_bf16(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
+    if (dtype == DAE_DTYPE_BF16_EXACT) return dae_launch_prepack_bf16(ctx, W_dec, b_dec, V, H, col_lo, col_hi, 1);
     return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int dae_exact_bounds(dae_ctx* ctx, float* eps_out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!eps_out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    const dae_packed& pk = ctx->pk_bf16;
+    if (!pk.valid || !pk.exact) return dae_fail(ctx, DAE_ERR_STATE, "decoder weights not prepacked with DAE_DTYPE_BF16_EXACT");
+    DAE_HIP_CHECK(ctx, hipMemcpyAsync(eps_out, pk.eps.p, (size_t)(pk.col_hi - pk.col_lo) * sizeof(float),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    return DAE_OK;
 }
 
 int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int apply_sigmoid,
@@ -303,11 +327,16 @@ static long long geom_key(int B, int H, int R_TILE)
 }
 
 // decode + rank with the hidden tile already packed in ctx->h_packed for geometry g
+// dtype_in == DAE_DTYPE_BF16_EXACT: h32 = the fp32 hidden rows [B][H] the packed bf16 image was rounded from,
+// row_bad (nullable) = rows of h32 outside [0, 1]
 static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B,
                             int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                            int k, int out_kind, float* out_score, int32_t* out_idx, int dtype)
+                            int k, int out_kind, float* out_score, int32_t* out_idx, int dtype_in,
+                            const float* h32 = nullptr, const int* row_bad = nullptr)
 {
     int rc;
+    const bool exact = dtype_in == DAE_DTYPE_BF16_EXACT;
+    const int dtype = exact ? DAE_DTYPE_BF16 : dtype_in;          // the arithmetic of the GEMM launches
     const int ntiles = pk->ntiles;
     const int n_valid_col = n_tracks < pk->col_hi ? n_tracks : pk->col_hi;       // global bound
     int nrank = n_valid_col - pk->col_lo;                                         // ranked columns
@@ -324,7 +353,9 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     int S = (ntiles + rounds * n_simd - 1) / (rounds * n_simd);
     static const int s_env = dae_exp_env("DAE_SAMPLE_S") ? atoi(dae_exp_env("DAE_SAMPLE_S")) : 0;                   // experiments
     if (s_env > 1) S = s_env;
-    const bool fused = S >= 2 && nrank > 0;
+    // exact mode: the same launches whatever the size (a small problem's "sample" is every tile: S = 1)
+    if (exact && S < 2) S = 1;
+    const bool fused = (S >= 2 || exact) && nrank > 0;
     const int n_samp = fused ? (ntiles + S - 1) / S : ntiles;
     const int n_other = ntiles - n_samp;
     g_plan = Plan{g.R_TILE, g.n_rg, g.nb_rg, fused ? S : 1, n_samp, n_other, fused ? 1 : 0, ntiles};
@@ -357,6 +388,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     const int gmax_per_wave = ld_g < 4 * (int64_t)k ? 1 : 0;
     if (gmax_per_wave) ld_g *= g.waves;
     const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
+    if (mixed && exact) return dae_fail(ctx, DAE_ERR_ARG, "DAE_DTYPE_BF16_EXACT is not available with dae_set_score_mix");
     if (mixed) out_kind = DAE_OUT_LOGIT;                   // ... which is a probability already: it goes out as it is
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
@@ -369,11 +401,14 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     // the group maxima only, the threshold kernel emits no survivors, and every candidate comes from the filter launch.
     // (fp32 keeps the buffer: the same tiles are 13.6 us of its matrix time.)
     static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
-    const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && !gmax_per_wave && !mixed && !no_whole;
+    // exact mode (DAE_DTYPE_BF16_EXACT): always so, on BOUNDS -- phase A decodes with the bias b - eps (its maxima are
+    // lower bounds of fp32 logits, so tau is a valid threshold for the fp32 ranking), the filter launch with b + eps
+    // (nothing whose fp32 logit reaches tau is dropped), and the final selection recomputes every survivor in fp32
+    const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && ((!gmax_per_wave && !mixed && !no_whole) || exact);
     if (whole_b) g_plan.n_other = ntiles;
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
     rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, whole_b ? nullptr : sample, ld_s, 1, dtype, gmax, ld_g,
-                                     gmax_per_wave);
+                                     gmax_per_wave, exact ? 1 : 0);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
@@ -413,7 +448,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     rc = prof_begin(ctx); if (rc) return rc;
     rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
                                       n_valid_col, static_cast<uint2*>(ctx->cand.p),
-                                      static_cast<int*>(ctx->cand_cnt.p), cap, dtype);
+                                      static_cast<int*>(ctx->cand_cnt.p), cap, dtype, exact ? 2 : 0);
     if (rc) return rc;
     rc = prof_end(ctx); if (rc) return rc;
     if (ctx->gate_record) DAE_HIP_CHECK(ctx, hipEventRecord(ctx->gate_record, ctx->stream));
@@ -424,6 +459,11 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
     ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
     ta.out_score = out_score; ta.out_idx = out_idx;
+    if (exact) {
+        dae_exact_src xs{h32, (int64_t)pk->H, pk->H, static_cast<const float*>(pk->W32.p),
+                         static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad};
+        return dae_launch_topk_exact(ctx, g1, xs, ta);
+    }
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
 }
 
@@ -431,7 +471,7 @@ static int check_topk_args(dae_ctx* ctx, int dtype, int k, const int32_t* seed_r
                            const int32_t* seed_col, const void* out_score, const void* out_idx)
 {
     if (!out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
-    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
+    if (!known_dtype(dtype)) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
     if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
     if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
         return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
@@ -497,7 +537,7 @@ static int decode_topk_slab(dae_ctx* ctx, const float* h, int B, int H, int dtyp
     rc = pack_hidden(ctx, dtype, h, B, H, g);
     if (rc) return rc;
     return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                            out_score, out_idx, dtype);
+                            out_score, out_idx, dtype, h, static_cast<const int*>(ctx->row_bad.p));
 }
 
 static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
@@ -515,7 +555,7 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
     const dae_packed* pk = packed_for(ctx, dtype, H);
     if (!pk) return DAE_ERR_STATE;
     if (B <= 0) return DAE_OK;
-    if (dtype == DAE_DTYPE_BF16) {
+    if (dtype != DAE_DTYPE_F32) {
         // encode stays fp32 (north_star: bf16 decode GEMM + fp32 encode / top-k); the hidden rows leave the encode
         // kernel rounded to bf16, already in the MFMA operand order (no [B,H] round trip, no re-tiling launch)
         const dae_rowgeom g16 = dae_row_geometry_bf16(B, pk->Hp);
@@ -530,11 +570,19 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
             ctx->h16_geom_key = key16;
             ctx->h16_geom_ptr = ctx->h_packed16.p;
         }
-        rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, nullptr, nullptr, 0, RB16,
+        // exact mode: the fp32 rows as well -- the survivors of the bf16 filter are recomputed from them (the encoder's
+        // sigmoid keeps them in [0, 1], the precondition of the bound: no row check needed)
+        float* h32 = nullptr;
+        if (dtype == DAE_DTYPE_BF16_EXACT) {
+            rc = dae_reserve(ctx, ctx->h_scratch, (size_t)B * H * sizeof(float));
+            if (rc) return rc;
+            h32 = static_cast<float*>(ctx->h_scratch.p);
+        }
+        rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, h32, nullptr, 0, RB16,
                                nullptr, nullptr, static_cast<unsigned short*>(ctx->h_packed16.p), NS);
         if (rc) return rc;
         return decode_topk_core(ctx, pk, g16, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                                out_score, out_idx, dtype);
+                                out_score, out_idx, dtype, h32, nullptr);
     }
     const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
     const int G = pk->Hp / DAE_KG, RB = g.R_TILE / 32;

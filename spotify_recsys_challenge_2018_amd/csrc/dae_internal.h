@@ -43,6 +43,14 @@ struct dae_packed {            // one prepacked decoder image
     dae_buf ident;             // [ntiles] int32: 0, 1, 2, ... (the tile list of "all tiles")
     int order_nrank = -1;      // rankable columns the order was built for (-1: none)
     int order_nsamp = -1;
+    // DAE_DTYPE_BF16_EXACT (bf16 image only; decode_f32.hip exact_bounds_kernel): per column c a rigorous bound
+    // eps_c >= |z32(r, c) - z16(r, c)| for every hidden row with entries in [0, 1], the bias fragments of
+    // b - eps (phase A: lower bounds of the fp32 logits) and b + eps (filter: upper bounds), and a row-major fp32
+    // copy of the image's decoder rows for the exact re-scoring of the survivors (topk.hip ExactSrc)
+    bool exact = false;
+    dae_buf eps;               // [ntiles*32] fp32, zero padded
+    dae_buf bias16_lo, bias16_hi;   // [ntiles][64] uint4, as bias16
+    dae_buf W32;               // [col_hi - col_lo][H] fp32 row-major
 };
 
 struct dae_ctx {
@@ -79,6 +87,7 @@ struct dae_ctx {
     int adam_t = 0; float adam_b1 = 0.f, adam_b2 = 0.f, adam_b1p = 1.f, adam_b2p = 1.f;   // running beta powers of dae_adam_alpha
     int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)
     dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
+    dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -200,8 +209,9 @@ struct dae_rowgeom {        // how B rows are cut into row groups for the decode
 dae_rowgeom dae_row_geometry(int B, int Hp);
 dae_rowgeom dae_row_geometry_bf16(int B, int Hp);
 int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,
-                            int col_lo, int col_hi);
-int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
+                            int col_lo, int col_hi, int exact = 0);
+// row_bad (nullable): [g.Bpad] int32, 1 where a row of h has an entry outside [0, 1] (the exact mode's precondition)
+int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g, int* row_bad = nullptr);
 
 // encode.hip
 int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
@@ -230,11 +240,12 @@ struct dae_tileset {        // which wave tiles a decode launch walks
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
                                 int fill_pad, int dtype = DAE_DTYPE_F32, float* gmax = nullptr,
-                                int64_t ld_gmax = 0, int gmax_per_wave = 0);
+                                int64_t ld_gmax = 0, int gmax_per_wave = 0, int bias_sel = 0);
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
-                                 int cap, int dtype = DAE_DTYPE_F32);
+                                 int cap, int dtype = DAE_DTYPE_F32, int bias_sel = 0);
+// bias_sel (bf16 image prepacked with DAE_DTYPE_BF16_EXACT): 0 = b, 1 = b - eps (lower bounds), 2 = b + eps (upper bounds)
 
 int dae_launch_decode_scaled_T(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, const float* row_scale,
                                float* outT, int64_t ldT, int dtype = DAE_DTYPE_F32);
@@ -346,3 +357,11 @@ int dae_launch_topk_pairs(dae_ctx* ctx, const dae_pair_group& g0, const dae_pair
                           const dae_topk_args& a);
 int dae_launch_topk_soa(dae_ctx* ctx, int G, const float* logit, const int32_t* idx,
                         const dae_topk_args& a);
+// DAE_DTYPE_BF16_EXACT: the final selection over candidate lists whose logits are RECOMPUTED in fp32 -- the canonical
+// fmaf chain over k = 0..H-1 of h[row][k] * W32[col - col_lo][k], + bias[col - col_lo] -- before they are ranked
+struct dae_exact_src {
+    const float* h; int64_t ld_h; int H;          // fp32 hidden rows [B][ld_h]
+    const float* W32; const float* bias; int col_lo;
+    const int* row_bad;                           // nullable: rows flagged 1 return no candidates (idx -1)
+};
+int dae_launch_topk_exact(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, const dae_topk_args& a);

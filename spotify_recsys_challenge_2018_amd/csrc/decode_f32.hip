@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int row = rg * R_TILE + rb * 32 + j;
-                if (row >= p.B) continue;
+                if (row >= p.B || (EPI == EPI_GMAX && !p.out)) continue;      // maxima only (bf16 whole-launch filter)
                 float* orow = p.out + (size_t)row * p.ld + (size_t)item * 32 + 4 * hi;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
@@ -1355,6 +1355,76 @@ __global__ __launch_bounds__(256) void prepack_tile_kernel(const float* __restri
     }
 }
 
+// ---- DAE_DTYPE_BF16_EXACT: per-column bound of |fp32 logit - bf16 logit| -----------------------------------------
+// z32(r, c) = the canonical fp32 chain acc = fmaf(h[k], W[c][k], acc), + b[c]  (oracle orc_decode, DAEs.py:141-145)
+// z16(r, c) = what the bf16 kernels of this file leave in an accumulator: bias terms e0 + e1 + e2 and the products
+//             bf16(h[k]) * bf16(W[c][k]) (exact in fp32) summed by v_mfma_f32_32x32x16_bf16 in an unspecified order.
+// With h[k] in [0, 1] (sigmoid outputs): |bf16(h) - h| <= 2^-9, bf16(h) <= 1, hence against the real-number value
+//   | sum bf16(h) bf16(W) - sum h W | <= d_c + 2^-9 n_c,   d_c = sum_k |bf16(W[c][k]) - W[c][k]|,  n_c = sum_k |W[c][k]|
+// (d_c is the rounding this image really made: on average a third of the worst case 2^-8 n_c);
+//   accumulation, bf16 MFMA: every term runs through at most Hp + 3 additions of unknown order; an addition is taken
+//     to err by <= 2^-23 relative (TWICE fp32's unit roundoff: covers a truncating adder), and the total is doubled
+//     again: A16 = (Hp + 16) 2^-22 times the sum of the magnitudes (n_c + d_c + |b| + eps);
+//     tests/test_gpu_exact.py pins the assumption: measured |z16 - exact| stays below a quarter of this term;
+//   accumulation, fp32 chain: (H + 2) 2^-24 (1 + 2^-10) (n_c + |b|)   (standard recursive-summation bound, fma);
+//   the three-term bf16 split of b -+ eps: exact to 2^-24 relative (taken as 2^-23).
+// Everything in double, rounded away from b when stored.  One 256-thread workgroup per 32-column tile: 8 threads per
+// column.  bias16_lo / bias16_hi: bias fragments (see prepack_tile_kernel) of b - eps and b + eps.
+__device__ __forceinline__ uint4 bias_fragment(float bv)
+{
+    const unsigned e0 = bf16_rne(bv);
+    const float r1 = bv - __uint_as_float(e0 << 16);
+    const unsigned e1 = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(e1 << 16);
+    const unsigned e2 = bf16_rne(r2);
+    return make_uint4(e0 | (e1 << 16), e2, 0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                           int H, int Hp, int col_lo, int col_hi, int ntiles,
+                                                           float* __restrict__ eps, uint4* __restrict__ bias16_lo,
+                                                           uint4* __restrict__ bias16_hi)
+{
+    const int tid = threadIdx.x;
+    const int c = tid >> 3, part = tid & 7;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int v = col_lo + t * 32 + c;
+        double n = 0.0, d = 0.0;
+        if (v < col_hi) {
+            const float* row = W + (size_t)v * H;
+            for (int k = part; k < H; k += 8) {
+                const float w = row[k];
+                const float w16 = __uint_as_float(bf16_rne(w) << 16);
+                n += fabs((double)w);
+                d += fabs((double)w16 - (double)w);
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 8; sh <<= 1) { n += __shfl_xor(n, sh); d += __shfl_xor(d, sh); }
+        if (part == 0) {
+            float e_f = 0.0f, lo_f = 0.0f, hi_f = 0.0f;
+            if (v < col_hi) {
+                const double bv = (double)b[v], ab = fabs(bv);
+                const double A16 = (double)(Hp + 16) * 0x1p-22;
+                const double A32 = (double)(H + 2) * 0x1p-24 * (1.0 + 0x1p-10);
+                double e = d + 0x1p-9 * n + A16 * (n + d + 1.01 * ab) + A32 * (n + ab);
+                e = e * (1.0 + 4.0 * A16) + 0x1p-23 * (ab + e) + 1e-30;      // eps feeds back through the shifted bias; split error
+                e *= 1.0 + 1e-6;
+                e_f = (float)e;
+                if ((double)e_f < e) e_f = __uint_as_float(__float_as_uint(e_f) + 1u);      // e > 0: next float up
+                const double lo = bv - (double)e_f, hi = bv + (double)e_f;
+                lo_f = (float)lo; if ((double)lo_f > lo) lo_f = nextafterf(lo_f, -__builtin_inff());
+                hi_f = (float)hi; if ((double)hi_f < hi) hi_f = nextafterf(hi_f, __builtin_inff());
+            }
+            eps[t * 32 + c] = e_f;
+            bias16_lo[t * 64 + c] = bias_fragment(lo_f);
+            bias16_hi[t * 64 + c] = bias_fragment(hi_f);
+            bias16_lo[t * 64 + 32 + c] = make_uint4(0u, 0u, 0u, 0u);
+            bias16_hi[t * 64 + 32 + c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
 // ---- tile order for the fused path's threshold sample -------------------------------------------
 // The sample only has to be SOME subset of the rankable columns (its k-th largest logit is a lower
 // bound of the row's k-th largest whatever the subset), but the tighter that bound, the fewer
@@ -1443,9 +1513,11 @@ __global__ __launch_bounds__(256) void pack_h_kernel(const float* __restrict__ h
 }
 
 // out uint4 index = ((rg*NS + s)*RB + rb)*64 + lane: bf16 of h[(rg*RB+rb)*32+j][16s+8hi+0..7]
+// row_bad (nullable, zeroed by the launcher): set to 1 for rows with an entry outside [0, 1] (or NaN) -- the
+// precondition of DAE_DTYPE_BF16_EXACT's bound
 __global__ __launch_bounds__(256) void pack_h_bf16_kernel(const float* __restrict__ h, int B, int H,
                                                           int NS, int RB, int n_rg,
-                                                          uint4* __restrict__ hp)
+                                                          uint4* __restrict__ hp, int* __restrict__ row_bad)
 {
     const size_t total = (size_t)n_rg * NS * RB * 64;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
@@ -1457,11 +1529,15 @@ __global__ __launch_bounds__(256) void pack_h_bf16_kernel(const float* __restric
         const int hi = lane >> 5, jj = lane & 31;
         const int r = (rg * RB + rb) * 32 + jj;
         unsigned e[8];
+        bool bad = false;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k = 16 * s + 8 * hi + c;
-            e[c] = (r < B && k < H) ? bf16_rne(h[(size_t)r * H + k]) : 0u;
+            const float hv = (r < B && k < H) ? h[(size_t)r * H + k] : 0.0f;
+            bad = bad || !(hv >= 0.0f && hv <= 1.0f);
+            e[c] = bf16_rne(hv);
         }
+        if (row_bad && bad) row_bad[r] = 1;
         hp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
 }
@@ -1540,7 +1616,7 @@ bool bf16_fast_filter(const dae_rowgeom& g, int dtype, int G)
 }
 
 int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p,
-                int dtype = DAE_DTYPE_F32)
+                int dtype = DAE_DTYPE_F32, int bias_sel = 0)
 {
     const dae_packed& pk = dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16;
     const dae_buf& hb = dtype == DAE_DTYPE_F32 ? ctx->h_packed : ctx->h_packed16;
@@ -1550,6 +1626,11 @@ int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts
     p.Wp = static_cast<const float4*>(pk.W.p);
     p.bias = static_cast<const float*>(pk.bias.p);
     p.bias16 = static_cast<const uint4*>(pk.bias16.p);
+    if (bias_sel) {                                        // DAE_DTYPE_BF16_EXACT: bounds instead of the logits
+        if (dtype != DAE_DTYPE_BF16 || !pk.exact)
+            return dae_fail(ctx, DAE_ERR_STATE, "decoder not prepacked with DAE_DTYPE_BF16_EXACT");
+        p.bias16 = static_cast<const uint4*>(bias_sel == 1 ? pk.bias16_lo.p : pk.bias16_hi.p);
+    }
     p.hp = static_cast<const float4*>(hb.p);
     p.G = dtype == DAE_DTYPE_F32 ? pk.Hp / DAE_KG : pk.Hp / 16;
     p.ncols = pk.col_hi - pk.col_lo;
@@ -1640,10 +1721,11 @@ int launch_prepack_tiles(dae_ctx* ctx, const float* W, const float* b, int H, in
 }  // namespace
 
 int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,
-                            int col_lo, int col_hi)
+                            int col_lo, int col_hi, int exact)
 {
     dae_packed& pk = ctx->pk_bf16;
-    pk.valid = false; pk.order_nrank = -1;
+    pk.valid = false; pk.order_nrank = -1; pk.exact = false;
+    if (exact && (H & 3)) return dae_fail(ctx, DAE_ERR_ARG, "DAE_DTYPE_BF16_EXACT needs H %% 4 == 0 (H=%d)", H);
     const int Hp = dae_round_up(H, DAE_HPAD);
     if ((size_t)32 * Hp * 2 > 128 * 1024)
         return dae_fail(ctx, DAE_ERR_ARG, "hidden size %d too large", H);
@@ -1664,11 +1746,29 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
     hipLaunchKernelGGL(tile_iota_kernel, dim3((ntiles + 255) / 256 > 0 ? (ntiles + 255) / 256 : 1), dim3(256), 0,
                        ctx->stream, ntiles, static_cast<int*>(pk.ident.p));
     DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
+    if (exact) {
+        rc = dae_reserve(ctx, pk.eps, (size_t)ntiles * 32 * sizeof(float));
+        if (rc) return rc;
+        rc = dae_reserve(ctx, pk.bias16_lo, (size_t)ntiles * 64 * sizeof(uint4));
+        if (rc) return rc;
+        rc = dae_reserve(ctx, pk.bias16_hi, (size_t)ntiles * 64 * sizeof(uint4));
+        if (rc) return rc;
+        const size_t wbytes = (size_t)(col_hi - col_lo) * H * sizeof(float);
+        rc = dae_reserve(ctx, pk.W32, wbytes);
+        if (rc) return rc;
+        const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
+        hipLaunchKernelGGL(exact_bounds_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, Hp, col_lo, col_hi,
+                           ntiles, static_cast<float*>(pk.eps.p), static_cast<uint4*>(pk.bias16_lo.p),
+                           static_cast<uint4*>(pk.bias16_hi.p));
+        DAE_CHECK_LAUNCH(ctx, "exact_bounds_kernel");
+        DAE_HIP_CHECK(ctx, hipMemcpyAsync(pk.W32.p, W + (size_t)col_lo * H, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        pk.exact = true;
+    }
     pk.valid = true;
     return DAE_OK;
 }
 
-int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g)
+int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g, int* row_bad)
 {
     const int Hp = dae_round_up(H, DAE_HPAD);
     const int NS = Hp / 16, RB = g.R_TILE / 32;
@@ -1677,8 +1777,9 @@ int dae_launch_pack_h_bf16(dae_ctx* ctx, const float* h, int B, int H, const dae
     if (rc) return rc;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
+    if (row_bad) DAE_HIP_CHECK(ctx, hipMemsetAsync(row_bad, 0, (size_t)g.Bpad * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(pack_h_bf16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, h, B, H, NS, RB,
-                       g.n_rg, static_cast<uint4*>(ctx->h_packed16.p));
+                       g.n_rg, static_cast<uint4*>(ctx->h_packed16.p), row_bad);
     DAE_CHECK_LAUNCH(ctx, "pack_h_bf16_kernel");
     ctx->h16_geom_key = ((long long)B << 32) | ((long long)H << 12) | (long long)g.R_TILE;   // whole image rewritten, pads zero
     ctx->h16_geom_ptr = ctx->h_packed16.p;
@@ -1747,14 +1848,14 @@ int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowg
 
 int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
-                                int fill_pad, int dtype, float* gmax, int64_t ld_gmax, int gmax_per_wave)
+                                int fill_pad, int dtype, float* gmax, int64_t ld_gmax, int gmax_per_wave, int bias_sel)
 {
     DecP p;
-    int rc = fill_common(ctx, g, B, ts, p, dtype);
+    int rc = fill_common(ctx, g, B, ts, p, dtype, bias_sel);
     if (rc) return rc;
     p.out = out; p.ld = ld; p.apply_sigmoid = apply_sigmoid; p.mask_from_col = mask_from_col;
     p.gmax = gmax; p.ld_gmax = ld_gmax; p.gmax_per_wave = gmax_per_wave;
-    if (!out && (!gmax || gmax_per_wave)) return dae_fail(ctx, DAE_ERR_ARG, "dense decode without an output");
+    if (!out && !gmax) return dae_fail(ctx, DAE_ERR_ARG, "dense decode without an output");
 #ifdef DAE_EXPERIMENTS
     static const bool dbgA = dae_exp_env("DAE_DBG_A") != nullptr;
     static long long* abuf = nullptr;
@@ -1844,10 +1945,10 @@ int dae_launch_decode_loss_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, float 
 
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,
-                                 int cap, int dtype)
+                                 int cap, int dtype, int bias_sel)
 {
     DecP p;
-    int rc = fill_common(ctx, g, B, ts, p, dtype);
+    int rc = fill_common(ctx, g, B, ts, p, dtype, bias_sel);
     if (rc) return rc;
     p.tau = tau; p.n_valid_col = n_valid_col; p.cand = cand; p.cand_cnt = cand_cnt; p.cap = cap;
     static const bool f32_generic = dae_exp_env("DAE_F32_GENERIC") != nullptr;          // A/B against the generic body

@@ -1,0 +1,244 @@
+"""GPU (-m gpu): DAE_DTYPE_BF16_EXACT -- the decode as a bf16 MFMA GEMM whose top-k lists are BIT-IDENTICAL to the
+fp32 path (BASELINE.json north_star; the reference ranks fp32 y_pred, main_challenge.py:26-36).  The bf16 GEMM only
+filters on rigorous bounds; survivors are recomputed with the canonical fp32 fmaf chain (oracle orc_decode).  Every
+comparison below is against the fp32 oracle with tolerance 0: indices AND scores."""
+import numpy as np
+import pytest
+
+import oracle
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+
+pytestmark = pytest.mark.gpu
+EX, BF = _lib.DAE_DTYPE_BF16_EXACT, _lib.DAE_DTYPE_BF16
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _bf16(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _problem(V, n_tracks, H, B, seed=0, dist="zipf", bias="zeros", scale=1.0):
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=seed, bias=bias, n_tracks=n_tracks)
+    W_dec = (W_dec * scale).astype(np.float32)
+    b_enc = (np.random.default_rng(seed + 7).standard_normal(H) * 0.1).astype(np.float32)
+    pos, ones, seeds = make_playlists(B, n_tracks, V - n_tracks, seed=seed + 1, dist=dist)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, n_tracks)
+    return dict(W_enc=W_enc, b_enc=b_enc, W_dec=W_dec, b_dec=b_dec, rp=rp, col=col, val=val,
+                srp=srp, sc=sc, seeds=seeds, V=V, H=H, B=B, n_tracks=n_tracks)
+
+
+def _check(idx_g, sc_g, idx_r, sc_r):
+    assert np.array_equal(idx_g, idx_r)
+    assert np.array_equal(sc_g.view(np.uint32), sc_r.view(np.uint32))
+
+
+@pytest.mark.parametrize("V,H,B,bias,scale", [(3000, 256, 300, "zipf", 1.0), (2000, 32, 8, "zeros", 1.0),
+                                              (5000, 128, 130, "zipf", 40.0), (4096, 256, 64, "zipf", 300.0),
+                                              (1111, 96, 70, "zeros", 1e-3)])
+def test_bound_holds_and_the_accumulation_assumption_has_margin(ctx, V, H, B, bias, scale):
+    """eps_c >= |fp32 logit - bf16 logit| for every (row, column) -- the inequality the exact mode stands on -- and the
+    bf16 matrix-core accumulation errs by less than a QUARTER of what the bound allows for it (the one term of the
+    bound that rests on an assumption about the hardware: include/dae_hip.h)."""
+    import torch
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=3, bias=bias)
+    W_dec = (W_dec * scale).astype(np.float32)
+    rng = np.random.default_rng(0)
+    h = rng.random((B, H)).astype(np.float32)
+    h[0] = 1.0; h[1] = 0.0; h[2] = np.float32(1.0) - np.float32(2.0 ** -9)      # corners of [0, 1]
+    ctx.prepack_decoder(_dev(W_dec), _dev(b_dec), dtype=EX)
+    eps = torch.empty(V, dtype=torch.float32, device="cuda")
+    ctx.exact_bounds(eps)
+    out = torch.empty((B, V), dtype=torch.float32, device="cuda")
+    ctx.decode_dense(_dev(h), out, apply_sigmoid=False, dtype=BF)
+    z16 = out.cpu().numpy().astype(np.float64)
+    z32 = oracle.decode(h, W_dec, b_dec).astype(np.float64)
+    e = eps.cpu().numpy().astype(np.float64)
+    assert (e > 0).all()
+    assert (np.abs(z32 - z16) <= e[None, :]).all()
+    # the accumulation term alone: z16 against the exactly summed bf16 operands
+    Wb, hb = _bf16(W_dec).astype(np.float64), _bf16(h).astype(np.float64)
+    z_exact16 = hb @ Wb.T + b_dec.astype(np.float64)[None, :]
+    Hp = (H + 31) // 32 * 32
+    n_c = np.abs(W_dec.astype(np.float64)).sum(1)
+    a16 = (Hp + 16) * 2.0 ** -22 * (n_c + np.abs(b_dec.astype(np.float64)))
+    assert (np.abs(z16 - z_exact16) <= 0.25 * a16[None, :] + 1e-30).all()
+    # and the bound is not vacuous: within 4x of the worst difference seen on this image
+    ratio = e[None, :] / np.maximum(np.abs(z32 - z16), 1e-300)
+    assert np.min(ratio) < 64.0
+
+
+@pytest.mark.parametrize("V,nt,H,B,k,dist,bias", [
+    (2000, 1500, 32, 8, 500, "zipf", "zeros"),          # small: every tile is "sample"
+    (70000, 60000, 64, 40, 500, "zipf", "zipf"),
+    (50000, 41000, 256, 130, 500, "uniform", "zeros"),  # uninformative bias: many survivors per row
+    (40000, 40000, 96, 300, 100, "zipf", "zipf"),
+    (33000, 30000, 256, 256, 500, "zipf", "zipf"),
+    (3000, 2000, 1024, 9, 1024, "zipf", "zipf"),
+    (31, 31, 32, 3, 500, "zipf", "zipf"),
+])
+def test_exact_decode_topk_is_the_fp32_oracle_bit_for_bit(ctx, V, nt, H, B, k, dist, bias):
+    import torch
+    p = _problem(V, nt, H, B, dist=dist, bias=bias)
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(sc), k, score, idx, dtype=EX)
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"], 0, nt)
+    sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+    _check(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(sc), k, score, idx, out_kind=_lib.DAE_OUT_LOGIT, dtype=EX)
+    sc_l, idx_l = oracle.topk(z_ref, k, p["srp"], p["sc"], out_kind=1)
+    _check(idx.cpu().numpy(), score.cpu().numpy(), idx_l, sc_l)
+
+
+@pytest.mark.parametrize("V,nt,H,B,k", [(50000, 41000, 256, 130, 500), (33000, 30000, 72, 77, 500),
+                                        (2000, 1500, 32, 8, 100), (5000, 5000, 512, 40, 500)])
+def test_exact_score_topk_is_the_fp32_oracle_bit_for_bit(ctx, V, nt, H, B, k):
+    import torch
+    p = _problem(V, nt, H, B, bias="zipf")
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+    for _ in range(2):
+        ctx.score_topk(_dev(p["rp"]), _dev(p["col"]), _dev(p["val"]), _dev(p["W_enc"]), _dev(p["b_enc"]),
+                       nt, _dev(p["srp"]), _dev(sc), k, score, idx, dtype=EX)
+    s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"],
+                                      p["b_dec"], nt, nt, p["srp"], p["sc"], k)
+    _check(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
+
+
+def test_exact_with_logits_packed_around_the_threshold(ctx):
+    """Adversarial for a FILTER: thousands of columns whose fp32 logits differ by a few ulps around the rank-k value --
+    bf16 cannot order them, so every one of them has to survive the filter and be recomputed.  Built from duplicated
+    decoder rows (exact ties broken by column id) plus rows perturbed in their last bits, with a zero bias, and a
+    plateau of saturated scores (sigmoid == 1.0f) on top."""
+    import torch
+    V, nt, H, B, k = 40000, 36000, 256, 64, 500
+    p = _problem(V, nt, H, B, bias="zeros", dist="uniform")
+    rng = np.random.default_rng(5)
+    W = p["W_dec"]
+    base = W[7].copy()
+    for c in range(100, 3100):                              # 3000 near-copies of one row
+        W[c] = base
+        if c % 3 == 0:
+            j = rng.integers(0, H, 4)
+            W[c, j] = np.nextafter(W[c, j], np.float32(1.0))   # one ulp up in 4 places
+        if c % 3 == 1:
+            j = rng.integers(0, H, 4)
+            W[c, j] = np.nextafter(W[c, j], np.float32(-1.0))
+    p["b_dec"][20000:20400] = 60.0                          # saturated plateau: sigmoid == 1.0f, order by column id
+    p["b_dec"][100:3100] = 0.5                              # lift the pack above the bulk: rank k falls inside it
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(W), _dev(p["b_dec"]), dtype=EX)
+    for kk in (k, 50, 1000):
+        score = torch.empty((B, kk), dtype=torch.float32, device="cuda")
+        idx = torch.empty((B, kk), dtype=torch.int32, device="cuda")
+        ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(p["sc"]), kk, score, idx, dtype=EX)
+        z_ref = oracle.decode(h, W, p["b_dec"], 0, nt)
+        sc_r, idx_r = oracle.topk(z_ref, kk, p["srp"], p["sc"])
+        _check(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+
+
+def test_exact_large_weights_and_mixed_signs(ctx):
+    """A trained-like decoder: weights 300x the initial scale (logit spread of tens), bias of both signs."""
+    import torch
+    V, nt, H, B, k = 60000, 50000, 256, 96, 500
+    p = _problem(V, nt, H, B, bias="zipf", scale=300.0, seed=4)
+    p["b_dec"][::5] *= -0.3
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"], 0, nt)
+    sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+    _check(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+
+
+def test_exact_rows_outside_the_unit_interval_return_nothing(ctx):
+    """The bound assumes sigmoid outputs; dae_decode_topk flags rows that leave [0, 1] instead of ranking them."""
+    import torch
+    V, nt, H, B, k = 40000, 33000, 64, 12, 100
+    p = _problem(V, nt, H, B, bias="zipf")
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    h[3, 5] = 1.5
+    h[7, 0] = -0.25
+    h[9, 63] = np.nan
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    ig, sg = idx.cpu().numpy(), score.cpu().numpy()
+    bad = [3, 7, 9]
+    assert (ig[bad] == -1).all() and np.isneginf(sg[bad]).all()
+    good = [r for r in range(B) if r not in bad]
+    hg = h.copy(); hg[bad] = 0.5
+    z_ref = oracle.decode(hg, p["W_dec"], p["b_dec"], 0, nt)
+    sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+    _check(ig[good], sg[good], idx_r[good], sc_r[good])
+
+
+def test_exact_needs_its_own_prepack_and_rejects_the_title_mix(ctx):
+    import torch
+    V, nt, H, B, k = 3000, 2500, 64, 8, 50
+    p = _problem(V, nt, H, B)
+    h = _dev(oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"]))
+    c2 = _lib.Context(0)
+    c2.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=BF)        # plain bf16 image: no bounds
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.DaeError):
+        c2.decode_topk(h, nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    c2.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    mixT = torch.zeros((nt, B), device="cuda"); wt = torch.ones(B, device="cuda")
+    c2.set_score_mix(mixT, wt)
+    with pytest.raises(_lib.DaeError):
+        c2.decode_topk(h, nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    c2.set_score_mix()
+    c2.decode_topk(h, nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    c2.decode_topk(h, nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=BF)   # the exact image serves plain bf16 too
+    c2.close()
+
+
+@pytest.mark.parametrize("bias,B", [("zipf", 256), ("zeros", 256), ("zipf", 1024)])
+def test_exact_full_size_equals_the_fp32_path(bias, B):
+    """BASELINE.json configs[1] at full size (V = 170 000, H = 256): the exact mode's lists are the fp32 MFMA path's
+    lists, bit for bit in indices and scores; rows 0..31 are also checked against the CPU oracle."""
+    import torch
+    ctx = _lib.Context(0)
+    V, nt, H, k = 170000, 140000, 256, 500
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=bias, n_tracks=nt)
+    pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
+    rp, col, val = coo_to_csr(pos, ones, B, V)
+    srp, sc = seeds_to_csr(seeds, B, nt)
+    d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+    ctx.prepack_decoder(d[5], d[6])
+    ctx.prepack_decoder(d[5], d[6], dtype=EX)
+    s32 = torch.empty((B, k), device="cuda"); i32 = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    sx = torch.empty_like(s32); ix = torch.empty_like(i32)
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s32, i32)
+    ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, sx, ix, dtype=EX)
+    assert torch.equal(i32, ix) and torch.equal(s32.view(torch.int32), sx.view(torch.int32))
+    nchk = 32
+    s_ref, i_ref = oracle.score_batch(rp[:nchk + 1], col, val, W_enc, b_enc, W_dec, b_dec, nt, nt, srp[:nchk + 1], sc, k)
+    _check(ix.cpu().numpy()[:nchk], sx.cpu().numpy()[:nchk], i_ref, s_ref)
+    ctx.close()
