@@ -1,37 +1,56 @@
-"""Quick steady-state timing of dae_score_topk per decode mode (one stream, one context): ms per call at full size."""
+"""Steady-state timing of dae_score_topk per decode mode at full size: ms per step with N batches in flight (N contexts
+on N streams, round robin).  usage: time_modes.py [B] [bias] [modes f32,bf16,exact] [streams 1,2,3]"""
+import os
 import sys
 import time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spotify_recsys_challenge_2018_amd import _lib
 from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 bias = sys.argv[2] if len(sys.argv) > 2 else "zipf"
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "bf16", "exact"]
+nstr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1]
 V, nt, H, k = 170000, 140000, 256, 500
 W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=bias, n_tracks=nt)
 pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
 rp, col, val = coo_to_csr(pos, ones, B, V)
 srp, sc = seeds_to_csr(seeds, B, nt)
 d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
-ctx = _lib.Context(0)
-ctx.prepack_decoder(d[5], d[6])
-ctx.prepack_decoder(d[5], d[6], dtype=_lib.DAE_DTYPE_BF16_EXACT)
-s = torch.empty((B, k), device="cuda"); i = torch.empty((B, k), dtype=torch.int32, device="cuda")
+NS = max(nstr)
+ctxs = [_lib.Context(0) for _ in range(NS)]
+streams = [torch.cuda.Stream() for _ in range(NS)]
+for c, st in zip(ctxs, streams):
+    with torch.cuda.stream(st):
+        c.bind_stream()
+        if "f32" in only:
+            c.prepack_decoder(d[5], d[6])
+        c.prepack_decoder(d[5], d[6], dtype=_lib.DAE_DTYPE_BF16_EXACT)
+torch.cuda.synchronize()
+outs = [(torch.empty((B, k), device="cuda"), torch.empty((B, k), dtype=torch.int32, device="cuda")) for _ in range(NS)]
 ref = None
 for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):
-    for _ in range(30):
-        ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s, i, dtype=dt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 300
-    for _ in range(n):
-        ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s, i, dtype=dt)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    if name == "f32":
-        ref = (s.clone(), i.clone())
-    same = bool(torch.equal(i, ref[1]) and torch.equal(s.view(torch.int32), ref[0].view(torch.int32)))
-    print(f"{name}: {ms:.4f} ms/call  {B / ms * 1e3 / 1e6:.3f} M playlists/s  identical_to_f32={same}  plan={ctx.last_plan()}", flush=True)
+    if name not in only:
+        continue
+    for n in nstr:
+        def step(i):
+            j = i % n
+            with torch.cuda.stream(streams[j]):
+                ctxs[j].score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, outs[j][0], outs[j][1], dtype=dt)
+        for i in range(60):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        N = 600
+        for i in range(N):
+            step(i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / N * 1e3
+        s, i_ = outs[0]
+        if name == "f32" and ref is None:
+            ref = (s.clone(), i_.clone())
+        same = ref is not None and bool(torch.equal(i_, ref[1]) and torch.equal(s.view(torch.int32), ref[0].view(torch.int32)))
+        print(f"{name} streams={n}: {ms:.4f} ms/step  {B / ms * 1e3 / 1e6:.3f} M playlists/s  identical_to_f32={same}", flush=True)

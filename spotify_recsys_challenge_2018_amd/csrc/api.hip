@@ -461,8 +461,10 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     ta.out_score = out_score; ta.out_idx = out_idx;
     if (exact) {
         dae_exact_src xs{h32, (int64_t)pk->H, pk->H, static_cast<const float*>(pk->W32.p),
-                         static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad};
-        return dae_launch_topk_exact(ctx, g1, xs, ta);
+                         static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad,
+                         static_cast<const float*>(pk->eps.p) + (size_t)pk->ntiles * 32};
+        rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr);
+        if (rc) return rc;
     }
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
 }

@@ -48,7 +48,7 @@ struct dae_packed {            // one prepacked decoder image
     // b - eps (phase A: lower bounds of the fp32 logits) and b + eps (filter: upper bounds), and a row-major fp32
     // copy of the image's decoder rows for the exact re-scoring of the survivors (topk.hip ExactSrc)
     bool exact = false;
-    dae_buf eps;               // [ntiles*32] fp32, zero padded
+    dae_buf eps;               // [ntiles*32] fp32, zero padded; then one more float: the maximum (eps_max)
     dae_buf bias16_lo, bias16_hi;   // [ntiles][64] uint4, as bias16
     dae_buf W32;               // [col_hi - col_lo][H] fp32 row-major
 };
@@ -357,11 +357,15 @@ int dae_launch_topk_pairs(dae_ctx* ctx, const dae_pair_group& g0, const dae_pair
                           const dae_topk_args& a);
 int dae_launch_topk_soa(dae_ctx* ctx, int G, const float* logit, const int32_t* idx,
                         const dae_topk_args& a);
-// DAE_DTYPE_BF16_EXACT: the final selection over candidate lists whose logits are RECOMPUTED in fp32 -- the canonical
-// fmaf chain over k = 0..H-1 of h[row][k] * W32[col - col_lo][k], + bias[col - col_lo] -- before they are ranked
+// DAE_DTYPE_BF16_EXACT (refine.hip): the candidate lists of the bf16 filter launch hold upper bounds u of the fp32
+// logits; in place, every candidate that can still be among the k best non-seeds gets its logit RECOMPUTED in fp32 --
+// the canonical fmaf chain over k = 0..H-1 of h[row][k] * W32[col - col_lo][k], + bias[col - col_lo] -- and every other
+// one -inf (absent for the selection kernel)
 struct dae_exact_src {
     const float* h; int64_t ld_h; int H;          // fp32 hidden rows [B][ld_h]
     const float* W32; const float* bias; int col_lo;
     const int* row_bad;                           // nullable: rows flagged 1 return no candidates (idx -1)
+    const float* eps_max;                         // device scalar: max over the image's columns of eps_c
 };
-int dae_launch_topk_exact(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, const dae_topk_args& a);
+int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
+                            const int32_t* seed_row_ptr);

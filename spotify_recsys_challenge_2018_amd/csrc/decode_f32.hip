@@ -1385,6 +1385,7 @@ __global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restri
                                                            float* __restrict__ eps, uint4* __restrict__ bias16_lo,
                                                            uint4* __restrict__ bias16_hi)
 {
+    float* eps_max = eps + (size_t)ntiles * 32;          // zeroed by the launcher; positive floats order like their bits
     const int tid = threadIdx.x;
     const int c = tid >> 3, part = tid & 7;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -1417,6 +1418,7 @@ __global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restri
                 hi_f = (float)hi; if ((double)hi_f < hi) hi_f = nextafterf(hi_f, __builtin_inff());
             }
             eps[t * 32 + c] = e_f;
+            if (e_f > 0.0f) atomicMax(reinterpret_cast<unsigned*>(eps_max), __float_as_uint(e_f));
             bias16_lo[t * 64 + c] = bias_fragment(lo_f);
             bias16_hi[t * 64 + c] = bias_fragment(hi_f);
             bias16_lo[t * 64 + 32 + c] = make_uint4(0u, 0u, 0u, 0u);
@@ -1747,8 +1749,9 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
                        ctx->stream, ntiles, static_cast<int*>(pk.ident.p));
     DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
     if (exact) {
-        rc = dae_reserve(ctx, pk.eps, (size_t)ntiles * 32 * sizeof(float));
+        rc = dae_reserve(ctx, pk.eps, ((size_t)ntiles * 32 + 1) * sizeof(float));
         if (rc) return rc;
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(static_cast<float*>(pk.eps.p) + (size_t)ntiles * 32, 0, sizeof(float), ctx->stream));
         rc = dae_reserve(ctx, pk.bias16_lo, (size_t)ntiles * 64 * sizeof(uint4));
         if (rc) return rc;
         rc = dae_reserve(ctx, pk.bias16_hi, (size_t)ntiles * 64 * sizeof(uint4));

@@ -1,0 +1,251 @@
+// refine.hip -- DAE_DTYPE_BF16_EXACT: between the bf16 filter launch and the final selection, turn the candidates'
+// stored values into what the fp32 path would have computed -- or into "absent".
+//
+// The filter launch (decode_f32.hip, bias b + eps) leaves per (decode workgroup, row) lists of (u, column) where
+// u is an UPPER bound of the column's fp32 logit z32 with z32 >= u - 2 eps_c (api.hip decode_topk_core; the bound is
+// derived next to exact_bounds_kernel).  One 512-thread workgroup per row:
+//   1. narrow: with need = k + n_seeds, the need-th largest u (to 20 key bits) minus 2 eps_max is a threshold tau'
+//      that `need` distinct columns provably reach in fp32, so a candidate with u < tau' cannot be among the k best
+//      non-seeds: it is overwritten with -inf (absent for the selection kernel).  What is left is ~k columns plus the
+//      ones within 2 eps of the cut -- not the thousands a loose phase-A threshold lets through when the bias says
+//      nothing (--bias zeros: ~6 700 candidates per row, ~900 after this step).  Skipped when it cannot pay
+//      (fewer than 1.25 need candidates);
+//   2. recompute: the survivors' logits with the canonical chain acc = fmaf(h[k], W[c][k], acc) over k = 0 .. H-1
+//      from +0, then + b[c] -- oracle/dae_oracle.c orc_decode, the operation v_mfma_f32_32x32x2_f32 performs in the
+//      fp32 kernels (main_challenge.py:26-36 ranks those values) -- written back IN PLACE.
+//      A lane owns a candidate and runs its chain; the decoder rows (1 KiB each, row-major fp32 copy of the image)
+//      are fetched so that the 4 lanes of a quad read 64 CONTIGUOUS bytes of one row per instruction -- a lane reading
+//      its own row 16 bytes at a time made every load instruction touch 64 lines and the address unit, not the
+//      memory, was the limit (14 us per launch) -- and re-distributed through 5 KiB of LDS per wave (80-byte row
+//      stride: conflict-free b128 accesses both ways); 8 blocks of 16 k (32 x 16 bytes per lane) are in flight.
+// The selection kernel (topk.hip, PairSrc) then ranks the lists as it does for the other modes.
+#include "dae_internal.h"
+
+namespace {
+
+constexpr int RF_THREADS = 512, RF_WAVES = RF_THREADS / 64;
+constexpr int RF_STAGE = 16384;        // candidates of a row whose u fit the staging area (floats; the waves' buffers reuse it)
+constexpr int RF_SURV = 2048;          // survivors listed per flush
+constexpr int RF_MAX_SEG = 1024;
+constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (16 data + 4 pad)
+constexpr int RF_DEPTH = 8;            // blocks of 16 k in flight per lane
+
+struct RefineP {
+    uint2* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
+    dae_exact_src x;
+    const int32_t* seed_row_ptr; int k;
+};
+
+__global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
+    __shared__ int seg_prefix[RF_MAX_SEG + 2];
+    __shared__ __attribute__((aligned(16))) float hrow[1024];
+    __shared__ int surv_off[RF_SURV];
+    __shared__ int surv_col[RF_SURV];
+    __shared__ unsigned cnts[32];
+    __shared__ int s_n;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const int nseg = p.nseg;
+    const bool bad = p.x.row_bad && p.x.row_bad[row] != 0;          // precondition of the bound violated: nothing survives
+    for (int s = tid; s < nseg; s += RF_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
+    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
+    if (tid < 32) cnts[tid] = 0u;
+    for (int i = tid; i < (p.x.H >> 2); i += RF_THREADS)
+        reinterpret_cast<float4*>(hrow)[i] = reinterpret_cast<const float4*>(p.x.h + (size_t)row * p.x.ld_h)[i];
+    __syncthreads();
+    if (tid < 64) {
+        int carry = 0;
+        for (int b0 = 0; b0 < nseg; b0 += 64) {
+            const int i = b0 + tid;
+            int v = i < nseg ? seg_prefix[i + 1] : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d);
+                if (tid >= d) v += o;
+            }
+            if (i < nseg) seg_prefix[i + 1] = v + carry;
+            carry += __shfl(v, 63);
+        }
+    }
+    __syncthreads();
+    const int total = seg_prefix[nseg];
+    if (total == 0) return;
+    const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
+
+    // flat candidate index -> offset of its pair in the lists
+    auto offset_of = [&](int e) -> int {
+        int lo = 0, hi = nseg;                              // largest s with seg_prefix[s] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_prefix[mid] <= e) lo = mid; else hi = mid;
+        }
+        return (int)((int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]));
+    };
+
+    // ---- 1. narrow ------------------------------------------------------------------------------------------------
+    float* stage_u = reinterpret_cast<float*>(rf_dyn);
+    float taup = bad ? __builtin_inff() : -__builtin_inff();
+    const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 2);
+    if (staged) {
+        for (int i = tid; i < total; i += RF_THREADS) stage_u[i] = __uint_as_float(p.base[offset_of(i)].x);
+        __syncthreads();
+        // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
+        unsigned P = 0u;
+        int step = 0;
+        for (int bp = 30; bp >= 12; bp -= 2, ++step) {
+            const unsigned c1 = P + (1u << bp), c2 = P + (2u << bp), c3 = P + (3u << bp);
+            unsigned n1 = 0, n2 = 0, n3 = 0;
+            for (int i0 = 0; i0 < total; i0 += RF_THREADS) {
+                const int i = i0 + tid;
+                const bool v = i < total;
+                const unsigned key = v ? dae_okey(stage_u[i]) : 0u;
+                n1 += (unsigned)__popcll(__ballot(v && key >= c1));
+                n2 += (unsigned)__popcll(__ballot(v && key >= c2));
+                n3 += (unsigned)__popcll(__ballot(v && key >= c3));
+            }
+            if (lane == 0) {
+                if (n1) atomicAdd(&cnts[3 * step + 0], n1);
+                if (n2) atomicAdd(&cnts[3 * step + 1], n2);
+                if (n3) atomicAdd(&cnts[3 * step + 2], n3);
+            }
+            __syncthreads();
+            const unsigned un = (unsigned)need;
+            P = cnts[3 * step + 2] >= un ? c3 : cnts[3 * step + 1] >= un ? c2 : cnts[3 * step + 0] >= un ? c1 : P;
+        }
+        if (P > DAE_KEY_NEG_INF + 2u) {
+            taup = dae_okey_inv(P) - 2.0f * p.x.eps_max[0] * 1.000001f;
+            taup = dae_okey_inv(dae_okey(taup) - 2u);          // two floats further down: the subtraction rounded
+        }
+    }
+
+    // ---- 2. recompute the survivors, flush by flush ---------------------------------------------------------------
+    float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // the staging area is dead by then
+    const int H16 = p.x.H >> 4;                                  // blocks of 16 k (H % 16 remainder handled below)
+    const int Hrem4 = (p.x.H & 15) >> 2;                         // float4 left over after the whole blocks
+
+    auto rescore_listed = [&](int n) {
+        for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
+            const int mine = g0 + lane;
+            const bool in = mine < n;
+            // quad Q, lane q: the four rows this lane helps to fetch are those of candidates 4Q + i
+            const int Q = lane >> 2, q = lane & 3;
+            const float4* rp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ci = g0 + 4 * Q + i;
+                const int colv = surv_col[ci < n ? ci : g0];     // clamp: a valid row, values unused
+                rp[i] = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * p.x.H) + q;
+            }
+            float4 v[RF_DEPTH][4];
+#pragma unroll
+            for (int d = 0; d < RF_DEPTH; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[d][i] = d < H16 ? rp[i][4 * d] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float acc = 0.0f;
+            for (int j0 = 0; j0 < H16; j0 += RF_DEPTH) {
+#pragma unroll
+                for (int d = 0; d < RF_DEPTH; ++d) {
+                    const int j = j0 + d;
+                    if (j < H16) {                                // wave-uniform
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * RF_ROWSTRIDE + 4 * q) = v[d][i];
+                        __builtin_amdgcn_wave_barrier();          // (a wave's LDS accesses execute in order; keep the compiler from moving them)
+                        const int jn = j + RF_DEPTH;
+                        if (jn < H16) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
+                        }
+                        float4 w[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(tbuf + lane * RF_ROWSTRIDE + 4 * t);
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * j + 4 * t);
+                            acc = fmaf(hv.x, w[t].x, acc);
+                            acc = fmaf(hv.y, w[t].y, acc);
+                            acc = fmaf(hv.z, w[t].z, acc);
+                            acc = fmaf(hv.w, w[t].w, acc);
+                        }
+                    }
+                }
+            }
+            if (Hrem4 && in) {                                   // hidden sizes that are not a multiple of 16: the tail, lane-owned
+                const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(surv_col[mine] - p.x.col_lo) * p.x.H);
+                for (int t = 0; t < Hrem4; ++t) {
+                    const float4 wv = wr[4 * H16 + t];
+                    const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * H16 + 4 * t);
+                    acc = fmaf(hv.x, wv.x, acc);
+                    acc = fmaf(hv.y, wv.y, acc);
+                    acc = fmaf(hv.z, wv.z, acc);
+                    acc = fmaf(hv.w, wv.w, acc);
+                }
+            }
+            if (in) {
+                const float z = acc + p.x.bias[surv_col[mine] - p.x.col_lo];
+                p.base[surv_off[mine]].x = __float_as_uint(z);
+            }
+        }
+    };
+
+    __syncthreads();                                             // the search is done with the staging area: the waves' buffers take it over
+    for (int c0 = 0; c0 < total; c0 += RF_THREADS) {
+        const int i = c0 + tid;
+        const bool has = i < total;
+        int off = 0;
+        uint2 pr = make_uint2(0u, 0u);
+        if (has) { off = offset_of(i); pr = p.base[off]; }
+        const float u = __uint_as_float(pr.x);                   // still the bound: only earlier flushes' candidates were rewritten
+        const bool keep = has && u >= taup;
+        if (has && !keep) p.base[off].x = __float_as_uint(-__builtin_inff());
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int b = 0;
+            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
+            b = __shfl(b, leader);
+            if (keep) {
+                const int slot = b + __popcll(bal & ((1ull << lane) - 1ull));
+                surv_off[slot] = off;
+                surv_col[slot] = (int)pr.y;
+            }
+        }
+        __syncthreads();
+        const int n = s_n;
+        if (n + RF_THREADS > RF_SURV || c0 + RF_THREADS >= total) {   // the list could overflow next round, or this was the last
+            rescore_listed(n);
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
+                            const int32_t* seed_row_ptr)
+{
+    if (B <= 0) return DAE_OK;
+    if (g1.nseg > RF_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
+    if (!x.h || !x.W32 || !x.bias || !x.eps_max || (x.H & 3) || x.H > 1024 || !g1.cnt)
+        return dae_fail(ctx, DAE_ERR_ARG, "exact refine: bad arguments (H=%d)", x.H);
+    RefineP p;
+    p.base = const_cast<uint2*>(g1.base); p.cnt = g1.cnt; p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;
+    p.cnt_seg_stride = g1.cnt_seg_stride; p.nseg = g1.nseg; p.x = x; p.seed_row_ptr = seed_row_ptr; p.k = k;
+    if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
+        return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
+    size_t dyn = (size_t)RF_STAGE * sizeof(float);
+    if (dyn < (size_t)RF_WAVES * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)RF_WAVES * 64 * RF_ROWSTRIDE * sizeof(float);
+    static const char key = 0;
+    if (dae_first_use(ctx, &key))
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(RF_THREADS), dyn, ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "exact_refine_kernel");
+    return DAE_OK;
+}

@@ -39,11 +39,10 @@ struct DenseSrc {
     static constexpr bool kFixedSlots = true;      // for_each visits q = tid, tid + 1024, ... in order
     dae_dense_src s;
     int max_keys() const { return s.n; }                  // host: most keys a row can hold
-    static constexpr int kHidden = 0;
-    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*, float*) const {}
+    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return s.n; }
     template <int NTH, typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, const int*, const float*, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
         constexpr int TK_THREADS = NTH;                // (shadows the file-level constant inside this body)
         const float* rp = s.logits + (size_t)row * s.ld;
@@ -84,9 +83,8 @@ struct PairSrc {
         return g.cnt ? g.cnt[(size_t)seg * g.cnt_seg_stride + row] : g.fixed_cnt;
     }
     // exclusive prefix of segment sizes in LDS: seg_prefix[0..nseg]
-    static constexpr int kHidden = 0;
     template <int NTH>
-    __device__ __forceinline__ void prepare(int row, int tid, int* seg_prefix, float*) const
+    __device__ __forceinline__ void prepare(int row, int tid, int* seg_prefix) const
     {
         constexpr int TK_THREADS = NTH;
         const int nseg = g0.nseg + g1.nseg;
@@ -115,7 +113,7 @@ struct PairSrc {
         return seg_prefix[g0.nseg + g1.nseg];
     }
     template <int NTH, typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, const float*, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, F f) const
     {
         constexpr int TK_THREADS = NTH, TK_WAVES = NTH / 64;
         // group 0 (few, long segments: the sample winners): flat over the whole workgroup
@@ -160,104 +158,15 @@ struct PairSrc {
     }
 };
 
-// DAE_DTYPE_BF16_EXACT: the candidate lists of the bf16 filter launch (per decode workgroup, like PairSrc's group 1)
-// with every logit RECOMPUTED in fp32 before it is ranked: z = the canonical chain acc = fmaf(h[k], W[c][k], acc) over
-// k = 0 .. H-1 from +0, then + b[c] -- oracle/dae_oracle.c orc_decode, the operation v_mfma_f32_32x32x2_f32 performs
-// in the fp32 kernels.  The stored value (an upper bound z_bf16 + eps) is ignored.  A thread owns one candidate: the
-// row's hidden vector sits in LDS (broadcast reads), the decoder row comes from the row-major fp32 copy of the image
-// (1 KiB per candidate, mostly L2 hits: popular columns survive in every row), 8 x 16 bytes in flight per thread.
-// Candidates are addressed FLAT over the segments (binary search in the prefix table), so the ~k survivors of a row
-// occupy ~k threads of one pass whatever their spread over the 128 lists.
-struct ExactSrc {
-    static constexpr int kSegs = TK_MAX_SEG;
-    static constexpr bool kFixedSlots = false;
-    static constexpr int kHidden = 1024;                   // largest hidden size of the decode kernels
-    dae_pair_group g1;
-    dae_exact_src x;
-    int max_keys() const { return 4096; }
-    template <int NTH>
-    __device__ __forceinline__ void prepare(int row, int tid, int* seg_prefix, float* hbuf) const
-    {
-        const bool bad = x.row_bad && x.row_bad[row] != 0;  // precondition violated: the row ranks nothing
-        const int nseg = g1.nseg;
-        for (int s = tid; s < nseg; s += NTH)
-            seg_prefix[s + 1] = bad ? 0 : g1.cnt[(size_t)s * g1.cnt_seg_stride + row];
-        if (tid == 0) seg_prefix[0] = 0;
-        for (int i = tid; i < (x.H >> 2); i += NTH)
-            reinterpret_cast<float4*>(hbuf)[i] = reinterpret_cast<const float4*>(x.h + (size_t)row * x.ld_h)[i];
-        __syncthreads();
-        if (tid < 64) {
-            int carry = 0;
-            for (int base = 0; base < nseg; base += 64) {
-                const int i = base + tid;
-                int v = i < nseg ? seg_prefix[i + 1] : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(v, d);
-                    if (tid >= d) v += o;
-                }
-                if (i < nseg) seg_prefix[i + 1] = v + carry;
-                carry += __shfl(v, 63);
-            }
-        }
-        __syncthreads();
-    }
-    __device__ __forceinline__ int count(int, const int* seg_prefix) const { return seg_prefix[g1.nseg]; }
-    template <int NTH, typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, const int* seg_prefix, const float* hbuf, F f) const
-    {
-        const int total = seg_prefix[g1.nseg];
-        const int H4 = x.H >> 2;
-        const float4* h4 = reinterpret_cast<const float4*>(hbuf);
-        for (int e0 = 0; e0 < total; e0 += NTH) {
-            const int e = e0 + tid;
-            const bool in = e < total;
-            int colv = -1;
-            float z = 0.0f;
-            if (in) {
-                int lo = 0, hi = g1.nseg;                   // largest s with seg_prefix[s] <= e
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (seg_prefix[mid] <= e) lo = mid; else hi = mid;
-                }
-                const uint2 pr = g1.base[(size_t)lo * g1.seg_stride + (size_t)row * g1.row_stride + (e - seg_prefix[lo])];
-                colv = (int)pr.y;
-                const int lc = colv - x.col_lo;
-                const float4* wr = reinterpret_cast<const float4*>(x.W32 + (size_t)lc * x.H);
-                const float bv = x.bias[lc];
-                float acc = 0.0f;
-                for (int k4 = 0; k4 < H4; k4 += 8) {
-                    float4 w[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) w[u] = wr[k4 + u < H4 ? k4 + u : H4 - 1];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (k4 + u < H4) {
-                            const float4 hv = h4[k4 + u];
-                            acc = fmaf(hv.x, w[u].x, acc);
-                            acc = fmaf(hv.y, w[u].y, acc);
-                            acc = fmaf(hv.z, w[u].z, acc);
-                            acc = fmaf(hv.w, w[u].w, acc);
-                        }
-                    }
-                }
-                z = acc + bv;
-            }
-            f(z, colv, in);
-        }
-    }
-};
-
 struct SoaSrc {
     static constexpr int kSegs = 0;
     static constexpr bool kFixedSlots = false;
     const float* logit; const int32_t* idx; int G, B, k;
     int max_keys() const { return G * k; }
-    static constexpr int kHidden = 0;
-    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*, float*) const {}
+    template <int NTH> __device__ __forceinline__ void prepare(int, int, int*) const {}
     __device__ __forceinline__ int count(int, const int*) const { return G * k; }
     template <int NTH, typename F>
-    __device__ __forceinline__ void for_each(int row, int tid, const int*, const float*, F f) const
+    __device__ __forceinline__ void for_each(int row, int tid, const int*, F f) const
     {
         constexpr int TK_THREADS = NTH;
         const int total = G * k;
@@ -325,7 +234,6 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ unsigned hist[TK_BINS];
     __shared__ int seg_prefix[Src::kSegs + 2];
-    __shared__ __attribute__((aligned(16))) float src_h[Src::kHidden > 0 ? Src::kHidden : 4];   // ExactSrc: the row's hidden vector
     __shared__ unsigned wave_tot[TK_WAVES];
     __shared__ int s_bin;
     __shared__ unsigned s_above;
@@ -362,7 +270,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
             if (pcol >= 0 && pcol < a.bitmap_n) atomicOr(&bitmap[pcol >> 5], 1u << (pcol & 31));
         }
     }
-    src.template prepare<NTH>(row, tid, seg_prefix, src_h);
+    src.template prepare<NTH>(row, tid, seg_prefix);
     __syncthreads();
     if (DAE_EXP_ON(dbg_stop == 1)) return;
 
@@ -413,7 +321,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
             // ballot / leader atomic / shuffle per element group; the count is one atomic per wave
             unsigned cnt = 0;
             int calls = 0;
-            src.template for_each<NTH>(row, tid, seg_prefix, src_h, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
                 note_max(ck);
                 const int slot = tid + TK_THREADS * calls++;
@@ -429,7 +337,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
             if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
             if (tid == 0) s_slots = (unsigned)n_src;
         } else if (key_cap > 0) {
-            src.template for_each<NTH>(row, tid, seg_prefix, src_h, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
                 note_max(ck);
                 const bool v = ck != 0ull;
@@ -450,7 +358,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
         } else {
             // nothing is cached: count, min and max only -- one atomic per wave instead of one per element group
             unsigned cnt = 0;
-            src.template for_each<NTH>(row, tid, seg_prefix, src_h, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 const u64 ck = ckey(z, colv, in);
                 note_max(ck);
                 if (ck != 0ull) {
@@ -489,7 +397,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
                 f(i < n_cached ? keys[i] : 0ull);
             }
         } else {
-            src.template for_each<NTH>(row, tid, seg_prefix, src_h, [&](float z, int colv, bool in) {
+            src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
                 f(ckey(z, colv, in));
             });
         }
@@ -616,7 +524,7 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
             }
         }
     } else {
-        src.template for_each<NTH>(row, tid, seg_prefix, src_h, [&](float z, int colv, bool in) {
+        src.template for_each<NTH>(row, tid, seg_prefix, [&](float z, int colv, bool in) {
             const u64 ck = ckey(z, colv, in);
             const bool v = ck != 0ull && ck >= lo;
             const u64 bal = __ballot(v);
@@ -1177,7 +1085,7 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     aa.lean = want_lean ? 1 : 0;
     // a ranked range too wide for the LDS bitmap (> ~1 M columns) takes the bitmap-free mode instead of failing
     if ((((size_t)((a.bitmap_n + 31) / 32) * 4) + 15) + (size_t)sort_n * 8 + 22 * 1024 > (size_t)160 * 1024) aa.lean = 1;
-    const size_t lds_total = 160 * 1024, lds_static = 14 * 1024 + (size_t)Src::kHidden * 4;    // hist 8K + seg_prefix 4K + scalars (+ the hidden row)
+    const size_t lds_total = 160 * 1024, lds_static = 14 * 1024;    // hist 8K + seg_prefix 4K + scalars
     size_t dyn;
     int key_cap;
     if (aa.lean) {
@@ -1253,15 +1161,6 @@ int dae_launch_topk_soa(dae_ctx* ctx, int G, const float* logit, const int32_t* 
                         const dae_topk_args& a)
 {
     SoaSrc src{logit, idx, G, a.B, a.k};
-    return launch_topk(ctx, src, a);
-}
-
-int dae_launch_topk_exact(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, const dae_topk_args& a)
-{
-    if (g1.nseg > TK_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
-    if (!x.h || !x.W32 || !x.bias || (x.H & 3) || x.H > ExactSrc::kHidden || !g1.cnt)
-        return dae_fail(ctx, DAE_ERR_ARG, "exact re-scoring: bad arguments (H=%d)", x.H);
-    ExactSrc src{g1, x};
     return launch_topk(ctx, src, a);
 }
 
