@@ -63,15 +63,18 @@ def parse():
                          "would run (global batch N x batch-per-gpu, columns of shard --sim-rank); the "
                          "exchange is a 1-rank all-gather, so communication is NOT included")
     ap.add_argument("--sim-rank", type=int, default=0)
-    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="alltoall",
-                    help="N > 1: how the per-shard top-k lists meet.  alltoall: every rank receives and merges the rows "
-                         "it owns (1/N of the bytes and of the merge); allgather: every rank receives and merges all "
-                         "rows (BASELINE.json configs[2] as written; reported as an extra row when alltoall is timed)")
+    ap.add_argument("--exchange", choices=["alltoall", "allgather"], default="allgather",
+                    help="N > 1: how the per-shard top-k lists meet.  allgather (default: BASELINE.json north_star / configs[2] "
+                         "as written, and what DAE.shard_scoring runs by default): every rank receives and merges all rows; "
+                         "alltoall: every rank receives and merges the rows it owns (1/N of the bytes and of the merge).  The "
+                         "one not chosen is timed as a labelled extra row")
     ap.add_argument("--prime-ms", type=float, default=200.0,
                     help="setup: run the step for this long before the warm-up steps (device ramp; 0 = off)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL (the product path).  gloo: development rehearsal of the N > 1 flow on one GPU")
+    ap.add_argument("--n-batches", type=int, default=8, help="distinct resident batches the steps rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-rows", action="store_true", help="skip the bias-zeros / batch-1024 / exact-bf16 extra rows")
     ap.add_argument("--gate", type=int, default=-1,
                     help="two streams: alternate the dominant launches (dae_set_decode_gate).  Default: on for f32, where "
                          "that launch takes every CU (128 KiB of LDS per workgroup); off for bf16, where two of them "
@@ -100,17 +103,30 @@ def _pmc_traffic(key, kernel):
         return None
 
 
-def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k, V, n_steps, n_warm, idx_f32, peaks):
-    """Extra row of the default run (BASELINE.json configs[4]): the same step with the decode GEMM on bf16 operands
-    (v_mfma_f32_32x32x16_bf16, fp32 accumulate; encode, threshold and top-k stay fp32)."""
+def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k, n_steps, n_warm, ref32, oracle_ref,
+              peaks, traffic_key):
+    """Extra row of the default run: the same step (rotating the same resident batches) with another decode arithmetic.
+    dt = DAE_DTYPE_BF16 (BASELINE.json configs[4]: bf16 MFMA decode, fp32 accumulate; encode, threshold, top-k fp32) or
+    DAE_DTYPE_BF16_EXACT (north_star: that GEMM as a filter on rigorous bounds, survivors recomputed in fp32)."""
     PEAK_BF16_TFLOPS, PEAK_HBM_GBS = peaks
-    prepack(_lib.DAE_DTYPE_BF16)
-    outs, step = step_fn_factory(_lib.DAE_DTYPE_BF16)
+    d_We, d_be = enc
+    n_b = len(ctxs)
+    outs = [(torch.empty((B, k), dtype=torch.float32, device=d_We.device),
+             torch.empty((B, k), dtype=torch.int32, device=d_We.device)) for _ in range(n_b)]
+    cnt = [0]
+
+    def step(only=None, batch=None):
+        s_ = cnt[0] % n_b if only is None else only
+        f = feeds[cnt[0] % len(feeds)] if batch is None else feeds[batch]
+        cnt[0] += 1
+        with torch.cuda.stream(streams[s_]):
+            ctxs[s_].score_topk(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s_][0], outs[s_][1], dtype=dt)
     for _ in range(max(n_warm, 4)):
         step()
     torch.cuda.synchronize()
     for c in ctxs:
         c.profile_enable(True)
+    cnt[0] = 0
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step()
@@ -123,10 +139,9 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
         c.profile_enable(False)
     # the same launch with nothing else in flight (the timed region overlaps len(ctxs) batches, which stretches every
     # launch's event pair but raises throughput)
-    iso_outs, iso_step = step_fn_factory(_lib.DAE_DTYPE_BF16, only=0)
     ctxs[0].profile_enable(True)
     for _ in range(10):
-        iso_step()
+        step(only=0)
     torch.cuda.synchronize()
     iso_ms, iso_n = ctxs[0].profile_read()
     ctxs[0].profile_enable(False)
@@ -140,14 +155,16 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
     tf_ = flop / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
     gbs = alg_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
     t_mfma, t_hbm = flop / (PEAK_BF16_TFLOPS * 1e12), alg_bytes / (PEAK_HBM_GBS * 1e9)
-    a16, a32 = outs[0][1].cpu().numpy(), idx_f32.cpu().numpy()
-    rprec = {}
-    for R in (10, 100, 500):
-        rprec["R=%d" % R] = round(float(np.mean([met.get_r_precision(a32[r, :R].tolist(), a16[r].tolist())
-                                                  for r in range(a32.shape[0])])), 4)
+    step(only=0, batch=0)                       # batch 0 for the comparisons
+    torch.cuda.synchronize()
+    s16, i16 = outs[0]
+    exact = dt == _lib.DAE_DTYPE_BF16_EXACT
     row = {"value": round(B * n_steps / el, 1), "unit": "playlists/s", "ms_per_step": round(el / n_steps * 1e3, 4),
-           "steps": n_steps, "dtype": "bf16 decode GEMM (fp32 accumulate), fp32 encode / threshold / top-k",
-           "roofline": {"kernel": ctxs[0].profile_kernel(), "traffic": _pmc_traffic("bf16", ctxs[0].profile_kernel()),
+           "steps": n_steps, "streams": n_b, "batches_rotated": len(feeds),
+           "dtype": ("bf16 MFMA decode as a FILTER on per-column error bounds, survivors recomputed with the fp32 fmaf chain; "
+                     "fp32 encode / threshold / top-k" if exact else
+                     "bf16 decode GEMM (fp32 accumulate), fp32 encode / threshold / top-k"),
+           "roofline": {"kernel": ctxs[0].profile_kernel(), "traffic": _pmc_traffic(traffic_key, ctxs[0].profile_kernel()),
                         "bound": "hbm" if t_hbm > t_mfma else "mfma",
                         "mfma": {"achieved": round(tf_, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(tf_ / PEAK_BF16_TFLOPS, 4)},
@@ -160,11 +177,27 @@ def _bf16_row(torch, _lib, met, ctxs, streams, step_fn_factory, prepack, B, H, k
                                      "mfma_frac": round(flop / (iso_avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if iso_avg > 0 else None,
                                      "note": "same launch with no other batch in flight"},
                         "note": "%.1f us of matrix time at the bf16 peak, %.1f us to stream the launch's bytes at the "
-                                "HBM peak: the binding roof is the larger" % (t_mfma * 1e6, t_hbm * 1e6)},
-           "r_precision_vs_fp32_lists": rprec,
-           "note": "NOT the headline (the headline is the bit-exact fp32 path).  r-precision: the fp32 path's top-R of "
-                   "the same batch taken as the answers, the bf16 top-500 as the candidates (utils/metrics.py)"}
-    prepack(_lib.DAE_DTYPE_F32)
+                                "HBM peak: the binding roof is the larger" % (t_mfma * 1e6, t_hbm * 1e6)}}
+    if exact:
+        s32, i32 = ref32
+        row["identical_to_fp32_path"] = bool(torch.equal(i16, i32) and torch.equal(s16.view(torch.int32), s32.view(torch.int32)))
+        if oracle_ref is not None:
+            s_ref, i_ref = oracle_ref
+            ns = i_ref.shape[0]
+            row["gpu_matches_oracle_bitwise"] = bool(
+                np.array_equal(i16[:ns].cpu().numpy(), i_ref) and
+                np.array_equal(s16[:ns].cpu().numpy().view(np.uint32), s_ref.view(np.uint32)))
+        row["note"] = ("NOT the headline (the headline is the fp32 MFMA path).  Same top-500 lists as that path -- indices AND "
+                       "scores, checked on batch 0 -- from a bf16 GEMM: include/dae_hip.h DAE_DTYPE_BF16_EXACT, DESIGN.md 2b")
+    else:
+        a16, a32 = i16.cpu().numpy(), ref32[1].cpu().numpy()
+        rprec = {}
+        for R in (10, 100, 500):
+            rprec["R=%d" % R] = round(float(np.mean([met.get_r_precision(a32[r, :R].tolist(), a16[r].tolist())
+                                                      for r in range(a32.shape[0])])), 4)
+        row["r_precision_vs_fp32_lists"] = rprec
+        row["note"] = ("NOT the headline (the headline is the bit-exact fp32 path).  r-precision: the fp32 path's top-R of "
+                       "batch 0 taken as the answers, the bf16 top-500 as the candidates (utils/metrics.py)")
     return row
 
 
@@ -210,6 +243,26 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 20 * 1e3
         row[name] = {"ms_per_step": round(ms, 3), "playlists_per_s": round(B / ms * 1e3, 1), "cost": round(float(cost.item()), 3)}
+        # step-level roofline (algorithmic minimum, DESIGN.md section 4 "Training"): three GEMMs of 2 B V H FLOP against
+        # the dense MFMA peak of their operand type, and the HBM bytes no schedule can avoid -- W_dec read by K5 and K7,
+        # dL/dz^T written once and read twice (fp32 or bf16), the dense Adam passes (p, m, v read and written, the
+        # gradient written and read: 7 x 4 V H per matrix; 6 x when the decoder's update sits in the gradient kernel and
+        # its gradient never reaches HBM) and the clearing of the encoder gradient
+        gemm_flop = 3 * 2.0 * B * V * H
+        mat = 4.0 * V * H
+        dz = (2.0 if dt == _lib.DAE_DTYPE_BF16 else 4.0) * B * V
+        hbm = 2 * mat + 3 * dz + (6 if fz else 7) * mat + 7 * mat + mat
+        peak_tf = PEAK_BF16_TFLOPS if dt == _lib.DAE_DTYPE_BF16 else PEAK_F32_TFLOPS
+        t_mfma, t_hbm = gemm_flop / (peak_tf * 1e12) * 1e3, hbm / (PEAK_HBM_GBS * 1e9) * 1e3
+        row[name]["roofline"] = {"bound": "hbm" if t_hbm > t_mfma else "mfma", "gemm_flop_per_step": gemm_flop,
+                                 "hbm_bytes_per_step": hbm, "t_mfma_ms": round(t_mfma, 4), "t_hbm_ms": round(t_hbm, 4),
+                                 "achieved": round((hbm / (ms * 1e-3) / 1e9) if t_hbm > t_mfma else (gemm_flop / (ms * 1e-3) / 1e12), 1),
+                                 "peak": PEAK_HBM_GBS if t_hbm > t_mfma else peak_tf,
+                                 "unit": "GB/s" if t_hbm > t_mfma else "TFLOP/s",
+                                 "frac": round(max(t_mfma, t_hbm) / ms, 4),
+                                 "frac_if_serial": round((t_mfma + t_hbm) / ms, 4),
+                                 "note": "whole step against its binding roof (the larger of matrix time and byte time); "
+                                         "frac_if_serial counts both, for a schedule that cannot overlap them"}
     ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
     row["note"] = ("NOT the headline.  The model (models/DAEs.py) runs the last variant plus rows-Adam on the encoder "
                    "(dae_adam_rows_*: no HBM passes over rows without gradient); scripts/bench_epoch.py times that loop "
@@ -257,17 +310,29 @@ def main():
 
     # ---- synthetic model + one batch, resident in HBM -------------------------------------------
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=args.bias, n_tracks=n_tracks)
-    pos, ones, seeds = make_playlists(B, n_tracks, args.n_artists, seed=1, dist=args.dist)
-    rp, col, val = coo_to_csr(pos, ones, B, V)
-    srp, sc = seeds_to_csr(seeds, B, n_tracks)
-    mean_nnz = float(col.size) / B
 
     def up(a, dt):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
 
+    # N_BATCHES distinct batches resident in HBM, taken in turn by the steps (the reference's loop sees a new batch
+    # every iteration, main_challenge.py:72-93); batch 0 is the one the CPU oracle re-scores
+    def make_feed(batch_rows, seed):
+        pos_, ones_, seeds_ = make_playlists(batch_rows, n_tracks, args.n_artists, seed=seed, dist=args.dist)
+        rp_, col_, val_ = coo_to_csr(pos_, ones_, batch_rows, V)
+        srp_, sc_ = seeds_to_csr(seeds_, batch_rows, n_tracks)
+        dev_ = (up(rp_, torch.int32), up(col_, torch.int32), up(val_, torch.float32), up(srp_, torch.int32),
+                up(sc_ if sc_.size else np.zeros(1, np.int32), torch.int32))
+        return dev_, (pos_, ones_, rp_, col_, val_, srp_, sc_)
+    feeds, host0 = [], None
+    for b_ in range(max(1, args.n_batches)):
+        f_, h_ = make_feed(B, 1 + b_)
+        feeds.append(f_)
+        if b_ == 0:
+            host0 = h_
+    pos, ones, rp, col, val, srp, sc = host0
+    mean_nnz = float(np.mean([int(f_[1].numel()) for f_ in feeds])) / B
     d_We, d_be = up(W_enc, torch.float32), up(b_enc, torch.float32)
-    d_rp, d_col, d_val = up(rp, torch.int32), up(col, torch.int32), up(val, torch.float32)
-    d_srp, d_sc = up(srp, torch.int32), up(sc if sc.size else np.zeros(1, np.int32), torch.int32)
+    d_rp, d_col, d_val, d_srp, d_sc = feeds[0]
     col_lo, col_hi = shard_bounds(V, sim, args.sim_rank) if sim else shard_bounds(V, world, rank)
     n_str = args.streams if args.streams > 0 else (3 if args.dtype == "bf16" else 2)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
@@ -290,7 +355,7 @@ def main():
              torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
     score, idx = outs[0]
     B_own = B // world                           # rows whose final top-k this rank produces (alltoall)
-    feed = (d_rp, d_col, d_val, d_srp, d_sc)
+    feed = feeds[0]
     rankers = {}
     if sharded:
         # the product's own sharded-scoring objects (what DAE.shard_scoring builds): one ShardedRanker per batch in
@@ -322,17 +387,26 @@ def main():
     exchange = [args.exchange]
     last = [None] * n_str                        # (score, idx) of the last batch of each stream
 
-    def step():
+    def step(batch=None):
         s = step_no[0] % n_str
+        f = feeds[step_no[0] % len(feeds)] if batch is None else feeds[batch]
         step_no[0] += 1
         c = ctxs[s]
         with torch.cuda.stream(streams[s]):
             if not sharded:
-                c.score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, outs[s][0], outs[s][1],
+                c.score_topk(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s][0], outs[s][1],
                              dtype=DT)
                 last[s] = outs[s]
             else:
-                last[s] = rankers[exchange[0]][s].rank_batch(feed, k)
+                last[s] = rankers[exchange[0]][s].rank_batch(f, k)
+
+    def score_batch0():
+        """Batch 0 on context 0 (drained streams): the outputs the oracle / cross-path comparisons look at."""
+        torch.cuda.synchronize()
+        step_no[0] = 0
+        step(batch=0)
+        torch.cuda.synchronize()
+        step_no[0] = 0
 
     # setup, not warm-up: bring the device to its sustained state (clocks, Infinity Cache holding W) by running
     # the step for a fixed 0.2 s; measured throughput otherwise depends on how short the run is (1.07 M playlists/s
@@ -584,10 +658,25 @@ def main():
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,
     }
+    if roofline.get("traffic") is not None:
+        roofline["traffic_source"] = ("profiles/traffic_decode.json: FETCH_SIZE x 2 + WRITE_SIZE of this kernel from separate "
+                                      "rocprofv3 --pmc passes (scripts/gpu_pmc_round3.sh), not counters of this run")
+    if sharded:
+        # what the collectives of this run really spanned (n_gpus above is WORLD_SIZE from the launcher's environment)
+        coll = {"world": dist.get_world_size(), "backend": dist.get_backend(), "exchange": args.exchange}
+        try:
+            coll["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:
+            coll["rccl_version"] = "unavailable: %r" % (e,)
+        probe = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(probe)
+        coll["all_reduce_of_ones"] = int(probe.item())       # == world when every rank took part
+        out["collective"] = coll
 
-    # ---- the exchange as BASELINE.json configs[2] words it: all-gather, every rank merges every row ----------
-    if sharded and not sim and args.exchange == "alltoall":
-        exchange[0] = "allgather"
+    # ---- the OTHER exchange as a labelled extra row (headline: --exchange, default the all-gather north_star names) ----
+    if sharded and not sim:
+        head, other = args.exchange, ("alltoall" if args.exchange == "allgather" else "allgather")
+        exchange[0] = other
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -602,23 +691,27 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el_g = float(t.item())
-        # both exchanges once more on drained streams, then compare (not buffers left over from the timed loops)
+        # both exchanges once more on drained streams and the same batch, then compare
         r0_ = rank * B_own
-        torch.cuda.synchronize()
-        step(); step()
-        torch.cuda.synchronize()
-        ag = [(last[i][0].clone(), last[i][1].clone()) for i in range(n_str)]
-        exchange[0] = "alltoall"
-        step(); step()
-        torch.cuda.synchronize()
-        agree = bool(all(torch.equal(ag[i][1][r0_:r0_ + B_own], last[i][1]) and
-                         torch.equal(ag[i][0][r0_:r0_ + B_own], last[i][0]) for i in range(n_str)))
-        out["allgather_exchange"] = {"value": round(B * args.steps / el_g, 1), "unit": "playlists/s",
-                                     "ms_per_step": round(el_g / args.steps * 1e3, 4),
-                                     "same_indices_as_alltoall": agree,
-                                     "note": "same shards, the per-shard lists all-gathered and ALL rows merged on "
-                                             "every rank"}
-        exchange[0] = "alltoall"
+        res = {}
+        for ex in ("allgather", "alltoall"):
+            exchange[0] = ex
+            torch.cuda.synchronize()
+            step_no[0] = 0
+            for _ in range(n_str):
+                step(batch=0)
+            torch.cuda.synchronize()
+            res[ex] = [(last[i][0].clone(), last[i][1].clone()) for i in range(n_str)]
+        agree = bool(all(torch.equal(res["allgather"][i][1][r0_:r0_ + B_own], res["alltoall"][i][1]) and
+                         torch.equal(res["allgather"][i][0][r0_:r0_ + B_own], res["alltoall"][i][0]) for i in range(n_str)))
+        out[other + "_exchange"] = {"value": round(B * args.steps / el_g, 1), "unit": "playlists/s",
+                                    "ms_per_step": round(el_g / args.steps * 1e3, 4),
+                                    "same_lists_as_" + head: agree,
+                                    "note": ("same shards; every rank receives and merges only the rows it owns (1/N of the bytes "
+                                             "per link and of the merge work)" if other == "alltoall" else
+                                             "same shards, the per-shard lists all-gathered and ALL rows merged on every rank")}
+        exchange[0] = head
+        step_no[0] = 0
 
     # ---- the same job with the PLAYLISTS partitioned over the ranks instead of the vocabulary -------------
     # Not the headline (BASELINE.json configs[2] names the vocabulary shard): every rank holds the whole
@@ -664,8 +757,7 @@ def main():
         for c in ctxs:
             c.prepack_decoder(d_Wd_full, d_bd, col_lo, col_hi, dtype=DT)
         torch.cuda.synchronize()
-        step(); step()
-        torch.cuda.synchronize()
+        score_batch0()
         got = last[0] if exchange[0] == "alltoall" else (last[0][0][r0:r0 + bpg], last[0][1][r0:r0 + bpg])
         same = bool(torch.equal(got[1], lo_out[0][1]) and torch.equal(got[0], lo_out[0][0])) if args.dtype == "f32" else None
         out["playlist_sharded"] = {"value": round(B * args.steps / el_r, 1), "unit": "playlists/s",
@@ -696,14 +788,15 @@ def main():
                               "note": "NOT the headline: decodes the %d track columns only (the %d artist "
                                       "columns are sliced away by the reference after computing them); "
                                       "top-500 output identical" % (n_tracks, V - n_tracks)}
+        score_batch0()
         s2, i2 = outs[0][0].clone(), outs[0][1].clone()
         for c in ctxs:
             c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
-        step(); step()
-        torch.cuda.synchronize()
+        score_batch0()
         out["tracks_only"]["identical_to_all_columns"] = bool(torch.equal(i2, outs[0][1]) and torch.equal(s2, outs[0][0]))
 
     # ---- CPU baseline: the C oracle ("port"), one thread, bounded sample --------------------------
+    oracle_ref = None
     if args.dtype == "bf16":
         # W_dec bf16 is 87 MB: at batch 256 the decode is bounded by streaming it (2*B/2 = 256 FLOP/B
         # < the 400 FLOP/B machine balance); report the HBM view next to the MFMA one
@@ -728,6 +821,8 @@ def main():
                     if tf_ver is None else
                     "tensorflow %s imports here, but the reference graph needs the TF1 API (tf.contrib, "
                     "tf.placeholder): this is the CPU restatement, not TF1" % tf_ver)
+        score_batch0()
+        oracle_ref = (s_ref, i_ref)
         ok = bool(np.array_equal(idx[rows].cpu().numpy(), i_ref) and
                   np.array_equal(score[rows].cpu().numpy().view(np.uint32), s_ref.view(np.uint32)))
         out["cpu_baseline"] = {"value": round(ns / cpu_s, 2), "unit": "playlists/s", "cores": 1,
@@ -767,50 +862,117 @@ def main():
         except Exception as e:                      # never let the extra row break the contract line
             out["cpu_baseline"]["dense_numpy"] = {"error": repr(e)}
 
-    # ---- bf16 decode (BASELINE.json configs[4]) as an extra row of the default run ---------------------------
+    # ---- extra rows of the default run: other decode arithmetics, an uninformative bias, batch 1024 ---------------------
     if not sharded and args.dtype == "f32" and not args.no_bf16_row:
         try:
             from spotify_recsys_challenge_2018_amd.utils import metrics as met
-            step(); step()
-            torch.cuda.synchronize()
-            idx_f32 = outs[0][1].clone()
-            for c in ctxs:                                  # the bf16 launch runs ungated (two share a CU)
+            score_batch0()
+            ref32 = (outs[0][0].clone(), outs[0][1].clone())
+            for c in ctxs:                                  # the bf16 launches run ungated (two share a CU)
                 c.check(c.lib.dae_set_decode_gate(c.h, None, None))
-            # three batches in flight for this row (what `--dtype bf16` runs by default): one more context + stream
+            # three batches in flight for these rows (what `--dtype bf16` runs by default): one more context + stream
             ctxs_b, streams_b = list(ctxs), list(streams)
             while len(ctxs_b) < 3:
                 c3, s3 = _lib.Context(local_rank), torch.cuda.Stream(device=dev)
                 with torch.cuda.stream(s3):
                     c3.bind_stream()
                 ctxs_b.append(c3); streams_b.append(s3)
-            n_b = len(ctxs_b)
-
-            def prepack_all(dt):
-                for c in ctxs_b:
-                    c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
-                torch.cuda.synchronize()
-
-            def factory(dt, only=None):
-                o16 = [(torch.empty((B, k), dtype=torch.float32, device=dev),
-                        torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_b)]
-                cnt = [0]
-
-                def st():
-                    s_ = cnt[0] % n_b if only is None else only
-                    cnt[0] += 1
-                    with torch.cuda.stream(streams_b[s_]):
-                        ctxs_b[s_].score_topk(d_rp, d_col, d_val, d_We, d_be, n_tracks, d_srp, d_sc, k, o16[s_][0],
-                                              o16[s_][1], dtype=dt)
-                return o16, st
-            out["bf16_decode"] = _bf16_row(torch, _lib, met, ctxs_b, streams_b, factory, prepack_all, B, H, k, V,
-                                           args.steps, args.warmup, idx_f32, (PEAK_BF16_TFLOPS, PEAK_HBM_GBS))
-            out["bf16_decode"]["streams"] = n_b
+            for c in ctxs_b:                                # the exact prepack serves the plain bf16 mode as well
+                c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=_lib.DAE_DTYPE_BF16_EXACT)
+            torch.cuda.synchronize()
+            peaks = (PEAK_BF16_TFLOPS, PEAK_HBM_GBS)
+            out["bf16_decode"] = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds, (d_We, d_be), n_tracks,
+                                           _lib.DAE_DTYPE_BF16, B, H, k, args.steps, args.warmup, ref32, oracle_ref, peaks, "bf16")
+            if not args.no_extra_rows:
+                out["exact_bf16_decode"] = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds, (d_We, d_be), n_tracks,
+                                                     _lib.DAE_DTYPE_BF16_EXACT, B, H, k, args.steps, args.warmup, ref32,
+                                                     oracle_ref, peaks, "exact_bf16")
             if gate_events:
                 for i, c in enumerate(ctxs):
                     c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),
                                                       ctypes.c_void_p(gate_events[i].cuda_event)))
-        except Exception as e:                              # the row is an extra: never lose the headline over it
-            out["bf16_decode"] = {"error": repr(e)}
+        except Exception as e:                              # the rows are extras: never lose the headline over them
+            out.setdefault("bf16_decode", {"error": repr(e)})
+            out.setdefault("exact_bf16_decode", {"error": repr(e)})
+
+    if not sharded and args.dtype == "f32" and not args.no_extra_rows:
+        # (a) the same fp32 step with an UNINFORMATIVE bias (b_dec = 0: the threshold sample cannot pick the hot tiles,
+        #     ~10x the candidates per row) -- the worst case of the fused selection, not a different workload
+        try:
+            if args.bias != "zeros":
+                d_b0 = torch.zeros_like(d_bd)
+                for c in ctxs:
+                    c.prepack_decoder(d_Wd, d_b0, col_lo, col_hi, dtype=DT)
+                torch.cuda.synchronize()
+                for _ in range(max(args.warmup, 4)):
+                    step()
+                torch.cuda.synchronize()
+                for c in ctxs:
+                    c.profile_enable(True)
+                nz = max(args.steps // 2, 10)
+                t0 = time.perf_counter()
+                for _ in range(nz):
+                    step()
+                torch.cuda.synchronize()
+                elz = time.perf_counter() - t0
+                kz, nkz = 0.0, 0
+                for c in ctxs:
+                    a_, b_ = c.profile_read()
+                    kz += a_; nkz += b_
+                    c.profile_enable(False)
+                out["bias_zeros"] = {"value": round(B * nz / elz, 1), "unit": "playlists/s",
+                                     "ms_per_step": round(elz / nz * 1e3, 4), "steps": nz,
+                                     "dominant_kernel_ms": round(kz / max(nkz, 1), 4),
+                                     "mfma_frac": round(flop_per_launch / (kz / max(nkz, 1) * 1e-3) / 1e12 / peak_tf, 4) if kz > 0 else None,
+                                     "note": "NOT the headline: same model with b_dec = 0 (no popularity prior for the threshold "
+                                             "sample to use); same kernels, same exactness"}
+                for c in ctxs:
+                    c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
+                torch.cuda.synchronize()
+        except Exception as e:
+            out["bias_zeros"] = {"error": repr(e)}
+        # (b) batch 1024 on one GPU (the per-GPU batch of BASELINE.json configs[2]), fp32
+        try:
+            if B != 1024:
+                Bb = 1024
+                feeds_b = [make_feed(Bb, 101 + i_)[0] for i_ in range(2)]
+                outs_b = [(torch.empty((Bb, k), dtype=torch.float32, device=dev),
+                           torch.empty((Bb, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
+                cb = [0]
+
+                def step_b():
+                    s_ = cb[0] % n_str
+                    f = feeds_b[cb[0] % len(feeds_b)]
+                    cb[0] += 1
+                    with torch.cuda.stream(streams[s_]):
+                        ctxs[s_].score_topk(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs_b[s_][0],
+                                            outs_b[s_][1], dtype=DT)
+                for _ in range(6):
+                    step_b()
+                torch.cuda.synchronize()
+                for c in ctxs:
+                    c.profile_enable(True)
+                nb_ = max(args.steps // 4, 10)
+                t0 = time.perf_counter()
+                for _ in range(nb_):
+                    step_b()
+                torch.cuda.synchronize()
+                elb = time.perf_counter() - t0
+                kb, nkb = 0.0, 0
+                for c in ctxs:
+                    a_, b_ = c.profile_read()
+                    kb += a_; nkb += b_
+                    c.profile_enable(False)
+                pl = ctx.last_plan()
+                flop_b = 2.0 * Bb * H * (pl["n_filter_tiles"] if pl["fused"] else pl["n_tiles"]) * 32
+                out["batch_1024"] = {"value": round(Bb * nb_ / elb, 1), "unit": "playlists/s",
+                                     "ms_per_step": round(elb / nb_ * 1e3, 4), "steps": nb_, "global_batch": Bb,
+                                     "dominant_kernel_ms": round(kb / max(nkb, 1), 4),
+                                     "mfma_frac": round(flop_b / (kb / max(nkb, 1) * 1e-3) / 1e12 / peak_tf, 4) if kb > 0 else None,
+                                     "note": "NOT the headline: the same fp32 step at 1024 playlists per launch"}
+                del feeds_b, outs_b
+        except Exception as e:
+            out["batch_1024"] = {"error": repr(e)}
 
     # ---- the training step that produces these weights (BASELINE.json configs[3]), NOT part of `value` --------------
     # forward with dropout + weighted-BCE loss + backward + dense TF1-Adam on all four variables, same V / H / batch;

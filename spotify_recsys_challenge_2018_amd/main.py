@@ -3,7 +3,7 @@ the same config.ini schema:
 
     python -m spotify_recsys_challenge_2018_amd.main --dir D {--pretrain|--dae|--challenge} [--testmode]
 
-    [BASE] verbose data_dir result_dir testsize   (+ optional, this build only: train_dtype, decode_dtype = f32 | bf16)
+    [BASE] verbose data_dir result_dir testsize   (+ optional, this build only: train_dtype = f32 | bf16, decode_dtype = f32 | bf16 | exact_bf16)
     [DAE] epochs batch lr reg_lambda hidden test_seed update_seed keep_prob input_kp firstN_range initval save
     [PRETRAIN] epochs batch lr reg_lambda save
     [TITLE] ... (parsed for compatibility; the title models are outside the scoring path)
@@ -71,12 +71,14 @@ class Conf:
         self._load('BASE')
         # two OPTIONAL [BASE] keys this build adds (absent from the reference's files, which then mean fp32):
         #   train_dtype  = f32 | bf16   arithmetic of the training step's three GEMMs (BASELINE.json configs[3])
-        #   decode_dtype = f32 | bf16   arithmetic of the scoring decode (configs[4]); fp32 is the bit-exact path
-        for key in ('train_dtype', 'decode_dtype'):
+        #   decode_dtype = f32 | bf16 | exact_bf16   arithmetic of the scoring decode: fp32 MFMA (bit-exact path), bf16
+        #                  (configs[4]), or the bf16 GEMM as a filter with the survivors recomputed in fp32 (north_star:
+        #                  the fp32 lists, bit for bit)
+        for key, allowed in (('train_dtype', ('f32', 'bf16')), ('decode_dtype', ('f32', 'bf16', 'exact_bf16'))):
             if key in self.ini['BASE']:
                 val = self.ini['BASE'][key].strip().lower()
-                if val not in ('f32', 'bf16'):
-                    raise ValueError("[BASE] %s must be f32 or bf16, not %r" % (key, val))
+                if val not in allowed:
+                    raise ValueError("[BASE] %s must be one of %s, not %r" % (key, ' | '.join(allowed), val))
                 setattr(self, key, val)
 
     def _load(self, section):

@@ -24,6 +24,16 @@ import numpy as np
 from .. import _lib
 
 
+# [BASE] decode_dtype values -> the C ABI's decode arithmetic (include/dae_hip.h)
+_DECODE_DTYPES = {"f32": _lib.DAE_DTYPE_F32, "bf16": _lib.DAE_DTYPE_BF16, "exact_bf16": _lib.DAE_DTYPE_BF16_EXACT}
+
+
+def _title_dtype(dtype):
+    """Title-mixed launches rank a MIXED score, which the exact mode's bound does not cover: they run the fp32 kernels
+    (the lists exact_bf16 promises are the fp32 lists)."""
+    return _lib.DAE_DTYPE_F32 if dtype == _lib.DAE_DTYPE_BF16_EXACT else dtype
+
+
 class _Placeholder:
     """Stands in for a tf.placeholder: only used as a feed_dict key."""
 
@@ -137,11 +147,12 @@ class DAE_tied:
         self.ctx = None
         self._adam = None
         self._step = 0
-        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True, _lib.DAE_DTYPE_BF16_EXACT: True}
         self._packed_cols = {}
-        # decode arithmetic of recommend(): "f32" (bit-exact path) or "bf16" (BASELINE configs[4])
-        self.decode_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "decode_dtype", "f32")) == "bf16" \
-            else _lib.DAE_DTYPE_F32
+        # decode arithmetic of recommend(): "f32" (fp32 MFMA, bit-exact path), "bf16" (BASELINE configs[4]) or
+        # "exact_bf16" (BASELINE north_star: bf16 MFMA filter + fp32 recomputation of the survivors -- the fp32
+        # path's lists, bit for bit, at close to the bf16 rate)
+        self.decode_dtype = _DECODE_DTYPES.get(str(getattr(conf, "decode_dtype", "f32")), _lib.DAE_DTYPE_F32)
         # arithmetic of the training forward GEMM: "f32" (default) or "bf16" (BASELINE configs[3]: bf16 operands,
         # fp32 accumulate; loss, backward GEMMs, parameters and Adam stay fp32)
         self.train_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "train_dtype", "f32")) == "bf16" \
@@ -272,7 +283,7 @@ class DAE_tied:
 
     def _mark_dirty(self):
         """The packed decoder images of the context(s) no longer hold the current weights."""
-        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True}
+        self._packed_dirty = {_lib.DAE_DTYPE_F32: True, _lib.DAE_DTYPE_BF16: True, _lib.DAE_DTYPE_BF16_EXACT: True}
         self._packed_cols = {}
         self._weights_gen = self.__dict__.get("_weights_gen", 0) + 1
 
@@ -368,6 +379,13 @@ class DAE_tied:
             self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], cols[0], cols[1], dtype)
             self._packed_dirty[dtype] = False
             self._packed_cols[dtype] = cols
+            # "bf16" and "exact_bf16" share the context's bf16 image: the exact prepack serves both, a plain bf16
+            # prepack drops the bounds the exact mode needs
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT:
+                self._packed_dirty[_lib.DAE_DTYPE_BF16] = False
+                self._packed_cols[_lib.DAE_DTYPE_BF16] = cols
+            elif dtype == _lib.DAE_DTYPE_BF16:
+                self._packed_dirty[_lib.DAE_DTYPE_BF16_EXACT] = True
 
     def encode(self, x_positions, x_ones, keep_prob=1.0, input_keep_prob=1.0, seed=0):
         """DAEs.py:40-42 + :64-70 -> hidden [n_batch, n_hidden] (torch CUDA tensor)."""
@@ -393,8 +411,13 @@ class DAE_tied:
         return res
 
     def _dtype_of(self, dtype):
-        return self.decode_dtype if dtype is None else (
-            _lib.DAE_DTYPE_BF16 if dtype in ("bf16", _lib.DAE_DTYPE_BF16) else _lib.DAE_DTYPE_F32)
+        if dtype is None:
+            return self.decode_dtype
+        if dtype in _DECODE_DTYPES:
+            return _DECODE_DTYPES[dtype]
+        if dtype in _DECODE_DTYPES.values():
+            return int(dtype)
+        raise ValueError("decode dtype %r: one of %s" % (dtype, sorted(_DECODE_DTYPES)))
 
     def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None):
         """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
@@ -472,7 +495,9 @@ class DAE_tied:
         dtype = self._dtype_of(dtype)
         self._ensure_packed(dtype)
         if getattr(self, "title_model", None) is not None:
-            self.title_model._ensure_packed(dtype)
+            self.title_model._ensure_packed(_title_dtype(dtype))
+            if _title_dtype(dtype) != dtype:
+                self._ensure_packed(_title_dtype(dtype))     # titled launches of an exact_bf16 model run the fp32 kernels
         self.ctx.bind_stream()
         fs = self.__dict__.get("_fetch_stream")
         if fs is None:
@@ -622,6 +647,10 @@ class DAE_tied:
             with torch.cuda.stream(s2):
                 ctx2.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0, self.n_input, dtype)
             st["packed"][dtype] = gen
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT:          # one bf16 image per context: see _ensure_packed
+                st["packed"][_lib.DAE_DTYPE_BF16] = gen
+            elif dtype == _lib.DAE_DTYPE_BF16:
+                st["packed"].pop(_lib.DAE_DTYPE_BF16_EXACT, None)
         gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
         e0, e1 = st["ev"]
         import ctypes
@@ -901,6 +930,7 @@ class DAE_title(DAE):
         import torch
         tm = self.title_model
         tm.ctx.bind_stream()
+        dtype = _title_dtype(dtype)
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
         csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
@@ -933,7 +963,7 @@ class DAE_title(DAE):
         if self._score_shard is not None:
             raise _lib.DaeError("title-mixed batches are not vocabulary-sharded: run --challenge with titles on one "
                                 "GPU per process group (playlist partitioning), or without the title variables")
-        dtype = self._dtype_of(dtype)
+        dtype = _title_dtype(self._dtype_of(dtype))
         self._ensure_packed(dtype)
         self.title_model._ensure_packed(dtype)
         self.ctx.bind_stream()

@@ -31,7 +31,8 @@ def _dev(a):
 
 
 @pytest.mark.parametrize("dtype,world,B", [(_lib.DAE_DTYPE_F32, 4, 1024), (_lib.DAE_DTYPE_BF16, 4, 1024),
-                                           (_lib.DAE_DTYPE_F32, 8, 512), (_lib.DAE_DTYPE_F32, 8, 2048)])     # 2048 rows: the wave-per-row threshold kernel
+                                           (_lib.DAE_DTYPE_F32, 8, 512), (_lib.DAE_DTYPE_F32, 8, 2048),     # 2048 rows: the wave-per-row threshold kernel
+                                           (_lib.DAE_DTYPE_BF16_EXACT, 4, 1024), (_lib.DAE_DTYPE_BF16_EXACT, 8, 512)])
 def test_shard_contexts_full_size_equal_unsharded(dtype, world, B):
     import torch
     V, nt, H, k = 170000, 140000, 256, 500
@@ -45,6 +46,11 @@ def test_shard_contexts_full_size_equal_unsharded(dtype, world, B):
     full.prepack_decoder(d_Wd, d_bd, 0, V, dtype=dtype)
     s0 = torch.empty((B, k), device="cuda"); i0 = torch.empty((B, k), dtype=torch.int32, device="cuda")
     full.score_topk(feed[0], feed[1], feed[2], d_We, d_be, nt, feed[3], feed[4], k, s0, i0, dtype=dtype)
+    if dtype == _lib.DAE_DTYPE_BF16_EXACT:       # the exact mode's lists ARE the fp32 path's lists
+        full.prepack_decoder(d_Wd, d_bd, 0, V)
+        s32 = torch.empty_like(s0); i32 = torch.empty_like(i0)
+        full.score_topk(feed[0], feed[1], feed[2], d_We, d_be, nt, feed[3], feed[4], k, s32, i32)
+        assert torch.equal(i0, i32) and torch.equal(s0.view(torch.int32), s32.view(torch.int32))
     ctxs, stages = [], []
     for lo, hi in all_shard_bounds(V, world):
         c = _lib.Context(0)

@@ -13,7 +13,7 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype,B", [("f32", 256), ("bf16", 256), ("f32", 150), ("f32", 250)])
+@pytest.mark.parametrize("dtype,B", [("f32", 256), ("bf16", 256), ("f32", 150), ("f32", 250), ("exact_bf16", 256), ("exact_bf16", 150)])
 def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
     """7 feeds (short ones among them) through the streamed loop: coalesced 4 or 5 to a launch (256 / 250 -> 4, the
     reference's challenge batch of 150 -> 5), launches alternating between two contexts."""
@@ -32,6 +32,10 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
     rows = [B, B, 100, B, 1, B, 37]                                                # short last batches of a file
     assert m._coalesce_count() == {256: 4, 250: 4, 150: 5}[B]
     want = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
+    if dtype == "exact_bf16":                     # north_star: the fp32 path's lists, indices and scores, bit for bit
+        for (p, o, s), n, (wi, ws) in zip(batches, rows, want):
+            fi, fs = m.recommend(p, o, s, k=k, n_rows=n, dtype="f32")
+            assert np.array_equal(fi, wi) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
     feeds = [(p, o, SEEDS_FROM_INPUT, n) for (p, o, _s), n in zip(batches, rows)]
     got = list(m.recommend_iter(feeds, k=k, dtype=dtype))
     assert len(got) == len(want) and len(m._scoring_lanes(m._dtype_of(dtype))) == 2
