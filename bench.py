@@ -302,7 +302,7 @@ def main():
 
     from spotify_recsys_challenge_2018_amd import _lib
     from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
-    from spotify_recsys_challenge_2018_amd.sharding import HipRankStages, ShardedRanker, shard_bounds
+    from spotify_recsys_challenge_2018_amd.sharding import HipRankStages, ShardedRanker, prepack_scoring_shard, scoring_shard
     from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 
     n_tracks, V, H, k = args.n_tracks, args.n_tracks + args.n_artists, args.hidden, args.k
@@ -333,23 +333,34 @@ def main():
     mean_nnz = float(np.mean([int(f_[1].numel()) for f_ in feeds])) / B
     d_We, d_be = up(W_enc, torch.float32), up(b_enc, torch.float32)
     d_rp, d_col, d_val, d_srp, d_sc = feeds[0]
-    col_lo, col_hi = shard_bounds(V, sim, args.sim_rank) if sim else shard_bounds(V, world, rank)
+    # N > 1: this rank's equal slice of the track columns and of the artist columns (sharding.scoring_shard); N = 1: all
+    shard = scoring_shard(n_tracks, V, sim, args.sim_rank) if sim else scoring_shard(n_tracks, V, world, rank)
+    col_lo, col_hi = 0, V
+    rank_bound = shard[0][1] if sharded else n_tracks
+    shard_rows = []
+
+    def prepack_ctx(c, dt):
+        if sharded:
+            shard_rows.append(prepack_scoring_shard(c, d_Wd_all, d_bd, shard, dt)[1])
+        else:
+            c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
     n_str = args.streams if args.streams > 0 else (3 if args.dtype == "bf16" else 2)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     ctx = ctxs[0]
     d_Wd, d_bd = up(W_dec, torch.float32), up(b_dec, torch.float32)
+    d_Wd_all = d_Wd
     DT = _lib.DAE_DTYPE_BF16 if args.dtype == "bf16" else _lib.DAE_DTYPE_F32
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
+    prepack_ctx(ctx, DT)
     torch.cuda.synchronize()
     prepack_ms = (time.perf_counter() - t0) * 1e3
     for c in ctxs[1:]:
-        c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=DT)
+        prepack_ctx(c, DT)
     torch.cuda.synchronize()
     if sharded:
-        del d_Wd            # a shard owner only keeps its packed slice
+        del d_Wd, d_Wd_all  # a shard owner only keeps its own rows (one copy per context) and their packed image
     h = torch.empty((B, H), dtype=torch.float32, device=dev)
     outs = [(torch.empty((B, k), dtype=torch.float32, device=dev),
              torch.empty((B, k), dtype=torch.int32, device=dev)) for _ in range(n_str)]
@@ -363,7 +374,7 @@ def main():
         for ex in ("alltoall", "allgather"):
             rankers[ex] = []
             for c in ctxs:
-                st = HipRankStages(c, d_We, d_be, n_tracks, DT)
+                st = HipRankStages(c, d_We, d_be, rank_bound, DT)
                 rows = B if ex == "alltoall" else world * B
                 bufs = (torch.empty((rows, k), dtype=torch.float32, device=dev),
                         torch.empty((rows, k), dtype=torch.int32, device=dev))
@@ -754,8 +765,9 @@ def main():
         el_r = float(t.item())
         # same rows, same model: the two partitionings must agree bit for bit (the shard images first: the timed loop
         # above ran on the whole decoder)
+        del shard_rows[:]
         for c in ctxs:
-            c.prepack_decoder(d_Wd_full, d_bd, col_lo, col_hi, dtype=DT)
+            shard_rows.append(prepack_scoring_shard(c, d_Wd_full, d_bd, shard, DT)[1])
         torch.cuda.synchronize()
         score_batch0()
         got = last[0] if exchange[0] == "alltoall" else (last[0][0][r0:r0 + bpg], last[0][1][r0:r0 + bpg])

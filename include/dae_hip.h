@@ -187,6 +187,26 @@ int dae_score_topk(dae_ctx* ctx,
                    int k, int out_kind,
                    float* out_score, int32_t* out_idx);
 
+/* dae_score_topk in two halves, for vocabulary-sharded scoring with a THRESHOLD EXCHANGE between them:
+ *   begin:  encode + the threshold sample of this image's columns -> tau_out[B] (device): per row a valid lower bound
+ *           of the k-th largest rankable non-seed logit among THIS image's columns (-inf when the image is small enough
+ *           to be ranked densely).  The k-th largest logit over ALL shards is at least every shard's bound, so the
+ *           element-wise MAXIMUM of the shards' tau_out (one all-gather of 4 B per row and rank) is a valid -- and far
+ *           tighter -- threshold for every shard.
+ *   finish: the filter launch with `tau` (tau_out, or that maximum), the selection: out_score / out_idx hold the image's
+ *           columns with logit >= tau in rank order, at most k, padded with (-inf, -1): merged over the shards
+ *           (dae_topk_merge) they give exactly what the unsharded call returns.
+ * One begin / finish pair at a time per context, same stream, 1 <= B <= 4096; seed_row_ptr of finish is the one
+ * begin was given.  Replaces the same graph section as dae_score_topk (main_challenge.py:80-90, one batch). */
+int dae_score_topk_begin(dae_ctx* ctx,
+                         const int32_t* row_ptr, const int32_t* col, const float* val,
+                         const float* W_enc, const float* b_enc,
+                         int V, int H, int B, int dtype, int n_tracks,
+                         const int32_t* seed_row_ptr, int k, float* tau_out);
+int dae_score_topk_finish(dae_ctx* ctx, const float* tau,
+                          const int32_t* seed_row_ptr, const int32_t* seed_col,
+                          int out_kind, float* out_score, int32_t* out_idx);
+
 /* Unfused ranking of caller-provided dense logits/scores [B, ld] whose column 0 is global
  * column `col_base`; ranks columns [0, ncols).  Same order/seed rules as dae_decode_topk.
  * (parity path: dae_decode_dense + dae_topk_dense must equal dae_decode_topk.) */

@@ -16,7 +16,7 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
     "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_exact_bounds", "dae_decode_dense", "dae_decode_topk",
-    "dae_score_topk", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
+    "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
@@ -69,6 +69,8 @@ def load():
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_score_topk.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp,
                                    c_int, c_int, vp, vp]
+    lib.dae_score_topk_begin.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp]
+    lib.dae_score_topk_finish.argtypes = [vp, vp, vp, vp, c_int, vp, vp]
     lib.dae_topk_dense.argtypes = [vp, vp, c_i64, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_topk_merge.argtypes = [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]
     lib.dae_set_train_dtype.argtypes = [vp, c_int]
@@ -194,6 +196,17 @@ class Context:
         self.check(self.lib.dae_prepack_decoder(self.h, _ptr(W_dec), _ptr(b_dec), V, H,
                                                 int(col_lo), int(col_hi), int(dtype)))
 
+    def prepack_decoder_rows(self, W_rows, b_rows, col_lo, dtype=DAE_DTYPE_F32):
+        """Prepack a decoder image from a RANK-LOCAL copy of its rows: W_rows [n, H] / b_rows [n] hold the global
+        columns col_lo .. col_lo + n.  (dae_prepack_decoder indexes its arguments by global column: the pointers are
+        shifted back by col_lo rows, so that row col_lo of the argument is row 0 of the copy; nothing below col_lo is
+        ever read.)"""
+        n, H = W_rows.shape
+        assert W_rows.is_contiguous() and b_rows.is_contiguous() and b_rows.numel() == n
+        wp = ctypes.c_void_p(W_rows.data_ptr() - int(col_lo) * H * 4)
+        bp = ctypes.c_void_p(b_rows.data_ptr() - int(col_lo) * 4)
+        self.check(self.lib.dae_prepack_decoder(self.h, wp, bp, int(col_lo) + n, H, int(col_lo), int(col_lo) + n, int(dtype)))
+
     def exact_bounds(self, eps_out):
         """Per-column bounds |fp32 logit - bf16 logit| <= eps of the image prepacked with DAE_DTYPE_BF16_EXACT."""
         self.check(self.lib.dae_exact_bounds(self.h, _ptr(eps_out)))
@@ -219,6 +232,19 @@ class Context:
                                            _ptr(W_enc), _ptr(b_enc), V, H, B, int(dtype),
                                            int(n_tracks), _ptr(seed_row_ptr), _ptr(seed_col),
                                            int(k), int(out_kind), _ptr(out_score), _ptr(out_idx)))
+
+    def score_topk_begin(self, row_ptr, col, val, W_enc, b_enc, n_tracks, seed_row_ptr, k, tau_out, dtype=DAE_DTYPE_F32):
+        """First half of score_topk: encode + threshold sample -> tau_out [B] (this image's per-row lower bounds)."""
+        V, H = W_enc.shape
+        B = row_ptr.numel() - 1
+        self.check(self.lib.dae_score_topk_begin(self.h, _ptr(row_ptr), _ptr(col), _ptr(val), _ptr(W_enc), _ptr(b_enc),
+                                                 V, H, B, int(dtype), int(n_tracks), _ptr(seed_row_ptr), int(k),
+                                                 _ptr(tau_out)))
+
+    def score_topk_finish(self, tau, seed_row_ptr, seed_col, out_score, out_idx, out_kind=DAE_OUT_SCORE):
+        """Second half: filter with `tau` [B] (the own bounds or the maximum over the shards) + selection."""
+        self.check(self.lib.dae_score_topk_finish(self.h, _ptr(tau), _ptr(seed_row_ptr), _ptr(seed_col), int(out_kind),
+                                                  _ptr(out_score), _ptr(out_idx)))
 
     def topk_dense(self, logits, ncols, col_base, seed_row_ptr, seed_col, k, out_score, out_idx,
                    out_kind=DAE_OUT_SCORE):

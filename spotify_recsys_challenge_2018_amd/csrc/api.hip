@@ -196,6 +196,12 @@ int dae_profile_read(dae_ctx* ctx, double* ms_total, int* launches)
 const char* dae_profile_kernel(const dae_ctx* ctx) { return ctx ? ctx->prof_kernel.c_str() : ""; }
 
 namespace {
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* dst, int n, float v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks)
 {
     if (threadIdx.x != 0) return;
@@ -326,15 +332,20 @@ static long long geom_key(int B, int H, int R_TILE)
     return ((long long)B << 32) | ((long long)H << 12) | (long long)R_TILE;
 }
 
-// decode + rank with the hidden tile already packed in ctx->h_packed for geometry g
+// ---- decode + rank with the hidden tile already packed in the context for geometry g, in two halves -----------------
+// topk_phase_a: the plan, the threshold sample (phase A) and tau_select -> tau_dst[B] (a valid lower bound, per row, of
+//   the k-th largest rankable non-seed logit among THIS image's columns); small problems: the dense logits, tau = -inf.
+// topk_phase_b: the filter launch with tau_src[B] (the same values, or larger ones that are still lower bounds of the
+//   row's k-th largest logit over ALL shards: dae_score_topk_finish), the exact mode's refine step, the final selection.
+// What phase B needs from phase A travels in ctx->tk.
 // dtype_in == DAE_DTYPE_BF16_EXACT: h32 = the fp32 hidden rows [B][H] the packed bf16 image was rounded from,
 // row_bad (nullable) = rows of h32 outside [0, 1]
-static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B,
-                            int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                            int k, int out_kind, float* out_score, int32_t* out_idx, int dtype_in,
-                            const float* h32 = nullptr, const int* row_bad = nullptr)
+static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B, int n_tracks,
+                        const int32_t* seed_row_ptr, int k, int dtype_in, float* tau_dst)
 {
     int rc;
+    dae_topk_state& tk = ctx->tk;
+    tk.valid = false;
     const bool exact = dtype_in == DAE_DTYPE_BF16_EXACT;
     const int dtype = exact ? DAE_DTYPE_BF16 : dtype_in;          // the arithmetic of the GEMM launches
     const int ntiles = pk->ntiles;
@@ -360,12 +371,6 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     const int n_other = ntiles - n_samp;
     g_plan = Plan{g.R_TILE, g.n_rg, g.nb_rg, fused ? S : 1, n_samp, n_other, fused ? 1 : 0, ntiles};
 
-    dae_topk_args ta;
-    memset(&ta, 0, sizeof(ta));
-    ta.B = B; ta.k = k;
-    ta.bitmap_base = pk->col_lo; ta.bitmap_n = nrank;
-    ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
-
     // phase A (or the whole problem when it is small): dense logits of the sampled tiles
     const int64_t ld_s = (int64_t)n_samp * 32;
     rc = dae_reserve(ctx, ctx->sample, (size_t)B * ld_s * sizeof(float));
@@ -389,7 +394,6 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     if (gmax_per_wave) ld_g *= g.waves;
     const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
     if (mixed && exact) return dae_fail(ctx, DAE_ERR_ARG, "DAE_DTYPE_BF16_EXACT is not available with dae_set_score_mix");
-    if (mixed) out_kind = DAE_OUT_LOGIT;                   // ... which is a probability already: it goes out as it is
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
         if (rc) return rc;
@@ -403,7 +407,7 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
     // exact mode (DAE_DTYPE_BF16_EXACT): always so, on BOUNDS -- phase A decodes with the bias b - eps (its maxima are
     // lower bounds of fp32 logits, so tau is a valid threshold for the fp32 ranking), the filter launch with b + eps
-    // (nothing whose fp32 logit reaches tau is dropped), and the final selection recomputes every survivor in fp32
+    // (nothing whose fp32 logit reaches tau is dropped), and the refine step recomputes every survivor in fp32
     const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && ((!gmax_per_wave && !mixed && !no_whole) || exact);
     if (whole_b) g_plan.n_other = ntiles;
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
@@ -412,54 +416,81 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
 
-    dae_dense_src ds{sample, ld_s, (int)ld_s, pk->col_lo, 1, fused ? order : nullptr};
-    if (!fused) {
-        ta.out_kind = out_kind; ta.out_score = out_score; ta.out_idx = out_idx;
-        return dae_launch_topk_dense(ctx, ds, ta);
+    tk.pk = pk; tk.g = g; tk.B = B; tk.k = k; tk.dtype = dtype; tk.exact = exact; tk.fused = fused; tk.mixed = mixed;
+    tk.whole_b = whole_b; tk.S = S; tk.n_samp = n_samp; tk.n_other = n_other; tk.n_valid_col = n_valid_col; tk.nrank = nrank;
+    tk.ld_s = ld_s; tk.order = order; tk.sample_cnt = nullptr;
+    if (!fused) {                                          // phase B ranks the dense rows; no threshold exists
+        if (tau_dst) {
+            // (-inf: 0xFF800000 is not a byte pattern hipMemset can write)
+            hipLaunchKernelGGL(fill_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, tau_dst, B, -__builtin_inff());
+            DAE_CHECK_LAUNCH(ctx, "fill_f32_kernel");
+        }
+        tk.valid = true;
+        return DAE_OK;
     }
 
     // tau: the (k + n_seeds)-th largest of the sample's group maxima (written by the phase-A launch: the maximum
     // over the tiles a workgroup decodes together, per position in the tile) -- a valid lower bound of the row's k-th
     // largest rankable non-seed logit -- and, from the same launch, the sample logits >= tau as one flat list per row.
     // No selection over the 15 k dense sample logits of a row happens any more.
-    rc = dae_reserve(ctx, ctx->tau, (size_t)g.Bpad * sizeof(float));
-    if (rc) return rc;
     const int64_t pstride = ld_s;                          // worst case (tau = -inf): every sample logit survives
     rc = dae_reserve(ctx, ctx->sample_top, ((size_t)g.Bpad * pstride) * sizeof(uint2) + (size_t)g.Bpad * sizeof(int));
     if (rc) return rc;
-    int* sample_cnt = reinterpret_cast<int*>(static_cast<uint2*>(ctx->sample_top.p) + (size_t)g.Bpad * pstride);
+    tk.sample_cnt = reinterpret_cast<int*>(static_cast<uint2*>(ctx->sample_top.p) + (size_t)g.Bpad * pstride);
     rc = dae_launch_tau_select(ctx, gmax, ld_g, (int)ld_g, whole_b ? gmax : sample, whole_b ? 0 : ld_s,
                                whole_b ? 0 : (int)ld_s, order, pk->col_lo, B, k,
-                               seed_row_ptr, static_cast<float*>(ctx->tau.p), static_cast<uint2*>(ctx->sample_top.p),
-                               pstride, sample_cnt);
+                               seed_row_ptr, tau_dst, static_cast<uint2*>(ctx->sample_top.p),
+                               pstride, tk.sample_cnt);
     if (rc) return rc;
+    tk.valid = true;
+    return DAE_OK;
+}
+
+static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                        int out_kind, float* out_score, int32_t* out_idx, const float* h32, const int* row_bad)
+{
+    int rc;
+    dae_topk_state& tk = ctx->tk;
+    if (!tk.valid) return dae_fail(ctx, DAE_ERR_STATE, "no scoring call in progress on this context");
+    tk.valid = false;
+    const dae_packed* pk = tk.pk;
+    const dae_rowgeom& g = tk.g;
+    const int B = tk.B, k = tk.k, dtype = tk.dtype;
+    if (tk.mixed) out_kind = DAE_OUT_LOGIT;                // the mixed score is a probability already: it goes out as it is
+    dae_topk_args ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.B = B; ta.k = k;
+    ta.bitmap_base = pk->col_lo; ta.bitmap_n = tk.nrank;
+    ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
+    ta.out_kind = out_kind; ta.out_score = out_score; ta.out_idx = out_idx;
+    if (!tk.fused) {
+        dae_dense_src ds{static_cast<const float*>(ctx->sample.p), tk.ld_s, (int)tk.ld_s, pk->col_lo, 1, nullptr};
+        return dae_launch_topk_dense(ctx, ds, ta);
+    }
 
     // phase B: everything else through the threshold filter
-    const int n_filter = whole_b ? ntiles : n_other;
-    const int cap = dae_filter_block_tiles(g, n_filter, dtype, pk->Hp, mixed) * 32;    // worst case: everything passes
+    const int n_filter = tk.whole_b ? pk->ntiles : tk.n_other;
+    const int cap = dae_filter_block_tiles(g, n_filter, dtype, pk->Hp, tk.mixed) * 32;    // worst case: everything passes
     rc = dae_reserve(ctx, ctx->cand, (size_t)g.nb_rg * g.Bpad * cap * sizeof(uint2));
     if (rc) return rc;
     rc = dae_reserve(ctx, ctx->cand_cnt, (size_t)g.nb_rg * g.Bpad * sizeof(int));
     if (rc) return rc;
-    dae_tileset tsB{n_filter, S, 3, whole_b ? order : order + n_samp};
+    dae_tileset tsB{n_filter, tk.S, 3, tk.whole_b ? tk.order : tk.order + tk.n_samp};
     // dae_set_decode_gate: the dominant launch takes every CU, so two of them in flight on two streams only queue
     // behind each other; the gate makes this one wait for the other context's and announces its own end
     if (ctx->gate_wait) DAE_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->gate_wait, 0));
     rc = prof_begin(ctx); if (rc) return rc;
-    rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, static_cast<const float*>(ctx->tau.p),
-                                      n_valid_col, static_cast<uint2*>(ctx->cand.p),
-                                      static_cast<int*>(ctx->cand_cnt.p), cap, dtype, exact ? 2 : 0);
+    rc = dae_launch_decode_filter_f32(ctx, g, B, tsB, tau_src, tk.n_valid_col, static_cast<uint2*>(ctx->cand.p),
+                                      static_cast<int*>(ctx->cand_cnt.p), cap, dtype, tk.exact ? 2 : 0);
     if (rc) return rc;
     rc = prof_end(ctx); if (rc) return rc;
     if (ctx->gate_record) DAE_HIP_CHECK(ctx, hipEventRecord(ctx->gate_record, ctx->stream));
 
     // final: exact top-k of (sample survivors) U (phase-B survivors), seeds removed
-    dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), sample_cnt, 0, pstride, 0, 1, 0};
+    dae_pair_group g0{static_cast<const uint2*>(ctx->sample_top.p), tk.sample_cnt, 0, tk.ld_s, 0, 1, 0};
     dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
-    ta.out_kind = out_kind; ta.out_pairs = nullptr; ta.out_tau = nullptr;
-    ta.out_score = out_score; ta.out_idx = out_idx;
-    if (exact) {
+    if (tk.exact) {
         dae_exact_src xs{h32, (int64_t)pk->H, pk->H, static_cast<const float*>(pk->W32.p),
                          static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad,
                          static_cast<const float*>(pk->eps.p) + (size_t)pk->ntiles * 32};
@@ -467,6 +498,19 @@ static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeo
         if (rc) return rc;
     }
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
+}
+
+static int decode_topk_core(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g, int B,
+                            int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                            int k, int out_kind, float* out_score, int32_t* out_idx, int dtype_in,
+                            const float* h32 = nullptr, const int* row_bad = nullptr)
+{
+    int rc = dae_reserve(ctx, ctx->tau, (size_t)g.Bpad * sizeof(float));
+    if (rc) return rc;
+    rc = topk_phase_a(ctx, pk, g, B, n_tracks, seed_row_ptr, k, dtype_in, static_cast<float*>(ctx->tau.p));
+    if (rc) return rc;
+    return topk_phase_b(ctx, static_cast<const float*>(ctx->tau.p), seed_row_ptr, seed_col, out_kind, out_score, out_idx,
+                        h32, row_bad);
 }
 
 static int check_topk_args(dae_ctx* ctx, int dtype, int k, const int32_t* seed_row_ptr,
@@ -542,21 +586,19 @@ static int decode_topk_slab(dae_ctx* ctx, const float* h, int B, int H, int dtyp
                             out_score, out_idx, dtype, h, static_cast<const int*>(ctx->row_bad.p));
 }
 
-static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
-                           const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
-                           int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                           int k, int out_kind, float* out_score, int32_t* out_idx)
+// encode a slab's rows straight into the packed hidden image of `dtype` (+ the fp32 rows in the exact mode)
+static int score_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                        const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                        const dae_packed** pk_out, dae_rowgeom* g_out, const float** h32_out)
 {
-    if (!ctx) return DAE_ERR_ARG;
     if (!row_ptr || !W_enc || !b_enc) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
     if (H <= 0 || (H % 4) != 0) return dae_fail(ctx, DAE_ERR_ARG, "H=%d must be a positive multiple of 4", H);
     if ((reinterpret_cast<uintptr_t>(W_enc) | reinterpret_cast<uintptr_t>(b_enc)) % 16)
         return dae_fail(ctx, DAE_ERR_ARG, "W_enc, b_enc must be 16-byte aligned");
-    int rc = check_topk_args(ctx, dtype, k, seed_row_ptr, seed_col, out_score, out_idx);
-    if (rc) return rc;
     const dae_packed* pk = packed_for(ctx, dtype, H);
     if (!pk) return DAE_ERR_STATE;
-    if (B <= 0) return DAE_OK;
+    *pk_out = pk; *h32_out = nullptr;
+    int rc;
     if (dtype != DAE_DTYPE_F32) {
         // encode stays fp32 (north_star: bf16 decode GEMM + fp32 encode / top-k); the hidden rows leave the encode
         // kernel rounded to bf16, already in the MFMA operand order (no [B,H] round trip, no re-tiling launch)
@@ -583,8 +625,8 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
         rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, h32, nullptr, 0, RB16,
                                nullptr, nullptr, static_cast<unsigned short*>(ctx->h_packed16.p), NS);
         if (rc) return rc;
-        return decode_topk_core(ctx, pk, g16, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                                out_score, out_idx, dtype, h32, nullptr);
+        *g_out = g16; *h32_out = h32;
+        return DAE_OK;
     }
     const dae_rowgeom g = dae_row_geometry(B, pk->Hp);
     const int G = pk->Hp / DAE_KG, RB = g.R_TILE / 32;
@@ -601,8 +643,53 @@ static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* 
     rc = dae_launch_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0U, nullptr,
                            static_cast<float*>(ctx->h_packed.p), G, RB);
     if (rc) return rc;
+    *g_out = g;
+    return DAE_OK;
+}
+
+static int score_topk_slab(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                           const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                           int n_tracks, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                           int k, int out_kind, float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    int rc = check_topk_args(ctx, dtype, k, seed_row_ptr, seed_col, out_score, out_idx);
+    if (rc) return rc;
+    if (B <= 0) return packed_for(ctx, dtype, H) ? DAE_OK : DAE_ERR_STATE;
+    const dae_packed* pk; dae_rowgeom g; const float* h32;
+    rc = score_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, dtype, &pk, &g, &h32);
+    if (rc) return rc;
     return decode_topk_core(ctx, pk, g, B, n_tracks, seed_row_ptr, seed_col, k, out_kind,
-                            out_score, out_idx, dtype);
+                            out_score, out_idx, dtype, h32, nullptr);
+}
+
+int dae_score_topk_begin(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val,
+                         const float* W_enc, const float* b_enc, int V, int H, int B, int dtype,
+                         int n_tracks, const int32_t* seed_row_ptr, int k, float* tau_out)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!tau_out) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (!known_dtype(dtype)) return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
+    if (k < 1 || k > DAE_MAX_K) return dae_fail(ctx, DAE_ERR_ARG, "k=%d out of [1,%d]", k, DAE_MAX_K);
+    if (B < 1 || B > DAE_ROW_SLAB) return dae_fail(ctx, DAE_ERR_ARG, "dae_score_topk_begin takes 1..%d rows (B=%d)", DAE_ROW_SLAB, B);
+    if (ctx->mixT) return dae_fail(ctx, DAE_ERR_ARG, "dae_score_topk_begin is not available with dae_set_score_mix");
+    const dae_packed* pk; dae_rowgeom g; const float* h32;
+    int rc = score_encode(ctx, row_ptr, col, val, W_enc, b_enc, V, H, B, dtype, &pk, &g, &h32);
+    if (rc) return rc;
+    rc = topk_phase_a(ctx, pk, g, B, n_tracks, seed_row_ptr, k, dtype, tau_out);
+    if (rc) return rc;
+    ctx->tk.pend_h32 = h32;
+    return DAE_OK;
+}
+
+int dae_score_topk_finish(dae_ctx* ctx, const float* tau, const int32_t* seed_row_ptr, const int32_t* seed_col,
+                          int out_kind, float* out_score, int32_t* out_idx)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!tau || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
+        return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
+    return topk_phase_b(ctx, tau, seed_row_ptr, seed_col, out_kind, out_score, out_idx, ctx->tk.pend_h32, nullptr);
 }
 
 int dae_decode_mix_term(dae_ctx* ctx, const float* h, int B, int H, int dtype, const float* row_scale, int n_cols,

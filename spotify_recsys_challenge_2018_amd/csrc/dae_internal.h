@@ -53,6 +53,29 @@ struct dae_packed {            // one prepacked decoder image
     dae_buf W32;               // [col_hi - col_lo][H] fp32 row-major
 };
 
+struct dae_rowgeom {        // how B rows are cut into row groups for the decode kernels
+    int R_TILE;             // rows per group: 128, 64 or 32 (LDS-resident h tile)
+    int n_rg;               // ceil(B / R_TILE)
+    int Bpad;               // n_rg * R_TILE
+    int nb_rg;              // thread blocks per row group
+    int grid;               // n_rg * nb_rg
+    int waves;              // waves per workgroup (4 or 8)
+};
+
+struct dae_topk_state {     // what the second half of a fused scoring call needs from the first (api.hip topk_phase_a / _b)
+    bool valid = false;
+    const dae_packed* pk = nullptr;
+    dae_rowgeom g{};
+    int B = 0, k = 0, dtype = 0, S = 0, n_samp = 0, n_other = 0, n_valid_col = 0, nrank = 0;
+    bool exact = false, fused = false, mixed = false, whole_b = false;
+    int64_t ld_s = 0;
+    const int* order = nullptr;
+    int* sample_cnt = nullptr;
+    // dae_score_topk_begin / _finish: arguments of the pending call
+    int pend_H = 0, pend_dtype = 0, pend_n_tracks = 0;
+    const float* pend_h32 = nullptr;
+};
+
 struct dae_ctx {
     int device = 0;
     // per-context (= per-device) one-time setup done so far, e.g. hipFuncSetAttribute of a kernel: a process-wide
@@ -87,6 +110,7 @@ struct dae_ctx {
     int adam_t = 0; float adam_b1 = 0.f, adam_b2 = 0.f, adam_b1p = 1.f, adam_b2p = 1.f;   // running beta powers of dae_adam_alpha
     int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)
     dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
+    dae_topk_state tk;
     dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
 
     // profiling of the dominant kernel
@@ -198,14 +222,6 @@ constexpr uint32_t DAE_KEY_NEG_INF = 0x007FFFFFU;   // dae_okey(-inf): "absent" 
 // ---------------------------------------------------------------------------------------------
 // launchers (each defined next to its kernels)
 // ---------------------------------------------------------------------------------------------
-struct dae_rowgeom {        // how B rows are cut into row groups for the decode kernels
-    int R_TILE;             // rows per group: 128, 64 or 32 (LDS-resident h tile)
-    int n_rg;               // ceil(B / R_TILE)
-    int Bpad;               // n_rg * R_TILE
-    int nb_rg;              // thread blocks per row group
-    int grid;               // n_rg * nb_rg
-    int waves;              // waves per workgroup (4 or 8)
-};
 dae_rowgeom dae_row_geometry(int B, int Hp);
 dae_rowgeom dae_row_geometry_bf16(int B, int Hp);
 int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V, int H,

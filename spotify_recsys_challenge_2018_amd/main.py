@@ -7,7 +7,7 @@ the same config.ini schema:
     [DAE] epochs batch lr reg_lambda hidden test_seed update_seed keep_prob input_kp firstN_range initval save
     [PRETRAIN] epochs batch lr reg_lambda save
     [TITLE] ... (parsed for compatibility; the title models are outside the scoring path)
-    [CHALLENGE] batch challenge_data result   (+ optional, this build only: allow_no_title, shard_exchange)
+    [CHALLENGE] batch challenge_data result   (+ optional, this build only: allow_no_title, shard_exchange, shard_tau_exchange)
 
 Kept on purpose: `[DAE]` is always read first, so --pretrain inherits hidden / keep_prob /
 input_kp / firstN_range / test_seed from it (main.py:121, load-bearing per SURVEY App. A).
@@ -131,11 +131,16 @@ class Conf:
     def set_challenge_oonf(self):          # (sic) the reference's spelling, main.py:88
         os.makedirs(self.result_dir, exist_ok=True)
         sec = self._load('CHALLENGE')
-        # two OPTIONAL [CHALLENGE] keys this build adds (absent from the reference's files):
-        #   allow_no_title = True        score with the plain DAE when <[TITLE] save>.pkl is missing (default: error)
+        # three OPTIONAL [CHALLENGE] keys this build adds (absent from the reference's files):
+        #   allow_no_title = True        score with the plain DAE when <[TITLE] save>.pkl is missing (default: error --
+        #                                the reference fails there too; also an error while any playlist has no seeds)
         #   shard_exchange = allgather | alltoall    under torch.distributed.run: how the per-shard top-500 meet
+        #   shard_tau_exchange = True    ... and the shards' thresholds meet before their filter launches (one more
+        #                                collective of 4 bytes per row and rank; same result)
         if 'allow_no_title' in sec:
             self.allow_no_title = _truth(sec['allow_no_title'])
+        if 'shard_tau_exchange' in sec:
+            self.shard_tau_exchange = _truth(sec['shard_tau_exchange'])
         if 'shard_exchange' in sec:
             val = sec['shard_exchange'].strip().lower()
             if val not in ('allgather', 'alltoall'):

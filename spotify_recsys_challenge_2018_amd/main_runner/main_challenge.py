@@ -104,6 +104,7 @@ def run(conf, model=None):
 
     use_titles = False
     exchange = getattr(conf, 'shard_exchange', 'allgather')
+    tau_x = bool(getattr(conf, 'shard_tau_exchange', False))
     if model is None:
         from ..models.DAEs import DAE, DAE_title
         from ..models.title_models import get_model
@@ -134,16 +135,24 @@ def run(conf, model=None):
         if sharded:
             # optional key of this build, [CHALLENGE] shard_exchange = allgather (default; configs[2] as written:
             # every rank ends with every row) | alltoall (every rank ends with the rows it owns)
-            model.shard_scoring(rank, world, exchange=exchange)
+            model.shard_scoring(rank, world, exchange=exchange, tau_exchange=tau_x)
         model.fit()
     else:
         use_titles = bool(getattr(model, 'title_model', None))
         sharded = world > 1 and not use_titles
         if sharded:
-            model.shard_scoring(rank, world, exchange=exchange)
+            if exchange == 'alltoall' and model.n_batch % world:
+                # shard_scoring can only round n_batch up BEFORE fit(): say so here instead of failing inside it
+                raise ValueError("[CHALLENGE] shard_exchange = alltoall needs the model's batch (%d) to be a multiple of the "
+                                 "world size (%d) when a fitted model is passed in: build the model with such a batch, or "
+                                 "use shard_exchange = allgather" % (model.n_batch, world))
+            try:
+                model.shard_scoring(rank, world, exchange=exchange, tau_exchange=tau_x)
+            except TypeError:                                  # a model object of the older protocol
+                model.shard_scoring(rank, world, exchange=exchange)
     if sharded:
-        log_write(conf, 'vocabulary columns sharded over %d ranks (%s exchange of the per-shard top-500)'
-                  % (world, exchange))
+        log_write(conf, 'vocabulary columns sharded over %d ranks (%s exchange of the per-shard top-500%s)'
+                  % (world, exchange, ', thresholds exchanged first' if tau_x else ''))
     elif world > 1:
         # title-mixed scores are not vocabulary-sharded: the batches are dealt round-robin to the ranks instead
         # (whole model on every GPU, no collective in the data path)

@@ -288,26 +288,28 @@ class DAE_tied:
         self._weights_gen = self.__dict__.get("_weights_gen", 0) + 1
 
     # -- multi-GPU scoring (BASELINE.json configs[2]): vocabulary columns sharded over the ranks ----
-    def shard_scoring(self, rank, world, group=None, exchange="allgather"):
+    def shard_scoring(self, rank, world, group=None, exchange="allgather", tau_exchange=False):
         """`recommend` through sharding.ShardedRanker: this rank decodes and ranks only the vocabulary columns
-        `shard_bounds(n_input, world, rank)` (W_enc is replicated, so every rank computes the same hidden
+        `sharding.scoring_shard(n_tracks, n_input, world, rank)` (W_enc is replicated, so every rank computes the same hidden
         activations with no collective), the per-shard top-k lists meet in ONE exchange (RCCL all-gather, or an
         all-to-all of the rows each rank owns) and are merged with the same key -- exact, since a shard's top-k
         holds its share of the global top-k.  Every rank feeds the same batches.
 
         exchange = "allgather": `recommend` returns all rows on every rank (main_challenge: rank 0 writes).
         exchange = "alltoall":  `recommend` returns the rows this rank owns (`owned_rows()`); n_batch is rounded
-        up to a multiple of the world size (the extra rows are empty)."""
-        from ..sharding import shard_bounds
+        up to a multiple of the world size (the extra rows are empty).
+        tau_exchange: the shards' thresholds meet before the filter launches (one more collective of 4 bytes per row
+        and rank; sharding.ShardedRanker "threshold exchange"): same lists, less selection work per shard."""
+        from ..sharding import scoring_shard
         if exchange not in ("allgather", "alltoall"):
             raise ValueError("unknown exchange %r" % (exchange,))
         if exchange == "alltoall" and self.n_batch % world:
             if self.ctx is not None:
                 raise _lib.DaeError("shard_scoring(alltoall) must round n_batch up before fit()")
             self.n_batch += world - self.n_batch % world
-        lo, hi = shard_bounds(self.n_input, world, rank)
+        shard = scoring_shard(self.n_tracks, self.n_input, world, rank)
         self._score_shard = {"rank": int(rank), "world": int(world), "group": group, "exchange": exchange,
-                             "cols": (lo, hi), "rankers": {}}
+                             "cols": shard, "rank_bound": shard[0][1], "rankers": {}, "tau_exchange": bool(tau_exchange)}
         self._mark_dirty()
 
     def owned_rows(self):
@@ -323,8 +325,10 @@ class DAE_tied:
         sh = self._score_shard
         if dtype not in sh["rankers"]:
             from ..sharding import HipRankStages, ShardedRanker
-            st = HipRankStages(self.ctx, self.weights["encoder_h"], self.biases["encoder_b"], self.n_tracks, dtype)
-            sh["rankers"][dtype] = ShardedRanker(st.local_topk, st.merge, group=sh["group"], exchange=sh["exchange"])
+            # the rank's image holds its track slice under the real ids, then its artist slice: rank only below the bound
+            st = HipRankStages(self.ctx, self.weights["encoder_h"], self.biases["encoder_b"], sh["rank_bound"], dtype)
+            two = dict(local_begin=st.local_begin, local_finish=st.local_finish) if sh.get("tau_exchange") else {}
+            sh["rankers"][dtype] = ShardedRanker(st.local_topk, st.merge, group=sh["group"], exchange=sh["exchange"], **two)
         return sh["rankers"][dtype]
 
     # -- multi-GPU training: rows of W_enc / W_dec / b_dec sharded over the ranks ---------
@@ -373,10 +377,16 @@ class DAE_tied:
         weights.  (A context keeps one image per dtype: a sharded `recommend` and a dense `predict` on the same
         model re-tile when they alternate -- 0.13 ms.)"""
         self.sync_params()
-        cols = (0, self.n_input) if cols is None else (int(cols[0]), int(cols[1]))
+        shard = cols is not None and isinstance(cols[0], (tuple, list))        # sharding.scoring_shard: (tracks, artists)
+        cols = (0, self.n_input) if cols is None else (tuple(map(tuple, cols)) if shard else (int(cols[0]), int(cols[1])))
         if self._packed_dirty[dtype] or self._packed_cols.get(dtype) != cols:
             self.ctx.bind_stream()
-            self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], cols[0], cols[1], dtype)
+            if shard:
+                from ..sharding import prepack_scoring_shard
+                _bound, self._shard_rows = prepack_scoring_shard(self.ctx, self.weights["decoder_h"],
+                                                                 self.biases["decoder_b"], cols, dtype)
+            else:
+                self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], cols[0], cols[1], dtype)
             self._packed_dirty[dtype] = False
             self._packed_cols[dtype] = cols
             # "bf16" and "exact_bf16" share the context's bf16 image: the exact prepack serves both, a plain bf16

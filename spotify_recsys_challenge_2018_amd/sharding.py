@@ -30,6 +30,33 @@ def all_shard_bounds(n_cols, world, align=TILE):
     return [shard_bounds(n_cols, world, g, align) for g in range(world)]
 
 
+def scoring_shard(n_tracks, n_input, world, rank):
+    """The columns rank `rank` of a vocabulary-sharded SCORING job decodes: an equal, tile-aligned slice of the TRACK
+    columns (the only ones that are ranked, main_challenge.py:87) and an equal slice of the artist columns (decoded
+    because the reference decodes every column, DAEs.py:143; never ranked) -> ((t_lo, t_hi), (a_lo, a_hi)).
+    Splitting [0, n_input) as one range (round 2) left the last ranks with artist columns only: same GEMM work, but
+    empty candidate lists there and all of the selection work on the first ranks."""
+    t_lo, t_hi = shard_bounds(n_tracks, world, rank)
+    a_lo, a_hi = shard_bounds(n_input - n_tracks, world, rank)
+    return (t_lo, t_hi), (n_tracks + a_lo, n_tracks + a_hi)
+
+
+def prepack_scoring_shard(ctx, W_dec, b_dec, shard, dtype=0):
+    """Prepack `ctx`'s decoder image with the rows of `shard` (= scoring_shard(...)): the rank keeps ONE contiguous
+    copy [track rows | artist rows] of its part of the decoder (a shard owner holds 1/G of the matrix).  The image's
+    global columns are [t_lo, t_lo + n): the track part under its real ids, the artist part under ids that are never
+    emitted because the rank bound the scoring calls pass is t_hi (the returned value: use it as `n_tracks` in
+    dae_score_topk / HipRankStages).  Seed lists and results stay in GLOBAL track ids.  Returns (rank_bound, keepalive)."""
+    import torch
+    (t_lo, t_hi), (a_lo, a_hi) = shard
+    W_loc = torch.cat([W_dec[t_lo:t_hi], W_dec[a_lo:a_hi]]).contiguous()
+    b_loc = torch.cat([b_dec[t_lo:t_hi], b_dec[a_lo:a_hi]]).contiguous()
+    if W_loc.shape[0] == 0:
+        raise ValueError("empty scoring shard %r" % (shard,))
+    ctx.prepack_decoder_rows(W_loc, b_loc, t_lo, dtype)
+    return t_hi, (W_loc, b_loc)
+
+
 def gather_shard_topk(local_logit, local_idx, group=None, out=None):
     """All-gather the per-shard candidate lists: [B,k] -> [G,B,k] (logit fp32, column int32).
     One collective per tensor; with RCCL over xGMI each rank sends its 2 x B x k x 4 bytes once."""
@@ -101,20 +128,50 @@ class ShardedRanker:
 
     bufs: optional preallocated (logit, idx) receive buffers of the exchange ([G*B,k] for the all-gather, [B,k]
     for the all-to-all), reused by every call.  gather: optional replacement of the collective,
-    `gather(l_logit, l_idx) -> (g_logit [G,rows,k], g_idx)` (single-process tests that hold every shard)."""
+    `gather(l_logit, l_idx) -> (g_logit [G,rows,k], g_idx)` (single-process tests that hold every shard).
 
-    def __init__(self, local_topk, merge, group=None, exchange="allgather", bufs=None, gather=None):
+    THRESHOLD EXCHANGE (optional: `local_begin` / `local_finish` given): a shard alone can only bound the row's k-th
+    largest logit by ITS OWN k-th largest, so it returns k candidates per row although only ~k/G of them can be in the
+    merged list.  `local_begin(feed, k) -> tau [B]` runs the shard's encode + threshold sample (dae_score_topk_begin),
+    the shards' bounds meet in one all-gather of 4 bytes per row and rank (8 KB per rank at 2048 rows), their
+    element-wise maximum -- still a lower bound of the global k-th largest -- goes to `local_finish(feed, k, tau) ->
+    (logit, idx)` (dae_score_topk_finish), and the lists come back holding only what can still matter (padded with
+    -inf / -1): the same merged result, less selection work per shard.  `gather_tau(tau) -> [G, B]` replaces that
+    collective in single-process tests."""
+
+    def __init__(self, local_topk, merge, group=None, exchange="allgather", bufs=None, gather=None,
+                 local_begin=None, local_finish=None, gather_tau=None):
         if exchange not in ("allgather", "alltoall"):
             raise ValueError("unknown exchange %r" % (exchange,))
+        if (local_begin is None) != (local_finish is None):
+            raise ValueError("local_begin and local_finish go together")
         self.local_topk = local_topk
         self.merge = merge
         self.group = group
         self.exchange = exchange
         self.bufs = bufs
         self.gather = gather
+        self.local_begin, self.local_finish, self.gather_tau = local_begin, local_finish, gather_tau
+        self._tau_buf = None
+
+    def _exchange_tau(self, tau):
+        """[B] per-shard lower bounds -> their maximum over the shards (device tensor, [B])."""
+        import torch
+        if self.gather_tau is not None:
+            return torch.amax(self.gather_tau(tau), dim=0)
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        if self._tau_buf is None or self._tau_buf.numel() != world * tau.numel() or self._tau_buf.device != tau.device:
+            self._tau_buf = torch.empty(world * tau.numel(), dtype=tau.dtype, device=tau.device)
+        _collective(dist.all_gather_into_tensor, self._tau_buf, tau.contiguous(), self.group)
+        return torch.amax(self._tau_buf.view(world, -1), dim=0)
 
     def rank_batch(self, feed, k):
-        l_logit, l_idx = self.local_topk(feed, k)
+        if self.local_begin is not None:
+            tau = self._exchange_tau(self.local_begin(feed, k))
+            l_logit, l_idx = self.local_finish(feed, k, tau)
+        else:
+            l_logit, l_idx = self.local_topk(feed, k)
         if self.gather is not None:
             g_logit, g_idx = self.gather(l_logit, l_idx)
         elif self.exchange == "alltoall":
@@ -139,6 +196,7 @@ class HipRankStages:
         self.ctx, self.W_enc, self.b_enc = ctx, W_enc, b_enc
         self.n_tracks, self.dtype, self.out_kind = int(n_tracks), int(dtype), int(out_kind)
         self._loc, self._out = {}, {}
+        self._tau = None
 
     def _pair(self, cache, rows, k):
         import torch
@@ -155,6 +213,24 @@ class HipRankStages:
         logit, idx = self._pair(self._loc, rp.numel() - 1, k)
         self.ctx.score_topk(rp, col, val, self.W_enc, self.b_enc, self.n_tracks, srp, sc, k, logit, idx,
                             out_kind=DAE_OUT_LOGIT, dtype=self.dtype)
+        return logit, idx
+
+    def local_begin(self, feed, k):
+        """dae_score_topk_begin -> this shard's per-row lower bounds of the k-th largest logit, [B] (reused buffer)."""
+        import torch
+        rp, col, val, srp, _sc = feed
+        rows = rp.numel() - 1
+        if self._tau is None or self._tau.numel() != rows:
+            self._tau = torch.empty(rows, dtype=torch.float32, device=self.W_enc.device)
+        self.ctx.score_topk_begin(rp, col, val, self.W_enc, self.b_enc, self.n_tracks, srp, k, self._tau, dtype=self.dtype)
+        return self._tau
+
+    def local_finish(self, feed, k, tau):
+        """dae_score_topk_finish with the exchanged threshold: the shard's columns that can still be in the merged list."""
+        from ._lib import DAE_OUT_LOGIT
+        rp, _col, _val, srp, sc = feed
+        logit, idx = self._pair(self._loc, rp.numel() - 1, k)
+        self.ctx.score_topk_finish(tau, srp, sc, logit, idx, out_kind=DAE_OUT_LOGIT)
         return logit, idx
 
     def merge(self, g_logit, g_idx):

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
-from spotify_recsys_challenge_2018_amd.sharding import ShardedRanker, row_owner_bounds, shard_bounds
+from spotify_recsys_challenge_2018_amd.sharding import ShardedRanker, row_owner_bounds, scoring_shard
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_weights
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -35,8 +35,8 @@ class OracleDAE:
     def shard_scoring(self, rank, world, group=None, exchange="allgather"):
         if exchange == "alltoall" and self.n_batch % world:
             self.n_batch += world - self.n_batch % world
-        lo, hi = shard_bounds(self.n_input, world, rank)
-        self.shard = (rank, world, exchange, lo, min(hi, self.n_tracks))
+        lo, hi = scoring_shard(self.n_tracks, self.n_input, world, rank)[0]      # the rank's slice of the TRACK columns
+        self.shard = (rank, world, exchange, lo, hi)
 
     def owned_rows(self):
         if self.shard is None or self.shard[2] != "alltoall":

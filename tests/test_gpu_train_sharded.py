@@ -225,3 +225,71 @@ def test_sharded_stages_with_bf16_gemms_match_the_unsharded_bf16_step(tied, worl
         err = float((got[k].double() - u[k].double()).norm() / u[k].double().norm())
         assert err <= 1e-3, (k, err)
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_eight_shards_equal_the_unsharded_step(dtype):
+    """BASELINE.json configs[3] "1 and 8 GPUs" at FULL size (V = 170 000, H = 256, B = 256, untied): the three shard
+    stages of all eight vocabulary-row shards (21 250 rows each; shard 7 holds artist rows only) run back to back on
+    the one GPU of the box, the two all-reduces done by hand -- cost, gb_enc and every shard's slice of gW_enc /
+    gW_dec / gb_dec against the unsharded entry point on the same draws (reference step: main_train.py:193-213).
+    fp32: 2e-4 of each tensor's norm (K7's split over vocabulary chunks re-associates); bf16 GEMMs: 1e-3."""
+    import torch
+    V, nt, H, B, world, tied = 170000, 140000, 256, 256, 8, False
+    ctx = _lib.Context(0)
+    if dtype == "bf16":
+        ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    st = HipTrainStages(ctx)
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt, tied=tied)
+    b_enc = (np.random.default_rng(2).standard_normal(H) * 0.1).astype(np.float32)
+    pos, ones, _ = make_playlists(B, nt, V - nt, seed=6)
+    x = tuple(_dev(a) for a in coo_to_csr(pos, ones, B, V))
+    y = tuple(_dev(a) for a in coo_to_csr(pos, np.ones(len(pos), np.float32), B, V))
+    seed, ikp, kp, lam = 977, 0.75, 0.8, 0.0
+    be = _dev(b_enc)
+    d_We, d_Wd, d_bd = _dev(W_enc), _dev(W_dec), _dev(b_dec)
+    bounds = all_shard_bounds(V, world)
+    assert bounds[0] == (0, 21250) and bounds[7][0] >= nt            # shard 7: artist rows only
+    sh = []
+    for lo, hi in bounds:
+        d = dict(lo=lo, hi=hi, We=d_We[lo:hi], bd=d_bd[lo:hi], Wd=d_Wd[lo:hi])        # views: a rank holds just its rows
+        d.update(gWe=torch.zeros((hi - lo, H), device="cuda"), gbd=torch.zeros(hi - lo, device="cuda"),
+                 gWd=torch.zeros((hi - lo, H), device="cuda"), gbe=torch.zeros(H, device="cuda"),
+                 pre=torch.zeros((B, H), device="cuda"), dh=torch.zeros((B, H), device="cuda"),
+                 cost=torch.zeros(1, device="cuda"))
+        sh.append(d)
+    for d in sh:
+        st.encode(x, d["We"], d["lo"], d["hi"], ikp, seed, d["pre"])
+    pre = sum(d["pre"] for d in sh)                                   # all-reduce #1
+    for d in sh:
+        st.decode(pre, be, y, d["We"], d["Wd"], d["bd"], d["lo"], d["hi"], B, tied, kp, seed, lam,
+                  d["gWd"], d["gbd"], d["dh"], d["cost"])
+    dh = sum(d["dh"] for d in sh)                                     # all-reduce #2
+    cost = float(sum(d["cost"] for d in sh).item())
+    for d in sh:
+        st.decode(pre, be, y, d["We"], d["Wd"], d["bd"], d["lo"], d["hi"], B, tied, kp, seed, lam,
+                  d["gWd"], d["gbd"], d["dh"], d["cost"])              # re-establish this shard's scratch (one ctx, many shards)
+        st.finish(dh, x, d["We"], be, d["Wd"], d["bd"], d["lo"], d["hi"], tied, ikp, kp, seed, lam,
+                  d["gWe"], d["gbe"], d["gWd"], d["gbd"])
+    torch.cuda.synchronize()
+    P = _lib._ptr
+    u = dict(We=torch.zeros((V, H), device="cuda"), be=torch.zeros(H, device="cuda"),
+             Wd=torch.zeros((V, H), device="cuda"), bd=torch.zeros(V, device="cuda"))
+    ucost = torch.zeros(1, device="cuda")
+    ctx.check(ctx.lib.dae_train_forward_backward(
+        ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(d_We), P(be), P(d_Wd), P(d_bd),
+        V, H, B, B, 0, float(ikp), float(kp), seed, float(lam), P(u["We"]), P(u["be"]), P(u["Wd"]), P(u["bd"]), P(ucost)))
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == "f32" else 1e-3
+    assert abs(cost - float(ucost.item())) <= (2e-6 if dtype == "f32" else 1e-4) * abs(cost)
+    for d in sh[1:]:
+        assert torch.equal(d["gbe"], sh[0]["gbe"])                   # replicated and identical on every rank
+    err = float((sh[0]["gbe"].double() - u["be"].double()).norm() / u["be"].double().norm())
+    assert err <= tol, ("gb_enc", err)
+    for g, d in enumerate(sh):                                       # every rank's slices, shard 0 and shard 7 included
+        for name, key in (("gWe", "We"), ("gWd", "Wd"), ("gbd", "bd")):
+            ref = u[key][d["lo"]:d["hi"]].double()
+            nrm = float(ref.norm())
+            diff = float((d[name].double() - ref).norm())
+            assert diff <= tol * max(nrm, 1e-30) + 1e-12, (g, name, diff, nrm)
+    ctx.close()

@@ -9,7 +9,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from spotify_recsys_challenge_2018_amd.sharding import ShardedRanker, all_shard_bounds, row_owner_bounds, shard_bounds
+from spotify_recsys_challenge_2018_amd.sharding import (ShardedRanker, all_shard_bounds, row_owner_bounds, scoring_shard,
+                                                        shard_bounds)
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_weights
 
 
@@ -26,6 +27,23 @@ def test_shard_bounds_tile_aligned_partition():
         assert max(sizes) - min(sizes) < 64 or n < 32 * w      # one tile + the ragged last tile
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+def test_scoring_shards_split_tracks_and_artists_evenly():
+    """Every rank ranks an equal, tile-aligned slice of the TRACK columns and decodes an equal slice of the artist
+    columns: no rank is left with artist columns only."""
+    for nt, V, w in [(140000, 170000, 8), (140000, 170000, 4), (2262, 3000, 2), (1000, 1000, 3), (100, 5000, 8)]:
+        sh = [scoring_shard(nt, V, w, g) for g in range(w)]
+        assert sh[0][0][0] == 0 and sh[-1][0][1] == nt and sh[0][1][0] == nt and sh[-1][1][1] == V
+        for g in range(w):
+            (tl, th), (al, ah) = sh[g]
+            assert tl % 32 == 0 or tl == nt
+            assert 0 <= tl <= th <= nt <= al <= ah <= V
+            if g:
+                assert tl == sh[g - 1][0][1] and al == sh[g - 1][1][1]
+        if nt >= 32 * w:
+            sizes = [th - tl for (tl, th), _ in sh]
+            assert min(sizes) > 0 and max(sizes) - min(sizes) < 64
 
 
 def _worker(rank, world, port, q):
@@ -57,6 +75,28 @@ def _worker(rank, world, port, q):
     r0, r1 = row_owner_bounds(B, world, rank)
     ok = ok and i.shape == (r1 - r0, k) and bool(
         np.array_equal(i.numpy(), i0[r0:r1]) and np.array_equal(s.numpy().view(np.uint32), s0[r0:r1].view(np.uint32)))
+
+    # threshold exchange: every shard bounds the row's k-th largest by its OWN k-th largest, the bounds meet in one
+    # all-gather, and each shard then returns only what reaches their maximum (padded) -- same merged lists
+    def local_begin(h_t, kk):
+        s_loc, _ = local_topk(h_t, kk)
+        return s_loc[:, kk - 1].clone()                     # the shard's kk-th largest logit (-inf when it has fewer)
+
+    def local_finish(h_t, kk, tau):
+        s_loc, i_loc = local_topk(h_t, kk)
+        keep = s_loc >= tau[:, None]
+        kept.append(int(keep.sum()))
+        return (torch.where(keep, s_loc, torch.full_like(s_loc, -np.inf)), torch.where(keep, i_loc, torch.full_like(i_loc, -1)))
+    kept = []
+    for ex in ("allgather", "alltoall"):
+        s, i = ShardedRanker(local_topk, merge, exchange=ex, local_begin=local_begin,
+                             local_finish=local_finish).rank_batch(torch.from_numpy(h), k)
+        a, b = (0, B) if ex == "allgather" else (r0, r1)
+        ok = ok and bool(np.array_equal(i.numpy(), i0[a:b]) and np.array_equal(s.numpy().view(np.uint32), s0[a:b].view(np.uint32)))
+    # the two shards together keep barely more than k per row (k + ties), not 2 k
+    tot = torch.tensor([kept[0]], dtype=torch.int64)
+    dist.all_reduce(tot)
+    ok = ok and int(tot.item()) <= B * (k + 8) and int(tot.item()) >= B * k
     q.put((rank, ok))
     dist.destroy_process_group()
 
