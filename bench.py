@@ -68,6 +68,13 @@ def parse():
                          "as written, and what DAE.shard_scoring runs by default): every rank receives and merges all rows; "
                          "alltoall: every rank receives and merges the rows it owns (1/N of the bytes and of the merge).  The "
                          "one not chosen is timed as a labelled extra row")
+    ap.add_argument("--no-tau-exchange", dest="tau_exchange", action="store_false",
+                    help="N > 1: by default the shards' thresholds meet (one all-gather of 4 bytes per row and rank) before "
+                         "their filter launches (sharding.ShardedRanker threshold exchange: the rank holding the popular tracks "
+                         "sets the bar for all, without it the ranks holding the unpopular ones keep ~10x the candidates and "
+                         "run 25 %% longer); this switches it off.  With --sim-world the maximum over ALL shards' thresholds is "
+                         "computed once per resident batch outside the timed region and fed to the simulated rank: compute "
+                         "only, the collective itself is not in the number")
     ap.add_argument("--prime-ms", type=float, default=200.0,
                     help="setup: run the step for this long before the warm-up steps (device ramp; 0 = off)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -378,7 +385,28 @@ def main():
                 rows = B if ex == "alltoall" else world * B
                 bufs = (torch.empty((rows, k), dtype=torch.float32, device=dev),
                         torch.empty((rows, k), dtype=torch.int32, device=dev))
-                rankers[ex].append(ShardedRanker(st.local_topk, st.merge, exchange=ex, bufs=bufs))
+                two = {}
+                if args.tau_exchange:
+                    two = dict(local_begin=st.local_begin, local_finish=st.local_finish)
+                    if sim:                  # the other shards' thresholds: precomputed per resident batch (sim_taus below)
+                        two["gather_tau"] = (lambda t: sim_taus[id_of_feed[0]])
+                rankers[ex].append(ShardedRanker(st.local_topk, st.merge, exchange=ex, bufs=bufs, **two))
+        sim_taus, id_of_feed = {}, [0]
+        if sim and args.tau_exchange:
+            # what the all-gather of the thresholds would deliver: every shard's own bound for every resident batch
+            d_Wd_sim = up(W_dec, torch.float32)
+            for g_ in range(sim):
+                cg = _lib.Context(local_rank)
+                bound_g, rows_g = prepack_scoring_shard(cg, d_Wd_sim, d_bd, scoring_shard(n_tracks, V, sim, g_), DT)
+                stg = HipRankStages(cg, d_We, d_be, bound_g, DT)
+                for bi, f_ in enumerate(feeds):
+                    t_ = stg.local_begin(f_, k).clone()
+                    sim_taus[bi] = t_[None] if g_ == 0 else torch.cat([sim_taus[bi], t_[None]])
+                    stg.local_finish(f_, k, t_)          # closes the call
+                torch.cuda.synchronize()
+                cg.close()
+                del rows_g
+            del d_Wd_sim
     for c, st in zip(ctxs, streams):
         with torch.cuda.stream(st):
             c.bind_stream()
@@ -409,6 +437,8 @@ def main():
                              dtype=DT)
                 last[s] = outs[s]
             else:
+                if sim and args.tau_exchange:
+                    id_of_feed[0] = (step_no[0] - 1) % len(feeds) if batch is None else batch
                 last[s] = rankers[exchange[0]][s].rank_batch(f, k)
 
     def score_batch0():
@@ -664,7 +694,7 @@ def main():
                                    "vocab column shard x%d + RCCL %s of the per-shard top-%d" % (
                                        world, "all-to-all (each rank merges the %d rows it owns)" % (B // world)
                                        if args.exchange == "alltoall" else "all-gather (each rank merges all rows)", k)),
-                   "plan": plan, "streams": n_str, "decode_gate": bool(gate_events),
+                   "plan": plan, "streams": n_str, "decode_gate": bool(gate_events), "tau_exchange": bool(args.tau_exchange and sharded),
                    "host_issue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "prepack_ms": round(prepack_ms, 2), "prime_ms": args.prime_ms,
                    "decoder_prepacked": "once at model load (outside the timed region)"},
         "roofline": roofline, "roofline_encode": roofline_encode,

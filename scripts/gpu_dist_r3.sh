@@ -1,0 +1,23 @@
+# round 3: the N > 1 code paths on one GPU -- simulated ranks (compute only), 1-rank RCCL, 2-rank gloo rehearsal
+cd $GRAFT_REPO_ROOT
+o=gpurun_out; mkdir -p $o
+X="--no-train-row --no-cpu-baseline --no-bf16-row --no-extra-rows"
+for n in 2 4 8; do python bench.py --sim-world $n $X > $o/r03_bench_sim$n.json 2> $o/err_sim$n.txt; done
+python bench.py --sim-world 8 --sim-rank 7 $X > $o/r03_bench_sim8_rank7.json 2> $o/err_sim8r7.txt
+python bench.py --sim-world 8 --tau-exchange $X > $o/r03_bench_sim8_tau.json 2> $o/err_sim8tau.txt
+python bench.py --sim-world 8 --sim-rank 7 --tau-exchange $X > $o/r03_bench_sim8_rank7_tau.json 2> $o/err_sim8r7tau.txt
+python bench.py --sim-world 8 --dtype bf16 $X > $o/r03_bench_sim8_bf16.json 2> $o/err_sim8bf.txt
+python bench.py --force-dist $X > $o/r03_bench_forcedist.json 2> $o/err_forcedist.txt
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --backend gloo --steps 20 --warmup 4 $X > $o/r03_bench_gloo2.json 2> $o/err_gloo2.txt
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --backend gloo --steps 20 --warmup 4 --tau-exchange $X > $o/r03_bench_gloo2_tau.json 2> $o/err_gloo2tau.txt
+for f in sim2 sim4 sim8 sim8_rank7 sim8_tau sim8_rank7_tau sim8_bf16 forcedist gloo2 gloo2_tau; do python - $o/r03_bench_$f.json $f <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
+    ex={k:{a:b for a,b in v.items() if a!='note'} for k,v in d.items() if k.endswith('_exchange') or k in ('playlist_sharded','collective')}
+    print('%-15s value=%10.0f ms=%.4f kern=%.4f frac=%.3f %s' % (sys.argv[2], d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], ex))
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e)
+PY
+done
+for f in $o/err_*.txt; do if grep -q Traceback $f; then echo "== $f"; grep -A12 Traceback $f | head -30; fi; done

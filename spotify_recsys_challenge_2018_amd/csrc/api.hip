@@ -447,7 +447,8 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
 }
 
 static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_row_ptr, const int32_t* seed_col,
-                        int out_kind, float* out_score, int32_t* out_idx, const float* h32, const int* row_bad)
+                        int out_kind, float* out_score, int32_t* out_idx, const float* h32, const int* row_bad,
+                        bool tau_is_foreign = false)
 {
     int rc;
     dae_topk_state& tk = ctx->tk;
@@ -463,6 +464,10 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
     ta.bitmap_base = pk->col_lo; ta.bitmap_n = tk.nrank;
     ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
     ta.out_kind = out_kind; ta.out_score = out_score; ta.out_idx = out_idx;
+    // an exchanged threshold (dae_score_topk_finish) also cuts what the sample left behind under the image's own, lower
+    // one; with the own threshold nothing below it was ever kept.  (Exact mode: the lists hold recomputed fp32 logits
+    // by then, and tau bounds the fp32 ranking.)
+    ta.row_min = (tau_is_foreign && !tk.mixed) ? tau_src : nullptr;
     if (!tk.fused) {
         dae_dense_src ds{static_cast<const float*>(ctx->sample.p), tk.ld_s, (int)tk.ld_s, pk->col_lo, 1, nullptr};
         return dae_launch_topk_dense(ctx, ds, ta);
@@ -689,7 +694,7 @@ int dae_score_topk_finish(dae_ctx* ctx, const float* tau, const int32_t* seed_ro
     if (!tau || !out_score || !out_idx) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
     if ((seed_row_ptr == nullptr) != (seed_col == nullptr))
         return dae_fail(ctx, DAE_ERR_ARG, "seed_row_ptr and seed_col must both be given or both null");
-    return topk_phase_b(ctx, tau, seed_row_ptr, seed_col, out_kind, out_score, out_idx, ctx->tk.pend_h32, nullptr);
+    return topk_phase_b(ctx, tau, seed_row_ptr, seed_col, out_kind, out_score, out_idx, ctx->tk.pend_h32, nullptr, true);
 }
 
 int dae_decode_mix_term(dae_ctx* ctx, const float* h, int B, int H, int dtype, const float* row_scale, int n_cols,

@@ -359,6 +359,7 @@ struct dae_topk_args {
     float* out_tau;                       // [B] k-th logit or -inf (may be null)
     int pairs_stride;             // row stride of out_pairs
     int lean, sort_cap;           // set by the launcher (topk.hip): LDS mode, sort buffer keys
+    const float* row_min;         // nullable: [B] elements with logit < row_min[row] are absent (an exchanged threshold)
 };
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);
 // Threshold of the fused path + the sample's survivors (topk.hip tau_select_kernel):

@@ -287,8 +287,9 @@ __global__ __launch_bounds__(NTH) void topk_kernel(const Src src, const dae_topk
     };
 
     // composite key of one element; 0 = absent (masked seed, -inf padding, missing entry)
+    const float row_min = a.row_min ? a.row_min[row] : -__builtin_inff();
     auto ckey = [&](float z, int colv, bool in) -> u64 {
-        if (!in || colv < 0) return 0ull;
+        if (!in || colv < 0 || z < row_min) return 0ull;
         const unsigned key = dae_okey(z);
         if (key <= DAE_KEY_NEG_INF) return 0ull;
         if (!lean) {

@@ -135,8 +135,9 @@ class Conf:
         #   allow_no_title = True        score with the plain DAE when <[TITLE] save>.pkl is missing (default: error --
         #                                the reference fails there too; also an error while any playlist has no seeds)
         #   shard_exchange = allgather | alltoall    under torch.distributed.run: how the per-shard top-500 meet
-        #   shard_tau_exchange = True    ... and the shards' thresholds meet before their filter launches (one more
-        #                                collective of 4 bytes per row and rank; same result)
+        #   shard_tau_exchange = False   ... without the exchange of the shards' thresholds before their filter launches
+        #                                (default True: one more collective of 4 bytes per row and rank, same result,
+        #                                the ranks holding unpopular tracks stop keeping 10x the candidates)
         if 'allow_no_title' in sec:
             self.allow_no_title = _truth(sec['allow_no_title'])
         if 'shard_tau_exchange' in sec:

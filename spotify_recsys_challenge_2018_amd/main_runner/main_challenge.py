@@ -104,7 +104,7 @@ def run(conf, model=None):
 
     use_titles = False
     exchange = getattr(conf, 'shard_exchange', 'allgather')
-    tau_x = bool(getattr(conf, 'shard_tau_exchange', False))
+    tau_x = bool(getattr(conf, 'shard_tau_exchange', True))
     if model is None:
         from ..models.DAEs import DAE, DAE_title
         from ..models.title_models import get_model

@@ -288,7 +288,7 @@ class DAE_tied:
         self._weights_gen = self.__dict__.get("_weights_gen", 0) + 1
 
     # -- multi-GPU scoring (BASELINE.json configs[2]): vocabulary columns sharded over the ranks ----
-    def shard_scoring(self, rank, world, group=None, exchange="allgather", tau_exchange=False):
+    def shard_scoring(self, rank, world, group=None, exchange="allgather", tau_exchange=True):
         """`recommend` through sharding.ShardedRanker: this rank decodes and ranks only the vocabulary columns
         `sharding.scoring_shard(n_tracks, n_input, world, rank)` (W_enc is replicated, so every rank computes the same hidden
         activations with no collective), the per-shard top-k lists meet in ONE exchange (RCCL all-gather, or an

@@ -164,7 +164,7 @@ def test_two_rank_challenge_cli_on_one_device_equals_one_rank(tmp_path, exchange
     for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k_, None)
     results = {}
-    tau_x = "\nshard_tau_exchange = True" if exchange == "allgather" else ""
+    tau_x = "\nshard_tau_exchange = False" if exchange == "allgather" else ""        # (default: on)
     for name, world, extra in (("one", 1, ""), ("two", 2, "\nshard_exchange = " + exchange + tau_x)):
         run = _write_run(tmp_path, name, extra)
         with open(run / "w_dae", "wb") as f:
