@@ -141,7 +141,7 @@ def run(conf, model=None):
         use_titles = bool(getattr(model, 'title_model', None))
         sharded = world > 1 and not use_titles
         if sharded:
-            if exchange == 'alltoall' and model.n_batch % world:
+            if exchange == 'alltoall' and model.n_batch % world and getattr(model, 'ctx', None) is not None:
                 # shard_scoring can only round n_batch up BEFORE fit(): say so here instead of failing inside it
                 raise ValueError("[CHALLENGE] shard_exchange = alltoall needs the model's batch (%d) to be a multiple of the "
                                  "world size (%d) when a fitted model is passed in: build the model with such a batch, or "
