@@ -354,6 +354,11 @@ int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_
                               int32_t* seed_row_ptr, int32_t* seed_col)
 {
     if (B > SEED_MAX_ROWS) return dae_fail(ctx, DAE_ERR_ARG, "seeds_from_csr: %d rows (max %d)", B, SEED_MAX_ROWS);
+    static const char attr_key = 0;          // (B + 1) offsets in LDS: above 64 KiB from B = 16 383 on
+    if (dae_first_use(ctx, &attr_key))
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&seeds_from_csr_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)((SEED_MAX_ROWS + 1) * sizeof(int))));
     hipLaunchKernelGGL(seeds_from_csr_kernel, dim3(1), dim3(1024), (size_t)(B + 1) * sizeof(int), ctx->stream, row_ptr,
                        col, B, n_tracks, seed_row_ptr, seed_col);
     DAE_CHECK_LAUNCH(ctx, "seeds_from_csr_kernel");

@@ -872,7 +872,13 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
     }
     const bool found = lo >= p_min;
     TSTAMP(3)
-    const float tv = found ? dae_okey_inv(lo << 16) : -__builtin_inff();
+    // No dense sample (n_s == 0: the bf16 filter launch decodes the sample tiles AGAIN and every candidate comes from it):
+    // the element tau was taken from has to pass a compare in ANOTHER kernel.  Both kernels run the same MFMA sequence on
+    // the same operands, so the values agree bit for bit (tests/test_gpu_bf16.py); 4 ulp of slack make the row's k
+    // candidates independent of that (a tau sitting exactly on its element, and a last-bit difference, would otherwise
+    // leave the row one candidate short: -1 padding instead of an error).
+    const unsigned tkey = (p.n_s == 0 && (lo << 16) > DAE_KEY_NEG_INF + 8u) ? (lo << 16) - 4u : (lo << 16);
+    const float tv = found ? dae_okey_inv(tkey) : -__builtin_inff();
     if (tid == 0) p.tau[row] = tv;
     // ---- 3. the sample's survivors (never -inf: masked columns and pads are not candidates) ------------------------
     auto passes = [&](float z) { return z >= tv && z > -__builtin_inff(); };
@@ -992,7 +998,8 @@ __global__ __launch_bounds__(256) void tau_select_wave_kernel(const TauP p, cons
         else if (c[0] >= need) { lo = m1; hi = m2 - 1u; }
         else hi = m1 - 1u;
     }
-    const float tv = lo >= p_min ? dae_okey_inv(lo << 16) : -__builtin_inff();
+    const unsigned tkey = (p.n_s == 0 && (lo << 16) > DAE_KEY_NEG_INF + 8u) ? (lo << 16) - 4u : (lo << 16);   // see tau_select_kernel
+    const float tv = lo >= p_min ? dae_okey_inv(tkey) : -__builtin_inff();
     if (lane == 0) p.tau[row] = tv;
     auto passes = [&](float z) { return z >= tv && z > -__builtin_inff(); };
     unsigned mine = 0;

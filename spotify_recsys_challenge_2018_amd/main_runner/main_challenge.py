@@ -3,15 +3,18 @@
 
 Reference hot loop (main_challenge.py:72-93) per batch: COO build -> sess.run(y_pred) of the whole
 [batch, n_input] matrix -> host slice to tracks -> per row argsort + list.remove + [:500].
-Here: COO -> CSR on the host, then ONE library call (dae_score_topk) that encodes, decodes and
-ranks on the GPU; only [batch, 500] indices come back.
+Here: the raw COO feed goes to the device, the CSR and the seed lists are built there (dae_coo_to_csr,
+dae_seeds_from_csr), ONE library call (dae_score_topk) encodes, decodes and ranks; only [batch, 500]
+indices come back, batches streamed through `model.recommend_iter`.
 
 Titles: the reference mixes a character-CNN title score into y_pred (DAE_title, DAEs.py:176-181;
 weights restored from a TF checkpoint, main_challenge.py:68-69).  Here the title variables come from this
 package's own pickle `<[TITLE] save>.pkl` (models/title_models.py; a TF checkpoint cannot be read in this
-environment).  When that file exists, batches that carry titles are scored by DAE_title (mixed, unfused);
-when it does not, or for rows without a title, titles_use = 0 and the mix reduces exactly to the plain DAE
-(App. B.6) on the weights the [TITLE] section names (DAEval), through the fused path.
+environment).  When that file exists, batches that carry titles are scored by DAE_title -- the mix fused into
+the threshold path (dae_decode_mix_term + dae_set_score_mix: no [batch, n_input] matrix of either scorer).
+When it does not, the run fails like the reference's restore does, unless [CHALLENGE] allow_no_title = True
+(optional key of this build) asks for the plain DAE: titles_use = 0 reduces the mix exactly to it (App. B.6)
+on the weights the [TITLE] section names (DAEval); playlists without seeds still make that an error.
 """
 import datetime
 import os

@@ -256,11 +256,13 @@ class DAE_tied:
             d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
             d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
             rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, n_rows or self.n_batch, self.n_input)
-            pending = (self._csr_status or []) + [status]      # checked lazily (no sync on the scoring path)
+            # checked lazily (no sync on the scoring path).  A flag is written on the stream that is current NOW -- the
+            # main stream or the second scoring lane's -- so it travels with an event recorded behind its writer: whoever
+            # reads it later, on whichever stream, waits for exactly that
+            cur = torch.cuda.current_stream(self.device_index)
+            pending = (self._csr_status or []) + [(status, cur.record_event())]
             if len(pending) > 64:                               # un-fetched training steps: fold on the device
-                if self.__dict__.get("_lane2") is not None:     # flags of the other scoring lane: written on its stream
-                    torch.cuda.current_stream(self.device_index).wait_stream(self._lane2["stream"])
-                pending = [torch.cat(pending).max().reshape(1)]
+                pending = [(self._fold_status(pending), cur.record_event())]
             self._csr_status = pending
             return rp, c, v
         rp, c, v = coo_to_csr(positions, values, n_rows or self.n_batch, self.n_input)
@@ -268,15 +270,23 @@ class DAE_tied:
             c = np.zeros(1, np.int32); v = np.zeros(1, np.float32)
         return self._to_dev(rp, torch.int32), self._to_dev(c, torch.int32), self._to_dev(v, torch.float32)
 
+    def _fold_status(self, pending):
+        """max over the pending range flags, on the current stream, ordered behind every flag's writer."""
+        import torch
+        cur = torch.cuda.current_stream(self.device_index)
+        for st, ev in pending:
+            cur.wait_event(ev)
+            st.record_stream(cur)                               # allocated on its writer's stream, read (and freed) here
+        return torch.cat([st for st, _ev in pending]).max().reshape(1)
+
     def _check_feed(self):
-        """After the results of a call have been fetched (the stream is drained anyway): the device CSR
-        builder skips entries whose row / column is out of range and raises the flag checked here."""
+        """After the results of a call have been fetched: the device CSR builder skips entries whose row / column is
+        out of range and raises the flag checked here."""
         if self._csr_status:
-            import torch
-            bad = int(torch.cat(self._csr_status).max().item())
+            bad = int(self._fold_status(self._csr_status).item())
             self._csr_status = None
             if bad:
-                raise ValueError("feed holds a row or column index out of range [0,%d) x [0,%d)"
+                raise ValueError("feed holds a row or column index out of range (rows [0,%d) of each feed, columns [0,%d))"
                                  % (self.n_batch, self.n_input))
 
     check_feed = _check_feed
@@ -570,7 +580,15 @@ class DAE_tied:
                         use += u[:nb] + [0.0] * (nb - min(len(u), nb))
                     feed = feed + (titles, np.asarray(use, np.float32))
                 return feed, rows, len(buf) * nb
+            def titled(f):
+                return len(f) > 5 and f[5] is not None and bool(np.any(np.asarray(f[5])))
             for feed in feeds:
+                # a launch ranks EITHER the plain logits or the title-mixed score (DAE_title._submit decides per launch):
+                # a feed without titles in use must not share a launch with a titled one, or its rows would be ranked on
+                # sigmoid(z) * 1.0f -- same order up to fp32 saturation ties, not the bits `recommend` returns for it alone
+                if buf and titled(feed) != titled(buf[0]):
+                    yield flush()
+                    buf = []
                 buf.append(feed)
                 if len(buf) == group:
                     yield flush()

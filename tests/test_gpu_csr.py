@@ -154,3 +154,28 @@ def test_training_flags_a_bad_x_feed_even_when_the_y_feed_is_clean_and_can_run_u
     b.train_step(bad, np.append(ones, 1.0).astype(np.float32), pos, y1, 0.8, 0.7, fetch_cost=False)
     with pytest.raises(ValueError):
         b.check_feed()
+
+
+@pytest.mark.parametrize("B", [1, 700, 4096, 16384])
+def test_seeds_from_csr_up_to_the_row_limit(B):
+    """dae_seeds_from_csr: the track columns of every input row as the seed CSR -- including B = 16 384, where the
+    kernel's (B + 1) offsets no longer fit the default 64 KiB of dynamic LDS."""
+    import torch
+    ctx = _lib.Context(0)
+    nt, na = 5000, 1000
+    rng = np.random.default_rng(B)
+    rows = []
+    for r in range(B):
+        n = int(rng.integers(0, 12))
+        rows.append(np.unique(rng.integers(0, nt + na, size=n)))
+    rp = np.zeros(B + 1, np.int32)
+    rp[1:] = np.cumsum([len(x) for x in rows])
+    col = np.concatenate(rows + [np.zeros(0, np.int64)]).astype(np.int32)
+    d_rp = torch.from_numpy(rp).cuda()
+    d_col = torch.from_numpy(col if col.size else np.zeros(1, np.int32)).cuda()
+    srp, sc = ctx.seeds_from_csr(d_rp, d_col, nt)
+    srp, sc = srp.cpu().numpy(), sc.cpu().numpy()
+    want = [x[x < nt] for x in rows]
+    assert srp[0] == 0 and np.array_equal(np.diff(srp), [len(x) for x in want])
+    assert np.array_equal(sc[:srp[-1]], np.concatenate(want + [np.zeros(0, np.int64)]).astype(np.int32))
+    ctx.close()
