@@ -148,6 +148,14 @@ int dae_encode(dae_ctx* ctx,
 int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec,
                         int V, int H, int col_lo, int col_hi, int dtype);
 
+/* Let `dst` use the decoder image `src` prepacked for `dtype` instead of holding a copy of its own (the contexts of
+ * several batches in flight score with the same weights: one image stays resident in the 256 MB Infinity Cache where
+ * two or three copies of 87 / 174 MB evict each other; it also saves their memory and re-tiling).  `dst` borrows the
+ * buffers: `src` must outlive every use, must not be re-prepacked while `dst` has work in flight, and the caller orders
+ * `src`'s prepack before `dst`'s first launch (streams!).  A later dae_prepack_decoder on `dst` gives it an image of its
+ * own again.  Same device only. */
+int dae_share_decoder(dae_ctx* dst, const dae_ctx* src, int dtype);
+
 /* DAE_DTYPE_BF16_EXACT: copy the per-column bounds eps_c of the prepacked image (col_lo <= c < col_hi) to
  * eps_out (device, col_hi - col_lo floats).  |fp32 logit - bf16 logit| <= eps_c for every hidden row in [0, 1]^H;
  * DESIGN.md section 2b derives it, tests/test_gpu_exact.py checks it against measured differences. */

@@ -23,13 +23,21 @@ d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, col, val, W_
 NS = max(nstr)
 ctxs = [_lib.Context(0) for _ in range(NS)]
 streams = [torch.cuda.Stream() for _ in range(NS)]
-for c, st in zip(ctxs, streams):
+share = os.environ.get("SHARE", "1") != "0"          # one packed image for all contexts (dae_share_decoder)
+for n_, (c, st) in enumerate(zip(ctxs, streams)):
     with torch.cuda.stream(st):
         c.bind_stream()
+        if n_ == 0 or not share:
+            if "f32" in only:
+                c.prepack_decoder(d[5], d[6])
+            c.prepack_decoder(d[5], d[6], dtype=_lib.DAE_DTYPE_BF16_EXACT)
+    torch.cuda.synchronize()
+    if n_ > 0 and share:
         if "f32" in only:
-            c.prepack_decoder(d[5], d[6])
-        c.prepack_decoder(d[5], d[6], dtype=_lib.DAE_DTYPE_BF16_EXACT)
+            c.share_decoder(ctxs[0], 0)
+        c.share_decoder(ctxs[0], _lib.DAE_DTYPE_BF16_EXACT)
 torch.cuda.synchronize()
+print("shared image:", share, flush=True)
 outs = [(torch.empty((B, k), device="cuda"), torch.empty((B, k), dtype=torch.int32, device="cuda")) for _ in range(NS)]
 ref = None
 for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):

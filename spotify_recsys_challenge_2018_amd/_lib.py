@@ -15,7 +15,7 @@ DAE_DTYPE_F32, DAE_DTYPE_BF16, DAE_DTYPE_BF16_EXACT = 0, 1, 2
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
-    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_exact_bounds", "dae_decode_dense", "dae_decode_topk",
+    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_share_decoder", "dae_exact_bounds", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
@@ -64,6 +64,7 @@ def load():
     lib.dae_seeds_from_csr.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
+    lib.dae_share_decoder.argtypes = [vp, vp, c_int]
     lib.dae_exact_bounds.argtypes = [vp, vp]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
@@ -206,6 +207,12 @@ class Context:
         wp = ctypes.c_void_p(W_rows.data_ptr() - int(col_lo) * H * 4)
         bp = ctypes.c_void_p(b_rows.data_ptr() - int(col_lo) * 4)
         self.check(self.lib.dae_prepack_decoder(self.h, wp, bp, int(col_lo) + n, H, int(col_lo), int(col_lo) + n, int(dtype)))
+
+    def share_decoder(self, src, dtype=DAE_DTYPE_F32):
+        """Use `src`'s prepacked image of `dtype` instead of an own copy (see include/dae_hip.h dae_share_decoder: `src`
+        outlives every use; order src's prepack before this context's first launch)."""
+        self.check(self.lib.dae_share_decoder(self.h, src.h, int(dtype)))
+        self._shares = src                                   # keep the owner alive as long as this context
 
     def exact_bounds(self, eps_out):
         """Per-column bounds |fp32 logit - bf16 logit| <= eps of the image prepacked with DAE_DTYPE_BF16_EXACT."""

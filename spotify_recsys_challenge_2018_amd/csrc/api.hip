@@ -142,6 +142,8 @@ int dae_destroy(dae_ctx* ctx)
     if (!ctx) return DAE_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (dae_packed* pk : {&ctx->pk_f32, &ctx->pk_bf16})
+        if (pk->borrowed) pk->W = pk->bias = pk->bias16 = pk->bias16_lo = pk->bias16_hi = pk->eps = pk->W32 = dae_buf{};
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
@@ -282,6 +284,40 @@ int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const f
                              nullptr, 0, 0);
 }
 
+// a slot that borrows another context's image gets buffers of its own again before it is written
+static void unborrow(dae_packed& pk)
+{
+    if (!pk.borrowed) return;
+    pk.W = pk.bias = pk.bias16 = pk.bias16_lo = pk.bias16_hi = pk.eps = pk.W32 = dae_buf{};
+    pk.borrowed = false; pk.valid = false; pk.exact = false; pk.order_nrank = -1;
+}
+
+int dae_share_decoder(dae_ctx* dst, const dae_ctx* src, int dtype)
+{
+    if (!dst) return DAE_ERR_ARG;
+    if (!src || src == dst) return dae_fail(dst, DAE_ERR_ARG, "dae_share_decoder: needs another context");
+    if (dst->device != src->device) return dae_fail(dst, DAE_ERR_ARG, "dae_share_decoder: contexts on different devices");
+    if (!known_dtype(dtype)) return dae_fail(dst, DAE_ERR_ARG, "unknown dtype %d", dtype);
+    const dae_packed& sp = dtype == DAE_DTYPE_F32 ? src->pk_f32 : src->pk_bf16;
+    dae_packed& dp = dtype == DAE_DTYPE_F32 ? dst->pk_f32 : dst->pk_bf16;
+    if (!sp.valid || (dtype == DAE_DTYPE_BF16_EXACT && !sp.exact))
+        return dae_fail(dst, DAE_ERR_STATE, "dae_share_decoder: the source context holds no such image");
+    if (sp.borrowed) return dae_fail(dst, DAE_ERR_ARG, "dae_share_decoder: share from the context that owns the image");
+    if (!dp.borrowed) {                                    // drop the own image of this slot (after its last use)
+        hipError_t e = hipStreamSynchronize(dst->stream);
+        if (e != hipSuccess) return dae_fail(dst, DAE_ERR_HIP, "sync: %s", hipGetErrorString(e));
+        for (dae_buf* b : {&dp.W, &dp.bias, &dp.bias16, &dp.bias16_lo, &dp.bias16_hi, &dp.eps, &dp.W32})
+            if (b->p) { (void)hipFree(b->p); dst->scratch_total -= b->bytes; *b = dae_buf{}; }
+    }
+    const dae_buf order = dp.order, ident = dp.ident;      // the tile lists stay this context's own (small, built lazily)
+    dp = sp;
+    dp.order = order; dp.ident = ident; dp.order_nrank = -1; dp.order_nsamp = -1;
+    dp.borrowed = true;
+    int rc = dae_reserve(dst, dp.ident, (size_t)(dp.ntiles > 0 ? dp.ntiles : 1) * sizeof(int));
+    if (rc) return rc;
+    return dae_launch_tile_iota(dst, static_cast<int*>(dp.ident.p), dp.ntiles);
+}
+
 int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, int V, int H,
                         int col_lo, int col_hi, int dtype)
 {
@@ -289,6 +325,7 @@ int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, in
     if (!W_dec || !b_dec) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
     if (H <= 0 || V <= 0 || col_lo < 0 || col_hi > V || col_lo >= col_hi)
         return dae_fail(ctx, DAE_ERR_ARG, "bad shape V=%d H=%d cols=[%d,%d)", V, H, col_lo, col_hi);
+    unborrow(dtype == DAE_DTYPE_F32 ? ctx->pk_f32 : ctx->pk_bf16);
     if (dtype == DAE_DTYPE_F32) return dae_launch_prepack_f32(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
     if (dtype == DAE_DTYPE_BF16) return dae_launch_prepack_bf16(ctx, W_dec, b_dec, V, H, col_lo, col_hi);
     if (dtype == DAE_DTYPE_BF16_EXACT) return dae_launch_prepack_bf16(ctx, W_dec, b_dec, V, H, col_lo, col_hi, 1);

@@ -30,6 +30,7 @@ struct dae_buf {
 
 struct dae_packed {            // one prepacked decoder image
     bool valid = false;
+    bool borrowed = false;      // W / bias / bias16* / eps / W32 belong to ANOTHER context (dae_share_decoder): never freed here
     int V = 0, H = 0, Hp = 0;   // Hp = H padded to DAE_HPAD
     int col_lo = 0, col_hi = 0;
     int ntiles = 0;            // ceil((col_hi-col_lo)/32)
@@ -240,6 +241,7 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
 int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, int H,
                            int col_lo, int col_hi);
 int dae_launch_pack_h(dae_ctx* ctx, const float* h, int B, int H, const dae_rowgeom& g);
+int dae_launch_tile_iota(dae_ctx* ctx, int* dst, int ntiles);      // dst[i] = i
 // (re)build pk.order for `nrank` rankable columns; the first n_samp entries are the threshold sample
 int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp, bool mixed = false);
 int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, int S);

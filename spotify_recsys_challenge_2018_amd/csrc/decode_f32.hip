@@ -121,6 +121,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
 
     ASTAMP(0)
+    // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
+    // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
+    const int n_ws = p.nb_rg * NW;
+    const int item0 = wave * p.nb_rg + bir;
+    const bool has0 = item0 < p.ts.n_items;
+    // Tile indices come from a list in global memory.  A vector load that the code then waits for
+    // drains the WHOLE in-order load queue (s_waitcnt vmcnt(0)), i.e. the W prefetch ring; so the
+    // index of a tile is fetched two tiles ahead, before that tile's predecessor issues its W loads --
+    // and the first two go out HERE, ahead of the hidden tile's loads, so that the W ring can be started before
+    // the workgroup meets (the straight order -- tile, barrier, ids, W -- was one more dependent trip to memory
+    // in front of the first MFMA).
+    const int tv_cur = tile_of_item(p.ts, has0 ? item0 : 0);
+    const int tv_nxt = tile_of_item(p.ts, has0 ? (item0 + n_ws < p.ts.n_items ? item0 + n_ws : item0) : 0);
     // ---- hidden tile of this row group -> LDS, once ------------------------------------------
     const int n_h4 = RB * 64 * G;
     {
@@ -146,21 +159,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
             ltau[i] = rg * R_TILE + i < p.B ? p.tau[rg * R_TILE + i] : __builtin_inff();
         }
     }
-    __syncthreads();
-
-    float tau_r[RB];
-    if (EPI == EPI_FILTER) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
-    }
 
     ASTAMP(1)
     float loss_acc = 0.0f;
-    // wave-major slots: consecutive tiles go to different workgroups, so a partial round of tiles is
-    // spread over all CUs (and, with two waves per SIMD, over all SIMDs) instead of filling a few
-    const int n_ws = p.nb_rg * NW;
-    const int item0 = wave * p.nb_rg + bir;
-
     // W stream: the wave's tiles back to back; the register ring always holds the next 4 groups
     // of that stream, so the prefetch runs across tile boundaries (and under the epilogue).
     float4 wb0, wb1, wb2, wb3;
@@ -173,28 +174,32 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     uint4 bfrag = make_uint4(0u, 0u, 0u, 0u);                     // bias fragment of the wave's next tile
     const uint4 ones = bf16_ones_fragment(hi);
     const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
-    // Tile indices come from a list in global memory.  A vector load that the code then waits for
-    // drains the WHOLE in-order load queue (s_waitcnt vmcnt(0)), i.e. the W prefetch ring; so the
-    // index of a tile is fetched two tiles ahead, before that tile's predecessor issues its W loads.
-    int t_cur = 0, t_nxt = 0;
-    if (item0 < p.ts.n_items) {
-        t_cur = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item0));
-        t_nxt = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item0 + n_ws < p.ts.n_items ? item0 + n_ws : item0));
-    }
-    if (DT == DT_BF16 && item0 < p.ts.n_items) bfrag = p.bias16[(size_t)t_cur * 64 + lane];
-    if (item0 < p.ts.n_items) {
+    int t_cur = __builtin_amdgcn_readfirstlane(tv_cur), t_nxt = __builtin_amdgcn_readfirstlane(tv_nxt);
+    // the ring's first loads: unconditional (a wave without a tile reads the first listed tile and never uses it)
+    {
         const float4* w0 = p.Wp + (size_t)t_cur * G * 64 + lane;
         if (DT == DT_F32) {
             wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
         } else {
+            bfrag = p.bias16[(size_t)t_cur * 64 + lane];
             const uint4* q0 = reinterpret_cast<const uint4*>(w0);
 #pragma unroll
             for (int u = 0; u < QR; ++u) wq[u] = q0[(size_t)(u < G ? u : G - 1) * 64];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
         }
+    }
+    __syncthreads();
+
+    float tau_r[RB];
+    if (EPI == EPI_FILTER) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
+    }
+    if (DT == DT_F32) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
     }
 
     // EPI_GMAX: one exchange per round of tiles, joined by EVERY wave of the workgroup (a wave without a tile in
@@ -897,6 +902,23 @@ __global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const De
     const int bir = q * DAE_NUM_XCD + (rem_b % DAE_NUM_XCD);
 
     constexpr int n_h4 = RB * 64 * G;
+    // this wave's work: whole tiles ws + r * n_ws (r < R), then possibly one tile -- or half of one -- of
+    // the last round
+    const int n_items = p.ts.n_items;
+    const int n_ws = p.nb_rg * NW;
+    const int ws = wave * p.nb_rg + bir;
+    const int R = n_items / n_ws, rem = n_items - R * n_ws;
+    const bool split = rem > 0 && 2 * rem <= n_ws;
+    const int n_it = R + (ws < (split ? 2 * rem : rem) ? 1 : 0);
+    auto item_at = [&](int r) {
+        r = r < n_it - 1 ? r : n_it - 1;
+        r = r < 0 ? 0 : r;
+        const int it = r < R ? ws + r * n_ws : R * n_ws + (split ? (ws >> 1) : ws);
+        return it < n_items ? it : 0;
+    };
+    // the first two tile ids go out ahead of the hidden tile's loads, so that the W ring can start before the workgroup
+    // meets (tile, barrier, ids, W was one more dependent trip to memory in front of the first MFMA)
+    const int tv_cur = tile_of_item(p.ts, item_at(0)), tv_nxt = tile_of_item(p.ts, item_at(1));
     {
         const float4* src = p.hp + (size_t)rg * n_h4;
         constexpr int NT = NW * 64;
@@ -915,36 +937,20 @@ __global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const De
         lcnt[tid] = 0;
         ltau[tid] = rg * R_TILE + tid < p.B ? p.tau[rg * R_TILE + tid] : __builtin_inff();
     }
+    float4 wb0, wb1, wb2, wb3;
+    float4 bA[RB], bB[RB];
+    int t_cur = __builtin_amdgcn_readfirstlane(tv_cur), t_nxt = __builtin_amdgcn_readfirstlane(tv_nxt);
+    {
+        const float4* w0 = p.Wp + (size_t)t_cur * G * 64 + lane;     // (a wave without work reads a listed tile and drops it)
+        wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
+    }
     __syncthreads();
 
     float tau_r[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
-
-    // this wave's work: whole tiles ws + r * n_ws (r < R), then possibly one tile -- or half of one -- of
-    // the last round
-    const int n_items = p.ts.n_items;
-    const int n_ws = p.nb_rg * NW;
-    const int ws = wave * p.nb_rg + bir;
-    const int R = n_items / n_ws, rem = n_items - R * n_ws;
-    const bool split = rem > 0 && 2 * rem <= n_ws;
-    const int n_it = R + (ws < (split ? 2 * rem : rem) ? 1 : 0);
-    auto item_at = [&](int r) {
-        r = r < n_it - 1 ? r : n_it - 1;
-        return r < R ? ws + r * n_ws : R * n_ws + (split ? (ws >> 1) : ws);
-    };
-
-    float4 wb0, wb1, wb2, wb3;
-    float4 bA[RB], bB[RB];
-    int t_cur = 0, t_nxt = 0;
-    if (n_it > 0) {
-        t_cur = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_at(0)));
-        t_nxt = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_at(1)));
-        const float4* w0 = p.Wp + (size_t)t_cur * G * 64 + lane;
-        wb0 = w0[0]; wb1 = w0[64]; wb2 = w0[128]; wb3 = w0[192];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
-    }
+    for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
 
     for (int r = 0; r < n_it; ++r) {
         const int t = t_cur;
@@ -1093,38 +1099,9 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
 
     constexpr int n_h4 = RB * 64 * NS;
-    {
-        const float4* src = p.hp + (size_t)rg * n_h4;
-        constexpr int NTH = NW * 64;
-        constexpr int PER = (n_h4 + NTH - 1) / NTH;              // float4 per thread
-        constexpr int CH = PER < 8 ? PER : 8;                    // loads in flight per thread
-#pragma unroll
-        for (int i0 = 0; i0 < PER; i0 += CH) {
-            float4 v[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = (i0 + u) * NTH + tid;
-                v[u] = src[i < n_h4 ? i : n_h4 - 1];              // unconditional: a guarded write would push v[] to scratch
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int i = (i0 + u) * NTH + tid;
-                if (i0 + u < PER && i < n_h4) lds4[i] = v[u];
-            }
-        }
-    }
-    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
-    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
-    for (int i = tid; i < R_TILE; i += NW * 64) {
-        lcnt[i] = 0;
-        ltau[i] = rg * R_TILE + i < p.B ? p.tau[rg * R_TILE + i] : __builtin_inff();
-    }
-    __syncthreads();
-
-    float tau_r[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
-
+    constexpr int NTH = NW * 64;
+    constexpr int PER = (n_h4 + NTH - 1) / NTH;                  // float4 of the hidden tile per thread
+    constexpr int CH = PER < 8 ? PER : 8;                        // ... of which in flight at once
     const int n_items = p.ts.n_items;
     const int n_grp = (n_items + NT - 1) / NT;                   // groups of NT tiles
     const int n_ws = p.nb_rg * NW;
@@ -1135,27 +1112,75 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     // item of (group, nt), clamped to the group's first item when the last group is ragged
     auto item_of = [&](int grp, int nt) { const int i = NT * grp + nt; return i < n_items ? i : NT * grp; };
 
-    uint4 wq[NT][QR];
-    uint4 cb[2][RB];
-    uint4 bfr[NT];                                               // bias fragments of the NEXT group
+    // ---- prologue: the requests that depend on nothing go out together (tile ids, thresholds, the hidden tile), the W
+    // ring as soon as the ids are here and the tile has been handed to LDS -- it streams from HBM while the workgroup
+    // meets.  The straight order (tile, barrier, thresholds, ids, W) was one more dependent trip to memory before the
+    // first MFMA; keeping the tile's registers live across the ring's loads made the compiler park them in scratch.
     int t[NT], u[NT];                                            // tiles of this / the next group (uniform)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { t[nt] = 0; u[nt] = 0; bfr[nt] = make_uint4(0u, 0u, 0u, 0u); }
-    if (grp0 < n_grp) {
+    int tv0[NT], tv1[NT];
+    const bool has = grp0 < n_grp;
+    {
         const int gn = grp0 + n_ws < n_grp ? grp0 + n_ws : grp0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            t[nt] = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_of(grp0, nt)));
-            u[nt] = __builtin_amdgcn_readfirstlane(tile_of_item(p.ts, item_of(gn, nt)));
-            bfr[nt] = p.bias16[(size_t)t[nt] * 64 + lane];
+            tv0[nt] = tile_of_item(p.ts, has ? item_of(grp0, nt) : 0);
+            tv1[nt] = tile_of_item(p.ts, has ? item_of(gn, nt) : 0);
         }
-#pragma unroll
-        for (int k = 0; k < QR; ++k)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wq[nt][k] = Wq[(size_t)t[nt] * (NS * 64) + k * 64 + lane];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
     }
+    float tau_g[(R_TILE + NTH - 1) / NTH];
+#pragma unroll
+    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
+        const int i = e * NTH + tid;
+        tau_g[e] = (i < R_TILE && rg * R_TILE + i < p.B) ? p.tau[rg * R_TILE + i] : __builtin_inff();
+    }
+    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
+    {
+        const float4* hsrc = p.hp + (size_t)rg * n_h4;
+#pragma unroll
+        for (int e0 = 0; e0 < PER; e0 += CH) {
+            float4 hv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = (e0 + e) * NTH + tid;
+                hv[e] = hsrc[i < n_h4 ? i : n_h4 - 1];            // unconditional: a guarded load would push hv[] to scratch
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = (e0 + e) * NTH + tid;
+                if (e0 + e < PER && i < n_h4) lds4[i] = hv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
+        const int i = e * NTH + tid;
+        if (i < R_TILE) { lcnt[i] = 0; ltau[i] = tau_g[e]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 wq[NT][QR];
+    uint4 cb[2][RB];
+    uint4 bfr[NT];                                               // bias fragments of the NEXT group
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        t[nt] = __builtin_amdgcn_readfirstlane(tv0[nt]);
+        u[nt] = __builtin_amdgcn_readfirstlane(tv1[nt]);
+    }
+    // (unconditional: a wave without a tile reads tile list[0]'s fragments and never uses them)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bfr[nt] = p.bias16[(size_t)t[nt] * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < QR; ++k)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[nt][k] = Wq[(size_t)t[nt] * (NS * 64) + k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    float tau_r[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
 
     for (int grp = grp0; grp < n_grp; grp += n_ws) {
         const int gn = grp + n_ws < n_grp ? grp + n_ws : grp;
@@ -1813,6 +1838,14 @@ int dae_launch_prepack_f32(dae_ctx* ctx, const float* W, const float* b, int V, 
                        ctx->stream, ntiles, static_cast<int*>(pk.ident.p));
     DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
     pk.valid = true;
+    return DAE_OK;
+}
+
+int dae_launch_tile_iota(dae_ctx* ctx, int* dst, int ntiles)
+{
+    hipLaunchKernelGGL(tile_iota_kernel, dim3((ntiles + 255) / 256 > 0 ? (ntiles + 255) / 256 : 1), dim3(256), 0,
+                       ctx->stream, ntiles, dst);
+    DAE_CHECK_LAUNCH(ctx, "tile_iota_kernel");
     return DAE_OK;
 }
 

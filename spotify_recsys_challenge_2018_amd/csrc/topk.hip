@@ -770,7 +770,9 @@ struct TauP {
     float* tau; uint2* out_pairs; int64_t pairs_stride; int* out_cnt;
     long long* dbg;
 };
-template <int TAU_PER>               // maxima per thread held in registers: rows of <= 256 * TAU_PER maxima in one sweep
+// HAS_S = false: no dense sample to scan (n_s == 0: the bf16 / exact filter launch decodes every tile itself) -- tau only,
+// a third of the registers, so that the workgroup fits on a CU NEXT to a filter workgroup of another batch.
+template <int TAU_PER, bool HAS_S = true>   // TAU_PER: maxima per thread held in registers (rows of <= 256 * TAU_PER maxima in one sweep)
 __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
 {
     __shared__ unsigned wcnt[2][4][3];
@@ -804,16 +806,19 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
     for (int u = 0; u < TAU_PER; ++u) kreg[u] = dae_okey(graw[u]);     // -inf -> NEG_INF key: never counted
     __builtin_amdgcn_sched_barrier(0);
     const float4* srow = reinterpret_cast<const float4*>(p.samp + (size_t)row * p.ld_s);
-    const int n4 = p.n_s >> 2;
-    float4 zpre[TAU_PRE];
-#pragma unroll
-    for (int u = 0; u < TAU_PRE; ++u) {
-        const int f = u * 256 + tid;
-        zpre[u] = srow[f < n4 ? f : 0];
-    }
+    const int n4 = HAS_S ? p.n_s >> 2 : 0;
+    constexpr int NPRE = HAS_S ? TAU_PRE : 1;
+    float4 zpre[NPRE];
     // tiles of the preloaded part (one id per 8 float4) -> LDS: consumed only where something passes
-    __shared__ int ltile[TAU_PRE * 256 / 8];
-    for (int i = tid; i < TAU_PRE * 256 / 8; i += 256) ltile[i] = p.samp_list[i < (n4 + 7) / 8 ? i : 0];
+    __shared__ int ltile[HAS_S ? TAU_PRE * 256 / 8 : 1];
+    if (HAS_S) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int f = u * 256 + tid;
+            zpre[u] = srow[f < n4 ? f : 0];
+        }
+        for (int i = tid; i < TAU_PRE * 256 / 8; i += 256) ltile[i] = p.samp_list[i < (n4 + 7) / 8 ? i : 0];
+    }
     __builtin_amdgcn_sched_barrier(0);                           // keep every request above ahead of the search
     // ---- 2. tau -------------------------------------------------------------------------------------------------
     // counts of keys >= each of 3 probes over the row (block-uniform results); absent / -inf keys never count
@@ -880,12 +885,16 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
     const unsigned tkey = (p.n_s == 0 && (lo << 16) > DAE_KEY_NEG_INF + 8u) ? (lo << 16) - 4u : (lo << 16);
     const float tv = found ? dae_okey_inv(tkey) : -__builtin_inff();
     if (tid == 0) p.tau[row] = tv;
+    if (!HAS_S) {                                                // no sample to scan: the (empty) survivor list
+        if (tid == 0) p.out_cnt[row] = 0;
+        return;
+    }
     // ---- 3. the sample's survivors (never -inf: masked columns and pads are not candidates) ------------------------
     auto passes = [&](float z) { return z >= tv && z > -__builtin_inff(); };
     unsigned mine = 0;
     unsigned live = 0;                                           // bit u: some lane of this wave has a survivor in zpre[u]
 #pragma unroll
-    for (int u = 0; u < TAU_PRE; ++u) {
+    for (int u = 0; u < NPRE; ++u) {
         const float mx = fmaxf(fmaxf(zpre[u].x, zpre[u].y), fmaxf(zpre[u].z, zpre[u].w));
         if (__ballot(u * 256 + tid < n4 && passes(mx))) {        // wave-uniform: most groups hold nothing above tau
             live |= 1u << u;
@@ -921,7 +930,7 @@ __global__ __launch_bounds__(256) void tau_select_kernel(const TauP p)
         if (passes(z.w)) dst[at++] = make_uint2(__float_as_uint(z.w), cb + 3u);
     };
 #pragma unroll
-    for (int u = 0; u < TAU_PRE; ++u)
+    for (int u = 0; u < NPRE; ++u)
         if (((live >> u) & 1u) && u * 256 + tid < n4) emit4(zpre[u], u * 256 + tid, ltile[(u * 256 + tid) >> 3]);
     for (int f = TAU_PRE * 256 + tid; f < n4; f += 256) emit4(srow[f], f, p.samp_list[f >> 3]);
     TSTAMP(6)
@@ -1050,7 +1059,11 @@ int launch_tau_select(dae_ctx* ctx, const TauP& p, int B)
         DAE_CHECK_LAUNCH(ctx, "tau_select_wave_kernel");
         return DAE_OK;
     }
-    if (p.n_g <= 256 * 16)
+    if (p.n_g <= 256 * 16 && p.n_s == 0)
+        hipLaunchKernelGGL((tau_select_kernel<16, false>), dim3(B), dim3(256), 0, ctx->stream, q);
+    else if (p.n_g <= 256 * 32 && p.n_s == 0)
+        hipLaunchKernelGGL((tau_select_kernel<32, false>), dim3(B), dim3(256), 0, ctx->stream, q);
+    else if (p.n_g <= 256 * 16)
         hipLaunchKernelGGL(tau_select_kernel<16>, dim3(B), dim3(256), 0, ctx->stream, q);
     else if (p.n_g <= 256 * 32)        // batch 1024 on one GPU: 5 120 maxima per row -- half the compares of the 64-key shape
         hipLaunchKernelGGL(tau_select_kernel<32>, dim3(B), dim3(256), 0, ctx->stream, q);
