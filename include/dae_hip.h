@@ -229,6 +229,12 @@ int dae_topk_merge(dae_ctx* ctx, int G, int B, int k,
                    const float* cand_logit, const int32_t* cand_idx,
                    int out_kind, float* out_score, int32_t* out_idx);
 
+/* Tell the context that `batches_in_flight` batches are being scored concurrently on different streams (their own
+ * contexts).  With more than one, the latency-bound launches of the bf16 / exact paths take shapes that fit on a CU NEXT to
+ * another batch's filter workgroup (fewer threads and registers): each is a little slower alone and the step is faster
+ * (7.0 vs 6.5 M playlists/s with three batches in flight).  Results do not change.  Default: 1. */
+int dae_set_overlap_hint(dae_ctx* ctx, int batches_in_flight);
+
 /* Two batches in flight on two contexts / streams (bench.py): the dominant launch of the fused path (the threshold
  * filter over ~90 % of the vocabulary) occupies every CU, so two of them in flight only queue behind each other.  With a
  * gate, this context's launch waits for `wait_event` (a hipEvent_t the OTHER context records after its own launch) and

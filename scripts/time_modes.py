@@ -44,6 +44,9 @@ for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):
     if name not in only:
         continue
     for n in nstr:
+        for c in ctxs:
+            c.set_overlap_hint(n if os.environ.get("HINT", "1") != "0" else 1)
+
         def step(i):
             j = i % n
             with torch.cuda.stream(streams[j]):

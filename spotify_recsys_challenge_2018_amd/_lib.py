@@ -20,7 +20,7 @@ EXPORTS = [
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
-    "dae_arm_decoder_adam", "dae_set_decode_gate",
+    "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def load():
     lib.dae_set_enc_grad_prezeroed.argtypes = [vp, c_int]
     lib.dae_arm_decoder_adam.argtypes = [vp, vp, vp, c_f, c_f, c_f, c_f, c_int]
     lib.dae_set_decode_gate.argtypes = [vp, vp, vp]
+    lib.dae_set_overlap_hint.argtypes = [vp, c_int]
     for name in EXPORTS:
         if name not in ("dae_last_error", "dae_scratch_bytes", "dae_profile_kernel"):
             getattr(lib, name).restype = c_int
@@ -207,6 +208,10 @@ class Context:
         wp = ctypes.c_void_p(W_rows.data_ptr() - int(col_lo) * H * 4)
         bp = ctypes.c_void_p(b_rows.data_ptr() - int(col_lo) * 4)
         self.check(self.lib.dae_prepack_decoder(self.h, wp, bp, int(col_lo) + n, H, int(col_lo), int(col_lo) + n, int(dtype)))
+
+    def set_overlap_hint(self, batches_in_flight):
+        """Other batches are in flight on other streams: kernel shapes that share CUs (include/dae_hip.h)."""
+        self.check(self.lib.dae_set_overlap_hint(self.h, int(batches_in_flight)))
 
     def share_decoder(self, src, dtype=DAE_DTYPE_F32):
         """Use `src`'s prepacked image of `dtype` instead of an own copy (see include/dae_hip.h dae_share_decoder: `src`

@@ -505,6 +505,10 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
     // one; with the own threshold nothing below it was ever kept.  (Exact mode: the lists hold recomputed fp32 logits
     // by then, and tau bounds the fp32 ranking.)
     ta.row_min = (tau_is_foreign && !tk.mixed) ? tau_src : nullptr;
+    // batches in flight on other streams (dae_set_overlap_hint), bf16 arithmetic: the filter launch leaves ~112 registers
+    // per SIMD lane and 94 KB of LDS on every CU -- the 256-thread selection fits there and runs UNDER the other batch's
+    // launch (alone it is slower: 14 vs 11 us); the fp32 launches fill the LDS, nothing fits next to them
+    ta.prefer_small = (ctx->overlap_hint && dtype == DAE_DTYPE_BF16) ? 1 : 0;
     if (!tk.fused) {
         dae_dense_src ds{static_cast<const float*>(ctx->sample.p), tk.ld_s, (int)tk.ld_s, pk->col_lo, 1, nullptr};
         return dae_launch_topk_dense(ctx, ds, ta);
@@ -984,6 +988,13 @@ int dae_arm_decoder_adam(dae_ctx* ctx, float* m, float* v, float lr, float beta1
         return dae_fail(ctx, DAE_ERR_ARG, "m, v must be 16-byte aligned");
     ctx->arm_m = m; ctx->arm_v = v; ctx->arm_alpha = adam_alpha(ctx, lr, beta1, beta2, t);
     ctx->arm_b1 = beta1; ctx->arm_b2 = beta2; ctx->arm_eps = eps;
+    return DAE_OK;
+}
+
+int dae_set_overlap_hint(dae_ctx* ctx, int batches_in_flight)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    ctx->overlap_hint = batches_in_flight > 1 ? 1 : 0;
     return DAE_OK;
 }
 

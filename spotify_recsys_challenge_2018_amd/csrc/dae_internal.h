@@ -112,6 +112,7 @@ struct dae_ctx {
     int train_dtype = DAE_DTYPE_F32;   // arithmetic of the training forward GEMM (dae_set_train_dtype)
     dae_buf csr_tmp;           // COO -> CSR scratch (csr.hip)
     dae_topk_state tk;
+    int overlap_hint = 0;      // dae_set_overlap_hint: other batches are in flight on other streams -> kernel shapes that share CUs
     dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
 
     // profiling of the dominant kernel
@@ -361,6 +362,7 @@ struct dae_topk_args {
     float* out_tau;                       // [B] k-th logit or -inf (may be null)
     int pairs_stride;             // row stride of out_pairs
     int lean, sort_cap;           // set by the launcher (topk.hip): LDS mode, sort buffer keys
+    int prefer_small;             // candidate lists: the 256-thread shape (shares a CU with a bf16 filter workgroup)
     const float* row_min;         // nullable: [B] elements with logit < row_min[row] are absent (an exchanged threshold)
 };
 int dae_launch_topk_dense(dae_ctx* ctx, const dae_dense_src& src, const dae_topk_args& a);

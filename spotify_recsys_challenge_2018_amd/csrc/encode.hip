@@ -252,18 +252,18 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
     }
 
 // lanes past the row's end hold column 0 / weight 0, so no clamps or selects are needed; 16 slots
-// at a time so that short rows do not pay for 64
-#define ENC_ISSUE(X, CL, N)                                                                    \
-        _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                    \
+// at a time so that short rows do not pay for a whole chunk.  OFF = lane offset of the chunk inside its 64-entry register
+#define ENC_ISSUE(X, CL, OFF, N, CK)                                                           \
+        _Pragma("unroll") for (int k16 = 0; k16 < (CK) / 16; ++k16)                            \
             if (16 * k16 < (N)) {                                                              \
                 _Pragma("unroll") for (int u = 16 * k16; u < 16 * k16 + 16; ++u)               \
-                    X[u] = ld1(rs, voff, __builtin_amdgcn_readlane(CL, u) * hbytes);           \
+                    X[u] = ld1(rs, voff, __builtin_amdgcn_readlane(CL, (OFF) + u) * hbytes);   \
             }
-#define ENC_CHAIN(X, WL, N)                                                                    \
-        _Pragma("unroll") for (int k16 = 0; k16 < 4; ++k16)                                    \
+#define ENC_CHAIN(X, WL, OFF, N, CK)                                                           \
+        _Pragma("unroll") for (int k16 = 0; k16 < (CK) / 16; ++k16)                            \
             if (16 * k16 < (N)) {                                                              \
                 _Pragma("unroll") for (int u = 16 * k16; u < 16 * k16 + 16; ++u)               \
-                    acc = fmaf(rl_f(WL, u), X[u], acc);                                        \
+                    acc = fmaf(rl_f(WL, (OFF) + u), X[u], acc);                                \
             }
 
     for (int hb = 0; hb < hq; hb += 64) {
@@ -271,21 +271,24 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
         const bool active = hb + lane < hq;
         const int voff = (active ? hu : 0) * 4;
         float acc = 0.0f;
-        float xa[64], xb[64];
-        // chunks 0..3 from registers, double buffered: chunk c+1's 64 row reads are issued before
-        // chunk c's ordered fmaf chain runs
-        const int n0 = min(64, nnz), n1 = min(64, nnz - 64), n2 = min(64, nnz - 128), n3 = min(64, nnz - 192);
-        if (n0 > 0) {
-            ENC_ISSUE(xa, cl[0], n0)
-            if (n1 > 0) { ENC_ISSUE(xb, cl[1], n1) }
-            ENC_CHAIN(xa, wl[0], n0)
-            if (n1 > 0) {
-                if (n2 > 0) { ENC_ISSUE(xa, cl[2], n2) }
-                ENC_CHAIN(xb, wl[1], n1)
-                if (n2 > 0) {
-                    if (n3 > 0) { ENC_ISSUE(xb, cl[3], n3) }
-                    ENC_CHAIN(xa, wl[2], n2)
-                    if (n3 > 0) { ENC_CHAIN(xb, wl[3], n3) }
+        // The row's first 256 entries sit in registers (cl / wl); their W rows are fetched in chunks of 32, double
+        // buffered: chunk c + 1's 32 row reads are issued before chunk c's ordered fmaf chain runs, so 64 rows are in
+        // flight.  (Chunks of 64 -- 128 rows in flight, 128 registers of buffers -- were not faster, and at 159 registers
+        // a wave could not share a SIMD with the two filter waves of another batch's decode launch.)
+        constexpr int CK = 32;
+        float xa[CK], xb[CK];
+        const int nch = (min(nnz, 256) + CK - 1) / CK;            // chunks held in registers (wave-uniform)
+        if (nch > 0) { ENC_ISSUE(xa, cl[0], 0, min(CK, nnz), CK) }
+#pragma unroll
+        for (int c2 = 0; c2 < 256 / CK; ++c2) {
+            if (c2 < nch) {
+                const int n_cur = min(CK, nnz - CK * c2), n_nxt = min(CK, nnz - CK * (c2 + 1));
+                if (c2 & 1) {
+                    if (c2 + 1 < nch) { ENC_ISSUE(xa, cl[((c2 + 1) * CK) >> 6], ((c2 + 1) * CK) & 63, n_nxt, CK) }
+                    ENC_CHAIN(xb, wl[(c2 * CK) >> 6], (c2 * CK) & 63, n_cur, CK)
+                } else {
+                    if (c2 + 1 < nch) { ENC_ISSUE(xb, cl[((c2 + 1) * CK) >> 6], ((c2 + 1) * CK) & 63, n_nxt, CK) }
+                    ENC_CHAIN(xa, wl[(c2 * CK) >> 6], (c2 * CK) & 63, n_cur, CK)
                 }
             }
         }
@@ -300,8 +303,12 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
                 w_l = x / denom;
                 if (p.xhat_out && q == 0 && hb == 0) p.xhat_out[base + lane] = w_l;
             }
-            ENC_ISSUE(xa, c_l, n)
-            ENC_CHAIN(xa, w_l, n)
+            ENC_ISSUE(xa, c_l, 0, min(n, CK), CK)
+            ENC_CHAIN(xa, w_l, 0, min(n, CK), CK)
+            if (n > CK) {
+                ENC_ISSUE(xb, c_l, CK, n - CK, CK)
+                ENC_CHAIN(xb, w_l, CK, n - CK, CK)
+            }
         }
         if (DAE_EXP_ON(p.dbg_stop == 5)) { if (acc == -7.f) p.h_out[0] = 0.f; return; }
         if (active) {

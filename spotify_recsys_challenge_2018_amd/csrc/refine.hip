@@ -23,12 +23,14 @@
 
 namespace {
 
-constexpr int RF_THREADS = 512, RF_WAVES = RF_THREADS / 64;
 constexpr int RF_STAGE = 16384;        // candidates of a row whose u fit the staging area (floats; the waves' buffers reuse it)
 constexpr int RF_SURV = 2048;          // survivors listed per flush
 constexpr int RF_MAX_SEG = 1024;
 constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (16 data + 4 pad)
-constexpr int RF_DEPTH = 8;            // blocks of 16 k in flight per lane
+// Two shapes: <512 threads, 8 blocks of 16 k in flight per lane> -- fastest alone (186 registers, two waves per SIMD) --
+// and <256, 3> -- 1 wave per SIMD at <= 112 registers, which fits on a CU NEXT to the two filter waves per SIMD of
+// another batch's decode launch (dae_set_overlap_hint): slower alone, but it then runs under that launch instead of
+// waiting for it.
 
 struct RefineP {
     uint2* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
@@ -36,8 +38,10 @@ struct RefineP {
     const int32_t* seed_row_ptr; int k;
 };
 
+template <int RF_THREADS, int RF_DEPTH>
 __global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP p)
 {
+    constexpr int RF_WAVES = RF_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
     __shared__ int seg_prefix[RF_MAX_SEG + 2];
     __shared__ __attribute__((aligned(16))) float hrow[1024];
@@ -240,12 +244,18 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
     size_t dyn = (size_t)RF_STAGE * sizeof(float);
-    if (dyn < (size_t)RF_WAVES * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)RF_WAVES * 64 * RF_ROWSTRIDE * sizeof(float);
+    if (dyn < (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float);
     static const char key = 0;
-    if (dae_first_use(ctx, &key))
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
+    if (dae_first_use(ctx, &key)) {
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel<512, 8>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(RF_THREADS), dyn, ctx->stream, p);
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel<256, 3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    }
+    if (ctx->overlap_hint)
+        hipLaunchKernelGGL((exact_refine_kernel<256, 3>), dim3(B), dim3(256), dyn, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((exact_refine_kernel<512, 8>), dim3(B), dim3(512), dyn, ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "exact_refine_kernel");
     return DAE_OK;
 }

@@ -1151,7 +1151,7 @@ int launch_topk(dae_ctx* ctx, const Src& src, const dae_topk_args& a)
     // ... and candidate lists when the launch has many rows (>= 4 per CU: large batches, vocabulary shards): a row then
     // holds few candidates, four 256-thread workgroups share a CU, and the per-row fixed cost is what counts
     // (--sim-world 8, 2048 rows: step 322 -> 284 us; at 256 rows 256 threads lose: 22 vs 14 us)
-    const bool small = nth_env ? nth_env == 256 : ((!Src::kSegs && bound <= 4096) || (Src::kSegs && a.B >= 1024));
+    const bool small = nth_env ? nth_env == 256 : ((!Src::kSegs && bound <= 4096) || (Src::kSegs && (a.B >= 1024 || a.prefer_small)));
     if (small)
         hipLaunchKernelGGL((topk_kernel<Src, 256>), dim3(a.B), dim3(256), dyn, ctx->stream, src, aa, key_cap, dbg_stop);
     else
