@@ -46,6 +46,7 @@ for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):
     for n in nstr:
         for c in ctxs:
             c.set_overlap_hint(n if os.environ.get("HINT", "1") != "0" else 1)
+            c.profile_enable(os.environ.get("PROFILE", "0") == "1")     # event pairs around the dominant launch, as bench.py
 
         def step(i):
             j = i % n
@@ -60,6 +61,8 @@ for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):
             step(i)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / N * 1e3
+        for c in ctxs:
+            c.profile_read()
         s, i_ = outs[0]
         if name == "f32" and ref is None:
             ref = (s.clone(), i_.clone())

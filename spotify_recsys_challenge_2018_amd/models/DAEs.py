@@ -399,6 +399,9 @@ class DAE_tied:
                 self.ctx.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], cols[0], cols[1], dtype)
             self._packed_dirty[dtype] = False
             self._packed_cols[dtype] = cols
+            pg = self.__dict__.setdefault("_pack_gen", {})               # bumps whenever a slot of the context is re-tiled
+            slot = "f32" if dtype == _lib.DAE_DTYPE_F32 else "bf16"
+            pg[slot] = pg.get(slot, 0) + 1
             # "bf16" and "exact_bf16" share the context's bf16 image: the exact prepack serves both, a plain bf16
             # prepack drops the bounds the exact mode needs
             if dtype == _lib.DAE_DTYPE_BF16_EXACT:
@@ -669,16 +672,22 @@ class DAE_tied:
             ev[0].record(cur); ev[1].record(s2)           # materialise the hipEvent_t handles
             st = self._lane2 = {"ctx": ctx2, "stream": s2, "ev": ev, "packed": {}}
         ctx2, s2 = st["ctx"], st["stream"]
-        gen = self.__dict__.get("_weights_gen", 0)
-        if st["packed"].get(dtype) != gen:                 # the second image follows the weights like the first
-            s2.wait_stream(torch.cuda.current_stream(self.device_index))
-            with torch.cuda.stream(s2):
-                ctx2.prepack_decoder(self.weights["decoder_h"], self.biases["decoder_b"], 0, self.n_input, dtype)
+        # the second lane scores from the FIRST context's packed image (dae_share_decoder: one copy stays in the Infinity
+        # Cache, two evict each other), borrowed again whenever that context has re-tiled the slot (`_pack_gen`)
+        self._ensure_packed(dtype)
+        slot = "f32" if dtype == _lib.DAE_DTYPE_F32 else "bf16"
+        gen = (self.__dict__.get("_pack_gen") or {}).get(slot, 0)
+        if st["packed"].get(dtype) != gen:
+            torch.cuda.current_stream(self.device_index).synchronize()    # the owner's prepack is done ...
+            s2.synchronize()                                               # ... and nothing of the old image is in flight
+            ctx2.share_decoder(self.ctx, dtype)
+            for d_ in ([_lib.DAE_DTYPE_F32] if slot == "f32" else [_lib.DAE_DTYPE_BF16, _lib.DAE_DTYPE_BF16_EXACT]):
+                st["packed"].pop(d_, None)
             st["packed"][dtype] = gen
-            if dtype == _lib.DAE_DTYPE_BF16_EXACT:          # one bf16 image per context: see _ensure_packed
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT:          # the exact image serves plain bf16 launches as well
                 st["packed"][_lib.DAE_DTYPE_BF16] = gen
-            elif dtype == _lib.DAE_DTYPE_BF16:
-                st["packed"].pop(_lib.DAE_DTYPE_BF16_EXACT, None)
+            self.ctx.set_overlap_hint(2)
+            ctx2.set_overlap_hint(2)
         gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
         e0, e1 = st["ev"]
         import ctypes
