@@ -27,8 +27,8 @@ constexpr int RF_STAGE = 16384;        // candidates of a row whose u fit the st
 constexpr int RF_SURV = 2048;          // survivors listed per flush
 constexpr int RF_MAX_SEG = 1024;
 constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (16 data + 4 pad)
-// Two shapes: <512 threads, 8 blocks of 16 k in flight per lane> -- fastest alone (186 registers, two waves per SIMD) --
-// and <256, 3> -- 1 wave per SIMD at <= 112 registers, which fits on a CU NEXT to the two filter waves per SIMD of
+// Two shapes: 512 threads, 8 blocks of 16 k in flight per lane -- fastest alone (~190 registers, two waves per SIMD) --
+// and 256 threads, 2 blocks -- 1 wave per SIMD at <= 112 registers, which fits on a CU NEXT to the two filter waves per SIMD of
 // another batch's decode launch (dae_set_overlap_hint): slower alone, but it then runs under that launch instead of
 // waiting for it.
 
@@ -39,7 +39,7 @@ struct RefineP {
 };
 
 template <int RF_THREADS, int RF_DEPTH>
-__global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP p)
+__device__ __forceinline__ void refine_body(const RefineP& p)
 {
     constexpr int RF_WAVES = RF_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
@@ -89,12 +89,27 @@ __global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP 
         return (int)((int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]));
     };
 
+    // every candidate of the row, segment by segment: wave w takes segments w, w + RF_WAVES, ... and a lane one entry
+    // (no per-entry search for the segment; f(flat index, offset of the pair, the pair) -- called by whole waves)
+    auto for_candidates = [&](auto f) {
+        for (int sg = wave; sg < nseg; sg += RF_WAVES) {
+            const int b0 = seg_prefix[sg], cnt = seg_prefix[sg + 1] - b0;
+            const int off0 = (int)((int64_t)sg * p.seg_stride + (int64_t)row * p.row_stride);
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int i = i0 + lane;
+                const bool in = i < cnt;
+                const uint2 pr = in ? p.base[off0 + i] : make_uint2(0u, 0u);
+                f(b0 + i, off0 + i, pr, in);
+            }
+        }
+    };
+
     // ---- 1. narrow ------------------------------------------------------------------------------------------------
     float* stage_u = reinterpret_cast<float*>(rf_dyn);
     float taup = bad ? __builtin_inff() : -__builtin_inff();
     const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 2);
     if (staged) {
-        for (int i = tid; i < total; i += RF_THREADS) stage_u[i] = __uint_as_float(p.base[offset_of(i)].x);
+        for_candidates([&](int e, int, uint2 pr, bool in) { if (in) stage_u[e] = __uint_as_float(pr.x); });
         __syncthreads();
         // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
         unsigned P = 0u;
@@ -125,87 +140,123 @@ __global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP 
         }
     }
 
-    // ---- 2. recompute the survivors, flush by flush ---------------------------------------------------------------
+    // ---- 2. recompute the survivors -------------------------------------------------------------------------------
     float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // the staging area is dead by then
     const int H16 = p.x.H >> 4;                                  // blocks of 16 k (H % 16 remainder handled below)
     const int Hrem4 = (p.x.H & 15) >> 2;                         // float4 left over after the whole blocks
 
-    auto rescore_listed = [&](int n) {
-        for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
-            const int mine = g0 + lane;
-            const bool in = mine < n;
-            // quad Q, lane q: the four rows this lane helps to fetch are those of candidates 4Q + i
-            const int Q = lane >> 2, q = lane & 3;
-            const float4* rp[4];
+    // one group of <= 64 candidates, a lane each: its column `colv` (any valid column for lanes without one: `in` false)
+    // -> the fp32 logit.  The rows are fetched quad-wise (see the header), the lanes' columns travel by shuffle.
+    auto rescore_group = [&](int colv, bool in) -> float {
+        const int Q = lane >> 2, q = lane & 3;
+        const float4* rp[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ci = g0 + 4 * Q + i;
-                const int colv = surv_col[ci < n ? ci : g0];     // clamp: a valid row, values unused
-                rp[i] = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * p.x.H) + q;
-            }
-            float4 v[RF_DEPTH][4];
+        for (int i = 0; i < 4; ++i) {
+            const int ci = __shfl(colv, 4 * Q + i);
+            rp[i] = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(ci - p.x.col_lo) * p.x.H) + q;
+        }
+        float4 v[RF_DEPTH][4];
 #pragma unroll
-            for (int d = 0; d < RF_DEPTH; ++d)
+        for (int d = 0; d < RF_DEPTH; ++d)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[d][i] = d < H16 ? rp[i][4 * d] : make_float4(0.f, 0.f, 0.f, 0.f);
-            float acc = 0.0f;
-            for (int j0 = 0; j0 < H16; j0 += RF_DEPTH) {
+            for (int i = 0; i < 4; ++i) v[d][i] = d < H16 ? rp[i][4 * d] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc = 0.0f;
+        for (int j0 = 0; j0 < H16; j0 += RF_DEPTH) {
 #pragma unroll
-                for (int d = 0; d < RF_DEPTH; ++d) {
-                    const int j = j0 + d;
-                    if (j < H16) {                                // wave-uniform
+            for (int d = 0; d < RF_DEPTH; ++d) {
+                const int j = j0 + d;
+                if (j < H16) {                                    // wave-uniform
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * RF_ROWSTRIDE + 4 * q) = v[d][i];
-                        __builtin_amdgcn_wave_barrier();          // (a wave's LDS accesses execute in order; keep the compiler from moving them)
-                        const int jn = j + RF_DEPTH;
-                        if (jn < H16) {
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * RF_ROWSTRIDE + 4 * q) = v[d][i];
+                    __builtin_amdgcn_wave_barrier();              // (a wave's LDS accesses execute in order; keep the compiler from moving them)
+                    const int jn = j + RF_DEPTH;
+                    if (jn < H16) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
-                        }
-                        float4 w[4];
+                        for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
+                    }
+                    float4 w[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(tbuf + lane * RF_ROWSTRIDE + 4 * t);
-                        __builtin_amdgcn_wave_barrier();
+                    for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(tbuf + lane * RF_ROWSTRIDE + 4 * t);
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * j + 4 * t);
-                            acc = fmaf(hv.x, w[t].x, acc);
-                            acc = fmaf(hv.y, w[t].y, acc);
-                            acc = fmaf(hv.z, w[t].z, acc);
-                            acc = fmaf(hv.w, w[t].w, acc);
-                        }
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * j + 4 * t);
+                        acc = fmaf(hv.x, w[t].x, acc);
+                        acc = fmaf(hv.y, w[t].y, acc);
+                        acc = fmaf(hv.z, w[t].z, acc);
+                        acc = fmaf(hv.w, w[t].w, acc);
                     }
                 }
             }
-            if (Hrem4 && in) {                                   // hidden sizes that are not a multiple of 16: the tail, lane-owned
-                const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(surv_col[mine] - p.x.col_lo) * p.x.H);
-                for (int t = 0; t < Hrem4; ++t) {
-                    const float4 wv = wr[4 * H16 + t];
-                    const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * H16 + 4 * t);
-                    acc = fmaf(hv.x, wv.x, acc);
-                    acc = fmaf(hv.y, wv.y, acc);
-                    acc = fmaf(hv.z, wv.z, acc);
-                    acc = fmaf(hv.w, wv.w, acc);
-                }
-            }
-            if (in) {
-                const float z = acc + p.x.bias[surv_col[mine] - p.x.col_lo];
-                p.base[surv_off[mine]].x = __float_as_uint(z);
+        }
+        if (Hrem4 && in) {                                       // hidden sizes that are not a multiple of 16: the tail, lane-owned
+            const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * p.x.H);
+            for (int t = 0; t < Hrem4; ++t) {
+                const float4 wv = wr[4 * H16 + t];
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * H16 + 4 * t);
+                acc = fmaf(hv.x, wv.x, acc);
+                acc = fmaf(hv.y, wv.y, acc);
+                acc = fmaf(hv.z, wv.z, acc);
+                acc = fmaf(hv.w, wv.w, acc);
             }
         }
+        return acc + p.x.bias[colv - p.x.col_lo];
     };
 
-    __syncthreads();                                             // the search is done with the staging area: the waves' buffers take it over
+    if (!staged && !bad) {
+        // every candidate is recomputed (few enough that narrowing cannot pay, or too many to stage): the waves work
+        // independently on flat groups of 64 -- no list, no barrier
+        __syncthreads();                                         // (the staging area / tbuf are not in use: nothing to wait for but the prefix)
+        for (int g0 = wave * 64; g0 < total; g0 += RF_WAVES * 64) {
+            const int e = g0 + lane;
+            const bool in = e < total;
+            const int off = offset_of(in ? e : g0);
+            const uint2 pr = p.base[off];
+            const float z = rescore_group((int)pr.y, in);
+            if (in) p.base[off].x = __float_as_uint(z);
+        }
+        return;
+    }
+
+    // narrowed (or a row that must return nothing): ONE pass marks what is out (-inf) and lists what is left ...
+    __syncthreads();
+    for_candidates([&](int, int off, uint2 pr, bool in) {
+        const bool keep = in && __uint_as_float(pr.x) >= taup;
+        if (in && !keep) p.base[off].x = __float_as_uint(-__builtin_inff());
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int b = 0;
+            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
+            b = __shfl(b, leader);
+            const int slot = b + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && slot < RF_SURV) { surv_off[slot] = off; surv_col[slot] = (int)pr.y; }
+        }
+    });
+    __syncthreads();
+    const int n_kept = s_n;
+    if (n_kept <= RF_SURV) {                                     // ... and the list is recomputed, a lane per entry
+        for (int g0 = wave * 64; g0 < n_kept; g0 += RF_WAVES * 64) {
+            const int e = g0 + lane;
+            const bool in = e < n_kept;
+            const float z = rescore_group(surv_col[in ? e : g0], in);
+            if (in) p.base[surv_off[e]].x = __float_as_uint(z);
+        }
+        return;
+    }
+    // more survivors than the list holds (thousands of logits within 2 eps of the cut): list by list.  The entries already
+    // recomputed hold fp32 logits >= ... no: nothing has been recomputed yet, the kept entries still hold their bounds
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
     for (int c0 = 0; c0 < total; c0 += RF_THREADS) {
         const int i = c0 + tid;
         const bool has = i < total;
         int off = 0;
         uint2 pr = make_uint2(0u, 0u);
         if (has) { off = offset_of(i); pr = p.base[off]; }
-        const float u = __uint_as_float(pr.x);                   // still the bound: only earlier flushes' candidates were rewritten
-        const bool keep = has && u >= taup;
-        if (has && !keep) p.base[off].x = __float_as_uint(-__builtin_inff());
+        const bool keep = has && __uint_as_float(pr.x) >= taup;  // (-inf entries of the pass above fail this)
         const unsigned long long bal = __ballot(keep);
         if (bal) {
             const int leader = __ffsll((long long)bal) - 1;
@@ -221,12 +272,24 @@ __global__ __launch_bounds__(RF_THREADS) void exact_refine_kernel(const RefineP 
         __syncthreads();
         const int n = s_n;
         if (n + RF_THREADS > RF_SURV || c0 + RF_THREADS >= total) {   // the list could overflow next round, or this was the last
-            rescore_listed(n);
+            for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
+                const int e = g0 + lane;
+                const bool in = e < n;
+                const float z = rescore_group(surv_col[in ? e : g0], in);
+                if (in) p.base[surv_off[e]].x = __float_as_uint(z);
+            }
             __syncthreads();
             if (tid == 0) s_n = 0;
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
+// the shape that shares a CU with another batch's filter workgroup: one wave per SIMD within the 112 registers those leave
+__global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
+{
+    refine_body<256, 2>(p);
 }
 
 }  // namespace
@@ -247,15 +310,15 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     if (dyn < (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float);
     static const char key = 0;
     if (dae_first_use(ctx, &key)) {
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel<512, 8>),
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel<256, 3>),
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_slim_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     }
     if (ctx->overlap_hint)
-        hipLaunchKernelGGL((exact_refine_kernel<256, 3>), dim3(B), dim3(256), dyn, ctx->stream, p);
+        hipLaunchKernelGGL(exact_refine_slim_kernel, dim3(B), dim3(256), dyn, ctx->stream, p);
     else
-        hipLaunchKernelGGL((exact_refine_kernel<512, 8>), dim3(B), dim3(512), dyn, ctx->stream, p);
+        hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(512), dyn, ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "exact_refine_kernel");
     return DAE_OK;
 }
