@@ -227,43 +227,80 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
     ctx.bind_stream()
 
     fuse = [False]
+    rows = [None]                 # rows-Adam state of the encoder (dae_adam_rows_*): what the model runs by default
+    flush_every = 32
 
     def step(i):
+        lz = rows[0]
+        tstep = (lz["t"] + 1) if lz is not None else (i + 1)       # Adam's 1-based step count
         if fuse[0]:      # W_dec's Adam inside the decoder-gradient kernel (bit-identical parameters)
-            ctx.check(ctx.lib.dae_arm_decoder_adam(ctx.h, P(mom["Wd"][0]), P(mom["Wd"][1]), 0.005, 0.9, 0.999, 1e-8, i + 1))
+            ctx.check(ctx.lib.dae_arm_decoder_adam(ctx.h, P(mom["Wd"][0]), P(mom["Wd"][1]), 0.005, 0.9, 0.999, 1e-8, tstep))
+        if lz is not None:       # the rows this step's input names become current BEFORE the encode reads them
+            rows_arg = (P(x[1]), ctypes.c_void_p(x[0].data_ptr() + 4 * B), int(x[1].numel()))
+            ctx.check(ctx.lib.dae_adam_rows_begin(ctx.h, P(t["We"]), P(mom["We"][0]), P(mom["We"][1]), P(lz["state"]), P(lz["tab"]),
+                                                  lz["tab"].numel(), V, H, rows_arg[0], rows_arg[1], rows_arg[2],
+                                                  0.9, 0.999, 1e-8, tstep))
         ctx.check(ctx.lib.dae_train_forward_backward(
             ctx.h, P(x[0]), P(x[1]), P(x[2]), P(y[0]), P(y[1]), P(y[2]), P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]),
             V, H, B, B, 0, 0.75, 0.8, 100 + i, 0.0, P(g["We"]), P(g["be"]), P(g["Wd"]), P(g["bd"]), P(cost)))
         for n in t:
             if fuse[0] and n == "Wd":
                 continue
+            if lz is not None and n == "We":
+                lz["t"] = tstep
+                ctx.check(ctx.lib.dae_adam_rows_apply(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), P(lz["state"]),
+                                                      P(lz["tab"]), lz["tab"].numel(), V, H, rows_arg[0], rows_arg[1],
+                                                      rows_arg[2], 0.005, 0.9, 0.999, 1e-8, lz["t"]))
+                if lz["t"] - lz["flushed"] >= flush_every:       # every row current again (bounds the replay of rare rows)
+                    ctx.check(ctx.lib.dae_adam_rows_flush(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(lz["state"]), P(lz["tab"]),
+                                                          lz["tab"].numel(), V, H, 0.9, 0.999, 1e-8, lz["t"]))
+                    lz["flushed"] = lz["t"]
+                continue
             ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(),
-                                            0.005, 0.9, 0.999, 1e-8, i + 1))
+                                            0.005, 0.9, 0.999, 1e-8, tstep))
     row = {"unit": "ms per step of %d playlists" % B, "what": "untied: forward (dropout) + loss + backward + dense "
            "TF1-Adam on W_enc, W_dec, b_enc, b_dec; fp32 parameters and moments", "steps": 20}
     k = 0
-    for name, dt, fz in (("f32", _lib.DAE_DTYPE_F32, False), ("bf16_gemms", _lib.DAE_DTYPE_BF16, False),
-                         ("bf16_gemms_decoder_adam_in_kernel", _lib.DAE_DTYPE_BF16, H % 128 == 0)):
+    for name, dt, fz, ra in (("f32", _lib.DAE_DTYPE_F32, False, False), ("bf16_gemms", _lib.DAE_DTYPE_BF16, False, False),
+                             ("bf16_gemms_decoder_adam_in_kernel", _lib.DAE_DTYPE_BF16, H % 128 == 0, False),
+                             ("model_default_bf16", _lib.DAE_DTYPE_BF16, H % 128 == 0, True)):
         ctx.set_train_dtype(dt)
         fuse[0] = fz
+        n_t = 20
+        if ra:
+            # the model's own step (models/DAEs.py train_step): + the encoder's Adam on the rows the batch names only
+            # (dae_adam_rows_*: bit-identical parameters), every row brought up to date every 32 steps -- timed over 32
+            # steps so that exactly one such flush is inside.  A fresh Adam state: the step counters restart.
+            for n in mom:
+                mom[n][0].zero_(); mom[n][1].zero_()
+            g["We"].zero_()
+            rows[0] = {"state": torch.zeros(2 * V, dtype=torch.int32, device="cuda"),
+                       "tab": torch.zeros(1 << 12, dtype=torch.float32, device="cuda"), "t": 0, "flushed": 0}
+            ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 1))
+            k = 0
+            n_t = flush_every
         for _ in range(3):
             step(k); k += 1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(n_t):
             step(k); k += 1
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 20 * 1e3
-        row[name] = {"ms_per_step": round(ms, 3), "playlists_per_s": round(B / ms * 1e3, 1), "cost": round(float(cost.item()), 3)}
+        ms = (time.perf_counter() - t0) / n_t * 1e3
+        row[name] = {"ms_per_step": round(ms, 3), "playlists_per_s": round(B / ms * 1e3, 1), "cost": round(float(cost.item()), 3),
+                     "steps": n_t}
         # step-level roofline (algorithmic minimum, DESIGN.md section 4 "Training"): three GEMMs of 2 B V H FLOP against
         # the dense MFMA peak of their operand type, and the HBM bytes no schedule can avoid -- W_dec read by K5 and K7,
         # dL/dz^T written once and read twice (fp32 or bf16), the dense Adam passes (p, m, v read and written, the
         # gradient written and read: 7 x 4 V H per matrix; 6 x when the decoder's update sits in the gradient kernel and
-        # its gradient never reaches HBM) and the clearing of the encoder gradient
+        # its gradient never reaches HBM) and the clearing of the encoder gradient; with rows-Adam the encoder costs the
+        # named rows (~4 %% of the matrix) plus 1/32 of a pass over everything
         gemm_flop = 3 * 2.0 * B * V * H
         mat = 4.0 * V * H
         dz = (2.0 if dt == _lib.DAE_DTYPE_BF16 else 4.0) * B * V
-        hbm = 2 * mat + 3 * dz + (6 if fz else 7) * mat + 7 * mat + mat
+        enc = (7 * mat * (float(np.unique(coo_to_csr(pos[pos[:, 1] < n_tracks], ones[pos[:, 1] < n_tracks], B, V)[1]).size) / V)
+               + 7 * mat / flush_every) if ra else (7 * mat + mat)
+        hbm = 2 * mat + 3 * dz + (6 if fz else 7) * mat + enc
         peak_tf = PEAK_BF16_TFLOPS if dt == _lib.DAE_DTYPE_BF16 else PEAK_F32_TFLOPS
         t_mfma, t_hbm = gemm_flop / (peak_tf * 1e12) * 1e3, hbm / (PEAK_HBM_GBS * 1e9) * 1e3
         row[name]["roofline"] = {"bound": "hbm" if t_hbm > t_mfma else "mfma", "gemm_flop_per_step": gemm_flop,
@@ -275,10 +312,12 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
                                  "frac_if_serial": round((t_mfma + t_hbm) / ms, 4),
                                  "note": "whole step against its binding roof (the larger of matrix time and byte time); "
                                          "frac_if_serial counts both, for a schedule that cannot overlap them"}
+    rows[0] = None
+    ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 0))
     ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
-    row["note"] = ("NOT the headline.  The model (models/DAEs.py) runs the last variant plus rows-Adam on the encoder "
-                   "(dae_adam_rows_*: no HBM passes over rows without gradient); scripts/bench_epoch.py times that loop "
-                   "with the reader and the device CSR builds")
+    row["note"] = ("NOT the headline.  model_default_bf16 is the step models/DAEs.py runs with train_dtype = bf16 (decoder Adam in "
+                   "the gradient kernel, rows-Adam on the encoder: bit-identical parameters, no HBM passes over rows without "
+                   "gradient); scripts/bench_epoch.py times that loop with the reader and the device CSR builds")
     return row
 
 
