@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--k", type=int, default=500)
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--bias", default="zipf", choices=["zipf", "zeros"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="decode arithmetic: f32 = bit-exact headline path, bf16 = BASELINE configs[4]")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "exact_bf16"],
+                    help="decode arithmetic: f32 = fp32 MFMA, the bit-exact headline path; bf16 = BASELINE configs[4]; exact_bf16 = "
+                         "the bf16 GEMM as a filter + fp32 recomputation of the survivors (north_star: the fp32 lists, bit for bit)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: each has its own library context and HIP stream, so the "
                          "latency-bound kernels of one batch overlap the decode of the other.  Default: 2 for f32 (a third "
@@ -127,12 +128,14 @@ def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k
              torch.empty((B, k), dtype=torch.int32, device=d_We.device)) for _ in range(n_b)]
     cnt = [0]
 
+    handles = [[c.score_topk_handle(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s_][0], outs[s_][1], dtype=dt)
+                for f in feeds] for s_, c in enumerate(ctxs)]          # every context is bound to its own stream
+
     def step(only=None, batch=None):
         s_ = cnt[0] % n_b if only is None else only
-        f = feeds[cnt[0] % len(feeds)] if batch is None else feeds[batch]
+        bi = cnt[0] % len(feeds) if batch is None else batch
         cnt[0] += 1
-        with torch.cuda.stream(streams[s_]):
-            ctxs[s_].score_topk(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s_][0], outs[s_][1], dtype=dt)
+        handles[s_][bi]()
     for _ in range(max(n_warm, 4)):
         step()
     torch.cuda.synchronize()
@@ -396,13 +399,14 @@ def main():
         else:
             c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
 
-    n_str = args.streams if args.streams > 0 else (4 if args.dtype == "bf16" else 2)
+    lowp = args.dtype in ("bf16", "exact_bf16")          # the GEMM launches run on bf16 operands
+    n_str = args.streams if args.streams > 0 else (4 if lowp else 2)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     ctx = ctxs[0]
     d_Wd, d_bd = up(W_dec, torch.float32), up(b_dec, torch.float32)
     d_Wd_all = d_Wd
-    DT = _lib.DAE_DTYPE_BF16 if args.dtype == "bf16" else _lib.DAE_DTYPE_F32
+    DT = {"f32": _lib.DAE_DTYPE_F32, "bf16": _lib.DAE_DTYPE_BF16, "exact_bf16": _lib.DAE_DTYPE_BF16_EXACT}[args.dtype]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     prepack_ctx(ctx, DT)
@@ -473,11 +477,21 @@ def main():
     exchange = [args.exchange]
     last = [None] * n_str                        # (score, idx) of the last batch of each stream
 
+    # one pre-marshalled call per (context, resident batch): each context is bound to its own stream, so issuing a step
+    # is one foreign-function call (no torch stream context, no argument conversion in the loop)
+    handles = None if sharded else [[c.score_topk_handle(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s_][0],
+                                                          outs[s_][1], dtype=DT) for f in feeds] for s_, c in enumerate(ctxs)]
+
     def step(batch=None):
         s = step_no[0] % n_str
-        f = feeds[step_no[0] % len(feeds)] if batch is None else feeds[batch]
+        bi = step_no[0] % len(feeds) if batch is None else batch
+        f = feeds[bi]
         step_no[0] += 1
         c = ctxs[s]
+        if not sharded:
+            handles[s][bi]()
+            last[s] = outs[s]
+            return
         with torch.cuda.stream(streams[s]):
             if not sharded:
                 c.score_topk(f[0], f[1], f[2], d_We, d_be, n_tracks, f[3], f[4], k, outs[s][0], outs[s][1],
@@ -553,18 +567,18 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
     if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 256 and not sim:
         try:
-            tj = json.load(open(tpath)).get("bf16" if args.dtype == "bf16" else "f32", {})
+            tj = json.load(open(tpath)).get("bf16" if lowp else "f32", {})
             # PMC passes are separate rocprofv3 runs (scripts/gpu_pmc_traffic.sh); the figure is quoted only when it
             # was collected for the kernel this run timed
             traffic = tj.get("hbm_bytes_per_launch") if tj.get("kernel") == ctx.profile_kernel() else None
             pmc_mfma = tj.get("mfma") if tj.get("kernel") == ctx.profile_kernel() else None
         except Exception:
             traffic = None
-    peak_tf = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    peak_tf = PEAK_BF16_TFLOPS if lowp else PEAK_F32_TFLOPS
     # Which roof binds this launch: its matrix time at the dense MFMA peak, or the time to stream its algorithmic
     # bytes (W tiles + bias + hidden + candidate lists) at the HBM peak.  fp32 is MFMA-bound at every
     # batch size; bf16 at batch 256 is BELOW the ridge (256 flop per byte of W against 2.5 PF / 8 TB/s = 312).
-    esz = 2 if args.dtype == "bf16" else 4
+    esz = 2 if lowp else 4
     alg_bytes = dom_tiles * 32 * H * esz + 4 * dom_tiles * 32 + B * H * esz + 8 * B * k
     t_mfma = flop_per_launch / (peak_tf * 1e12)
     t_hbm = alg_bytes / (PEAK_HBM_GBS * 1e9)
@@ -852,7 +866,7 @@ def main():
         torch.cuda.synchronize()
         score_batch0()
         got = last[0] if exchange[0] == "alltoall" else (last[0][0][r0:r0 + bpg], last[0][1][r0:r0 + bpg])
-        same = bool(torch.equal(got[1], lo_out[0][1]) and torch.equal(got[0], lo_out[0][0])) if args.dtype == "f32" else None
+        same = bool(torch.equal(got[1], lo_out[0][1]) and torch.equal(got[0], lo_out[0][0])) if args.dtype != "bf16" else None
         out["playlist_sharded"] = {"value": round(B * args.steps / el_r, 1), "unit": "playlists/s",
                                    "ms_per_step": round(el_r / args.steps * 1e3, 4),
                                    "identical_to_vocab_sharded": same,
@@ -894,14 +908,14 @@ def main():
 
     # ---- CPU baseline: the C oracle ("port"), one thread, bounded sample --------------------------
     oracle_ref = None
-    if args.dtype == "bf16":
+    if lowp:
         # W_dec bf16 is 87 MB: at batch 256 the decode is bounded by streaming it (2*B/2 = 256 FLOP/B
         # < the 400 FLOP/B machine balance); report the HBM view next to the MFMA one
         w_bytes = dom_tiles * 32 * H * 2
         out["roofline_hbm_view"] = {"kernel": roofline["kernel"], "bound": "hbm",
                                     "achieved": round(w_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0,
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "bytes_per_launch": w_bytes}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype != "bf16":
         import oracle
         ns = min(args.cpu_sample, B)
         rows = slice(0, ns)
@@ -990,7 +1004,7 @@ def main():
             if not args.no_extra_rows:
                 out["exact_bf16_decode"] = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds, (d_We, d_be), n_tracks,
                                                      _lib.DAE_DTYPE_BF16_EXACT, B, H, k, args.steps, args.warmup, ref32,
-                                                     oracle_ref, peaks, "exact_bf16")
+                                                     oracle_ref, peaks, "bf16")
             if gate_events:
                 for i, c in enumerate(ctxs):
                     c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc_round2.sh into the two JSON files bench.py quotes
+"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc_round3.sh (round 2: gpu_pmc_round2.sh, prefix r02) into the two JSON files bench.py quotes
 (`roofline.traffic`, `roofline_encode.traffic`): HBM-side bytes per launch = FETCH_SIZE x 2 (gfx950 correction for
 wide coalesced reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, counters in KB."""
 import collections
@@ -10,6 +10,7 @@ import subprocess
 import sys
 
 root = sys.argv[1]
+PFX = sys.argv[2] if len(sys.argv) > 2 else "r03"        # file prefix of the passes: <PFX>_pmc_<cfg>_<set>.csv
 
 
 def per_kernel(path):
@@ -46,16 +47,16 @@ try:
     sha = subprocess.check_output(["git", "-C", os.path.dirname(root), "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     sha = os.environ.get("DAE_GIT_SHA", "unknown")
-dec = {"source": "rocprofv3 --kernel-trace --pmc <set>, one pass per counter set (scripts/gpu_pmc_round2.sh): bench.py "
-                 "--streams 1 --steps 6, default workload (B=256, V=170000, H=256); raw CSVs profiles/r02_pmc_*.csv",
+dec = {"source": "rocprofv3 --kernel-trace --pmc <set>, one pass per counter set (scripts/gpu_pmc_round3.sh): bench.py "
+                 "--streams 1 --steps 6, default workload (B=256, V=170000, H=256); raw CSVs profiles/%s_pmc_*.csv" % PFX,
        "fetch_correction": "hbm_bytes_per_launch = FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half) + "
                            "WRITE_SIZE; counters are KB", "git": sha}
 enc = {"source": dec["source"], "fetch_correction": dec["fetch_correction"], "git": sha}
 for cfg, ksub, peak_mops in (("f32", "decode_f32_h256_filter_kernel", "SQ_INSTS_VALU_MFMA_MOPS_F32"),
                              ("bf16", "decode_bf16_h256_filter_kernel", "SQ_INSTS_VALU_MFMA_MOPS_BF16")):
-    f = per_kernel(os.path.join(root, "r02_pmc_%s_fetch.csv" % cfg))
-    w = per_kernel(os.path.join(root, "r02_pmc_%s_write.csv" % cfg))
-    m = per_kernel(os.path.join(root, "r02_pmc_%s_mfma.csv" % cfg))
+    f = per_kernel(os.path.join(root, "%s_pmc_%s_fetch.csv" % (PFX, cfg)))
+    w = per_kernel(os.path.join(root, "%s_pmc_%s_write.csv" % (PFX, cfg)))
+    m = per_kernel(os.path.join(root, "%s_pmc_%s_mfma.csv" % (PFX, cfg)))
     kname, fd = find(f, ksub)
     _, wd = find(w, ksub)
     _, md = find(m, ksub)
@@ -91,6 +92,16 @@ for cfg, ksub, peak_mops in (("f32", "decode_f32_h256_filter_kernel", "SQ_INSTS_
             enc[key] = {"kernel": short_name(kn),
                         "launches": len(fv), "fetch_size_kb": round(mean(fv), 1), "write_size_kb": round(mean(wv), 1),
                         "hbm_bytes_per_launch": int((2 * mean(fv) + mean(wv)) * 1024)}
+# the exact mode's refine launch (DAE_DTYPE_BF16_EXACT): bytes its row gathers really pull through the fabric
+f = per_kernel(os.path.join(root, "%s_pmc_exact_fetch.csv" % PFX))
+w = per_kernel(os.path.join(root, "%s_pmc_exact_write.csv" % PFX))
+for key, sub in (("exact_refine", "exact_refine"), ("exact_filter", "decode_bf16_h256_filter_kernel")):
+    kn, fd = find(f, sub)
+    _, wd = find(w, sub)
+    if kn:
+        fetch, write = mean(fd.get("FETCH_SIZE", [0])), mean(wd.get("WRITE_SIZE", [0]))
+        dec[key] = {"kernel": short_name(kn), "launches": len(fd.get("FETCH_SIZE", [])), "fetch_size_kb": round(fetch, 1),
+                    "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
 json.dump(dec, open(os.path.join(root, "traffic_decode.json"), "w"), indent=1)
 json.dump(enc, open(os.path.join(root, "traffic_encode.json"), "w"), indent=1)
 print(json.dumps(dec, indent=1))

@@ -245,6 +245,24 @@ class Context:
                                            int(n_tracks), _ptr(seed_row_ptr), _ptr(seed_col),
                                            int(k), int(out_kind), _ptr(out_score), _ptr(out_idx)))
 
+    def score_topk_handle(self, row_ptr, col, val, W_enc, b_enc, n_tracks, seed_row_ptr, seed_col, k,
+                          out_score, out_idx, out_kind=DAE_OUT_SCORE, dtype=DAE_DTYPE_F32):
+        """`score_topk` with its arguments marshalled ONCE: returns a zero-argument callable that enqueues the call on
+        the context's stream (a driver that scores resident batches issues one every ~30 us: building 17 ctypes
+        arguments and a torch stream context per call was a third of that).  The tensors must stay alive and in place."""
+        V, H = W_enc.shape
+        B = row_ptr.numel() - 1
+        args = (self.h, _ptr(row_ptr), _ptr(col), _ptr(val), _ptr(W_enc), _ptr(b_enc), V, H, B, int(dtype), int(n_tracks),
+                _ptr(seed_row_ptr), _ptr(seed_col), int(k), int(out_kind), _ptr(out_score), _ptr(out_idx))
+        fn, check = self.lib.dae_score_topk, self.check
+        keep = (row_ptr, col, val, W_enc, b_enc, seed_row_ptr, seed_col, out_score, out_idx)
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc:
+                check(rc)
+        return call
+
     def score_topk_begin(self, row_ptr, col, val, W_enc, b_enc, n_tracks, seed_row_ptr, k, tau_out, dtype=DAE_DTYPE_F32):
         """First half of score_topk: encode + threshold sample -> tau_out [B] (this image's per-row lower bounds)."""
         V, H = W_enc.shape
