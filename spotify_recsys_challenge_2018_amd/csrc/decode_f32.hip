@@ -1092,6 +1092,12 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int j = lane & 31;
+#ifdef DAE_EXPERIMENTS          // stage stamps of wave 0 of workgroups 0 and 100 (DAE_DBG_F): cycle counter at the marked points
+#define FSTAMP(i) if (p.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) p.stamps[(blockIdx.x ? 16 : 0) + (i)] = __builtin_readcyclecounter();
+#else
+#define FSTAMP(i)
+#endif
+    FSTAMP(0)
 
     const int gs = DAE_NUM_XCD * p.n_rg;
     const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
@@ -1174,7 +1180,9 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wq[nt][k] = Wq[(size_t)t[nt] * (NS * 64) + k * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
+    FSTAMP(1)                                                    // every request of the prologue is out
     __syncthreads();
+    FSTAMP(2)                                                    // the workgroup has met
 
     float tau_r[RB];
 #pragma unroll
@@ -1292,10 +1300,14 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { t[nt] = u[nt]; u[nt] = __builtin_amdgcn_readfirstlane(wv[nt]); }
+        FSTAMP(3 + (grp - grp0) / n_ws)                          // tile (group) done, epilogue included
     }
+    FSTAMP(13)
     __syncthreads();
+    FSTAMP(14)
     for (int i = tid; i < R_TILE; i += NW * 64) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + i] = lcnt[i];
 }
+#undef FSTAMP
 
 // ---- prepack: W_dec rows -> MFMA A-operand order ----------------------------------------------
 // One workgroup per 32-column tile: the tile's 32 rows of W (32 x H floats, contiguous 4 H bytes each) are read
@@ -2007,6 +2019,25 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
         return DAE_OK;
     }
     if (bf16_fast_filter(g, dtype, p.G) && !p.mixT) {
+#ifdef DAE_EXPERIMENTS
+        static const bool dbgF = dae_exp_env("DAE_DBG_F") != nullptr;     // stage stamps of the dedicated bf16 filter kernel
+        static long long* fbuf = nullptr;
+        static int fcalls = 0;
+        if (dbgF) {
+            if (!fbuf) { (void)hipMalloc(&fbuf, 32 * 8); (void)hipMemset(fbuf, 0, 32 * 8); }
+            p.stamps = fbuf;
+            if ((++fcalls % 100) == 0) {
+                long long h[32];
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpy(h, fbuf, sizeof(h), hipMemcpyDeviceToHost);
+                for (int w = 0; w < 2; ++w) {
+                    fprintf(stderr, "FILTER wg%d:", w ? 100 : 0);
+                    for (int i = 1; i < 15; ++i) if (h[16 * w + i]) fprintf(stderr, " [%d]%lld", i, h[16 * w + i] - h[16 * w]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+#endif
         const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * (sizeof(int) + sizeof(float));
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {
