@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity sweep (not part of the test suite: minutes of GPU time): many random shapes of the scoring
 path against the C oracle, bit for bit in fp32 -- fused path, decode_dense + topk_dense, shard + merge -- and the
-bf16 fused path against its own unfused path.  Prints every mismatch with the shape that produced it."""
+bf16 fused path against its own unfused path, the exact-bf16 path against the oracle.  Prints every mismatch with the shape that produced it."""
 import os
 import sys
 import time
@@ -73,9 +73,15 @@ def main():
             ctx.decode_dense(h, z, apply_sigmoid=False, dtype=_lib.DAE_DTYPE_BF16)
             ctx.topk_dense(z, nt, 0, d[7], d[8], k, su, iu)
             ok4 = torch.equal(i16, iu) and torch.equal(s16, su)
-            if not (ok and ok2 and ok3 and ok4):
+            # exact bf16 (bf16 GEMM filter on error bounds + fp32 refine) vs the fp32 oracle
+            ctx.prepack_decoder(d[5], d[6], 0, V, _lib.DAE_DTYPE_BF16_EXACT)
+            sx = torch.empty_like(s); ix = torch.empty_like(i)
+            ctx.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, sx, ix, dtype=_lib.DAE_DTYPE_BF16_EXACT)
+            ok5 = np.array_equal(ix.cpu().numpy(), i_ref) and np.array_equal(sx.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+            if not (ok and ok2 and ok3 and ok4 and ok5):
                 bad += 1
-                print("MISMATCH", tag, "oracle=%s unfused=%s shards(G=%d)=%s bf16=%s plan=%s" % (ok, ok2, G, ok3, ok4, ctx.last_plan()))
+                print("MISMATCH", tag, "oracle=%s unfused=%s shards(G=%d)=%s bf16=%s exact=%s plan=%s"
+                      % (ok, ok2, G, ok3, ok4, ok5, ctx.last_plan()))
         except Exception as e:                                                   # noqa: BLE001
             bad += 1
             print("ERROR", tag, repr(e))

@@ -18,6 +18,7 @@ except Exception as e:
 PY
 done
 bash scripts/gpu_prof.sh r03_default
+bash scripts/gpu_prof.sh r03_headline --no-extra-rows --no-train-row --no-cpu-baseline --no-bf16-row
 bash scripts/gpu_prof.sh r03_1stream --streams 1 --no-train-row --no-cpu-baseline --no-bf16-row --no-extra-rows
 bash scripts/gpu_prof.sh r03_bf16_1stream --dtype bf16 --streams 1 --no-train-row --no-cpu-baseline
 bash scripts/gpu_prof.sh r03_exact_1stream --dtype exact_bf16 --streams 1 --no-train-row --no-cpu-baseline

@@ -1,6 +1,6 @@
 """GPU (-m gpu): a short run of the randomised parity sweep scripts/fuzz_gpu.py (random vocabulary / hidden /
-batch / k / bias / seed patterns; fused vs oracle, unfused, shard + merge, bf16 fused vs unfused -- all bit for
-bit).  The long sweeps (1000+ shapes, also under DAE_TOPK_LEAN / DAE_SAMPLE=strided / DAE_TOPK_THREADS=256) are
+batch / k / bias / seed patterns; fused vs oracle, unfused, shard + merge, bf16 fused vs unfused, exact bf16 vs
+oracle -- all bit for bit).  The long sweeps (1000+ shapes, also under DAE_TOPK_LEAN / DAE_SAMPLE=strided / DAE_TOPK_THREADS=256) are
 run by hand; this keeps a slice of them in every test run."""
 import os
 import subprocess
