@@ -1,0 +1,57 @@
+"""cProfile of the drivers' loop (recommend_iter, device seeds, idx only) -- where the host time per launch goes."""
+import cProfile
+import os
+import pickle
+import pstats
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import importlib
+_m = importlib.import_module("spotify_recsys_challenge_2018_amd.models." + os.environ.get("DAE_MOD", "DAEs"))
+DAE, SEEDS_FROM_INPUT = _m.DAE, _m.SEEDS_FROM_INPUT
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+import torch
+nt, na, H = 140000, 30000, 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+mode = sys.argv[2] if len(sys.argv) > 2 else "exact_bf16"
+V = nt + na
+W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+path = "/tmp/_shim_init.pkl"
+pickle.dump([W_enc, W_dec, b_enc, b_dec], open(path, "wb"))
+
+
+class C:
+    save = "/tmp/_shim_unused"; batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
+    n_tracks = nt; initval = path
+
+
+m = DAE(C()); m.fit()
+if os.environ.get("COPIES"):
+    m.iter_copies = os.environ["COPIES"]
+if os.environ.get("LANES"):
+    m.n_lanes = int(os.environ["LANES"])
+if os.environ.get("COALESCE"):
+    m.coalesce = int(os.environ["COALESCE"])
+batches = [make_playlists(B, nt, na, seed=s) for s in range(8)]
+
+
+def feeds(reps):
+    for _ in range(reps):
+        for p_, o_, s_ in batches:
+            yield p_, o_, SEEDS_FROM_INPUT, B
+
+
+def run(reps):
+    n = 0
+    for _idx, _sc in m.recommend_iter(feeds(reps), k=500, want_scores=False, dtype=mode):
+        n += B
+    return n
+
+
+run(4); torch.cuda.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); n = run(150); dt = time.perf_counter() - t0
+    print("%s B=%d: %.0f playlists/s, %.3f ms per feed" % (mode, B, n / dt, dt / (n / B) * 1e3))
+pr = cProfile.Profile(); pr.enable(); run(40); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

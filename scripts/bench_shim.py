@@ -47,7 +47,7 @@ def main():
     # batch n), seeds cut out of the input on the device, indices only -- what main.py --challenge runs
     from spotify_recsys_challenge_2018_amd.models.DAEs import SEEDS_FROM_INPUT
     m.device_csr = True
-    it_dtype = "bf16" if "--bf16" in sys.argv else None      # decode GEMM of the streamed loop on bf16 operands
+    it_dtype = "bf16" if "--bf16" in sys.argv else ("exact_bf16" if "--exact" in sys.argv else None)   # decode mode of the streamed loop
     if "--alone" in sys.argv:                 # one feed per launch, one context: the loop before coalescing / two lanes
         m.coalesce = 1
         m.two_lanes = False
@@ -62,10 +62,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
-        for _idx, _sc in m.recommend_iter(feeds(5), k=500, want_scores=scores, dtype=it_dtype):
+        for _idx, _sc in m.recommend_iter(feeds(5 if scores else 100), k=500, want_scores=scores, dtype=it_dtype):
             n += B
         dt = time.perf_counter() - t0
-        print("model.recommend_iter%s (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (" bf16" if it_dtype else "", label, n / dt, dt / (n / B) * 1e3, B))
+        print("model.recommend_iter%s (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (" " + it_dtype if it_dtype else "", label, n / dt, dt / (n / B) * 1e3, B))
     # same answers either way
     a = m.recommend(batches[0][0], batches[0][1], batches[0][2], k=500)
     b = next(iter(m.recommend_iter([(batches[0][0], batches[0][1], SEEDS_FROM_INPUT, B)], k=500)))

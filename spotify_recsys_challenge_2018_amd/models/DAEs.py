@@ -241,20 +241,57 @@ class DAE_tied:
         t.record_stream(cur)
         return t
 
-    def _upload_csr(self, positions, values, side_stream=False, ctx=None, n_rows=None):
+    @staticmethod
+    def _feed_arrays(positions, values):
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64).reshape(-1, 2))
+        vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+        if vals.size != 1 and vals.size != pos.shape[0]:
+            raise ValueError("positions (%d) and values (%d) differ in length" % (pos.shape[0], vals.size))
+        return pos, vals
+
+    def _stage_pinned(self, slot, positions, values):
+        """The raw feed -> device COO through the pinned host buffers of `slot` (recommend_iter's staging ring), copied
+        asynchronously on the copy stream.  The host does not wait: a copy from pageable memory would block it until
+        the copy engine (a blit kernel that queues behind the decode launches) got to it.  -> `staged` for
+        `_upload_csr` (which makes the launch's stream wait for the copies' event)."""
+        import torch
+        pos, vals = self._feed_arrays(positions, values)
+        dev = torch.device("cuda", self.device_index)
+        n, nv = max(pos.shape[0], 1), max(vals.size, 1)
+        pp = _pinned(slot, "pos", 2 * n, torch.int64)
+        pv = _pinned(slot, "val", nv, torch.float32)
+        if pos.shape[0] and not np.may_share_memory(pp.numpy(), pos):
+            np.copyto(pp.numpy()[:2 * n].reshape(n, 2), pos)
+        if vals.size and not np.may_share_memory(pv.numpy(), vals):
+            np.copyto(pv.numpy()[:nv], vals)
+        cs = self.__dict__.get("_copy_stream")
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(cs):                         # not the launch's stream: the other lane's decode would wait
+            d_pos = torch.empty((n, 2), dtype=torch.int64, device=dev)
+            d_val = torch.empty(nv, dtype=torch.float32, device=dev)
+            d_pos.copy_(pp[:2 * n].view(n, 2), non_blocking=True)
+            d_val.copy_(pv[:nv], non_blocking=True)
+            ev = slot["busy"] = cs.record_event()
+        return d_pos[:pos.shape[0]], d_val, ev
+
+    def _upload_csr(self, positions, values, side_stream=False, ctx=None, n_rows=None, staged=None):
         """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
         and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
-        restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
+        restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly).  `staged`: the feed is
+        on the device already (`_stage_pinned`)."""
         import torch
         if self.device_csr:
-            pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64).reshape(-1, 2))
-            vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
-            if vals.size != 1 and vals.size != pos.shape[0]:
-                raise ValueError("positions (%d) and values (%d) differ in length" % (pos.shape[0], vals.size))
-            if pos.shape[0] == 0:
-                pos = np.zeros((0, 2), np.int64)
-            d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
-            d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
+            if staged is not None:
+                d_pos, d_val, ev_up = staged
+                if ev_up is not None:                       # copied on another stream
+                    cur = torch.cuda.current_stream(self.device_index)
+                    cur.wait_event(ev_up)
+                    d_pos.record_stream(cur); d_val.record_stream(cur)
+            else:
+                pos, vals = self._feed_arrays(positions, values)
+                d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
+                d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
             rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, n_rows or self.n_batch, self.n_input)
             # checked lazily (no sync on the scoring path).  A flag is written on the stream that is current NOW -- the
             # main stream or the second scoring lane's -- so it travels with an event recorded behind its writer: whoever
@@ -457,15 +494,16 @@ class DAE_tied:
         return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
 
     def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
-                n_rows=None):
+                n_rows=None, staged=None):
         """Enqueue one batch of the fused scoring path on the current stream; nothing is fetched.
         -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's); `n_rows`: rows of
-        this launch when it is not the model's batch (several feeds coalesced by recommend_iter)."""
+        this launch when it is not the model's batch (several feeds coalesced by recommend_iter); `staged`: the feed
+        as `_stage_pinned` left it on the device."""
         import torch
         ctx = ctx or self.ctx
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb, staged=staged)
         d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb)
         score = torch.empty((nb, k), dtype=torch.float32, device=dev)
         idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
@@ -504,10 +542,11 @@ class DAE_tied:
         main_challenge.py:72-93 / main_train.py:62-96): `feeds` yields (x_positions, x_ones, seeds, n_rows); the
         (DAE_title: + titles, titles_use) and the
         generator yields (idx [n_rows,k], score [n_rows,k] or None) in order, one pair per feed.  Consecutive feeds are
-        scored in ONE launch of up to 1024 rows (`_coalesce_count`: the reference's batches of 150 / 250 rows pad to 256
-        alone), the plain DAE alternates two library contexts (`_scoring_lanes`), launch n + 1 is uploaded (copy stream)
-        and enqueued BEFORE the results of launch n are fetched, and the fetch (a blocking copy to pageable memory) runs
-        on its own stream behind launch n's event; the reader builds the next feeds while the device scores.  Rows are
+        scored in ONE launch of up to 1024 rows (2048 in the bf16 modes; `_coalesce_count`: the reference's batches of 150 / 250 rows pad to 256
+        alone), the plain DAE alternates two library contexts (`_scoring_lanes`), launch n + 1 is uploaded (pinned staging
+        buffers, asynchronous copies) and enqueued BEFORE the results of launch n are handed out, and the fetch (an
+        asynchronous copy into pinned buffers) runs on its own stream behind launch n's event; the reader builds the
+        next feeds while the device scores.  Rows are
         scored independently: every feed gets the bits `recommend` returns for it alone (tests/test_gpu_stream_loop.py)."""
         import torch
         if self._score_shard is not None:
@@ -526,19 +565,8 @@ class DAE_tied:
         if fs is None:
             fs = self._fetch_stream = torch.cuda.Stream(device=self.weights["encoder_h"].device)
 
-        def fetch(ticket):
-            score, idx, ev, n_rows = ticket
-            fs.wait_event(ev)
-            with torch.cuda.stream(fs):
-                idx.record_stream(fs)
-                i_h = idx[:n_rows].cpu().numpy()
-                s_h = None
-                if want_scores:
-                    score.record_stream(fs)
-                    s_h = score[:n_rows].cpu().numpy()
-            return i_h, s_h
         lanes = self._scoring_lanes(dtype)              # [(context, stream)]: one, or two that take the batches in turn
-        group = self._coalesce_count()
+        group = self._coalesce_count(dtype if type(self)._submit is DAE._submit else None)
         pending = []
 
         def launches():
@@ -548,14 +576,33 @@ class DAE_tied:
             Rows are scored independently, so every row gets the bits it gets alone."""
             if group == 1:
                 for feed in feeds:
-                    yield feed, [self.n_batch if feed[3] is None else feed[3]], None
+                    yield (lambda slot, f=feed: (f, [self.n_batch if f[3] is None else f[3]], None))
                 return
             buf = []
 
-            def flush():
+            def flush(buf, slot):
+                # rows of feed i become rows i * n_batch ... of the launch; the launch's COO is written straight into
+                # the staging slot's pinned buffers (`slot`; None: DAE_title's own upload path takes host arrays)
                 nb = self.n_batch
-                pos = [np.asarray(f[0], np.int64).reshape(-1, 2) + np.array([i * nb, 0], np.int64) for i, f in enumerate(buf)]
-                ones = [np.broadcast_to(np.asarray(f[1], np.float32).reshape(-1), (len(pp),)) for f, pp in zip(buf, pos)]
+                raw = [np.asarray(f[0], np.int64).reshape(-1, 2) for f in buf]
+                n_pos = sum(r.shape[0] for r in raw)
+                if slot is None:
+                    P, O = np.empty((n_pos, 2), np.int64), np.empty(n_pos, np.float32)
+                else:
+                    P = _pinned(slot, "pos", 2 * max(n_pos, 1), torch.int64).numpy()[:2 * n_pos].reshape(n_pos, 2)
+                    O = _pinned(slot, "val", max(n_pos, 1), torch.float32).numpy()[:n_pos]
+                off = 0
+                for i, (f, r) in enumerate(zip(buf, raw)):
+                    m = r.shape[0]
+                    P[off:off + m] = r
+                    if i:
+                        P[off:off + m, 0] += i * nb       # (an [m, 2] + [2] broadcast costs 4 x this: inner loops of 2)
+                    v = np.asarray(f[1], np.float32).reshape(-1)
+                    if v.size != 1 and v.size != m:
+                        raise ValueError("positions (%d) and values (%d) differ in length" % (m, v.size))
+                    O[off:off + m] = v
+                    off += m
+                pos = [P[o_:o_ + r.shape[0]] for o_, r in zip(np.cumsum([0] + [r.shape[0] for r in raw[:-1]]), raw)]
                 if all(isinstance(f[2], str) for f in buf):
                     seeds = buf[0][2]
                 else:
@@ -570,8 +617,7 @@ class DAE_tied:
                         else:
                             seeds += list(f[2]) + [[] for _ in range(nb - len(f[2]))]
                 rows = [nb if f[3] is None else f[3] for f in buf]
-                feed = (np.concatenate(pos) if pos else np.zeros((0, 2), np.int64),
-                        np.concatenate(ones) if ones else np.zeros(0, np.float32), seeds, None)
+                feed = (P, O, seeds, None)
                 if any(len(f) > 4 for f in buf):           # DAE_title feeds: titles / titles_use, one entry per row
                     pad = [-1] * self.title_model.input_len
                     titles, use = [], []
@@ -590,60 +636,127 @@ class DAE_tied:
                 # a feed without titles in use must not share a launch with a titled one, or its rows would be ranked on
                 # sigmoid(z) * 1.0f -- same order up to fp32 saturation ties, not the bits `recommend` returns for it alone
                 if buf and titled(feed) != titled(buf[0]):
-                    yield flush()
+                    yield (lambda slot, b=buf: flush(b, slot))
                     buf = []
                 buf.append(feed)
                 if len(buf) == group:
-                    yield flush()
+                    yield (lambda slot, b=buf: flush(b, slot))
                     buf = []
             if buf:
-                yield flush()
+                yield (lambda slot, b=buf: flush(b, slot))
 
         def split(res, rows):
             i_h, s_h = res
             nb = self.n_batch
             for i, n in enumerate(rows):
                 yield i_h[i * nb:i * nb + n], (None if s_h is None else s_h[i * nb:i * nb + n])
+        # Nothing on the host side of a launch blocks: the feed goes up through pinned buffers, copied asynchronously on
+        # the launch's own stream, the lists come down into pinned buffers on the fetch stream, and the host waits for
+        # a fetch event only when it hands that launch's rows out -- one launch per lane later.  (Copies from / to
+        # pageable memory block their caller until a blit kernel got a turn between the decode launches: ~0.2 ms each
+        # next to a 0.2 ms launch.  profiles/r03_notes.md, "the drivers' loop".)
+        stage_ring = self.__dict__.get("_iter_ring")
+        if stage_ring is None or len(stage_ring) != len(lanes) + 2:
+            stage_ring = self._iter_ring = [{} for _ in range(len(lanes) + 2)]
+        # Measured at batch 256 (scripts/bench_shim.py): bf16 1.6 -> 4.3 M playlists/s, exact_bf16 1.65 -> 3.4 M.  The
+        # fp32 loop, limited by the device, runs at 1.22 M either way on average: with blocking copies it alternates
+        # between 1.33 M and ~0.95 M from one second to the next (the host's waits fall in or out of step with the two
+        # lanes' decode launches), asynchronous it is steady.  `model.iter_copies = "blocking"` brings the old loop back.
+        mode = self.__dict__.get("iter_copies") or "async"
+        if mode not in ("async", "blocking"):
+            raise ValueError("iter_copies: 'async' or 'blocking'")
+        # (a title model uploads titles / mix weights through its own calls: all of its copies stay blocking -- mixing
+        # the two kinds is worse than either)
+        blocking = mode == "blocking" or type(self)._submit is not DAE._submit or not self.device_csr
+        plain = not blocking
+        fetch_ring = self.__dict__.get("_iter_fetch_ring")
+        if fetch_ring is None or len(fetch_ring) != len(lanes) + 2:
+            fetch_ring = self._iter_fetch_ring = [{} for _ in range(len(lanes) + 2)]
+
+        def results(t):
+            # copied out of the ring's pinned buffers (30 us for 2 MB): a pinned allocation per launch instead costs a
+            # hipHostMalloc whenever torch's host cache has no free block of the size -- 0.66 M playlists/s at batch 150
+            if blocking:                                    # (score, idx, done event): a blocking copy on the fetch stream
+                score_, idx_, ev_, n_fetch, rws, nt_ = t
+                fs.wait_event(ev_)
+                with torch.cuda.stream(fs):
+                    idx_.record_stream(fs)
+                    i_h = idx_[:n_fetch].cpu().numpy()
+                    s_h = None
+                    if want_scores:
+                        score_.record_stream(fs)
+                        s_h = score_[:n_fetch].cpu().numpy()
+            else:
+                pin_i, pin_s, ev2, n_fetch, rws, nt_ = t
+                ev2.synchronize()
+                i_h = pin_i[:n_fetch * k].numpy().reshape(n_fetch, k).copy()
+                s_h = pin_s[:n_fetch * k].numpy().reshape(n_fetch, k).copy() if pin_s is not None else None
+            if nt_ is None:
+                yield i_h, s_h
+            else:
+                yield from split((i_h, s_h), rws)
         try:
-            for n_launch, (feed, rows, n_total) in enumerate(launches()):
+            for n_launch, make in enumerate(launches()):
+                sslot = stage_ring[n_launch % len(stage_ring)] if plain else None
+                if plain and sslot.get("busy") is not None:
+                    sslot["busy"].synchronize()             # its previous upload has left the buffers (long ago)
+                feed, rows, n_total = make(sslot)
                 x_positions, x_ones, seeds = feed[:3]
                 ctx, stream = lanes[n_launch % len(lanes)]
-                if stream is None and n_total is None:      # one feed, the model's own context (also DAE_title's _submit)
-                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:])
-                elif stream is None:
-                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:], n_rows=n_total)
+                kw = {} if n_total is None else {"n_rows": n_total}
+                if stream is None:                          # the model's own context (also DAE_title's _submit)
+                    if plain:
+                        kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
+                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:], **kw)
                 else:
                     with torch.cuda.stream(stream):
-                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, n_rows=n_total)
-                fetch_rows = rows[0] if n_total is None else n_total
-                pending.append(((score, idx, ev, fetch_rows), rows, n_total))
+                        if plain:
+                            kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
+                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, **kw)
+                n_fetch = rows[0] if n_total is None else n_total
+                if blocking:
+                    pending.append((score, idx, ev, n_fetch, rows, n_total))
+                    if len(pending) > len(lanes):
+                        yield from results(pending.pop(0))
+                    continue
+                fslot = fetch_ring[n_launch % len(fetch_ring)]      # free again: at most len(lanes) + 1 launches are pending
+                pin_i = _pinned(fslot, "idx", n_fetch * k, torch.int32)
+                pin_s = _pinned(fslot, "score", n_fetch * k, torch.float32) if want_scores else None
+                fs.wait_event(ev)
+                with torch.cuda.stream(fs):
+                    idx.record_stream(fs)
+                    pin_i[:n_fetch * k].view(n_fetch, k).copy_(idx[:n_fetch], non_blocking=True)
+                    if want_scores:
+                        score.record_stream(fs)
+                        pin_s[:n_fetch * k].view(n_fetch, k).copy_(score[:n_fetch], non_blocking=True)
+                    ev2 = fs.record_event()
+                pending.append((pin_i, pin_s, ev2, n_fetch, rows, n_total))
                 if len(pending) > len(lanes):              # one launch per lane stays in flight behind the fetch
-                    t, rws, nt_ = pending.pop(0)
-                    if nt_ is None:
-                        yield fetch(t)
-                    else:
-                        yield from split(fetch(t), rws)
+                    yield from results(pending.pop(0))
             while pending:
-                t, rws, nt_ = pending.pop(0)
-                if nt_ is None:
-                    yield fetch(t)
-                else:
-                    yield from split(fetch(t), rws)
+                yield from results(pending.pop(0))
         finally:
+            for t in pending:                               # a consumer that stopped early: the rings are idle again
+                t[2].synchronize()                          # (the launch's event, or its fetch's)
             if len(lanes) > 1:
-                torch.cuda.current_stream(self.device_index).wait_stream(lanes[1][1])
+                for _c, s_ in lanes[1:]:
+                    torch.cuda.current_stream(self.device_index).wait_stream(s_)
                 for c, _s in lanes:                          # other entry points run ungated
                     c.check(c.lib.dae_set_decode_gate(c.h, None, None))
         self._check_feed()
 
-    def _coalesce_count(self):
-        """Feeds per launch of the streamed loop: the count (<= 8, <= 1024 rows) that wastes the fewest padded rows of
-        the 128-row groups the decode works in; more feeds on a tie.  150 -> 5 (750 of 768 rows), 250 -> 4 (1000 of
-        1024), 256 -> 4, batches of >= 512 rows stay alone.  `model.coalesce = n` overrides."""
+    def _coalesce_count(self, dtype=None):
+        """Feeds per launch of the streamed loop.  fp32 decode (the device is the limit): the count (<= 8, <= 1024 rows)
+        that wastes the fewest padded rows of the 128-row groups the decode works in; more feeds on a tie.  150 -> 5
+        (750 of 768 rows), 250 -> 4 (1000 of 1024), 256 -> 4, batches of >= 512 rows stay alone.  bf16 / exact_bf16
+        (the host is the limit: ~0.3 ms of Python per launch against 0.2 ms of kernels for 1 024 rows): as many feeds
+        as fit 2 048 rows, at most 8 (150 -> 8: 2.4 -> 3.3 M playlists/s).  `model.coalesce = n` overrides."""
         forced = self.__dict__.get("coalesce")
         if forced:
             return max(1, int(forced))
         nb = self.n_batch
+        if dtype is not None and dtype != _lib.DAE_DTYPE_F32:
+            return max(1, min(8, 2048 // nb))
         best, best_eff = 1, 0.0
         for m in range(1, 9):
             if m > 1 and m * nb > 1024:
@@ -654,47 +767,59 @@ class DAE_tied:
         return best
 
     def _scoring_lanes(self, dtype):
-        """Contexts the streamed scoring loop alternates between.  The plain DAE runs TWO (what bench.py measures): the
-        second has its own HIP stream and its own packed decoder image, the dominant launches of the two take turns
-        (dae_set_decode_gate, fp32) and everything else of one batch overlaps the other batch's decode -- 0.30 ->
-        ~0.23 ms per batch through the drivers' loop.  A title model keeps one (its mix runs on two contexts already)."""
+        """Contexts the streamed scoring loop hands its launches to in turn.  The plain DAE runs SEVERAL: every extra
+        lane has its own HIP stream and library context and scores from the first context's packed decoder image
+        (dae_share_decoder); with the fp32 decode the dominant launches take turns around the ring of lanes
+        (dae_set_decode_gate) and everything else of a launch -- CSR build, seed lists, encode, threshold, selection --
+        runs next to the other lanes' decodes.  Two by default: three or four measured no better in any mode (fp32 1.03 -
+        1.17 M against 1.22 M playlists/s through the loop, exact_bf16 3.2 against 3.5 M; profiles/r03_notes.md);
+        `model.n_lanes` overrides, `model.two_lanes = False`: one.  A title model keeps one (its mix runs on two
+        contexts already)."""
+        import ctypes
         import torch
         if type(self)._submit is not DAE._submit or not self.__dict__.get("two_lanes", True):
             return [(self.ctx, None)]
-        st = self.__dict__.get("_lane2")
-        if st is None:
-            ctx2 = _lib.Context(self.device_index)
-            s2 = torch.cuda.Stream(device=self.weights["encoder_h"].device)
-            with torch.cuda.stream(s2):
-                ctx2.bind_stream()
-            ev = [torch.cuda.Event(), torch.cuda.Event()]
-            cur = torch.cuda.current_stream(self.device_index)
-            ev[0].record(cur); ev[1].record(s2)           # materialise the hipEvent_t handles
-            st = self._lane2 = {"ctx": ctx2, "stream": s2, "ev": ev, "packed": {}}
-        ctx2, s2 = st["ctx"], st["stream"]
-        # the second lane scores from the FIRST context's packed image (dae_share_decoder: one copy stays in the Infinity
-        # Cache, two evict each other), borrowed again whenever that context has re-tiled the slot (`_pack_gen`)
+        n_lanes = int(self.__dict__.get("n_lanes") or 2)
+        if n_lanes <= 1:
+            return [(self.ctx, None)]
+        extra = self.__dict__.setdefault("_lanes", [])
+        cur = torch.cuda.current_stream(self.device_index)
+        if "_lane_ev0" not in self.__dict__:
+            self._lane_ev0 = torch.cuda.Event()
+            self._lane_ev0.record(cur)                      # materialise the hipEvent_t handle
+        while len(extra) < n_lanes - 1:
+            ctx_n = _lib.Context(self.device_index)
+            s_n = torch.cuda.Stream(device=self.weights["encoder_h"].device)
+            with torch.cuda.stream(s_n):
+                ctx_n.bind_stream()
+            ev = torch.cuda.Event()
+            ev.record(s_n)
+            extra.append({"ctx": ctx_n, "stream": s_n, "ev": ev, "packed": {}})
+        lanes = extra[:n_lanes - 1]
+        # the extra lanes score from the FIRST context's packed image (one copy stays in the Infinity Cache, several evict
+        # each other), borrowed again whenever that context has re-tiled the slot (`_pack_gen`)
         self._ensure_packed(dtype)
         slot = "f32" if dtype == _lib.DAE_DTYPE_F32 else "bf16"
         gen = (self.__dict__.get("_pack_gen") or {}).get(slot, 0)
-        if st["packed"].get(dtype) != gen:
-            torch.cuda.current_stream(self.device_index).synchronize()    # the owner's prepack is done ...
-            s2.synchronize()                                               # ... and nothing of the old image is in flight
-            ctx2.share_decoder(self.ctx, dtype)
-            for d_ in ([_lib.DAE_DTYPE_F32] if slot == "f32" else [_lib.DAE_DTYPE_BF16, _lib.DAE_DTYPE_BF16_EXACT]):
-                st["packed"].pop(d_, None)
-            st["packed"][dtype] = gen
-            if dtype == _lib.DAE_DTYPE_BF16_EXACT:          # the exact image serves plain bf16 launches as well
-                st["packed"][_lib.DAE_DTYPE_BF16] = gen
-            self.ctx.set_overlap_hint(2)
-            ctx2.set_overlap_hint(2)
+        for st in lanes:
+            if st["packed"].get(dtype) != gen:
+                cur.synchronize()                           # the owner's prepack is done ...
+                st["stream"].synchronize()                  # ... and nothing of the old image is in flight
+                st["ctx"].share_decoder(self.ctx, dtype)
+                for d_ in ([_lib.DAE_DTYPE_F32] if slot == "f32" else [_lib.DAE_DTYPE_BF16, _lib.DAE_DTYPE_BF16_EXACT]):
+                    st["packed"].pop(d_, None)
+                st["packed"][dtype] = gen
+                if dtype == _lib.DAE_DTYPE_BF16_EXACT:      # the exact image serves plain bf16 launches as well
+                    st["packed"][_lib.DAE_DTYPE_BF16] = gen
+        for c in [self.ctx] + [st["ctx"] for st in lanes]:
+            c.set_overlap_hint(n_lanes)
         gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
-        e0, e1 = st["ev"]
-        import ctypes
+        evs = [self._lane_ev0] + [st["ev"] for st in lanes]
+        ctxs = [self.ctx] + [st["ctx"] for st in lanes]
         P = lambda e: ctypes.c_void_p(e.cuda_event) if gate else None      # noqa: E731
-        self.ctx.check(self.ctx.lib.dae_set_decode_gate(self.ctx.h, P(e1), P(e0)))
-        ctx2.check(ctx2.lib.dae_set_decode_gate(ctx2.h, P(e0), P(e1)))
-        return [(self.ctx, None), (ctx2, s2)]
+        for i, c in enumerate(ctxs):                        # lane i's decode waits for lane i - 1's, around the ring
+            c.check(c.lib.dae_set_decode_gate(c.h, P(evs[i - 1]), P(evs[i])))
+        return [(self.ctx, None)] + [(st["ctx"], st["stream"]) for st in lanes]
 
     # -- training -----------------------------------------------------------------------------------
     def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, fetch_cost=True):
@@ -794,6 +919,16 @@ class DAE_tied:
         """DAEs.py:107-111: pickle of the four float32 arrays in d_params order."""
         with open(self.save_dir, "wb") as f:
             pickle.dump(self.get_params(), f)
+
+
+def _pinned(slot, name, n, dtype):
+    """A pinned host buffer of >= n elements kept in `slot` (a dict of recommend_iter's staging / fetch rings)."""
+    import torch
+    t = slot.get(name)
+    if t is None or t.numel() < n or t.dtype != dtype:
+        t = slot[name] = torch.empty(max(int(n), 2 * (t.numel() if t is not None and t.dtype == dtype else 0)),
+                                     dtype=dtype, pin_memory=True)
+    return t
 
 
 class DAE(DAE_tied):

@@ -1,5 +1,5 @@
 """GPU (-m gpu): the drivers' streamed loop (`DAE.recommend_iter`: main_challenge.py:72-93 / main_train.py:62-96 with the
-host and the device overlapped, two library contexts taking the batches in turn) returns, batch for batch, what
+host and the device overlapped, two or three library contexts taking the launches in turn) returns, batch for batch, what
 `recommend` returns for the same feed -- fp32 bit for bit, bf16 likewise (same kernels, same order of operations)."""
 import pickle
 
@@ -55,6 +55,27 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
     got3 = list(m.recommend_iter(mixed, k=k, dtype=dtype))
     want3 = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got3, want3))
+    # both copy policies of the loop (pinned asynchronous copies by default, the blocking ones on request), three lanes,
+    # with and without the scores, twice over the staging ring; a consumer that stops early leaves the loop reusable
+    for mode in ("async", "blocking"):
+        m.iter_copies = mode
+        m.n_lanes = 3 if mode == "async" else None
+        for ws_ in (True, False):
+            got4 = list(m.recommend_iter(mixed * 2, k=k, dtype=dtype, want_scores=ws_))
+            assert len(got4) == 2 * len(want3)
+            for a, b in zip(got4, want3 * 2):
+                assert np.array_equal(a[0], b[0]) and (a[1] is None if not ws_ else np.array_equal(a[1], b[1]))
+        it = m.recommend_iter(mixed * 2, k=k, dtype=dtype)
+        first = next(it); it.close()
+        assert np.array_equal(first[0], want3[0][0])
+    m.n_lanes = None
+    m.iter_copies = "nonsense"
+    with pytest.raises(ValueError):
+        list(m.recommend_iter(mixed, k=k, dtype=dtype))
+    m.iter_copies = None
+    bad = [(np.array([[0, 1], [1, 2]], np.int64), np.ones(3, np.float32), SEEDS_FROM_INPUT, 2)]
+    with pytest.raises(ValueError):
+        list(m.recommend_iter(bad * 4, k=k, dtype=dtype))
 
 
 def test_clock_probe_reads_a_plausible_engine_clock():
