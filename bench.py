@@ -116,6 +116,52 @@ def _pmc_traffic(key, kernel):
         return None
 
 
+def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_artists, H, B, k, dist_name):
+    """The same scoring THROUGH the product's loop (models/DAEs.py DAE.recommend_iter, what main.py --challenge and the
+    evaluation of main.py --dae run): host feeds (COO positions as the reference's readers emit them) in, host index lists
+    out -- uploads, the device CSR build, the seed lists cut out of the input, two library contexts, the fetch.  PCIe and
+    Python inclusive: never `value`."""
+    import pickle
+    import tempfile
+    from spotify_recsys_challenge_2018_amd.models.DAEs import DAE, SEEDS_FROM_INPUT
+    V = n_tracks + n_artists
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "init.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        save = os.path.join(tmp, "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
+        initval = path
+    C.n_tracks = n_tracks
+    m = DAE(C()); m.fit()
+    batches = [make_playlists(B, n_tracks, n_artists, seed=200 + s_, dist=dist_name)[:2] for s_ in range(8)]
+
+    def feeds(reps):
+        for _ in range(reps):
+            for p_, o_ in batches:
+                yield p_, o_, SEEDS_FROM_INPUT, B
+    row = {"unit": "playlists/s", "what": _drivers_loop_row.__doc__.split("\n\n")[0].replace("\n    ", " "),
+           "feeds_per_launch": {}}
+    first = {}
+    for name, reps in (("f32", 25), ("exact_bf16", 60), ("bf16", 60)):
+        for i_, (idx_, _s) in enumerate(m.recommend_iter(feeds(3), k=k, want_scores=False, dtype=name)):
+            if i_ == 0:
+                first[name] = idx_.copy()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _idx, _s in m.recommend_iter(feeds(reps), k=k, want_scores=False, dtype=name):
+            n += B
+        el = time.perf_counter() - t0
+        row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B}
+        row["feeds_per_launch"][name] = m._coalesce_count(m._dtype_of(name))
+    row["exact_bf16"]["identical_to_fp32_lists"] = bool(np.array_equal(first["f32"], first["exact_bf16"]))
+    row["note"] = ("NOT the headline: host feeds in, host lists out (indices only; seeds = the playlist's own tracks, cut "
+                   "out of the input on the device).  scripts/bench_shim.py is the longer version")
+    return row
+
+
 def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k, n_steps, n_warm, ref32, oracle_ref,
               peaks, traffic_key):
     """Extra row of the default run: the same step (rotating the same resident batches) with another decode arithmetic.
@@ -1097,6 +1143,13 @@ def main():
                 del feeds_b, outs_b
         except Exception as e:
             out["batch_1024"] = {"error": repr(e)}
+        # (c) through the product's loop: host feeds in, host lists out
+        try:
+            torch.cuda.synchronize()
+            out["drivers_loop"] = _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks,
+                                                    args.n_artists, H, B, k, args.dist)
+        except Exception as e:
+            out["drivers_loop"] = {"error": repr(e)}
 
     # ---- the training step that produces these weights (BASELINE.json configs[3]), NOT part of `value` --------------
     # forward with dropout + weighted-BCE loss + backward + dense TF1-Adam on all four variables, same V / H / batch;

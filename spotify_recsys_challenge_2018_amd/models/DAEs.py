@@ -222,9 +222,9 @@ class DAE_tied:
         """Host array -> device tensor.  side_stream (the training loop): uploaded on a COPY stream.  A copy from pageable memory is stream-ordered
         and blocks the host until it has happened; on the compute stream that means "until everything queued before
         it has run", so the training loop could never get ahead of the GPU (0.25 ms per feed measured).  On its own
-        stream the copy waits for earlier copies only; the compute stream waits for its event.  (Pinned staging is
-        not an option here: torch's pinned host memory is uncached for CPU writes on this platform -- 3 ms to fill
-        400 KB.)"""
+        stream the copy waits for earlier copies only; the compute stream waits for its event.  (The scoring loop
+        stages through pinned buffers instead -- `_stage_pinned`; round 1 measured torch's pinned memory as uncached for
+        CPU writes, 3 ms to fill 400 KB, round 3 measures 14 us per MB on the same image: scripts/attic/host_copy_probe.py.)"""
         import torch
         src = torch.from_numpy(np.ascontiguousarray(a))
         dev = torch.device("cuda", self.device_index)
