@@ -31,6 +31,8 @@ if os.environ.get("COPIES"):
     m.iter_copies = os.environ["COPIES"]
 if os.environ.get("LANES"):
     m.n_lanes = int(os.environ["LANES"])
+if os.environ.get("HINT"):
+    m.lane_hint = int(os.environ["HINT"])
 if os.environ.get("COALESCE"):
     m.coalesce = int(os.environ["COALESCE"])
 batches = [make_playlists(B, nt, na, seed=s) for s in range(8)]

@@ -669,6 +669,9 @@ class DAE_tied:
         # the two kinds is worse than either)
         blocking = mode == "blocking" or type(self)._submit is not DAE._submit or not self.device_csr
         plain = not blocking
+        pool = self.__dict__.get("_iter_pool")
+        if pool is None:
+            pool = self._iter_pool = _PinnedPool()
         fetch_ring = self.__dict__.get("_iter_fetch_ring")
         if fetch_ring is None or len(fetch_ring) != len(lanes) + 2:
             fetch_ring = self._iter_fetch_ring = [{} for _ in range(len(lanes) + 2)]
@@ -689,8 +692,13 @@ class DAE_tied:
             else:
                 pin_i, pin_s, ev2, n_fetch, rws, nt_ = t
                 ev2.synchronize()
-                i_h = pin_i[:n_fetch * k].numpy().reshape(n_fetch, k).copy()
-                s_h = pin_s[:n_fetch * k].numpy().reshape(n_fetch, k).copy() if pin_s is not None else None
+                if isinstance(pin_i, _Lease):               # the lists ARE the pinned block (see _PinnedPool)
+                    i_h = pin_i.array(n_fetch, k)
+                    s_h = pin_s.array(n_fetch, k) if pin_s is not None else None
+                else:                                       # too many blocks out: copied out of the ring
+                    i_h = pin_i[:n_fetch * k].numpy().reshape(n_fetch, k).copy()
+                    s_h = pin_s[:n_fetch * k].numpy().reshape(n_fetch, k).copy() if pin_s is not None else None
+                del pin_i, pin_s, t
             if nt_ is None:
                 yield i_h, s_h
             else:
@@ -719,17 +727,26 @@ class DAE_tied:
                     if len(pending) > len(lanes):
                         yield from results(pending.pop(0))
                     continue
-                fslot = fetch_ring[n_launch % len(fetch_ring)]      # free again: at most len(lanes) + 1 launches are pending
-                pin_i = _pinned(fslot, "idx", n_fetch * k, torch.int32)
-                pin_s = _pinned(fslot, "score", n_fetch * k, torch.float32) if want_scores else None
+                # destination of the fetch: a leased pinned block the caller's arrays will be views of, or -- with too
+                # many blocks out -- this launch's slot of the ring, copied out on the host afterwards
+                n_el = -(-n_fetch // 256) * 256 * k                 # few distinct block sizes
+                pin_i = pool.take(n_el, torch.int32)
+                pin_s = pool.take(n_el, torch.float32) if want_scores and pin_i is not None else None
+                if pin_i is None or (want_scores and pin_s is None):
+                    fslot = fetch_ring[n_launch % len(fetch_ring)]  # free again: at most len(lanes) + 1 launches are pending
+                    pin_i = _pinned(fslot, "idx", n_fetch * k, torch.int32)
+                    pin_s = _pinned(fslot, "score", n_fetch * k, torch.float32) if want_scores else None
+                t_i = pin_i.t if isinstance(pin_i, _Lease) else pin_i
+                t_s = None if pin_s is None else (pin_s.t if isinstance(pin_s, _Lease) else pin_s)
                 fs.wait_event(ev)
                 with torch.cuda.stream(fs):
                     idx.record_stream(fs)
-                    pin_i[:n_fetch * k].view(n_fetch, k).copy_(idx[:n_fetch], non_blocking=True)
+                    t_i[:n_fetch * k].view(n_fetch, k).copy_(idx[:n_fetch], non_blocking=True)
                     if want_scores:
                         score.record_stream(fs)
-                        pin_s[:n_fetch * k].view(n_fetch, k).copy_(score[:n_fetch], non_blocking=True)
+                        t_s[:n_fetch * k].view(n_fetch, k).copy_(score[:n_fetch], non_blocking=True)
                     ev2 = fs.record_event()
+                del t_i, t_s
                 pending.append((pin_i, pin_s, ev2, n_fetch, rows, n_total))
                 if len(pending) > len(lanes):              # one launch per lane stays in flight behind the fetch
                     yield from results(pending.pop(0))
@@ -812,7 +829,7 @@ class DAE_tied:
                 if dtype == _lib.DAE_DTYPE_BF16_EXACT:      # the exact image serves plain bf16 launches as well
                     st["packed"][_lib.DAE_DTYPE_BF16] = gen
         for c in [self.ctx] + [st["ctx"] for st in lanes]:
-            c.set_overlap_hint(n_lanes)
+            c.set_overlap_hint(int(self.__dict__.get("lane_hint", n_lanes)))
         gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
         evs = [self._lane_ev0] + [st["ev"] for st in lanes]
         ctxs = [self.ctx] + [st["ctx"] for st in lanes]
@@ -929,6 +946,48 @@ def _pinned(slot, name, n, dtype):
         t = slot[name] = torch.empty(max(int(n), 2 * (t.numel() if t is not None and t.dtype == dtype else 0)),
                                      dtype=dtype, pin_memory=True)
     return t
+
+
+class _PinnedPool:
+    """Pinned host blocks for the lists recommend_iter hands out.  A launch's lists are copied into one block by the
+    device; the arrays the caller receives are views of that block (no second copy on the host: 0.2 ms per 4 MB that a
+    single core spends reading memory the DMA has just written), and the block returns to the pool when the last of
+    them is garbage.  At most `max_out` blocks are out at a time -- a caller that keeps every result (list(...)) gets
+    ordinary copies from then on, so the pinned memory held stays bounded."""
+
+    def __init__(self, max_out=12):
+        self.free = {}                # (dtype, n elements) -> [tensor]
+        self.out = 0
+        self.max_out = max_out
+
+    def take(self, n, dtype):
+        """-> a lease on a block of n elements, or None when too many are out."""
+        import torch
+        if self.out >= self.max_out:
+            return None
+        lst = self.free.get((dtype, n))
+        t = lst.pop() if lst else torch.empty(n, dtype=dtype, pin_memory=True)
+        self.out += 1
+        return _Lease(self, t, n, dtype)
+
+
+class _Lease:
+    """Owns one block of a _PinnedPool; numpy arrays made from it (`array()`) keep it alive through their base chain."""
+
+    def __init__(self, pool, t, n, dtype):
+        self.pool, self.t, self.key = pool, t, (dtype, n)
+        self.__array_interface__ = {"shape": (n,), "typestr": {4: "<i4" if not t.dtype.is_floating_point else "<f4"}[t.element_size()],
+                                    "data": (t.data_ptr(), False), "version": 3}
+
+    def array(self, rows, k):
+        return np.asarray(self)[:rows * k].reshape(rows, k)
+
+    def __del__(self):
+        try:
+            self.pool.free.setdefault(self.key, []).append(self.t)
+            self.pool.out -= 1
+        except Exception:             # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class DAE(DAE_tied):

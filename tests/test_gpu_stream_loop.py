@@ -78,6 +78,42 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
         list(m.recommend_iter(bad * 4, k=k, dtype=dtype))
 
 
+def test_recommend_iter_hands_out_leased_pinned_blocks(tmp_path):
+    """The lists of the asynchronous loop are views of pinned blocks leased from a pool: kept results stay intact while
+    the loop goes on, blocks return when the last view is garbage, and with the pool exhausted the loop copies instead."""
+    import gc
+    nt, na, H, k, B = 6000, 1000, 64, 100, 64
+    W_enc, b_enc, W_dec, b_dec = make_weights(nt + na, H, seed=4, bias="zipf", n_tracks=nt)
+    path = str(tmp_path / "init.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        save = str(tmp_path / "unused"); batch = B; n_input = nt + na; hidden = H; lr = 0.005; reg_lambda = 0.0
+        n_tracks = nt; initval = path
+    m = DAE(C()); m.fit()
+    batches = [make_playlists(B, nt, na, seed=30 + s) for s in range(6)]
+    want = [m.recommend(p, o, s, k=k) for p, o, s in batches]
+    feeds = [(p, o, SEEDS_FROM_INPUT, B) for p, o, _s in batches] * 4
+    kept = list(m.recommend_iter(feeds, k=k))
+    pool = m._iter_pool
+    assert 0 < pool.out <= pool.max_out
+    for (gi, gs), (wi, ws) in zip(kept, want * 4):
+        assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    pool.max_out = pool.out                      # exhausted: the next loop copies out of its ring
+    kept2 = list(m.recommend_iter(feeds, k=k))
+    assert pool.out == pool.max_out
+    for (gi, gs), (wi, ws) in zip(kept2, want * 4):
+        assert np.array_equal(gi, wi) and np.array_equal(gs, ws)
+    for (gi, gs), (wi, ws) in zip(kept, want * 4):   # the first loop's blocks were not touched by the second
+        assert np.array_equal(gi, wi) and np.array_equal(gs, ws)
+    del kept, kept2, gi, gs
+    gc.collect()
+    assert pool.out == 0 and sum(len(v) for v in pool.free.values()) > 0
+    again = list(m.recommend_iter(feeds[:6], k=k))                # served from the free lists
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(again, want))
+
+
 def test_clock_probe_reads_a_plausible_engine_clock():
     """dae_clock_probe (bench.py's `roofline.sustained_clock`): shader cycles over wall-clock ticks of one wave."""
     import torch
