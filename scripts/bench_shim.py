@@ -62,7 +62,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
-        for _idx, _sc in m.recommend_iter(feeds(5 if scores else 100), k=500, want_scores=scores, dtype=it_dtype):
+        for _idx, _sc in m.recommend_iter(feeds(25 if scores else 100), k=500, want_scores=scores, dtype=it_dtype):
             n += B
         dt = time.perf_counter() - t0
         print("model.recommend_iter%s (%s): %.0f playlists/s (%.3f ms per batch of %d)" % (" " + it_dtype if it_dtype else "", label, n / dt, dt / (n / B) * 1e3, B))

@@ -4,13 +4,13 @@ o=gpurun_out; mkdir -p $o
 X="--no-train-row --no-cpu-baseline --no-bf16-row --no-extra-rows"
 for n in 2 4 8; do python bench.py --sim-world $n $X > $o/r03_bench_sim$n.json 2> $o/err_sim$n.txt; done
 python bench.py --sim-world 8 --sim-rank 7 $X > $o/r03_bench_sim8_rank7.json 2> $o/err_sim8r7.txt
-python bench.py --sim-world 8 --tau-exchange $X > $o/r03_bench_sim8_tau.json 2> $o/err_sim8tau.txt
-python bench.py --sim-world 8 --sim-rank 7 --tau-exchange $X > $o/r03_bench_sim8_rank7_tau.json 2> $o/err_sim8r7tau.txt
+python bench.py --sim-world 8 --no-tau-exchange $X > $o/r03_bench_sim8_notau.json 2> $o/err_sim8notau.txt
+python bench.py --sim-world 8 --sim-rank 7 --no-tau-exchange $X > $o/r03_bench_sim8_rank7_notau.json 2> $o/err_sim8r7notau.txt
 python bench.py --sim-world 8 --dtype bf16 $X > $o/r03_bench_sim8_bf16.json 2> $o/err_sim8bf.txt
 python bench.py --force-dist $X > $o/r03_bench_forcedist.json 2> $o/err_forcedist.txt
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --backend gloo --steps 20 --warmup 4 $X > $o/r03_bench_gloo2.json 2> $o/err_gloo2.txt
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --backend gloo --steps 20 --warmup 4 --tau-exchange $X > $o/r03_bench_gloo2_tau.json 2> $o/err_gloo2tau.txt
-for f in sim2 sim4 sim8 sim8_rank7 sim8_tau sim8_rank7_tau sim8_bf16 forcedist gloo2 gloo2_tau; do python - $o/r03_bench_$f.json $f <<'PY'
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --backend gloo --steps 20 --warmup 4 --no-tau-exchange $X > $o/r03_bench_gloo2_notau.json 2> $o/err_gloo2notau.txt
+for f in sim2 sim4 sim8 sim8_rank7 sim8_notau sim8_rank7_notau sim8_bf16 forcedist gloo2 gloo2_notau; do python - $o/r03_bench_$f.json $f <<'PY'
 import json,sys
 try:
     d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']

@@ -24,3 +24,7 @@ bash scripts/gpu_prof.sh r03_bf16_1stream --dtype bf16 --streams 1 --no-train-ro
 bash scripts/gpu_prof.sh r03_exact_1stream --dtype exact_bf16 --streams 1 --no-train-row --no-cpu-baseline
 bash scripts/gpu_prof.sh r03_exact_4streams --dtype exact_bf16 --no-train-row --no-cpu-baseline
 bash scripts/gpu_prof.sh r03_bf16_4streams --dtype bf16 --no-train-row --no-cpu-baseline
+# the drivers' loop (host feeds in, host lists out) and the N > 1 code paths on one GPU
+(python scripts/bench_shim.py 256; python scripts/bench_shim.py 256 --bf16; python scripts/bench_shim.py 256 --exact; python scripts/bench_shim.py 150; python scripts/bench_shim.py 150 --bf16; python scripts/bench_shim.py 150 --exact; python scripts/bench_shim.py 250 --exact) 2>&1 | grep "recommend" > $GRAFT_REPO_ROOT/gpurun_out/r03_bench_shim.log
+grep "recommend_iter" $GRAFT_REPO_ROOT/gpurun_out/r03_bench_shim.log
+bash scripts/gpu_dist_r3.sh

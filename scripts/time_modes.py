@@ -16,6 +16,9 @@ only = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "bf16", "exact"]
 nstr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1]
 V, nt, H, k = 170000, 140000, 256, 500
 W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=bias, n_tracks=nt)
+if os.environ.get("SCALE"):            # a model whose rows rank the tracks differently (x40: scripts/tf_gap.py's third case)
+    W_enc = (W_enc * float(os.environ["SCALE"])).astype(np.float32)
+    W_dec = (W_dec * float(os.environ["SCALE"])).astype(np.float32)
 pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
 rp, col, val = coo_to_csr(pos, ones, B, V)
 srp, sc = seeds_to_csr(seeds, B, nt)

@@ -479,7 +479,7 @@ class DAE_tied:
             return int(dtype)
         raise ValueError("decode dtype %r: one of %s" % (dtype, sorted(_DECODE_DTYPES)))
 
-    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None):
+    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None, slot=None):
         """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
         SEEDS_FROM_INPUT: the seeds are the playlist's own tracks -- what both reference drivers pass -- and are cut
         out of the input CSR on the device (dae_seeds_from_csr): no per-row list handling, no uploads."""
@@ -491,10 +491,25 @@ class DAE_tied:
         srp, sc = seeds_to_csr(seeds, n_rows or self.n_batch, self.n_tracks)
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
+        if slot is not None:           # recommend_iter's asynchronous loop: through the slot's pinned buffers, like the feed
+            dev = torch.device("cuda", self.device_index)
+            ps, pc = _pinned(slot, "srp", srp.size, torch.int32), _pinned(slot, "sc", sc.size, torch.int32)
+            np.copyto(ps.numpy()[:srp.size], srp)
+            np.copyto(pc.numpy()[:sc.size], sc)
+            cur = torch.cuda.current_stream(self.device_index)
+            with torch.cuda.stream(self._copy_stream):
+                d_srp = torch.empty(srp.size, dtype=torch.int32, device=dev)
+                d_sc = torch.empty(sc.size, dtype=torch.int32, device=dev)
+                d_srp.copy_(ps[:srp.size], non_blocking=True)
+                d_sc.copy_(pc[:sc.size], non_blocking=True)
+                ev = slot["busy"] = self._copy_stream.record_event()
+            cur.wait_event(ev)
+            d_srp.record_stream(cur); d_sc.record_stream(cur)
+            return d_srp, d_sc
         return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
 
     def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
-                n_rows=None, staged=None):
+                n_rows=None, staged=None, seed_slot=None):
         """Enqueue one batch of the fused scoring path on the current stream; nothing is fetched.
         -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's); `n_rows`: rows of
         this launch when it is not the model's batch (several feeds coalesced by recommend_iter); `staged`: the feed
@@ -504,7 +519,7 @@ class DAE_tied:
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
         csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb, staged=staged)
-        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb, slot=seed_slot)
         score = torch.empty((nb, k), dtype=torch.float32, device=dev)
         idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
         ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
@@ -715,11 +730,13 @@ class DAE_tied:
                 if stream is None:                          # the model's own context (also DAE_title's _submit)
                     if plain:
                         kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
+                        kw["seed_slot"] = sslot
                     score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:], **kw)
                 else:
                     with torch.cuda.stream(stream):
                         if plain:
                             kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
+                            kw["seed_slot"] = sslot
                         score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, **kw)
                 n_fetch = rows[0] if n_total is None else n_total
                 if blocking:
