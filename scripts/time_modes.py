@@ -7,6 +7,8 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spotify_recsys_challenge_2018_amd import _lib
+if os.environ.get("DAE_LIB_AB"):       # A/B against another build of the library
+    _lib.LIB_PATH = os.environ["DAE_LIB_AB"]
 from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr, seeds_to_csr
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 
@@ -16,6 +18,9 @@ only = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "bf16", "exact"]
 nstr = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1]
 V, nt, H, k = 170000, 140000, 256, 500
 W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=bias, n_tracks=nt)
+if os.environ.get("HEAVY"):           # decoder rows of very different norms (popular tracks of a trained model): x (1 + HEAVY u^8)
+    fac = 1.0 + float(os.environ["HEAVY"]) * np.random.default_rng(5).random(V) ** 8
+    W_dec = (W_dec * fac[:, None]).astype(np.float32)
 if os.environ.get("SCALE"):            # a model whose rows rank the tracks differently (x40: scripts/tf_gap.py's third case)
     W_enc = (W_enc * float(os.environ["SCALE"])).astype(np.float32)
     W_dec = (W_dec * float(os.environ["SCALE"])).astype(np.float32)

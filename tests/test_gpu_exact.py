@@ -174,6 +174,30 @@ def test_exact_large_weights_and_mixed_signs(ctx):
     _check(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
 
 
+def test_exact_heavy_columns_do_not_widen_every_margin(ctx):
+    """A few decoder rows 200x the others (a trained decoder's popular tracks): the image's largest eps is theirs and is
+    what the refine step's narrowing subtracts for every candidate -- wider margins, the same lists as the fp32 path."""
+    import torch
+    V, nt, H, B, k = 60000, 50000, 256, 64, 500
+    p = _problem(V, nt, H, B, bias="zeros", seed=9)
+    rng = np.random.default_rng(3)
+    heavy = rng.choice(nt, size=40, replace=False)
+    p["W_dec"][heavy] *= 200.0
+    p["W_dec"][heavy[:20]] *= -1.0                       # some far below the cut, some far above
+    h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+    ctx.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+    eps = torch.empty(V, dtype=torch.float32, device="cuda")
+    ctx.exact_bounds(eps)
+    e = eps.cpu().numpy()
+    assert e[:nt].max() > 50 * np.median(e[:nt])
+    score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+    idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+    ctx.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+    z_ref = oracle.decode(h, p["W_dec"], p["b_dec"], 0, nt)
+    sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+    _check(idx.cpu().numpy(), score.cpu().numpy(), idx_r, sc_r)
+
+
 def test_exact_rows_outside_the_unit_interval_return_nothing(ctx):
     """The bound assumes sigmoid outputs; dae_decode_topk flags rows that leave [0, 1] instead of ranking them."""
     import torch
