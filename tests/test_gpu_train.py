@@ -162,6 +162,13 @@ def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
         named = [i for i in range(13) if (900000 + i) % 4]                # synth_challenge gives these a name
         assert any(res_mixed[i] != res_plain[i] for i in named)
         assert all(res_mixed[i] == res_plain[i] for i in range(13) if i not in named)      # titles_use = 0 rows
+        # [BASE] decode_dtype = exact_bf16 (north_star: the bf16 GEMM, the fp32 lists): the same result file, row for
+        # row -- the plain rows through the bf16 filter + fp32 refine, the title-mixed launches on the fp32 kernels
+        ini = open(work / "config.ini").read()
+        open(work / "config.ini", "w").write(ini.replace("[BASE]", "[BASE]\ndecode_dtype = exact_bf16"))
+        assert cli.main(["--dir", "run", "--challenge"]) == 0
+        res_exact = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
+        assert res_exact == res_mixed
     finally:
         os.chdir(cwd)
 
