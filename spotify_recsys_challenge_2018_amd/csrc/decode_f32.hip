@@ -102,8 +102,13 @@ __device__ __forceinline__ int tile_of_item(const dae_tileset& ts, int i)
 // GT > 0: hidden size known at compile time (G = GT groups of 8 k) -> the k loop is fully
 // unrolled, so no loop header sits between the register-ring loads and their use (hipcc drains
 // vmcnt to 0 at every loop header; with the loop gone the waits are exact counted vmcnt(3)).
-template <int RB, int EPI, int GT, int NW, int DT>
-__global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP p)
+// HALF (phase A of the fp32 fused path, one round of tiles): the workgroup takes HALF a row group of the packed hidden
+// image (RB row blocks of its 2 RB) and two workgroups share a CU -- two waves per SIMD, each with half the rows: the one's
+// MFMAs run under the other's prologue (hidden tile -> LDS) and epilogue (exchange, sample store), which a single wave per
+// SIMD leaves the matrix pipe idle for (28 us for 13.4 us of matrix work).  The exchange slots take the hidden tile's
+// place in LDS (dead after the only round), so two workgroups fit: 2 x 64.5 KiB.  Same groups, same chains, same bits.
+template <int RB, int EPI, int GT, int NW, int DT, int HALF = 0>
+__global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void decode_f32_kernel(const DecP p)
 {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     const int tid = threadIdx.x;
@@ -139,17 +144,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     {
         // 8 independent 16 B loads in flight per thread (a load->wait->ds_write chain per element
         // costs one L2 round trip each: ~25k cycles for the 128 KiB tile, measured with SQ_WAIT_ANY)
-        const float4* src = p.hp + (size_t)rg * n_h4;
+        const float4* src = p.hp + (HALF ? (size_t)(rg >> 1) * (2 * n_h4) : (size_t)rg * n_h4);
+        // HALF: the image is [g][2 RB row blocks][64]; this workgroup's RB blocks of every g
+        auto sidx = [&](int i) -> int {
+            return HALF ? (i / (RB * 64)) * (2 * RB * 64) + (rg & 1) * (RB * 64) + (i % (RB * 64)) : i;
+        };
         constexpr int NT = NW * 64;
         int i = tid;
         for (; i + 7 * NT < n_h4; i += 8 * NT) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[i + u * NT];
+            for (int u = 0; u < 8; ++u) v[u] = src[sidx(i + u * NT)];
 #pragma unroll
             for (int u = 0; u < 8; ++u) lds4[i + u * NT] = v[u];
         }
-        for (; i < n_h4; i += NT) lds4[i] = src[i];
+        for (; i < n_h4; i += NT) lds4[i] = src[sidx(i)];
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
@@ -207,7 +216,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void decode_f32_kernel(const DecP 
     // tile -- wave w writes its masked logits as float4 (slot = (quad, half, playlist): conflict-free), thread
     // (quad, half, playlist) takes the maximum over the waves and stores 4 maxima of its playlist's row
     auto gmax_round = [&](bool has, int round, const f32x16* accv, const float4* bqv, int tcol0v) {
-        float4* xl = reinterpret_cast<float4*>(lcnt + R_TILE);
+        // HALF: the slots ARE the hidden tile's LDS (one round only: every wave is past its k loop at the first barrier)
+        float4* xl = HALF ? lds4 : reinterpret_cast<float4*>(lcnt + R_TILE);
         if (p.gmax_per_wave) {
             // a sample too small for groups of NW (a vocabulary shard: 61 tiles for 64 wave slots): every element is
             // its own "group" -- the wave stores its masked logits, -inf where it had no tile this round
@@ -1924,6 +1934,22 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
     if (gmax) {
         if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "group maxima need 4-wave workgroups");
+        static const bool no_half = dae_exp_env("DAE_GMAX_FULL") != nullptr;             // A/B against one workgroup per CU
+        if (dtype == DAE_DTYPE_F32 && g.R_TILE == 128 && p.G == 32 && !gmax_per_wave && !p.mixT && !no_half &&
+            ts.n_items <= g.nb_rg * 4) {
+            // one round of tiles (the threshold sample at batch <= 256): half row groups, two workgroups per CU
+            p.n_rg = 2 * g.n_rg;
+            const size_t lds = (size_t)2 * 64 * p.G * sizeof(float4) + (size_t)2 * 32 * sizeof(int);
+            static const char attr_key = 0;
+            if (dae_first_use(ctx, &attr_key))
+                DAE_HIP_CHECK(ctx, hipFuncSetAttribute(
+                                       reinterpret_cast<const void*>(&decode_f32_kernel<2, EPI_GMAX, 32, 4, DT_F32, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL((decode_f32_kernel<2, EPI_GMAX, 32, 4, DT_F32, 1>), dim3(2 * g.grid), dim3(256), lds,
+                               ctx->stream, p);
+            DAE_CHECK_LAUNCH(ctx, "decode_f32_kernel (half row groups)");
+            return DAE_OK;
+        }
         return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_GMAX>(ctx, g, p) : launch_decode_rb_bf16<EPI_GMAX>(ctx, g, p);
     }
     return dtype == DAE_DTYPE_F32 ? launch_decode_rb<EPI_DENSE>(ctx, g, p)
