@@ -656,6 +656,12 @@ def main():
                                       "frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / peak_tf, 4),
                                       "flop_per_step": step_flop,
                                       "note": "all decoded tiles x 2 B H x 32 columns / ms_per_step, same peak"}
+            if n_str > 1:
+                roofline["note"] = ("avg_launch_ms is the launch's HIP event pair: from the head of its queue to its last wave, "
+                                    "so it includes the wait for CUs the other batch's threshold sample still holds (their LDS "
+                                    "footprints exclude each other); rocprofv3 times the kernel from its first wave "
+                                    "(profiles/r03_kernel_stats_headline.csv: ~148.5 us = 0.87), `isolated` is the same launch "
+                                    "with nothing else in flight")
     except Exception:
         pass
     if pmc_mfma:
