@@ -148,6 +148,13 @@ int dae_encode(dae_ctx* ctx,
 int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec,
                         int V, int H, int col_lo, int col_hi, int dtype);
 
+/* The same from a RANK-LOCAL copy of the rows (vocabulary shards: a rank holds only its own rows of W_dec):
+ * W_rows [n_rows, H] / b_rows [n_rows] are the global columns col_lo .. col_lo + n_rows; the image covers exactly
+ * those.  (dae_prepack_decoder indexes its arguments by global column; this entry point does the shift inside the
+ * library, where the prepack kernels' access range is known.)  Replaces the same section as dae_prepack_decoder. */
+int dae_prepack_decoder_rows(dae_ctx* ctx, const float* W_rows, const float* b_rows, int n_rows, int H, int col_lo,
+                             int dtype);
+
 /* Let `dst` use the decoder image `src` prepacked for `dtype` instead of holding a copy of its own (the contexts of
  * several batches in flight score with the same weights: one image stays resident in the 256 MB Infinity Cache where
  * two or three copies of 87 / 174 MB evict each other; it also saves their memory and re-tiling).  `dst` borrows the
@@ -160,6 +167,30 @@ int dae_share_decoder(dae_ctx* dst, const dae_ctx* src, int dtype);
  * eps_out (device, col_hi - col_lo floats).  |fp32 logit - bf16 logit| <= eps_c for every hidden row in [0, 1]^H;
  * DESIGN.md section 2b derives it, tests/test_gpu_exact.py checks it against measured differences. */
 int dae_exact_bounds(dae_ctx* ctx, float* eps_out);
+
+/* DAE_DTYPE_BF16_EXACT, the BOUND GUARD.  One term of eps_c -- the accumulation inside v_mfma_f32_32x32x16_bf16 -- rests
+ * on an error model of that instruction, not on a specification.  So every survivor the refine launch recomputes in
+ * fp32 is tested against what the filter launch promised for it (u - 2 eps_c <= z_fp32 <= u, u the stored upper bound;
+ * both numbers are in registers: the test is free), and a violation is COUNTED in two device words of the context
+ * instead of silently costing a true top-k column.  A caller that sees a count != 0 must treat the results of the calls
+ * since the last read as unproven and re-run them with DAE_DTYPE_F32 (models/DAEs.py recommend / recommend_iter do).
+ *   dae_exact_guard_read : synchronises the ctx stream; violations (count since the last read that returned != 0) and
+ *                          one violating global column (-1 when none); resets the words when the count is non-zero.
+ *   dae_exact_guard_words: the device address of {int32 violations, int32 column}, for a caller that fetches the words
+ *                          with its results (no synchronisation here); valid for the life of the ctx.
+ * The ranking values that reach main_challenge.py:26-36's argsort are fp32 either way: the guard protects the SET. */
+int dae_exact_guard_read(dae_ctx* ctx, int32_t* violations, int32_t* column);
+int dae_exact_guard_words(dae_ctx* ctx, const int32_t** words_dev);
+/* How selective the filter was (the exact mode's rate depends on it, its results never): since the last read, summed over
+ * the refine launches of this context, out3 = {rows refined, candidates the bf16 filter launch left for them, candidates
+ * recomputed in fp32 after the narrowing step}.  Synchronises the ctx stream; resets the sums. */
+int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3]);
+
+/* Factor on every eps_c computed by the NEXT dae_prepack_decoder(DAE_DTYPE_BF16_EXACT) of this context (default 1).
+ * > 1 widens the bounds: a safety margin for a caller who distrusts the error model (more survivors to recompute, same
+ * results).  < 1 VOIDS the guarantee and exists so that the guard can be exercised: results may then differ from the
+ * fp32 path, and dae_exact_guard_read reports it (tests/test_gpu_exact.py).  0 < scale <= 1024. */
+int dae_set_exact_margin(dae_ctx* ctx, float scale);
 
 /* ---- decode (DAEs.py:73-77 tied / :141-145 untied) ---------------------------------------- */
 

@@ -25,6 +25,13 @@ if os.environ.get("SCALE"):            # a model whose rows rank the tracks diff
     W_enc = (W_enc * float(os.environ["SCALE"])).astype(np.float32)
     W_dec = (W_dec * float(os.environ["SCALE"])).astype(np.float32)
 pos, ones, seeds = make_playlists(B, nt, V - nt, seed=1)
+if os.environ.get("TRAINED"):          # a model TRAINED on clustered synthetic playlists (utils/synthetic.py), its own kind of batch
+    from spotify_recsys_challenge_2018_amd.utils.synthetic import train_clustered_model
+    W_enc, b_enc, W_dec, b_dec, gen, info = train_clustered_model(nt, V - nt, H, steps=int(os.environ["TRAINED"]), log=print)
+    print("trained:", info, flush=True)
+    pos, ones, seeds = gen.scoring_feed(B, np.random.default_rng(77))
+    print("b_dec range", float(b_dec.min()), float(b_dec.max()), "|W_dec| row-norm1 mean/max",
+          float(np.abs(W_dec).sum(1).mean()), float(np.abs(W_dec).sum(1).max()), flush=True)
 rp, col, val = coo_to_csr(pos, ones, B, V)
 srp, sc = seeds_to_csr(seeds, B, nt)
 d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
@@ -75,4 +82,10 @@ for name, dt in (("f32", 0), ("bf16", 1), ("exact", 2)):
         if name == "f32" and ref is None:
             ref = (s.clone(), i_.clone())
         same = ref is not None and bool(torch.equal(i_, ref[1]) and torch.equal(s.view(torch.int32), ref[0].view(torch.int32)))
-        print(f"{name} streams={n}: {ms:.4f} ms/step  {B / ms * 1e3 / 1e6:.3f} M playlists/s  identical_to_f32={same}", flush=True)
+        extra = ""
+        if name == "exact":
+            st = [c.exact_stats_read() for c in ctxs[:n]]
+            extra = "  candidates/row=%.0f recomputed/row=%.0f guard=%s" % (
+                np.mean([x["candidates_per_row"] for x in st]), np.mean([x["recomputed_per_row"] for x in st]),
+                [c.exact_guard_read() for c in ctxs[:n]][0])
+        print(f"{name} streams={n}: {ms:.4f} ms/step  {B / ms * 1e3 / 1e6:.3f} M playlists/s  identical_to_f32={same}{extra}", flush=True)

@@ -11,11 +11,12 @@ LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
 DAE_OUT_SCORE, DAE_OUT_LOGIT = 0, 1
 DAE_DTYPE_F32, DAE_DTYPE_BF16, DAE_DTYPE_BF16_EXACT = 0, 1, 2
 
-# every symbol include/dae_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+# every symbol include/dae_hip.h declares (tests/test_abi_cpu.py checks the .so exports all of them)
 EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
-    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_share_decoder", "dae_exact_bounds", "dae_decode_dense", "dae_decode_topk",
+    "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_prepack_decoder_rows", "dae_share_decoder", "dae_exact_bounds",
+    "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
@@ -64,8 +65,13 @@ def load():
     lib.dae_seeds_from_csr.argtypes = [vp, vp, vp, c_int, c_int, vp, vp]
     lib.dae_encode.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_f, c_f, c_u32, vp]
     lib.dae_prepack_decoder.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int, c_int]
+    lib.dae_prepack_decoder_rows.argtypes = [vp, vp, vp, c_int, c_int, c_int, c_int]
     lib.dae_share_decoder.argtypes = [vp, vp, c_int]
     lib.dae_exact_bounds.argtypes = [vp, vp]
+    lib.dae_exact_guard_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    lib.dae_exact_guard_words.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.dae_set_exact_margin.argtypes = [vp, c_f]
+    lib.dae_exact_stats_read.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_score_topk.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp,
@@ -197,17 +203,23 @@ class Context:
             col_hi = V
         self.check(self.lib.dae_prepack_decoder(self.h, _ptr(W_dec), _ptr(b_dec), V, H,
                                                 int(col_lo), int(col_hi), int(dtype)))
+        self._drop_share(dtype)
+
+    @staticmethod
+    def _slot(dtype):
+        return "f32" if int(dtype) == DAE_DTYPE_F32 else "bf16"      # the two image slots of a context (dae_packed)
+
+    def _drop_share(self, dtype):
+        """The slot holds an image of its own again: the context it borrowed from need not be kept alive for it."""
+        self.__dict__.setdefault("_shares", {}).pop(self._slot(dtype), None)
 
     def prepack_decoder_rows(self, W_rows, b_rows, col_lo, dtype=DAE_DTYPE_F32):
         """Prepack a decoder image from a RANK-LOCAL copy of its rows: W_rows [n, H] / b_rows [n] hold the global
-        columns col_lo .. col_lo + n.  (dae_prepack_decoder indexes its arguments by global column: the pointers are
-        shifted back by col_lo rows, so that row col_lo of the argument is row 0 of the copy; nothing below col_lo is
-        ever read.)"""
+        columns col_lo .. col_lo + n (dae_prepack_decoder_rows)."""
         n, H = W_rows.shape
         assert W_rows.is_contiguous() and b_rows.is_contiguous() and b_rows.numel() == n
-        wp = ctypes.c_void_p(W_rows.data_ptr() - int(col_lo) * H * 4)
-        bp = ctypes.c_void_p(b_rows.data_ptr() - int(col_lo) * 4)
-        self.check(self.lib.dae_prepack_decoder(self.h, wp, bp, int(col_lo) + n, H, int(col_lo), int(col_lo) + n, int(dtype)))
+        self.check(self.lib.dae_prepack_decoder_rows(self.h, _ptr(W_rows), _ptr(b_rows), int(n), H, int(col_lo), int(dtype)))
+        self._drop_share(dtype)
 
     def set_overlap_hint(self, batches_in_flight):
         """Other batches are in flight on other streams: kernel shapes that share CUs (include/dae_hip.h)."""
@@ -217,11 +229,35 @@ class Context:
         """Use `src`'s prepacked image of `dtype` instead of an own copy (see include/dae_hip.h dae_share_decoder: `src`
         outlives every use; order src's prepack before this context's first launch)."""
         self.check(self.lib.dae_share_decoder(self.h, src.h, int(dtype)))
-        self._shares = src                                   # keep the owner alive as long as this context
+        self.__dict__.setdefault("_shares", {})[self._slot(dtype)] = src     # one owner per slot, alive while borrowed
 
     def exact_bounds(self, eps_out):
         """Per-column bounds |fp32 logit - bf16 logit| <= eps of the image prepacked with DAE_DTYPE_BF16_EXACT."""
         self.check(self.lib.dae_exact_bounds(self.h, _ptr(eps_out)))
+
+    def set_exact_margin(self, scale):
+        """Factor on every eps_c at the NEXT exact prepack (include/dae_hip.h: > 1 widens, < 1 voids the bound -- the
+        guard's test hook)."""
+        self.check(self.lib.dae_set_exact_margin(self.h, float(scale)))
+
+    def exact_guard_read(self):
+        """(violations, column) of the exact mode's bound guard since the last non-zero read; synchronises the stream."""
+        n, c = ctypes.c_int32(), ctypes.c_int32()
+        self.check(self.lib.dae_exact_guard_read(self.h, ctypes.byref(n), ctypes.byref(c)))
+        return int(n.value), int(c.value)
+
+    def exact_stats_read(self):
+        """{rows, candidates_per_row, recomputed_per_row} of the refine launches since the last read (synchronises)."""
+        a = (ctypes.c_uint64 * 3)()
+        self.check(self.lib.dae_exact_stats_read(self.h, a))
+        rows = max(int(a[0]), 1)
+        return {"rows": int(a[0]), "candidates_per_row": round(int(a[1]) / rows, 1), "recomputed_per_row": round(int(a[2]) / rows, 1)}
+
+    def exact_guard_words(self):
+        """Device address of the guard's two int32 words (for a fetch alongside the results)."""
+        p = ctypes.c_void_p()
+        self.check(self.lib.dae_exact_guard_words(self.h, ctypes.byref(p)))
+        return int(p.value)
 
     def decode_dense(self, h, out, apply_sigmoid=True, dtype=DAE_DTYPE_F32):
         B, H = h.shape

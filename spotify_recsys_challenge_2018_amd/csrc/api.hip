@@ -42,6 +42,8 @@ int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes)
     return DAE_OK;
 }
 
+constexpr size_t DAE_GUARD_BYTES = 2 * sizeof(int) + 3 * sizeof(uint64_t);   // {violations, column} + {rows, candidates, recomputed}
+
 namespace {
 
 struct Plan {            // geometry of the last dae_decode_topk call (dae_last_plan)
@@ -147,7 +149,7 @@ int dae_destroy(dae_ctx* ctx)
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
-                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
+                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -332,6 +334,21 @@ int dae_prepack_decoder(dae_ctx* ctx, const float* W_dec, const float* b_dec, in
     return dae_fail(ctx, DAE_ERR_ARG, "unknown dtype %d", dtype);
 }
 
+int dae_prepack_decoder_rows(dae_ctx* ctx, const float* W_rows, const float* b_rows, int n_rows, int H, int col_lo,
+                             int dtype)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!W_rows || !b_rows) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (n_rows <= 0 || H <= 0 || col_lo < 0 || (int64_t)col_lo + n_rows > INT_MAX)
+        return dae_fail(ctx, DAE_ERR_ARG, "bad shape n_rows=%d H=%d col_lo=%d", n_rows, H, col_lo);
+    // the prepack kernels index their arguments by GLOBAL column and read rows [col_lo, col_hi) only (prepack_tile_kernel,
+    // exact_bounds_kernel, the W32 copy: each forms W + v * H with col_lo <= v < col_hi): the shifted base is never
+    // dereferenced below row col_lo
+    const float* W = W_rows - (size_t)col_lo * H;
+    const float* b = b_rows - (size_t)col_lo;
+    return dae_prepack_decoder(ctx, W, b, col_lo + n_rows, H, col_lo, col_lo + n_rows, dtype);
+}
+
 int dae_exact_bounds(dae_ctx* ctx, float* eps_out)
 {
     if (!ctx) return DAE_ERR_ARG;
@@ -340,6 +357,54 @@ int dae_exact_bounds(dae_ctx* ctx, float* eps_out)
     if (!pk.valid || !pk.exact) return dae_fail(ctx, DAE_ERR_STATE, "decoder weights not prepacked with DAE_DTYPE_BF16_EXACT");
     DAE_HIP_CHECK(ctx, hipMemcpyAsync(eps_out, pk.eps.p, (size_t)(pk.col_hi - pk.col_lo) * sizeof(float),
                                       hipMemcpyDeviceToDevice, ctx->stream));
+    return DAE_OK;
+}
+
+int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3])
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!out3) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    out3[0] = out3[1] = out3[2] = 0;
+    if (!ctx->guard.p) return DAE_OK;
+    char* st = static_cast<char*>(ctx->guard.p) + 2 * sizeof(int);
+    DAE_HIP_CHECK(ctx, hipMemcpyAsync(out3, st, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    DAE_HIP_CHECK(ctx, hipMemsetAsync(st, 0, 3 * sizeof(uint64_t), ctx->stream));
+    DAE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return DAE_OK;
+}
+
+int dae_set_exact_margin(dae_ctx* ctx, float scale)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!(scale > 0.0f) || !(scale <= 1024.0f)) return dae_fail(ctx, DAE_ERR_ARG, "dae_set_exact_margin: scale must be in (0, 1024]");
+    ctx->exact_margin = scale;
+    return DAE_OK;
+}
+
+int dae_exact_guard_read(dae_ctx* ctx, int32_t* violations, int32_t* column)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    int32_t w[2] = {0, -1};
+    if (ctx->guard.p) {
+        DAE_HIP_CHECK(ctx, hipMemcpyAsync(w, ctx->guard.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+        DAE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (w[0] != 0) DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->guard.p, 0, sizeof(w), ctx->stream));
+    }
+    if (violations) *violations = w[0];
+    if (column) *column = w[0] ? w[1] : -1;
+    return DAE_OK;
+}
+
+int dae_exact_guard_words(dae_ctx* ctx, const int32_t** words_dev)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!words_dev) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (!ctx->guard.p) {
+        int rc = dae_reserve(ctx, ctx->guard, DAE_GUARD_BYTES);
+        if (rc) return rc;
+        DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->guard.p, 0, DAE_GUARD_BYTES, ctx->stream));
+    }
+    *words_dev = static_cast<const int32_t*>(ctx->guard.p);
     return DAE_OK;
 }
 
@@ -537,9 +602,15 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
     dae_pair_group g1{static_cast<const uint2*>(ctx->cand.p), static_cast<const int*>(ctx->cand_cnt.p),
                       (int64_t)g.Bpad * cap, cap, g.Bpad, g.nb_rg, 0};
     if (tk.exact) {
+        if (!ctx->guard.p) {                                  // the guard words of this context, zero until a bound fails
+            rc = dae_reserve(ctx, ctx->guard, DAE_GUARD_BYTES);
+            if (rc) return rc;
+            DAE_HIP_CHECK(ctx, hipMemsetAsync(ctx->guard.p, 0, DAE_GUARD_BYTES, ctx->stream));
+        }
         dae_exact_src xs{h32, (int64_t)pk->H, pk->H, static_cast<const float*>(pk->W32.p),
                          static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad,
-                         static_cast<const float*>(pk->eps.p) + (size_t)pk->ntiles * 32};
+                         static_cast<const float*>(pk->eps.p) + (size_t)pk->ntiles * 32,
+                         static_cast<const float*>(pk->eps.p), static_cast<int*>(ctx->guard.p)};
         rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr);
         if (rc) return rc;
     }

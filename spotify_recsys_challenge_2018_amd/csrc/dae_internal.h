@@ -114,6 +114,8 @@ struct dae_ctx {
     dae_topk_state tk;
     int overlap_hint = 0;      // dae_set_overlap_hint: other batches are in flight on other streams -> kernel shapes that share CUs
     dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
+    dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
+    float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -387,6 +389,8 @@ struct dae_exact_src {
     const float* W32; const float* bias; int col_lo;
     const int* row_bad;                           // nullable: rows flagged 1 return no candidates (idx -1)
     const float* eps_max;                         // device scalar: max over the image's columns of eps_c
+    const float* eps;                             // [ncols] the per-column bounds (the guard tests each recomputed survivor)
+    int* guard;                                   // nullable: device {violations, a violating column} (dae_exact_guard_read)
 };
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
                             const int32_t* seed_row_ptr);

@@ -204,16 +204,42 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         return acc + p.x.bias[colv - p.x.col_lo];
     };
 
+    // BOUND GUARD.  The filter launch promised u - 2 eps_c <= z32 <= u for the stored upper bound u of column c; the
+    // term of eps_c that covers the accumulation inside v_mfma_f32_32x32x16_bf16 rests on an error MODEL of that
+    // instruction (decode_f32.hip exact_bounds_kernel), so every recomputed survivor is tested against the promise --
+    // both numbers are in registers -- and a violation is COUNTED in the context's guard words (dae_exact_guard_read):
+    // a column whose bound fails may have a sibling that was wrongly filtered out, and the caller must know.
+    // (The lower end is taken two floats down: the subtraction rounds.)
+    auto guard = [&](float z, float u, int colv, bool in) {
+        if (!in || !p.x.guard) return;
+        const float e2 = 2.0f * p.x.eps[colv - p.x.col_lo] * 1.000001f;
+        const float lo = dae_okey_inv(dae_okey(u - e2) - 2u);
+        if (!(z <= u && z >= lo)) {
+            atomicAdd(p.x.guard, 1);
+            p.x.guard[1] = colv;
+        }
+    };
+
+    // statistics of the context (dae_exact_stats_read): rows refined, candidates the filter launch left, candidates recomputed
+    auto stat = [&](int n_in, int n_re) {
+        if (tid == 0 && p.x.guard) {
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(p.x.guard + 2);
+            atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)n_in); atomicAdd(st + 2, (unsigned long long)n_re);
+        }
+    };
+
     if (!staged && !bad) {
         // every candidate is recomputed (few enough that narrowing cannot pay, or too many to stage): the waves work
         // independently on flat groups of 64 -- no list, no barrier
         __syncthreads();                                         // (the staging area / tbuf are not in use: nothing to wait for but the prefix)
+        stat(total, total);
         for (int g0 = wave * 64; g0 < total; g0 += RF_WAVES * 64) {
             const int e = g0 + lane;
             const bool in = e < total;
             const int off = offset_of(in ? e : g0);
             const uint2 pr = p.base[off];
             const float z = rescore_group((int)pr.y, in);
+            guard(z, __uint_as_float(pr.x), (int)pr.y, in);
             if (in) p.base[off].x = __float_as_uint(z);
         }
         return;
@@ -236,12 +262,17 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     });
     __syncthreads();
     const int n_kept = s_n;
+    stat(total, n_kept);
     if (n_kept <= RF_SURV) {                                     // ... and the list is recomputed, a lane per entry
         for (int g0 = wave * 64; g0 < n_kept; g0 += RF_WAVES * 64) {
             const int e = g0 + lane;
             const bool in = e < n_kept;
-            const float z = rescore_group(surv_col[in ? e : g0], in);
-            if (in) p.base[surv_off[e]].x = __float_as_uint(z);
+            const int cv = surv_col[in ? e : g0];
+            const float z = rescore_group(cv, in);
+            if (in) {
+                guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
+                p.base[surv_off[e]].x = __float_as_uint(z);
+            }
         }
         return;
     }
@@ -271,12 +302,20 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         }
         __syncthreads();
         const int n = s_n;
+        // every thread has read n BEFORE anyone appends again: without this barrier a fast wave's next-round atomicAdd
+        // could change s_n under a slow wave, the waves would disagree on the flush branch below and meet different
+        // barriers
+        __syncthreads();
         if (n + RF_THREADS > RF_SURV || c0 + RF_THREADS >= total) {   // the list could overflow next round, or this was the last
             for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
                 const int e = g0 + lane;
                 const bool in = e < n;
-                const float z = rescore_group(surv_col[in ? e : g0], in);
-                if (in) p.base[surv_off[e]].x = __float_as_uint(z);
+                const int cv = surv_col[in ? e : g0];
+                const float z = rescore_group(cv, in);
+                if (in) {
+                    guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
+                    p.base[surv_off[e]].x = __float_as_uint(z);
+                }
             }
             __syncthreads();
             if (tid == 0) s_n = 0;
@@ -299,7 +338,7 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
 {
     if (B <= 0) return DAE_OK;
     if (g1.nseg > RF_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
-    if (!x.h || !x.W32 || !x.bias || !x.eps_max || (x.H & 3) || x.H > 1024 || !g1.cnt)
+    if (!x.h || !x.W32 || !x.bias || !x.eps_max || !x.eps || (x.H & 3) || x.H > 1024 || !g1.cnt)
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: bad arguments (H=%d)", x.H);
     RefineP p;
     p.base = const_cast<uint2*>(g1.base); p.cnt = g1.cnt; p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;

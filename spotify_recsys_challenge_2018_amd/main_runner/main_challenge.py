@@ -149,10 +149,12 @@ def run(conf, model=None):
                 raise ValueError("[CHALLENGE] shard_exchange = alltoall needs the model's batch (%d) to be a multiple of the "
                                  "world size (%d) when a fitted model is passed in: build the model with such a batch, or "
                                  "use shard_exchange = allgather" % (model.n_batch, world))
-            try:
+            import inspect
+            if 'tau_exchange' in inspect.signature(model.shard_scoring).parameters:
                 model.shard_scoring(rank, world, exchange=exchange, tau_exchange=tau_x)
-            except TypeError:                                  # a model object of the older protocol
+            else:                                              # a model object of the older protocol
                 model.shard_scoring(rank, world, exchange=exchange)
+                tau_x = False                                  # (what the log line below reports)
     if sharded:
         log_write(conf, 'vocabulary columns sharded over %d ranks (%s exchange of the per-shard top-500%s)'
                   % (world, exchange, ', thresholds exchanged first' if tau_x else ''))

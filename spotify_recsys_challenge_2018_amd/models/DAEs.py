@@ -152,7 +152,10 @@ class DAE_tied:
         # decode arithmetic of recommend(): "f32" (fp32 MFMA, bit-exact path), "bf16" (BASELINE configs[4]) or
         # "exact_bf16" (BASELINE north_star: bf16 MFMA filter + fp32 recomputation of the survivors -- the fp32
         # path's lists, bit for bit, at close to the bf16 rate)
-        self.decode_dtype = _DECODE_DTYPES.get(str(getattr(conf, "decode_dtype", "f32")), _lib.DAE_DTYPE_F32)
+        dd = str(getattr(conf, "decode_dtype", "f32"))
+        if dd not in _DECODE_DTYPES:
+            raise ValueError("decode_dtype %r: one of %s" % (dd, sorted(_DECODE_DTYPES)))
+        self.decode_dtype = _DECODE_DTYPES[dd]
         # arithmetic of the training forward GEMM: "f32" (default) or "bf16" (BASELINE configs[3]: bf16 operands,
         # fp32 accumulate; loss, backward GEMMs, parameters and Adam stay fp32)
         self.train_dtype = _lib.DAE_DTYPE_BF16 if str(getattr(conf, "train_dtype", "f32")) == "bf16" \
