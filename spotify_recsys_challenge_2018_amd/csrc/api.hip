@@ -149,7 +149,7 @@ int dae_destroy(dae_ctx* ctx)
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
-                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
+                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -611,8 +611,16 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
                          static_cast<const float*>(pk->bias.p), pk->col_lo, row_bad,
                          static_cast<const float*>(pk->eps.p) + (size_t)pk->ntiles * 32,
                          static_cast<const float*>(pk->eps.p), static_cast<int*>(ctx->guard.p)};
-        rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr);
+        // the survivors of a row leave the refine launch as ONE compact list (group 0 of the selection: the threshold kernel
+        // emits no sample survivors in this mode), the per-workgroup lists of the row are emptied
+        rc = dae_reserve(ctx, ctx->refined, (size_t)g.Bpad * DAE_REFINED_CAP * sizeof(uint2) + (size_t)g.Bpad * sizeof(int));
         if (rc) return rc;
+        uint2* rf = static_cast<uint2*>(ctx->refined.p);
+        int* rf_cnt = reinterpret_cast<int*>(rf + (size_t)g.Bpad * DAE_REFINED_CAP);
+        rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr, rf, rf_cnt, DAE_REFINED_CAP);
+        if (rc) return rc;
+        dae_pair_group gr{rf, rf_cnt, 0, DAE_REFINED_CAP, 0, 1, 0};
+        return dae_launch_topk_pairs(ctx, gr, g1, ta);
     }
     return dae_launch_topk_pairs(ctx, g0, g1, ta);
 }

@@ -22,6 +22,7 @@ constexpr int DAE_HPAD = 32;      // hidden size is zero-padded to a multiple of
 constexpr int DAE_MAX_K = 1024;   // largest top-k supported
 constexpr int DAE_NUM_CU = 256;   // MI355X
 constexpr int DAE_NUM_XCD = 8;
+constexpr int DAE_REFINED_CAP = 4096;   // survivors per row the exact mode's compact lists hold (more: refined in place)
 
 struct dae_buf {
     void* p = nullptr;
@@ -114,6 +115,7 @@ struct dae_ctx {
     dae_topk_state tk;
     int overlap_hint = 0;      // dae_set_overlap_hint: other batches are in flight on other streams -> kernel shapes that share CUs
     dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
+    dae_buf refined;           // DAE_DTYPE_BF16_EXACT: [Bpad][DAE_REFINED_CAP] (fp32 logit, column) pairs + [Bpad] counts (refine.hip)
     dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
 
@@ -392,5 +394,7 @@ struct dae_exact_src {
     const float* eps;                             // [ncols] the per-column bounds (the guard tests each recomputed survivor)
     int* guard;                                   // nullable: device {violations, a violating column} (dae_exact_guard_read)
 };
+// out / out_cnt / out_cap (nullable): per row a compact list [out_cap] of the survivors' (fp32 logit, column) pairs and its
+// length; rows that fit get it filled and their g1 lists emptied (counts zeroed), the others are refined in place
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
-                            const int32_t* seed_row_ptr);
+                            const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0);

@@ -33,9 +33,10 @@ constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's trans
 // waiting for it.
 
 struct RefineP {
-    uint2* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
+    uint2* base; int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
     dae_exact_src x;
     const int32_t* seed_row_ptr; int k;
+    uint2* out; int* out_cnt; int out_cap;        // compact output lists [row][out_cap] + counts (see the header comment)
 };
 
 template <int RF_THREADS, int RF_DEPTH>
@@ -45,7 +46,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
     __shared__ int seg_prefix[RF_MAX_SEG + 2];
     __shared__ __attribute__((aligned(16))) float hrow[1024];
-    __shared__ int surv_off[RF_SURV];
+    __shared__ int surv_off[RF_SURV];            // in-place mode: offset of the pair; compact mode: the bits of its bound u
     __shared__ int surv_col[RF_SURV];
     __shared__ unsigned cnts[32];
     __shared__ int s_n;
@@ -76,10 +77,15 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     }
     __syncthreads();
     const int total = seg_prefix[nseg];
-    if (total == 0) return;
+    if (total == 0) {
+        if (tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
+        return;
+    }
     const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
 
-    // flat candidate index -> offset of its pair in the lists
+    // flat candidate index -> offset of its pair in the lists.  Every pass below walks the FLAT index space, so the loads
+    // of a pass are independent of each other (a wave walking its segments one after another waited a memory round trip
+    // per segment: 16 trips per pass at 128 segments, 28 of the launch's 45 us on a model whose rows rank differently)
     auto offset_of = [&](int e) -> int {
         int lo = 0, hi = nseg;                              // largest s with seg_prefix[s] <= e
         while (hi - lo > 1) {
@@ -89,27 +95,13 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         return (int)((int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]));
     };
 
-    // every candidate of the row, segment by segment: wave w takes segments w, w + RF_WAVES, ... and a lane one entry
-    // (no per-entry search for the segment; f(flat index, offset of the pair, the pair) -- called by whole waves)
-    auto for_candidates = [&](auto f) {
-        for (int sg = wave; sg < nseg; sg += RF_WAVES) {
-            const int b0 = seg_prefix[sg], cnt = seg_prefix[sg + 1] - b0;
-            const int off0 = (int)((int64_t)sg * p.seg_stride + (int64_t)row * p.row_stride);
-            for (int i0 = 0; i0 < cnt; i0 += 64) {
-                const int i = i0 + lane;
-                const bool in = i < cnt;
-                const uint2 pr = in ? p.base[off0 + i] : make_uint2(0u, 0u);
-                f(b0 + i, off0 + i, pr, in);
-            }
-        }
-    };
-
     // ---- 1. narrow ------------------------------------------------------------------------------------------------
     float* stage_u = reinterpret_cast<float*>(rf_dyn);
     float taup = bad ? __builtin_inff() : -__builtin_inff();
-    const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 2);
+    const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 1);   // narrowing pays when it can drop a third
+    int n_kept = bad ? 0 : total;
     if (staged) {
-        for_candidates([&](int e, int, uint2 pr, bool in) { if (in) stage_u[e] = __uint_as_float(pr.x); });
+        for (int e = tid; e < total; e += RF_THREADS) stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
         __syncthreads();
         // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
         unsigned P = 0u;
@@ -138,10 +130,25 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             taup = dae_okey_inv(P) - 2.0f * p.x.eps_max[0] * 1.000001f;
             taup = dae_okey_inv(dae_okey(taup) - 2u);          // two floats further down: the subtraction rounded
         }
+        // how many pass: decides where the results go
+        unsigned nk = 0;
+        for (int i0 = 0; i0 < total; i0 += RF_THREADS) {
+            const int i = i0 + tid;
+            nk += (unsigned)__popcll(__ballot(i < total && stage_u[i] >= taup));
+        }
+        if (lane == 0 && nk) atomicAdd(&cnts[30], nk);
+        __syncthreads();
+        n_kept = (int)cnts[30];
     }
+    // COMPACT: the survivors' (fp32 logit, column) pairs go to this row's own list p.out[row][0 .. n_kept) and the
+    // filter launch's per-workgroup lists of the row are emptied (their counts zeroed): the selection kernel then reads one
+    // short list per row instead of walking 128 segments that hold mostly "absent" marks.  Rows with more survivors
+    // than the list holds (thousands of logits within 2 eps of the cut) are refined IN PLACE, as in round 3.
+    const bool compact = p.out != nullptr && n_kept <= p.out_cap;
+    uint2* const orow = compact ? p.out + (size_t)row * p.out_cap : nullptr;
 
     // ---- 2. recompute the survivors -------------------------------------------------------------------------------
-    float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // the staging area is dead by then
+    float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // (shares the staging area: see the barriers)
     const int H16 = p.x.H >> 4;                                  // blocks of 16 k (H % 16 remainder handled below)
     const int Hrem4 = (p.x.H & 15) >> 2;                         // float4 left over after the whole blocks
 
@@ -219,20 +226,27 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             p.x.guard[1] = colv;
         }
     };
-
     // statistics of the context (dae_exact_stats_read): rows refined, candidates the filter launch left, candidates recomputed
-    auto stat = [&](int n_in, int n_re) {
-        if (tid == 0 && p.x.guard) {
-            unsigned long long* st = reinterpret_cast<unsigned long long*>(p.x.guard + 2);
-            atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)n_in); atomicAdd(st + 2, (unsigned long long)n_re);
-        }
+    if (tid == 0 && p.x.guard) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.x.guard + 2);
+        atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)total); atomicAdd(st + 2, (unsigned long long)n_kept);
+    }
+    // the row's per-workgroup lists are empty from here on (compact), its own list holds n_kept entries
+    auto finish_compact = [&]() {
+        for (int s = tid; s < nseg; s += RF_THREADS) p.cnt[(size_t)s * p.cnt_seg_stride + row] = 0;
+        if (tid == 0) p.out_cnt[row] = n_kept;
     };
+    if (!compact && tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
 
-    if (!staged && !bad) {
+    if (bad) {                                                   // a row that must return nothing
+        if (compact) { finish_compact(); return; }
+        for (int e = tid; e < total; e += RF_THREADS) p.base[offset_of(e)].x = __float_as_uint(-__builtin_inff());
+        return;
+    }
+
+    if (!staged) {
         // every candidate is recomputed (few enough that narrowing cannot pay, or too many to stage): the waves work
-        // independently on flat groups of 64 -- no list, no barrier
-        __syncthreads();                                         // (the staging area / tbuf are not in use: nothing to wait for but the prefix)
-        stat(total, total);
+        // independently on flat groups of 64 -- no list, no barrier; slot of the result = the flat index
         for (int g0 = wave * 64; g0 < total; g0 += RF_WAVES * 64) {
             const int e = g0 + lane;
             const bool in = e < total;
@@ -240,54 +254,28 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const uint2 pr = p.base[off];
             const float z = rescore_group((int)pr.y, in);
             guard(z, __uint_as_float(pr.x), (int)pr.y, in);
-            if (in) p.base[off].x = __float_as_uint(z);
+            if (in) {
+                if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
+                else p.base[off].x = __float_as_uint(z);
+            }
         }
+        if (compact) finish_compact();
         return;
     }
 
-    // narrowed (or a row that must return nothing): ONE pass marks what is out (-inf) and lists what is left ...
-    __syncthreads();
-    for_candidates([&](int, int off, uint2 pr, bool in) {
-        const bool keep = in && __uint_as_float(pr.x) >= taup;
-        if (in && !keep) p.base[off].x = __float_as_uint(-__builtin_inff());
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            int b = 0;
-            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
-            b = __shfl(b, leader);
-            const int slot = b + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && slot < RF_SURV) { surv_off[slot] = off; surv_col[slot] = (int)pr.y; }
-        }
-    });
-    __syncthreads();
-    const int n_kept = s_n;
-    stat(total, n_kept);
-    if (n_kept <= RF_SURV) {                                     // ... and the list is recomputed, a lane per entry
-        for (int g0 = wave * 64; g0 < n_kept; g0 += RF_WAVES * 64) {
-            const int e = g0 + lane;
-            const bool in = e < n_kept;
-            const int cv = surv_col[in ? e : g0];
-            const float z = rescore_group(cv, in);
-            if (in) {
-                guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
-                p.base[surv_off[e]].x = __float_as_uint(z);
-            }
-        }
-        return;
-    }
-    // more survivors than the list holds (thousands of logits within 2 eps of the cut): list by list.  The entries already
-    // recomputed hold fp32 logits >= ... no: nothing has been recomputed yet, the kept entries still hold their bounds
-    __syncthreads();
-    if (tid == 0) s_n = 0;
-    __syncthreads();
+    // narrowed: the flat index space in chunks of RF_THREADS; what passes tau' is listed in LDS (its bound u is staged: only
+    // the survivors' pairs are fetched), and the list is recomputed -- a lane per entry -- whenever the next chunk could
+    // overflow it and at the end.  In place, what fails is marked absent (-inf).
+    __syncthreads();                                             // (the search's last reads of the staging area)
+    int n_out = 0;                                               // compact: entries written so far (block-uniform)
     for (int c0 = 0; c0 < total; c0 += RF_THREADS) {
         const int i = c0 + tid;
         const bool has = i < total;
+        const float u = has ? stage_u[i] : 0.0f;
+        const bool keep = has && u >= taup;
         int off = 0;
-        uint2 pr = make_uint2(0u, 0u);
-        if (has) { off = offset_of(i); pr = p.base[off]; }
-        const bool keep = has && __uint_as_float(pr.x) >= taup;  // (-inf entries of the pass above fail this)
+        if (keep || (has && !compact)) off = offset_of(i);
+        if (has && !keep && !compact) p.base[off].x = __float_as_uint(-__builtin_inff());
         const unsigned long long bal = __ballot(keep);
         if (bal) {
             const int leader = __ffsll((long long)bal) - 1;
@@ -296,32 +284,44 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             b = __shfl(b, leader);
             if (keep) {
                 const int slot = b + __popcll(bal & ((1ull << lane) - 1ull));
-                surv_off[slot] = off;
-                surv_col[slot] = (int)pr.y;
+                surv_off[slot] = compact ? (int)__float_as_uint(u) : off;
+                surv_col[slot] = (int)p.base[off].y;
             }
         }
         __syncthreads();
         const int n = s_n;
-        // every thread has read n BEFORE anyone appends again: without this barrier a fast wave's next-round atomicAdd
-        // could change s_n under a slow wave, the waves would disagree on the flush branch below and meet different
-        // barriers
-        __syncthreads();
-        if (n + RF_THREADS > RF_SURV || c0 + RF_THREADS >= total) {   // the list could overflow next round, or this was the last
+        const bool last = c0 + RF_THREADS >= total;
+        if (n + RF_THREADS > RF_SURV || last) {                   // the list could overflow next round, or this was the last
+            // the recomputation's buffers take the staging area's place: chunks not yet visited are re-staged after it
             for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
                 const int e = g0 + lane;
                 const bool in = e < n;
                 const int cv = surv_col[in ? e : g0];
                 const float z = rescore_group(cv, in);
                 if (in) {
-                    guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
-                    p.base[surv_off[e]].x = __float_as_uint(z);
+                    if (compact) {
+                        guard(z, __uint_as_float((unsigned)surv_off[e]), cv, true);
+                        orow[n_out + e] = make_uint2(__float_as_uint(z), (unsigned)cv);
+                    } else {
+                        guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
+                        p.base[surv_off[e]].x = __float_as_uint(z);
+                    }
                 }
             }
+            n_out += n;
             __syncthreads();
             if (tid == 0) s_n = 0;
+            if (!last)                                            // tbuf overwrote the head of the staging area
+                for (int e = c0 + RF_THREADS + tid; e < total; e += RF_THREADS)
+                    if (e < RF_WAVES * 64 * RF_ROWSTRIDE) stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
+            __syncthreads();
+        } else {
+            // every thread has read n BEFORE anyone appends again: a fast wave's next-round atomicAdd could otherwise change
+            // s_n under a slow wave, and the waves would disagree on the flush branch and meet different barriers
             __syncthreads();
         }
     }
+    if (compact) finish_compact();
 }
 
 __global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
@@ -334,15 +334,16 @@ __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 }  // namespace
 
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
-                            const int32_t* seed_row_ptr)
+                            const int32_t* seed_row_ptr, uint2* out, int* out_cnt, int out_cap)
 {
     if (B <= 0) return DAE_OK;
     if (g1.nseg > RF_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
     if (!x.h || !x.W32 || !x.bias || !x.eps_max || !x.eps || (x.H & 3) || x.H > 1024 || !g1.cnt)
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: bad arguments (H=%d)", x.H);
     RefineP p;
-    p.base = const_cast<uint2*>(g1.base); p.cnt = g1.cnt; p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;
+    p.base = const_cast<uint2*>(g1.base); p.cnt = const_cast<int*>(g1.cnt); p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;
     p.cnt_seg_stride = g1.cnt_seg_stride; p.nseg = g1.nseg; p.x = x; p.seed_row_ptr = seed_row_ptr; p.k = k;
+    p.out = (out && out_cnt && out_cap > 0) ? out : nullptr; p.out_cnt = p.out ? out_cnt : nullptr; p.out_cap = p.out ? out_cap : 0;
     if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
     size_t dyn = (size_t)RF_STAGE * sizeof(float);
