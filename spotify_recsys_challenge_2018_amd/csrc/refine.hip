@@ -24,7 +24,8 @@
 namespace {
 
 constexpr int RF_STAGE = 16384;        // candidates of a row whose u fit the staging area (floats; the waves' buffers reuse it)
-constexpr int RF_SURV = 2048;          // survivors listed per flush
+constexpr int RF_SURV = 4096;          // survivors listed per flush (offsets only)
+constexpr int RF_UNROLL = 4;           // flat passes: elements per thread and round, their loads in flight together
 constexpr int RF_MAX_SEG = 1024;
 constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (16 data + 4 pad)
 // Two shapes: 512 threads, 8 blocks of 16 k in flight per lane -- fastest alone (~190 registers, two waves per SIMD) --
@@ -46,8 +47,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
     __shared__ int seg_prefix[RF_MAX_SEG + 2];
     __shared__ __attribute__((aligned(16))) float hrow[1024];
-    __shared__ int surv_off[RF_SURV];            // in-place mode: offset of the pair; compact mode: the bits of its bound u
-    __shared__ int surv_col[RF_SURV];
+    __shared__ int surv_off[RF_SURV];            // offsets of the listed pairs
     __shared__ unsigned cnts[32];
     __shared__ int s_n;
 
@@ -101,7 +101,19 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 1);   // narrowing pays when it can drop a third
     int n_kept = bad ? 0 : total;
     if (staged) {
-        for (int e = tid; e < total; e += RF_THREADS) stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
+        for (int e0 = tid; e0 < total; e0 += RF_UNROLL * 2 * RF_THREADS) {          // 8 independent loads per thread in flight
+            unsigned uv[RF_UNROLL * 2];
+#pragma unroll
+            for (int q = 0; q < RF_UNROLL * 2; ++q) {
+                const int e = e0 + q * RF_THREADS;
+                uv[q] = p.base[offset_of(e < total ? e : total - 1)].x;
+            }
+#pragma unroll
+            for (int q = 0; q < RF_UNROLL * 2; ++q) {
+                const int e = e0 + q * RF_THREADS;
+                if (e < total) stage_u[e] = __uint_as_float(uv[q]);
+            }
+        }
         __syncthreads();
         // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
         unsigned P = 0u;
@@ -263,57 +275,59 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         return;
     }
 
-    // narrowed: the flat index space in chunks of RF_THREADS; what passes tau' is listed in LDS (its bound u is staged: only
-    // the survivors' pairs are fetched), and the list is recomputed -- a lane per entry -- whenever the next chunk could
-    // overflow it and at the end.  In place, what fails is marked absent (-inf).
-    __syncthreads();                                             // (the search's last reads of the staging area)
+    // narrowed: the flat index space in rounds of RF_UNROLL x RF_THREADS; what passes tau' is listed in LDS by the offset of
+    // its pair (the bounds are staged: no global load in this loop), and the list is recomputed -- a lane per entry, the
+    // pair fetched one group ahead -- whenever the next round could overflow it and at the end.  In place, what fails is
+    // marked absent (-inf).
+    __syncthreads();                                             // (the count's last reads of the staging area)
     int n_out = 0;                                               // compact: entries written so far (block-uniform)
-    for (int c0 = 0; c0 < total; c0 += RF_THREADS) {
-        const int i = c0 + tid;
-        const bool has = i < total;
-        const float u = has ? stage_u[i] : 0.0f;
-        const bool keep = has && u >= taup;
-        int off = 0;
-        if (keep || (has && !compact)) off = offset_of(i);
-        if (has && !keep && !compact) p.base[off].x = __float_as_uint(-__builtin_inff());
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            int b = 0;
-            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
-            b = __shfl(b, leader);
-            if (keep) {
-                const int slot = b + __popcll(bal & ((1ull << lane) - 1ull));
-                surv_off[slot] = compact ? (int)__float_as_uint(u) : off;
-                surv_col[slot] = (int)p.base[off].y;
+    constexpr int RND = RF_UNROLL * RF_THREADS;
+    for (int c0 = 0; c0 < total; c0 += RND) {
+#pragma unroll
+        for (int q = 0; q < RF_UNROLL; ++q) {
+            const int i = c0 + q * RF_THREADS + tid;
+            const bool has = i < total;
+            const bool keep = has && stage_u[has ? i : 0] >= taup;
+            int off = 0;
+            if (keep || (has && !compact)) off = offset_of(i);
+            if (has && !keep && !compact) p.base[off].x = __float_as_uint(-__builtin_inff());
+            const unsigned long long bal = __ballot(keep);
+            if (bal) {
+                const int leader = __ffsll((long long)bal) - 1;
+                int b = 0;
+                if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
+                b = __shfl(b, leader);
+                if (keep) surv_off[b + __popcll(bal & ((1ull << lane) - 1ull))] = off;
             }
         }
         __syncthreads();
         const int n = s_n;
-        const bool last = c0 + RF_THREADS >= total;
-        if (n + RF_THREADS > RF_SURV || last) {                   // the list could overflow next round, or this was the last
-            // the recomputation's buffers take the staging area's place: chunks not yet visited are re-staged after it
-            for (int g0 = wave * 64; g0 < n; g0 += RF_WAVES * 64) {
+        const bool last = c0 + RND >= total;
+        if (n + RND > RF_SURV || last) {                          // the list could overflow next round, or this was the last
+            // (the recomputation's buffers take the head of the staging area: rounds not yet visited are re-staged after it)
+            const int gstep = RF_WAVES * 64;
+            int g0 = wave * 64;
+            uint2 pr = make_uint2(0u, 0u);
+            if (g0 < n) pr = p.base[surv_off[g0 + lane < n ? g0 + lane : g0]];
+            for (; g0 < n; g0 += gstep) {
                 const int e = g0 + lane;
                 const bool in = e < n;
-                const int cv = surv_col[in ? e : g0];
-                const float z = rescore_group(cv, in);
+                const uint2 cur = pr;
+                const int gn = g0 + gstep;
+                if (gn < n) pr = p.base[surv_off[gn + lane < n ? gn + lane : gn]];      // next group's pairs, under this group's rows
+                const float z = rescore_group((int)cur.y, in);
+                guard(z, __uint_as_float(cur.x), (int)cur.y, in);
                 if (in) {
-                    if (compact) {
-                        guard(z, __uint_as_float((unsigned)surv_off[e]), cv, true);
-                        orow[n_out + e] = make_uint2(__float_as_uint(z), (unsigned)cv);
-                    } else {
-                        guard(z, __uint_as_float(p.base[surv_off[e]].x), cv, true);
-                        p.base[surv_off[e]].x = __float_as_uint(z);
-                    }
+                    if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
+                    else p.base[surv_off[e]].x = __float_as_uint(z);
                 }
             }
             n_out += n;
             __syncthreads();
             if (tid == 0) s_n = 0;
             if (!last)                                            // tbuf overwrote the head of the staging area
-                for (int e = c0 + RF_THREADS + tid; e < total; e += RF_THREADS)
-                    if (e < RF_WAVES * 64 * RF_ROWSTRIDE) stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
+                for (int e = c0 + RND + tid; e < total && e < RF_WAVES * 64 * RF_ROWSTRIDE; e += RF_THREADS)
+                    stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
             __syncthreads();
         } else {
             // every thread has read n BEFORE anyone appends again: a fast wave's next-round atomicAdd could otherwise change

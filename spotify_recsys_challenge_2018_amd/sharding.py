@@ -153,6 +153,38 @@ class ShardedRanker:
         self.gather = gather
         self.local_begin, self.local_finish, self.gather_tau = local_begin, local_finish, gather_tau
         self._tau_buf = None
+        self._marks = None            # profile_phases(True): per call, the stream events between the stages
+
+    # -- where a step's time goes (bench.py `phases`): events on the caller's stream between the stages -------------------
+    def profile_phases(self, on=True):
+        """Record a stream event after every stage of the following rank_batch calls (the collectives are ordered on the
+        caller's stream, so the pairs bracket them).  read_phases() returns the mean milliseconds per stage."""
+        self._marks = [] if on else None
+
+    def _mark(self, marks):
+        if marks is not None:
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+
+    def read_phases(self):
+        """{local_ms (encode + threshold sample [+ filter + selection without the threshold exchange]), tau_exchange_ms,
+        filter_select_ms, exchange_ms, merge_ms, calls}: means over the calls since profile_phases(True); synchronises."""
+        import torch
+        calls = self._marks or []
+        self._marks = [] if self._marks is not None else None
+        if not calls:
+            return None
+        torch.cuda.synchronize()
+        names = ["local_ms", "tau_exchange_ms", "filter_select_ms", "exchange_ms", "merge_ms"]
+        tot = dict.fromkeys(names, 0.0)
+        for ev in calls:
+            for i, n in enumerate(names):
+                tot[n] += ev[i].elapsed_time(ev[i + 1])
+        out = {n: round(v / len(calls), 4) for n, v in tot.items()}
+        out["calls"] = len(calls)
+        return out
 
     def _exchange_tau(self, tau):
         """[B] per-shard lower bounds -> their maximum over the shards (device tensor, [B])."""
@@ -167,18 +199,30 @@ class ShardedRanker:
         return torch.amax(self._tau_buf.view(world, -1), dim=0)
 
     def rank_batch(self, feed, k):
+        m = [] if self._marks is not None else None
+        self._mark(m)
         if self.local_begin is not None:
-            tau = self._exchange_tau(self.local_begin(feed, k))
+            tau = self.local_begin(feed, k)
+            self._mark(m)
+            tau = self._exchange_tau(tau)
+            self._mark(m)
             l_logit, l_idx = self.local_finish(feed, k, tau)
         else:
             l_logit, l_idx = self.local_topk(feed, k)
+            self._mark(m); self._mark(m)
+        self._mark(m)
         if self.gather is not None:
             g_logit, g_idx = self.gather(l_logit, l_idx)
         elif self.exchange == "alltoall":
             g_logit, g_idx = exchange_shard_topk(l_logit, l_idx, self.group, out=self.bufs)
         else:
             g_logit, g_idx = gather_shard_topk(l_logit, l_idx, self.group, out=self.bufs)
-        return self.merge(g_logit, g_idx)
+        self._mark(m)
+        res = self.merge(g_logit, g_idx)
+        self._mark(m)
+        if m is not None:
+            self._marks.append(m)
+        return res
 
 
 class HipRankStages:

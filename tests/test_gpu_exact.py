@@ -329,7 +329,8 @@ def test_wider_margin_keeps_the_lists(ctx):
         c.close()
 
 
-@pytest.mark.parametrize("V,nt,B,hmax", [(12000, 12000, 20, 1e-3),      # staged, then > 2048 kept: the list-by-list path
+@pytest.mark.parametrize("V,nt,B,hmax", [(12000, 12000, 20, 1e-3),      # staged, more kept than the compact list holds: in place, list by list
+                                         (3500, 3500, 12, 1e-3),        # staged, everything kept, fits the compact list
                                          (9000, 7000, 33, 3e-4),
                                          (40000, 40000, 6, 1e-3)])      # too many to stage: everything recomputed
 def test_more_survivors_than_the_refine_list_holds(ctx, V, nt, B, hmax):
