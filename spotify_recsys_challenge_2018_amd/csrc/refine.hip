@@ -38,7 +38,14 @@ struct RefineP {
     dae_exact_src x;
     const int32_t* seed_row_ptr; int k;
     uint2* out; int* out_cnt; int out_cap;        // compact output lists [row][out_cap] + counts (see the header comment)
+    long long* stamps;                            // experiments build: stage stamps of workgroup 0 (DAE_DBG_R)
 };
+
+#ifdef DAE_EXPERIMENTS
+#define RSTAMP(i) if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_readcyclecounter();
+#else
+#define RSTAMP(i)
+#endif
 
 template <int RF_THREADS, int RF_DEPTH>
 __device__ __forceinline__ void refine_body(const RefineP& p)
@@ -54,6 +61,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
     const int nseg = p.nseg;
+    RSTAMP(0)
     const bool bad = p.x.row_bad && p.x.row_bad[row] != 0;          // precondition of the bound violated: nothing survives
     for (int s = tid; s < nseg; s += RF_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
     if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
@@ -76,6 +84,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         }
     }
     __syncthreads();
+    RSTAMP(1)                                                    // counts + hidden row in LDS, prefix done
     const int total = seg_prefix[nseg];
     if (total == 0) {
         if (tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
@@ -115,6 +124,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             }
         }
         __syncthreads();
+        RSTAMP(2)                                                // bounds staged
         // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
         unsigned P = 0u;
         int step = 0;
@@ -142,6 +152,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             taup = dae_okey_inv(P) - 2.0f * p.x.eps_max[0] * 1.000001f;
             taup = dae_okey_inv(dae_okey(taup) - 2u);          // two floats further down: the subtraction rounded
         }
+        RSTAMP(3)                                                // search done
         // how many pass: decides where the results go
         unsigned nk = 0;
         for (int i0 = 0; i0 < total; i0 += RF_THREADS) {
@@ -151,6 +162,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         if (lane == 0 && nk) atomicAdd(&cnts[30], nk);
         __syncthreads();
         n_kept = (int)cnts[30];
+        RSTAMP(4)
     }
     // COMPACT: the survivors' (fp32 logit, column) pairs go to this row's own list p.out[row][0 .. n_kept) and the
     // filter launch's per-workgroup lists of the row are emptied (their counts zeroed): the selection kernel then reads one
@@ -303,6 +315,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         __syncthreads();
         const int n = s_n;
         const bool last = c0 + RND >= total;
+        if (last) { RSTAMP(5) }                                   // listed
         if (n + RND > RF_SURV || last) {                          // the list could overflow next round, or this was the last
             // (the recomputation's buffers take the head of the staging area: rounds not yet visited are re-staged after it)
             const int gstep = RF_WAVES * 64;
@@ -335,7 +348,9 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             __syncthreads();
         }
     }
+    RSTAMP(6)                                                    // recomputed
     if (compact) finish_compact();
+    RSTAMP(7)
 }
 
 __global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
@@ -360,6 +375,24 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     p.out = (out && out_cnt && out_cap > 0) ? out : nullptr; p.out_cnt = p.out ? out_cnt : nullptr; p.out_cap = p.out ? out_cap : 0;
     if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
+    p.stamps = nullptr;
+#ifdef DAE_EXPERIMENTS
+    static const bool dbgR = dae_exp_env("DAE_DBG_R") != nullptr;
+    static long long* rbuf = nullptr;
+    static int rcalls = 0;
+    if (dbgR) {
+        if (!rbuf) { (void)hipMalloc(&rbuf, 16 * 8); (void)hipMemset(rbuf, 0, 16 * 8); }
+        p.stamps = rbuf;
+        if ((++rcalls % 100) == 0) {
+            long long h[16];
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(h, rbuf, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "REFINE wg0:");
+            for (int i = 1; i < 8; ++i) if (h[i]) fprintf(stderr, " [%d]%lld", i, h[i] - h[0]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     size_t dyn = (size_t)RF_STAGE * sizeof(float);
     if (dyn < (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float);
     static const char key = 0;
