@@ -25,6 +25,7 @@ namespace {
 
 constexpr int RF_STAGE = 16384;        // candidates of a row whose u fit the staging area (floats; the waves' buffers reuse it)
 constexpr int RF_SURV = 4096;          // survivors listed per flush (offsets only)
+constexpr int RF_BINS = 2048;          // histogram of the narrowing step (lives in the survivor list's LDS)
 constexpr int RF_UNROLL = 4;           // flat passes: elements per thread and round, their loads in flight together
 constexpr int RF_MAX_SEG = 1024;
 constexpr int RF_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (16 data + 4 pad)
@@ -53,8 +54,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     constexpr int RF_WAVES = RF_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
     __shared__ int seg_prefix[RF_MAX_SEG + 2];
-    __shared__ __attribute__((aligned(16))) float hrow[1024];
-    __shared__ int surv_off[RF_SURV];            // offsets of the listed pairs
+    __shared__ float hrow[1024];
+    __shared__ int surv_off[RF_SURV];            // flat indices of the listed candidates (before that: the narrowing's histogram)
     __shared__ unsigned cnts[32];
     __shared__ int s_n;
 
@@ -65,9 +66,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     const bool bad = p.x.row_bad && p.x.row_bad[row] != 0;          // precondition of the bound violated: nothing survives
     for (int s = tid; s < nseg; s += RF_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
     if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
-    if (tid < 32) cnts[tid] = 0u;
-    for (int i = tid; i < (p.x.H >> 2); i += RF_THREADS)
-        reinterpret_cast<float4*>(hrow)[i] = reinterpret_cast<const float4*>(p.x.h + (size_t)row * p.x.ld_h)[i];
+    if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
+    for (int i = tid; i < 1024; i += RF_THREADS) hrow[i] = i < p.x.H ? p.x.h[(size_t)row * p.x.ld_h + i] : 0.0f;
     __syncthreads();
     if (tid < 64) {
         int carry = 0;
@@ -105,63 +105,123 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     };
 
     // ---- 1. narrow ------------------------------------------------------------------------------------------------
-    float* stage_u = reinterpret_cast<float*>(rf_dyn);
+    unsigned* skey = reinterpret_cast<unsigned*>(rf_dyn);         // staged bounds as order-preserving keys
     float taup = bad ? __builtin_inff() : -__builtin_inff();
+    unsigned ktau = 0u;                                          // its key (narrowed rows)
     const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 1);   // narrowing pays when it can drop a third
     int n_kept = bad ? 0 : total;
     if (staged) {
-        for (int e0 = tid; e0 < total; e0 += RF_UNROLL * 2 * RF_THREADS) {          // 8 independent loads per thread in flight
-            unsigned uv[RF_UNROLL * 2];
+        // the candidates' bounds as order-preserving KEYS, staged by segment: wave w takes segments w, w + RF_WAVES, ...,
+        // eight of them in flight at a time (a lane per entry; entries beyond 64 of a long segment follow serially) -- no
+        // search for the segment of a flat index (7 dependent LDS reads per element: 22 k cycles for 7 400 candidates)
+        unsigned kmx = 0u, kmn = 0xFFFFFFFFu;
+        for (int sg0 = wave; sg0 < nseg; sg0 += 8 * RF_WAVES) {
+            unsigned uv[8]; int b0[8], cn[8];
 #pragma unroll
-            for (int q = 0; q < RF_UNROLL * 2; ++q) {
-                const int e = e0 + q * RF_THREADS;
-                uv[q] = p.base[offset_of(e < total ? e : total - 1)].x;
+            for (int q = 0; q < 8; ++q) {
+                const int sg = sg0 + q * RF_WAVES;
+                const bool ok = sg < nseg;
+                b0[q] = seg_prefix[ok ? sg : 0];
+                cn[q] = ok ? seg_prefix[sg + 1] - b0[q] : 0;
+                const uint2* sp = p.base + ((int64_t)(ok ? sg : 0) * p.seg_stride + (int64_t)row * p.row_stride);
+                uv[q] = lane < cn[q] ? sp[lane].x : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < RF_UNROLL * 2; ++q) {
-                const int e = e0 + q * RF_THREADS;
-                if (e < total) stage_u[e] = __uint_as_float(uv[q]);
+            for (int q = 0; q < 8; ++q) {
+                if (lane < cn[q]) {
+                    const unsigned key = dae_okey(__uint_as_float(uv[q]));
+                    skey[b0[q] + lane] = key;
+                    kmx = key > kmx ? key : kmx; kmn = key < kmn ? key : kmn;
+                }
+                if (cn[q] > 64) {                                 // wave-uniform
+                    const uint2* sp = p.base + ((int64_t)(sg0 + q * RF_WAVES) * p.seg_stride + (int64_t)row * p.row_stride);
+                    for (int i = 64 + lane; i < cn[q]; i += 64) {
+                        const unsigned key = dae_okey(__uint_as_float(sp[i].x));
+                        skey[b0[q] + i] = key;
+                        kmx = key > kmx ? key : kmx; kmn = key < kmn ? key : kmn;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned a = __shfl_xor(kmx, d), b = __shfl_xor(kmn, d);
+            kmx = a > kmx ? a : kmx; kmn = b < kmn ? b : kmn;
+        }
+        if (lane == 0) { atomicMax(&cnts[0], kmx); atomicMin(&cnts[1], kmn); }
+        unsigned* hist = reinterpret_cast<unsigned*>(surv_off);
+        for (int i = tid; i < RF_BINS; i += RF_THREADS) hist[i] = 0u;
+        __syncthreads();
+        RSTAMP(2)                                                // bounds staged
+        // P = a staged key with count(key >= P) >= need, as large as a 2048-bin histogram over [min, max] of the row's keys
+        // resolves (bins linear in the KEY: any monotone map keeps the argument): one pass of LDS atomics, one scan from
+        // the top for the bin B holding the need-th largest key, one pass for the smallest key of that bin.  Everything in
+        // B survives, i.e. at most (bin population - 1) candidates more than an exact selection would keep -- a handful
+        // against the hundreds inside the 2 eps band.  (The ten 2-bit search steps of round 3 cost 33 k cycles on 7 400
+        // keys, a wave reduction and a barrier each.)
+        const unsigned kmin = cnts[1], kmax = cnts[0];
+        const float scale = 2047.999f / ((float)(kmax - kmin) + 1.0f);
+        auto bin_of = [&](unsigned key) -> int {
+            const unsigned bq = (unsigned)((float)(key - kmin) * scale);
+            return (int)(bq < (unsigned)(RF_BINS - 1) ? bq : (unsigned)(RF_BINS - 1));
+        };
+#pragma unroll 4
+        for (int i = tid; i < total; i += RF_THREADS) atomicAdd(&hist[bin_of(skey[i])], 1u);
+        __syncthreads();
+        constexpr int BPT = RF_BINS / RF_THREADS;
+        const int top = RF_BINS - 1 - BPT * tid;
+        unsigned hc[BPT], own = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) { hc[e] = hist[top - e]; own += hc[e]; }
+        unsigned incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) cnts[8 + wave] = incl;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int w = 0; w < wave; ++w) pre += cnts[8 + w];
+        incl += pre;
+        const unsigned excl = incl - own;
+        if (excl < (unsigned)need && (unsigned)need <= incl) {
+            unsigned run = excl;
+            bool done = false;
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) {
+                if (!done && run + hc[e] >= (unsigned)need) { cnts[2] = (unsigned)(top - e); done = true; }
+                run += hc[e];
             }
         }
         __syncthreads();
-        RSTAMP(2)                                                // bounds staged
-        // largest 20-bit key prefix P with count(key >= P) >= need: 10 four-way steps, counts by ballot, one barrier each
-        unsigned P = 0u;
-        int step = 0;
-        for (int bp = 30; bp >= 12; bp -= 2, ++step) {
-            const unsigned c1 = P + (1u << bp), c2 = P + (2u << bp), c3 = P + (3u << bp);
-            unsigned n1 = 0, n2 = 0, n3 = 0;
-            for (int i0 = 0; i0 < total; i0 += RF_THREADS) {
-                const int i = i0 + tid;
-                const bool v = i < total;
-                const unsigned key = v ? dae_okey(stage_u[i]) : 0u;
-                n1 += (unsigned)__popcll(__ballot(v && key >= c1));
-                n2 += (unsigned)__popcll(__ballot(v && key >= c2));
-                n3 += (unsigned)__popcll(__ballot(v && key >= c3));
-            }
-            if (lane == 0) {
-                if (n1) atomicAdd(&cnts[3 * step + 0], n1);
-                if (n2) atomicAdd(&cnts[3 * step + 1], n2);
-                if (n3) atomicAdd(&cnts[3 * step + 2], n3);
-            }
-            __syncthreads();
-            const unsigned un = (unsigned)need;
-            P = cnts[3 * step + 2] >= un ? c3 : cnts[3 * step + 1] >= un ? c2 : cnts[3 * step + 0] >= un ? c1 : P;
+        const int Bsel = (int)cnts[2];
+        unsigned kb = 0xFFFFFFFFu;
+#pragma unroll 4
+        for (int i = tid; i < total; i += RF_THREADS) {
+            const unsigned key = skey[i];
+            if (bin_of(key) == Bsel) kb = key < kb ? key : kb;
         }
-        if (P > DAE_KEY_NEG_INF + 2u) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(kb, d); kb = o < kb ? o : kb; }
+        if (lane == 0 && kb != 0xFFFFFFFFu) atomicMin(&cnts[3], kb);
+        __syncthreads();
+        const unsigned P = cnts[3];
+        if (P != 0xFFFFFFFFu && P > DAE_KEY_NEG_INF + 2u) {
             taup = dae_okey_inv(P) - 2.0f * p.x.eps_max[0] * 1.000001f;
             taup = dae_okey_inv(dae_okey(taup) - 2u);          // two floats further down: the subtraction rounded
         }
-        RSTAMP(3)                                                // search done
-        // how many pass: decides where the results go
-        unsigned nk = 0;
-        for (int i0 = 0; i0 < total; i0 += RF_THREADS) {
-            const int i = i0 + tid;
-            nk += (unsigned)__popcll(__ballot(i < total && stage_u[i] >= taup));
+        RSTAMP(3)                                                // selection done
+        // an upper bound of how many pass (whole bins down to tau''s): decides where the results go
+        ktau = dae_okey(taup);
+        const int Bt = ktau > kmin ? bin_of(ktau < kmax ? ktau : kmax) : 0;
+        if (top >= Bt && Bt > top - BPT) {                        // the thread that owns bin Bt
+            unsigned run = excl;
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) { run += hc[e]; if (top - e == Bt) cnts[4] = run; }
         }
-        if (lane == 0 && nk) atomicAdd(&cnts[30], nk);
         __syncthreads();
-        n_kept = (int)cnts[30];
+        n_kept = (int)cnts[4];
         RSTAMP(4)
     }
     // COMPACT: the survivors' (fp32 logit, column) pairs go to this row's own list p.out[row][0 .. n_kept) and the
@@ -192,10 +252,19 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[d][i] = d < H16 ? rp[i][4 * d] : make_float4(0.f, 0.f, 0.f, 0.f);
         float acc = 0.0f;
-        for (int j0 = 0; j0 < H16; j0 += RF_DEPTH) {
+        // hidden activations: the same for every lane.  Lane l holds h[64 c + l] of the current 64-k chunk c in ONE register and
+        // every product takes its factor by v_readlane (an SGPR operand of the v_fma) -- as four broadcast ds_read_b128 per
+        // 16 k they were a third of the LDS instructions of this loop, which is LDS-bound (stage stamps, DAE_DBG_R)
+        constexpr int RF_U = RF_DEPTH < 4 ? 4 : RF_DEPTH;         // blocks per trip: whole 64-k chunks, so a block's lanes are constants
+        for (int j0 = 0; j0 < H16; j0 += RF_U) {
+            float hq[RF_U / 4];
 #pragma unroll
-            for (int d = 0; d < RF_DEPTH; ++d) {
-                const int j = j0 + d;
+            for (int c = 0; c < RF_U / 4; ++c) hq[c] = hrow[(16 * j0 + 64 * c + lane) & 1023];      // (zero beyond H)
+#pragma unroll
+            for (int dd = 0; dd < RF_U; ++dd) {
+                const int j = j0 + dd;
+                constexpr int dmask = RF_DEPTH - 1;
+                const int d = dd & dmask;                         // ring slot (RF_DEPTH is a power of two)
                 if (j < H16) {                                    // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -210,13 +279,14 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(tbuf + lane * RF_ROWSTRIDE + 4 * t);
                     __builtin_amdgcn_wave_barrier();
+                    const int hc = (int)__float_as_uint(hq[dd >> 2]);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * j + 4 * t);
-                        acc = fmaf(hv.x, w[t].x, acc);
-                        acc = fmaf(hv.y, w[t].y, acc);
-                        acc = fmaf(hv.z, w[t].z, acc);
-                        acc = fmaf(hv.w, w[t].w, acc);
+                        const int l0 = 16 * (dd & 3) + 4 * t;
+                        acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0)), w[t].x, acc);
+                        acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 1)), w[t].y, acc);
+                        acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 2)), w[t].z, acc);
+                        acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 3)), w[t].w, acc);
                     }
                 }
             }
@@ -225,11 +295,11 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * p.x.H);
             for (int t = 0; t < Hrem4; ++t) {
                 const float4 wv = wr[4 * H16 + t];
-                const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * H16 + 4 * t);
-                acc = fmaf(hv.x, wv.x, acc);
-                acc = fmaf(hv.y, wv.y, acc);
-                acc = fmaf(hv.z, wv.z, acc);
-                acc = fmaf(hv.w, wv.w, acc);
+                const int hb = 16 * H16 + 4 * t;
+                acc = fmaf(hrow[hb], wv.x, acc);
+                acc = fmaf(hrow[hb + 1], wv.y, acc);
+                acc = fmaf(hrow[hb + 2], wv.z, acc);
+                acc = fmaf(hrow[hb + 3], wv.w, acc);
             }
         }
         return acc + p.x.bias[colv - p.x.col_lo];
@@ -253,17 +323,18 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     // statistics of the context (dae_exact_stats_read): rows refined, candidates the filter launch left, candidates recomputed
     if (tid == 0 && p.x.guard) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(p.x.guard + 2);
-        atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)total); atomicAdd(st + 2, (unsigned long long)n_kept);
+        atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)total);
+        if (!staged) atomicAdd(st + 2, (unsigned long long)n_kept);      // (narrowed rows add their count when it is known)
     }
     // the row's per-workgroup lists are empty from here on (compact), its own list holds n_kept entries
-    auto finish_compact = [&]() {
+    auto finish_compact = [&](int n_written) {
         for (int s = tid; s < nseg; s += RF_THREADS) p.cnt[(size_t)s * p.cnt_seg_stride + row] = 0;
-        if (tid == 0) p.out_cnt[row] = n_kept;
+        if (tid == 0) p.out_cnt[row] = n_written;
     };
     if (!compact && tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
 
     if (bad) {                                                   // a row that must return nothing
-        if (compact) { finish_compact(); return; }
+        if (compact) { finish_compact(0); return; }
         for (int e = tid; e < total; e += RF_THREADS) p.base[offset_of(e)].x = __float_as_uint(-__builtin_inff());
         return;
     }
@@ -283,14 +354,14 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                 else p.base[off].x = __float_as_uint(z);
             }
         }
-        if (compact) finish_compact();
+        if (compact) finish_compact(total);
         return;
     }
 
-    // narrowed: the flat index space in rounds of RF_UNROLL x RF_THREADS; what passes tau' is listed in LDS by the offset of
-    // its pair (the bounds are staged: no global load in this loop), and the list is recomputed -- a lane per entry, the
-    // pair fetched one group ahead -- whenever the next round could overflow it and at the end.  In place, what fails is
-    // marked absent (-inf).
+    // narrowed: the flat index space in rounds of RF_UNROLL x RF_THREADS; what passes tau' is listed in LDS by its flat index
+    // (the keys are staged: no global load and no segment search in this loop), and the list is recomputed -- a lane per
+    // entry, its pair located and fetched one group ahead -- whenever the next round could overflow it and at the end.
+    // In place, what fails is marked absent (-inf).
     __syncthreads();                                             // (the count's last reads of the staging area)
     int n_out = 0;                                               // compact: entries written so far (block-uniform)
     constexpr int RND = RF_UNROLL * RF_THREADS;
@@ -299,17 +370,15 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         for (int q = 0; q < RF_UNROLL; ++q) {
             const int i = c0 + q * RF_THREADS + tid;
             const bool has = i < total;
-            const bool keep = has && stage_u[has ? i : 0] >= taup;
-            int off = 0;
-            if (keep || (has && !compact)) off = offset_of(i);
-            if (has && !keep && !compact) p.base[off].x = __float_as_uint(-__builtin_inff());
+            const bool keep = has && skey[has ? i : 0] >= ktau;
+            if (has && !keep && !compact) p.base[offset_of(i)].x = __float_as_uint(-__builtin_inff());
             const unsigned long long bal = __ballot(keep);
             if (bal) {
                 const int leader = __ffsll((long long)bal) - 1;
                 int b = 0;
                 if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
                 b = __shfl(b, leader);
-                if (keep) surv_off[b + __popcll(bal & ((1ull << lane) - 1ull))] = off;
+                if (keep) surv_off[b + __popcll(bal & ((1ull << lane) - 1ull))] = i;
             }
         }
         __syncthreads();
@@ -321,18 +390,20 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const int gstep = RF_WAVES * 64;
             int g0 = wave * 64;
             uint2 pr = make_uint2(0u, 0u);
-            if (g0 < n) pr = p.base[surv_off[g0 + lane < n ? g0 + lane : g0]];
+            int off = 0;
+            if (g0 < n) { off = offset_of(surv_off[g0 + lane < n ? g0 + lane : g0]); pr = p.base[off]; }
             for (; g0 < n; g0 += gstep) {
                 const int e = g0 + lane;
                 const bool in = e < n;
                 const uint2 cur = pr;
+                const int off_cur = off;
                 const int gn = g0 + gstep;
-                if (gn < n) pr = p.base[surv_off[gn + lane < n ? gn + lane : gn]];      // next group's pairs, under this group's rows
+                if (gn < n) { off = offset_of(surv_off[gn + lane < n ? gn + lane : gn]); pr = p.base[off]; }   // next group's pairs, under this group's rows
                 const float z = rescore_group((int)cur.y, in);
                 guard(z, __uint_as_float(cur.x), (int)cur.y, in);
                 if (in) {
                     if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
-                    else p.base[surv_off[e]].x = __float_as_uint(z);
+                    else p.base[off_cur].x = __float_as_uint(z);
                 }
             }
             n_out += n;
@@ -340,7 +411,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             if (tid == 0) s_n = 0;
             if (!last)                                            // tbuf overwrote the head of the staging area
                 for (int e = c0 + RND + tid; e < total && e < RF_WAVES * 64 * RF_ROWSTRIDE; e += RF_THREADS)
-                    stage_u[e] = __uint_as_float(p.base[offset_of(e)].x);
+                    skey[e] = dae_okey(__uint_as_float(p.base[offset_of(e)].x));
             __syncthreads();
         } else {
             // every thread has read n BEFORE anyone appends again: a fast wave's next-round atomicAdd could otherwise change
@@ -349,7 +420,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         }
     }
     RSTAMP(6)                                                    // recomputed
-    if (compact) finish_compact();
+    if (tid == 0 && p.x.guard) atomicAdd(reinterpret_cast<unsigned long long*>(p.x.guard + 2) + 2, (unsigned long long)n_out);
+    if (compact) finish_compact(n_out);
     RSTAMP(7)
 }
 
