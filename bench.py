@@ -1207,6 +1207,26 @@ def main():
                 out["exact_bf16_decode"] = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds, (d_We, d_be), n_tracks,
                                                      _lib.DAE_DTYPE_BF16_EXACT, B, H, k, args.steps, args.warmup, ref32,
                                                      oracle_ref, peaks, "bf16")
+            if not args.no_extra_rows and B != 1024:
+                # the same mode at 1024 playlists per launch (the per-GPU batch of BASELINE.json configs[2]): the filter launch
+                # is MFMA-bound there (B flop per byte of W = 1024 > the ridge at 312)
+                try:
+                    feeds_k = [make_feed(1024, 301 + i_)[0] for i_ in range(2)]
+                    full_k = ctxs[0]
+                    s_k = torch.empty((1024, k), dtype=torch.float32, device=dev)
+                    i_k = torch.empty((1024, k), dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    full_k.score_topk(feeds_k[0][0], feeds_k[0][1], feeds_k[0][2], d_We, d_be, n_tracks, feeds_k[0][3],
+                                      feeds_k[0][4], k, s_k, i_k, dtype=DT)
+                    torch.cuda.synchronize()
+                    r_k = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds_k, (d_We, d_be), n_tracks, _lib.DAE_DTYPE_BF16_EXACT,
+                                    1024, H, k, max(args.steps // 2, 10), args.warmup, (s_k, i_k), None, peaks, None)
+                    r_k["global_batch"] = 1024
+                    r_k["note"] = "NOT the headline: exact_bf16 at 1024 playlists per launch; identical_to_fp32_path checked on batch 0"
+                    out["exact_b1024"] = r_k
+                    del feeds_k, s_k, i_k
+                except Exception as e:
+                    out["exact_b1024"] = {"error": repr(e)[:300]}
             if gate_events:
                 for i, c in enumerate(ctxs):
                     c.check(c.lib.dae_set_decode_gate(c.h, ctypes.c_void_p(gate_events[(i - 1) % n_str].cuda_event),

@@ -1319,6 +1319,175 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 }
 #undef FSTAMP
 
+// ---- bf16, hidden = 256, filter epilogue, MFMA-bound batches (>= 512 playlists per launch) ------------------------------
+// The kernel above reads every B operand (hidden fragment) of every MFMA from LDS: 1 KiB per v_mfma_f32_32x32x16_bf16,
+// i.e. 128 B/clk for the CU's four matrix pipes at their peak rate -- exactly the LDS bandwidth, so LDS and matrix pipes are
+// co-bound and the launch sits at 0.58 of the bf16 peak at batch 1024 (profiles/r03_notes.md).  Here the row group's
+// hidden tile lives in REGISTERS: one wave per SIMD owns all 512 registers of a lane (256 VGPR + 256 AGPR on gfx950), 256 of
+// them hold the 16 x 4 B fragments of the 128-row tile, and the main loop touches no LDS at all -- a W fragment from the
+// 16-deep ring (a whole tile ahead), four MFMAs, one prefetch.  The epilogue of a tile (max-reduce + one compare per row
+// block in the common case) is issued UNDER the first MFMAs of the next tile: two accumulator sets alternate.
+// Same tiles, same operands, same accumulation as decode_bf16_h256_filter_kernel: the candidate lists are identical.
+// MEASURED AND NOT THE DEFAULT (round 4, batch 1024, one batch in flight): 0.157 ms per step with two row blocks in
+// registers against 0.146 ms for the all-LDS kernel, 0.225 ms with three (hipcc then spills fragments to scratch and reloads
+// them every tile).  With one wave per SIMD hipcc issues a tile's 68 MFMAs back to back and the epilogue after them; the
+// second wave per SIMD of the all-LDS kernel hides more than the LDS reads cost.  Experiments build only (DAE_BF16_REGB).
+#ifdef DAE_EXPERIMENTS
+template <int RBR, int QR>
+__global__ __launch_bounds__(256, 1) void decode_bf16_h256_regb_filter_kernel(const DecP p)
+{
+    constexpr int NS = 16, RB = 4, RBL = RB - RBR, R_TILE = 128, NW = 4;
+    __shared__ int lcnt[R_TILE];
+    __shared__ uint4 hl[NS * RBL * 64];      // the fragments of the row blocks RBR .. 3 (16 KiB each): see below
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int n_items = p.ts.n_items;
+    const int n_ws = p.nb_rg * NW;
+    const int it0 = wave * p.nb_rg + bir;
+    const uint4* Wq = reinterpret_cast<const uint4*>(p.Wp);
+    const uint4 ones = bf16_ones_fragment(hi);
+
+    // tile ids two ahead, the thresholds, the hidden tile -> registers, the first tile's W ring
+    const bool has = it0 < n_items;
+    const int tv0 = tile_of_item(p.ts, has ? it0 : 0);
+    const int tv1 = tile_of_item(p.ts, has && it0 + n_ws < n_items ? it0 + n_ws : (has ? it0 : 0));
+    float tau_r[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rg * R_TILE + rb * 32 + j;
+        tau_r[rb] = row < p.B ? p.tau[row] : __builtin_inff();
+    }
+    // Register budget of the lane (512): 3 of the 4 row blocks' fragments (192), two accumulator sets (128), a W ring one whole
+    // tile deep (64: 2 176 cycles of prefetch distance).  The fourth row block's fragments would be 64 more -- hipcc then
+    // parks 64 of them in scratch and reloads them every tile -- so they stay in LDS (16 KiB, shared by the four waves):
+    // one ds_read_b128 per step and wave, a quarter of the LDS traffic that bounds the all-LDS kernel.
+    uint4 hf[NS][RBR];
+    {
+        const uint4* hsrc = reinterpret_cast<const uint4*>(p.hp) + (size_t)rg * (NS * RB * 64);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int rb = 0; rb < RBR; ++rb) hf[s][rb] = hsrc[(s * RB + rb) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < NS * RBL * 64 / (NW * 64); ++e) {
+            const int i = e * (NW * 64) + tid;                   // ((step, row block - RBR), lane)
+            const int f = i >> 6;
+            hl[i] = hsrc[((f / RBL) * RB + RBR + f % RBL) * 64 + (i & 63)];
+        }
+    }
+    if (tid < R_TILE) lcnt[tid] = 0;
+    int t = __builtin_amdgcn_readfirstlane(tv0), u = __builtin_amdgcn_readfirstlane(tv1);
+    uint4 wq[QR];
+    uint4 bfr = p.bias16[(size_t)t * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < QR; ++s) wq[s] = Wq[(size_t)t * (NS * 64) + s * 64 + lane];
+    __syncthreads();
+
+    // the filter epilogue of one finished tile (see decode_bf16_h256_filter_kernel): `mx` = the lane's maxima per row block
+    auto appends = [&](const f32x16 (&acc)[RB], const float (&mx)[RB], int tt) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float tv = tau_r[rb];
+            if (mx[rb] >= tv) {
+                unsigned m = 0;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int lc = tt * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
+                    if (acc[rb][reg] >= tv && lc < p.ncols && p.col_lo + lc < p.n_valid_col) m |= 1u << reg;
+                }
+                if (m) {
+                    int at = atomicAdd(&lcnt[rb * 32 + j], __popc(m));
+                    uint2* dst = p.cand + ((size_t)bir * p.Bpad + rg * R_TILE + rb * 32 + j) * (size_t)p.cap;
+                    const int cg = p.col_lo + tt * 32 + 4 * hi;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (m & (1u << reg))
+                            dst[at++] = make_uint2(__float_as_uint(acc[rb][reg]), (unsigned)(cg + (reg & 3) + 8 * (reg >> 2)));
+                }
+            }
+        }
+    };
+    auto maxima = [&](const f32x16 (&acc)[RB], float (&mx)[RB]) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float m = acc[rb][0];
+#pragma unroll
+            for (int reg = 1; reg < 16; ++reg) m = fmaxf(m, acc[rb][reg]);
+            mx[rb] = m;
+        }
+    };
+    // one tile: accumulators start at the bias (through the matrix pipe, as every bf16 kernel), 16 steps; after step s the
+    // ring slot s takes the same step of the NEXT tile
+    auto tile = [&](f32x16 (&acc)[RB], int tc, int tn) {
+        const uint4* cur = Wq + (size_t)tc * (NS * 64) + lane;
+        const uint4* nxt = Wq + (size_t)tn * (NS * 64) + lane;
+        const uint4 bc = bfr;
+        bfr = p.bias16[(size_t)tn * 64 + lane];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bc), as_bf16x8(ones), zero, 0, 0, 0);
+        uint4 cb[RBL];
+#pragma unroll
+        for (int r = 0; r < RBL; ++r) cb[r] = hl[r * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 a = wq[s % QR];
+            uint4 cbn[RBL];                                       // the LDS-resident fragments of the next step
+#pragma unroll
+            for (int r = 0; r < RBL; ++r) cbn[r] = hl[(((s + 1) % NS) * RBL + r) * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < RBR; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(hf[s][rb]), acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBL; ++r) {
+                acc[RBR + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(cb[r]), acc[RBR + r], 0, 0, 0);
+                cb[r] = cbn[r];
+            }
+            wq[s % QR] = (s + QR < NS) ? cur[(s + QR) * 64] : nxt[(s + QR - NS) * 64];
+        }
+    };
+
+    f32x16 accA[RB], accB[RB];
+    float mx[RB];
+    int it = it0;
+    int t_prev = 0;
+    bool pending = false;                                        // accB / accA of the previous tile still wait for their epilogue
+    // two tiles per trip: A then B; the epilogue of each runs after the MFMAs of the following tile have been issued
+    while (it < n_items) {
+        const int i1 = it + n_ws, i2 = i1 + n_ws;
+        const int w1 = tile_of_item(p.ts, i2 < n_items ? i2 : it);      // ids two tiles ahead
+        const int w2 = tile_of_item(p.ts, i2 + n_ws < n_items ? i2 + n_ws : it);
+        tile(accA, t, u);                                        // tile t; the ring refills with tile u
+        if (pending) { maxima(accB, mx); appends(accB, mx, t_prev); }
+        const int tA = t;
+        t = u; u = __builtin_amdgcn_readfirstlane(w1);
+        if (i1 < n_items) {
+            tile(accB, t, u);
+            maxima(accA, mx); appends(accA, mx, tA);
+            t_prev = t;
+            t = u; u = __builtin_amdgcn_readfirstlane(w2);
+            pending = true;
+        } else {
+            maxima(accA, mx); appends(accA, mx, tA);
+            pending = false;
+        }
+        it = i2;
+    }
+    if (pending) { maxima(accB, mx); appends(accB, mx, t_prev); }
+    __syncthreads();
+    for (int i = tid; i < R_TILE; i += NW * 64) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + i] = lcnt[i];
+}
+
+#endif  // DAE_EXPERIMENTS
+
 // ---- prepack: W_dec rows -> MFMA A-operand order ----------------------------------------------
 // One workgroup per 32-column tile: the tile's 32 rows of W (32 x H floats, contiguous 4 H bytes each) are read
 // with coalesced 16-byte loads into LDS and written out in operand order with coalesced 16-byte stores.
@@ -1665,6 +1834,16 @@ bool bf16_fast_filter(const dae_rowgeom& g, int dtype, int G)
     return dtype == DAE_DTYPE_BF16 && G == 16 && g.waves == 4 && (g.R_TILE == 128 || g.R_TILE == 256) && !off;
 }
 
+// ... and its MFMA-bound form (hidden fragments in registers, decode_bf16_h256_regb_filter_kernel): launches of four or
+// more row groups (>= 385 playlists), where W passes through every CU's L1 once per row group and the all-LDS kernel
+// is bound by its LDS reads.  0 = off; 2 / 3 = row blocks held in registers (experiments: DAE_BF16_REGB).
+int bf16_regb_variant(const dae_rowgeom& g)
+{
+    static const int env = dae_exp_env("DAE_BF16_REGB") ? atoi(dae_exp_env("DAE_BF16_REGB")) : -1;
+    if (g.R_TILE != 128) return 0;
+    return (env == 2 || env == 3) ? env : 0;                 // measured slower than the all-LDS kernel: never the default
+}
+
 int fill_common(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts, DecP& p,
                 int dtype = DAE_DTYPE_F32, int bias_sel = 0)
 {
@@ -1700,7 +1879,7 @@ int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp,
     if (bf16_fast_filter(g, dtype, Hp / 16) && !mixed) {
         const bool pair = g.R_TILE != 256 && bf16_pair_variant();
         const int nt = pair ? 2 : 1;
-        const int nw = (g.R_TILE == 256 || pair) ? 4 : 8;
+        const int nw = (g.R_TILE == 256 || pair || bf16_regb_variant(g)) ? 4 : 8;
         const int n_grp = (n_items + nt - 1) / nt;
         const int n_ws2 = g.nb_rg * nw;
         return nt * nw * ((n_grp + n_ws2 - 1) / n_ws2);
@@ -2076,6 +2255,25 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
+        const int regb = bf16_regb_variant(g);
+#ifdef DAE_EXPERIMENTS
+        if (regb) {
+            if (ctx->prof_armed) {
+                e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
+                ctx->prof_armed = false;
+                ctx->prof_used += 2;
+                ctx->prof_kernel = regb == 2 ? "decode_bf16_h256_regb_filter_kernel<2, 16>" : "decode_bf16_h256_regb_filter_kernel<3, 8>";
+            }
+            if (regb == 2)
+                hipExtLaunchKernelGGL((decode_bf16_h256_regb_filter_kernel<2, 16>), dim3(g.grid), dim3(256), 0, ctx->stream, e0, e1, 0, p);
+            else
+                hipExtLaunchKernelGGL((decode_bf16_h256_regb_filter_kernel<3, 8>), dim3(g.grid), dim3(256), 0, ctx->stream, e0, e1, 0, p);
+            DAE_CHECK_LAUNCH(ctx, "decode_bf16_h256_regb_filter_kernel");
+            return DAE_OK;
+        }
+#else
+        (void)regb;
+#endif
         if (ctx->prof_armed) {
             e0 = ctx->prof_ev[ctx->prof_used]; e1 = ctx->prof_ev[ctx->prof_used + 1];
             ctx->prof_armed = false;
