@@ -23,7 +23,33 @@ names = ["We", "be", "bd"] + ([] if tied else ["Wd"])
 g = {n: torch.zeros_like(t[n]) for n in names}
 mom = {n: (torch.zeros_like(t[n]), torch.zeros_like(t[n])) for n in names}
 cost = torch.zeros(1, device="cuda")
+default = "--default" in sys.argv and not tied      # models/DAEs.py train_step with train_dtype = bf16: the fused / row-sparse Adam forms
+if default:
+    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    lz = {"state": torch.zeros(2 * V, dtype=torch.int32, device="cuda"), "tab": torch.zeros(1 << 12, dtype=torch.float32, device="cuda"),
+          "flushed": 0}
+    ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 1))
+    import ctypes
+    rows_arg = (P(t["xc"]), ctypes.c_void_p(t["xr"].data_ptr() + 4 * B), int(t["xc"].numel()))
 def step(i):
+    if default:
+        ts = i + 1
+        ctx.check(ctx.lib.dae_arm_decoder_adam(ctx.h, P(mom["Wd"][0]), P(mom["Wd"][1]), 0.005, 0.9, 0.999, 1e-8, ts))
+        ctx.check(ctx.lib.dae_adam_rows_begin(ctx.h, P(t["We"]), P(mom["We"][0]), P(mom["We"][1]), P(lz["state"]), P(lz["tab"]),
+                                              lz["tab"].numel(), V, H, rows_arg[0], rows_arg[1], rows_arg[2], 0.9, 0.999, 1e-8, ts))
+        ctx.check(ctx.lib.dae_train_forward_backward(ctx.h, P(t["xr"]), P(t["xc"]), P(t["xv"]), P(t["yr"]), P(t["yc"]), P(t["yv"]),
+            P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]), V, H, B, B, 0, 0.75, 0.8, 100 + i, 0.0,
+            P(g["We"]), P(g["be"]), P(g["Wd"]), P(g["bd"]), P(cost)))
+        ctx.check(ctx.lib.dae_adam_rows_apply(ctx.h, P(t["We"]), P(mom["We"][0]), P(mom["We"][1]), P(g["We"]), P(lz["state"]),
+                                              P(lz["tab"]), lz["tab"].numel(), V, H, rows_arg[0], rows_arg[1], rows_arg[2],
+                                              0.005, 0.9, 0.999, 1e-8, ts))
+        if ts - lz["flushed"] >= 32:
+            ctx.check(ctx.lib.dae_adam_rows_flush(ctx.h, P(t["We"]), P(mom["We"][0]), P(mom["We"][1]), P(lz["state"]), P(lz["tab"]),
+                                                  lz["tab"].numel(), V, H, 0.9, 0.999, 1e-8, ts))
+            lz["flushed"] = ts
+        for n in ("be", "bd"):
+            ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(), 0.005, 0.9, 0.999, 1e-8, ts))
+        return
     ctx.check(ctx.lib.dae_train_forward_backward(ctx.h, P(t["xr"]), P(t["xc"]), P(t["xv"]), P(t["yr"]), P(t["yc"]), P(t["yv"]),
         P(t["We"]), P(t["be"]), P(t["Wd"]), P(t["bd"]), V, H, B, B, 1 if tied else 0, 0.75, 0.8, 100 + i, 0.0,
         P(g["We"]), P(g["be"]), None if tied else P(g["Wd"]), P(g["bd"]), P(cost)))
@@ -31,7 +57,7 @@ def step(i):
         ctx.check(ctx.lib.dae_adam_step(ctx.h, P(t[n]), P(mom[n][0]), P(mom[n][1]), P(g[n]), t[n].numel(), 0.005, 0.9, 0.999, 1e-8, i + 1))
 for i in range(3): step(i)
 torch.cuda.synchronize(); costs = []
-t0 = time.perf_counter(); K = 20
+t0 = time.perf_counter(); K = 32 if default else 20
 for i in range(K):
     step(3 + i)
 torch.cuda.synchronize()

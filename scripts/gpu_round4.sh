@@ -1,0 +1,34 @@
+# Round-4 session on the GPU box: the JSON lines and rocprofv3 kernel stats quoted in DESIGN.md / profiles/r04_notes.md
+# (copy gpurun_out/r04_* into profiles/ afterwards).  usage: bash scripts/gpu_round4.sh [quick]
+cd $GRAFT_REPO_ROOT
+export GPU_MAX_HW_QUEUES=8
+o=gpurun_out; mkdir -p $o
+python bench.py > $o/r04_bench_default.json 2> $o/err_default.txt
+python bench.py --dtype bf16 --no-train-row --no-cpu-baseline > $o/r04_bench_bf16.json 2> $o/err_bf16.txt
+python bench.py --dtype exact_bf16 --no-train-row > $o/r04_bench_exact.json 2> $o/err_exact.txt
+python bench.py --force-dist --no-train-row --no-cpu-baseline --no-bf16-row --no-extra-rows > $o/r04_bench_forcedist.json 2> $o/err_fd.txt
+for f in default bf16 exact forcedist; do python - $o/r04_bench_$f.json $f <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']
+    ex={k:(v.get('value'), v.get('ms_per_step')) for k,v in d.items() if isinstance(v,dict) and 'value' in v and k!='roofline'}
+    print('%-12s value=%10.0f ms=%.4f kern=%s %.4f frac=%.3f %s' % (sys.argv[2], d['value'], d['ms_per_step'], r['kernel'][:30], r['avg_launch_ms'], r['frac'], ex))
+    for k in ('exact_bf16_hard','trained_model','phases'):
+        if k in d: print(k, json.dumps(d[k])[:1500])
+except Exception as e:
+    print(sys.argv[2], 'FAILED', e); print(open(sys.argv[1].replace('r04_bench_','err_').replace('.json','.txt')).read()[-800:] if False else '')
+PY
+done
+bash scripts/gpu_prof.sh r04_headline --no-extra-rows --no-train-row --no-cpu-baseline --no-bf16-row
+bash scripts/gpu_prof.sh r04_1stream --streams 1 --no-train-row --no-cpu-baseline --no-bf16-row --no-extra-rows
+bash scripts/gpu_prof.sh r04_bf16_1stream --dtype bf16 --streams 1 --no-train-row --no-cpu-baseline
+bash scripts/gpu_prof.sh r04_exact_1stream --dtype exact_bf16 --streams 1 --no-train-row --no-cpu-baseline
+bash scripts/gpu_prof.sh r04_exact_4streams --dtype exact_bf16 --no-train-row --no-cpu-baseline
+# training step, per kernel: fp32 / bf16 GEMMs / the model's default step
+bash scripts/gpu_kprof.sh r04_train_f32 12 python $GRAFT_REPO_ROOT/scripts/bench_train.py
+bash scripts/gpu_kprof.sh r04_train_bf16 12 python $GRAFT_REPO_ROOT/scripts/bench_train.py --bf16
+bash scripts/gpu_kprof.sh r04_train_default 14 python $GRAFT_REPO_ROOT/scripts/bench_train.py --default
+# the exact mode on hard models, per kernel (one batch in flight)
+SCALE=40 bash scripts/gpu_kprof.sh r04_exact_x40 7 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zipf exact 1
+bash scripts/gpu_kprof.sh r04_exact_zeros 7 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zeros exact 1
+TRAINED=1500 bash scripts/gpu_kprof.sh r04_exact_trained 16 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zipf exact 1
