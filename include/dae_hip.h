@@ -273,6 +273,50 @@ int dae_set_overlap_hint(dae_ctx* ctx, int batches_in_flight);
  * caller-owned; NULL, NULL removes the gate.  Results are unaffected. */
 int dae_set_decode_gate(dae_ctx* ctx, void* wait_event, void* record_event);
 
+/* ---- the drivers' loop (main_challenge.py:72-93, main_train.py:62-96) ---------------------------------------------------
+ *
+ * The reference's loop per batch -- reader.next_batch() -> sess.run(y_pred, feed) -> cand_generate per row -- as a streaming
+ * pipeline inside the library: HOST feeds in (the COO positions / values the reference's readers emit, utils/data_reader.py),
+ * HOST top-k index lists out, nothing of the interpreter in between.  dae_pipeline_submit copies a feed into pinned staging
+ * memory and returns; a library-owned thread issues the launches (upload, dae_coo_to_csr, dae_seeds_from_csr, dae_score_topk,
+ * download) on `lanes` contexts / streams that take them in turn and share one packed decoder image; consecutive feeds share
+ * a launch of up to `group_rows` rows (rows are scored independently: every feed gets the bits dae_score_topk gives it alone).
+ * Seeds are the playlist's own tracks (the columns < n_tracks of its feed), what both reference drivers pass.
+ * This group is the exception to "device pointers only": feeds and results are HOST memory.  One caller thread.
+ *
+ *   create : W_enc / b_enc / W_dec / b_dec are caller-owned DEVICE arrays ([V,H], [H], [V,H], [V]) that outlive the pipeline;
+ *            dtype = DAE_DTYPE_*; a feed holds at most group_rows (<= 16384) rows and max_nnz entries; result_blocks pinned
+ *            result blocks (>= lanes + 1) bound how many launches' lists the caller may hold at once.
+ *   submit : positions [nnz,2] int64 (row in the FEED, column), values [nnz] fp32 (or one value: values_broadcast); n_rows
+ *            rows.  Returns DAE_OK and the feed's ticket, or DAE_PIPE_BUSY (> 0): every lane holds lists that were not
+ *            polled / released yet -- poll, then submit again.
+ *   flush  : close the launch being filled (end of input; poll(wait) does it as well).
+ *   poll   : the next feed IN SUBMISSION ORDER: *idx -> its [n_rows,k] global column ids (-1 = fewer candidates), *score
+ *            (may be NULL) -> canonical sigmoid scores, both inside pinned result block *block, valid until
+ *            dae_pipeline_release(block) (once per polled feed).  wait = 0: returns *n_rows = 0 when the feed is not ready.
+ *            DAE_DTYPE_BF16_EXACT: a launch whose bound guard fired (dae_exact_guard_read) is re-scored with DAE_DTYPE_F32
+ *            before its lists go out (dae_pipeline_stats counts it).
+ *   stats  : {launches issued, feeds submitted, launches re-scored in fp32 after a bound-guard hit}. */
+typedef struct dae_pipeline dae_pipeline;
+#define DAE_PIPE_BUSY 1
+int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                        int V, int H, int n_tracks, int dtype, int k, int group_rows, int64_t max_nnz, int lanes,
+                        int want_scores, int result_blocks, dae_pipeline** out);
+int dae_pipeline_destroy(dae_pipeline* p);
+int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                        int n_rows, uint64_t* ticket_out);
+int dae_pipeline_flush(dae_pipeline* p);
+int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t** idx, const float** score, int* n_rows,
+                      int* block);
+int dae_pipeline_release(dae_pipeline* p, int block);
+int dae_pipeline_stats(dae_pipeline* p, uint64_t out3[3]);
+/* Where the host side of the loop spent its time since creation, nanoseconds: {the library thread issuing launches, the
+ * library thread waiting for a staged launch, the caller inside dae_pipeline_submit, the caller waiting in dae_pipeline_poll}. */
+int dae_pipeline_times(dae_pipeline* p, uint64_t out4[4]);
+/* dae_set_exact_margin for the pipeline's own decoder image (re-tiled here; no feed may be in flight). */
+int dae_pipeline_exact_margin(dae_pipeline* p, float scale);
+const char* dae_pipeline_last_error(const dae_pipeline* p);
+
 /* ---- training step (DAEs.py:98-102) ------------------------------------------------------ */
 
 /* Arithmetic of the three GEMMs of the training step of this context (forward hidden x W_dec^T, gW_dec = dz^T h,

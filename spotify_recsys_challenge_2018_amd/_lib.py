@@ -22,7 +22,10 @@ EXPORTS = [
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
+    "dae_pipeline_create", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_flush", "dae_pipeline_poll",
+    "dae_pipeline_release", "dae_pipeline_stats", "dae_pipeline_exact_margin", "dae_pipeline_times", "dae_pipeline_last_error",
 ]
+DAE_PIPE_BUSY = 1
 
 _lib = None
 
@@ -108,8 +111,22 @@ def load():
     lib.dae_arm_decoder_adam.argtypes = [vp, vp, vp, c_f, c_f, c_f, c_f, c_int]
     lib.dae_set_decode_gate.argtypes = [vp, vp, vp]
     lib.dae_set_overlap_hint.argtypes = [vp, c_int]
+    u64p, i32pp, f32pp, ip = (ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.POINTER(ctypes.c_int32)),
+                              ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.POINTER(c_int))
+    lib.dae_pipeline_create.argtypes = [c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_int,
+                                        ctypes.POINTER(vp)]
+    lib.dae_pipeline_destroy.argtypes = [vp]
+    lib.dae_pipeline_submit.argtypes = [vp, vp, vp, c_int, c_i64, c_int, u64p]
+    lib.dae_pipeline_flush.argtypes = [vp]
+    lib.dae_pipeline_poll.argtypes = [vp, c_int, u64p, i32pp, f32pp, ip, ip]
+    lib.dae_pipeline_release.argtypes = [vp, c_int]
+    lib.dae_pipeline_stats.argtypes = [vp, u64p]
+    lib.dae_pipeline_exact_margin.argtypes = [vp, c_f]
+    lib.dae_pipeline_times.argtypes = [vp, u64p]
+    lib.dae_pipeline_last_error.argtypes = [vp]
+    lib.dae_pipeline_last_error.restype = ctypes.c_char_p
     for name in EXPORTS:
-        if name not in ("dae_last_error", "dae_scratch_bytes", "dae_profile_kernel"):
+        if name not in ("dae_last_error", "dae_scratch_bytes", "dae_profile_kernel", "dae_pipeline_last_error"):
             getattr(lib, name).restype = c_int
     _lib = lib
     return lib
@@ -367,3 +384,143 @@ class Context:
 
     def scratch_bytes(self):
         return int(self.lib.dae_scratch_bytes(self.h))
+
+
+class _Block:
+    """One polled feed's claim on a pinned result block of a Pipeline: released when the last array viewing it dies."""
+
+    def __init__(self, pipe, block):
+        self.pipe, self.block = pipe, block
+        pipe._held[block] = pipe._held.get(block, 0) + 1
+
+    def __del__(self):
+        try:
+            p = self.pipe
+            n = p._held.get(self.block, 0) - 1
+            if n > 0:
+                p._held[self.block] = n
+            else:
+                p._held.pop(self.block, None)
+            if p.h:
+                p.lib.dae_pipeline_release(p.h, self.block)
+                if p._closing and not p._held:           # close() was asked for while this array was alive
+                    p.close()
+        except Exception:
+            pass
+
+
+class Pipeline:
+    """The drivers' loop inside the library (include/dae_hip.h dae_pipeline_*): host feeds in, host top-k lists out; a
+    library-owned thread issues the launches on `lanes` contexts.  The weights are CUDA tensors the caller keeps alive.
+    `submit` / `results` from one thread."""
+
+    def __init__(self, W_enc, b_enc, W_dec, b_dec, n_tracks, dtype=DAE_DTYPE_F32, k=500, group_rows=1024, max_nnz=1 << 20,
+                 lanes=2, want_scores=True, result_blocks=None, device_index=0):
+        self.lib = load()
+        V, H = W_enc.shape
+        self._keep = (W_enc, b_enc, W_dec, b_dec)
+        self.k, self.want_scores, self.group_rows, self.max_nnz = int(k), bool(want_scores), int(group_rows), int(max_nnz)
+        h = ctypes.c_void_p()
+        n_slots = 2 * lanes + 2              # launches the pipeline holds at once (csrc/pipeline.hip)
+        n_blocks = max(int(result_blocks or 0), n_slots + 6)
+        self._held = {}                      # result block -> claims of arrays still alive in the caller's hands
+        self._closing = False
+        self.max_held = n_blocks - n_slots                    # more blocks out than this: poll() copies instead of lending
+        rc = self.lib.dae_pipeline_create(int(device_index), _ptr(W_enc), _ptr(b_enc), _ptr(W_dec), _ptr(b_dec), V, H, int(n_tracks),
+                                          int(dtype), int(k), int(group_rows), int(max_nnz), int(lanes), 1 if want_scores else 0,
+                                          n_blocks, ctypes.byref(h))
+        if rc != 0:
+            raise DaeError("dae_pipeline_create failed (%d): %s" % (rc, self.lib.dae_pipeline_last_error(None).decode()))
+        self.h = h
+        self.pending = 0                     # feeds submitted and not yet yielded
+
+    def _check(self, rc):
+        if rc < 0:
+            raise DaeError("dae_pipeline error %d: %s" % (rc, self.lib.dae_pipeline_last_error(self.h).decode()))
+        return rc
+
+    def submit(self, positions, values, n_rows):
+        """positions: int64 [nnz, 2] (C-contiguous numpy), values: float32 [nnz] or one value.  -> True, or False when every
+        lane holds lists that were not fetched yet (take `results()` first)."""
+        import numpy as np
+        if self._closing:
+            raise DaeError("dae_pipeline: closed")
+        pos = np.ascontiguousarray(positions, np.int64).reshape(-1, 2)
+        val = np.ascontiguousarray(values, np.float32).reshape(-1)
+        nnz = pos.shape[0]
+        if val.size != nnz and val.size != 1:
+            raise ValueError("positions (%d) and values (%d) differ in length" % (nnz, val.size))
+        t = ctypes.c_uint64()
+        rc = self._check(self.lib.dae_pipeline_submit(self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
+                                                      1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), ctypes.byref(t)))
+        if rc == DAE_PIPE_BUSY:
+            return False
+        self.pending += 1
+        return True
+
+    def flush(self):
+        self._check(self.lib.dae_pipeline_flush(self.h))
+
+    def poll(self, wait=True, copy=False):
+        """The next feed in submission order -> (idx [n_rows, k] int32, score or None), or None when it is not ready
+        (wait=False) or nothing is pending.  The arrays VIEW a pinned result block that returns to the pipeline when they
+        are garbage collected (copy=True: private copies, the block returns at once)."""
+        import numpy as np
+        if self.pending == 0:
+            return None
+        t, n, b = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int()
+        ip_, sp_ = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_float)()
+        rc = self._check(self.lib.dae_pipeline_poll(self.h, 1 if wait else 0, ctypes.byref(t), ctypes.byref(ip_),
+                                                    ctypes.byref(sp_) if self.want_scores else None, ctypes.byref(n), ctypes.byref(b)))
+        if rc == DAE_PIPE_BUSY:
+            raise DaeError("dae_pipeline: every result block is held (drop or copy the arrays of earlier feeds)")
+        if n.value == 0:
+            return None
+        self.pending -= 1
+        if b.value not in self._held and len(self._held) >= self.max_held:
+            copy = True                      # the caller keeps many results alive: this one is copied, its block goes back
+        owner = _Block(self, b.value)
+        n_el = n.value * self.k
+
+        def view(ptr, ctype, dt):
+            # the ctypes array object is the memory owner numpy sees: it carries the block's claim, so every array derived
+            # from the result (slices, views) keeps the block out of the pipeline's hands
+            buf = (ctype * n_el).from_address(ctypes.addressof(ptr.contents))
+            buf._owner = owner
+            return np.frombuffer(buf, dtype=dt).reshape(n.value, self.k)
+        idx = view(ip_, ctypes.c_int32, np.int32)
+        score = view(sp_, ctypes.c_float, np.float32) if self.want_scores else None
+        if copy:
+            idx, score = idx.copy(), (None if score is None else score.copy())
+        return idx, score
+
+    def exact_margin(self, scale):
+        self._check(self.lib.dae_pipeline_exact_margin(self.h, float(scale)))
+
+    def times(self):
+        """ms since creation: the library thread issuing / idle, the caller in submit / waiting in poll."""
+        a = (ctypes.c_uint64 * 4)()
+        self._check(self.lib.dae_pipeline_times(self.h, a))
+        return dict(zip(("issue_ms", "idle_ms", "submit_ms", "wait_ms"), [round(int(x) / 1e6, 2) for x in a]))
+
+    def stats(self):
+        a = (ctypes.c_uint64 * 3)()
+        self._check(self.lib.dae_pipeline_stats(self.h, a))
+        return {"launches": int(a[0]), "feeds": int(a[1]), "guard_fallbacks": int(a[2])}
+
+    def close(self):
+        """Destroys the pipeline -- once no array handed out by poll() views its pinned blocks any more (until then the
+        pipeline only stops taking feeds)."""
+        if getattr(self, "h", None):
+            if self._held:
+                self._closing = True
+                return
+            self.lib.dae_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self._held = {}              # (nothing can view the blocks any more: the claims hold a reference to this object)
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,488 @@
+// pipeline.hip -- the drivers' loop of the reference (main_challenge.py:72-93, main_train.py:62-96: read a batch, feed it,
+// fetch y_pred, rank, next batch) as a C-side streaming pipeline: HOST feeds in, HOST top-k lists out.
+//
+// What the Python loop of round 3 (models/DAEs.py recommend_iter) did per launch -- stage the COO feed in pinned memory,
+// upload, build the CSR and the seed lists on the device, score, fetch -- took ~0.3 ms of interpreter time against 0.05 -
+// 0.2 ms of kernels, and threads did not help it (the GIL).  Here the caller's thread only copies a feed into a pinned
+// staging buffer (dae_pipeline_submit) and picks finished lists up (dae_pipeline_poll: pointers into pinned result blocks,
+// no copy); a library-owned thread issues every launch -- H2D, dae_coo_to_csr, dae_seeds_from_csr, dae_score_topk, D2H --
+// on one of `lanes` contexts / streams that take the launches in turn and share ONE packed decoder image.  Consecutive
+// feeds are scored in one launch of up to `group_rows` rows: rows are scored independently, so every feed gets the bits
+// dae_score_topk returns for it alone.  Seeds are the playlist's own tracks (what both reference drivers pass).
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "dae_internal.h"
+
+namespace {
+
+struct Feed { uint64_t ticket; int row0, n_rows; };
+
+struct OutBlock {                 // pinned result block of one launch: idx [rows][k] (+ score), handed out by pointer
+    int32_t* idx = nullptr; float* score = nullptr;
+    int refs = 0;                 // feeds handed out and not yet released (+1 while its launch is pending)
+};
+
+struct Lane {                     // a context + stream + the device buffers its launches reuse in stream order
+    dae_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    int32_t *d_rp = nullptr, *d_col = nullptr, *d_status = nullptr, *d_srp = nullptr, *d_scol = nullptr, *d_idx = nullptr;
+    float *d_cval = nullptr, *d_score = nullptr;
+    bool has_f32 = false;         // (guard fallback) an fp32 image of its own
+};
+
+struct Slot {                     // one launch from staging to its last polled feed; more slots than lanes, so that the caller
+    int64_t* h_pos = nullptr;     // stages launch n + lanes while the lanes still score / hand out the ones before
+    float* h_val = nullptr;       // (pinned staging of the feed)
+    int32_t* h_flags = nullptr;   // pinned: {csr status, guard violations, guard column}
+    int64_t* d_pos = nullptr; float* d_val = nullptr;      // the feed on the device (uploaded on the copy stream, ahead of the lane)
+    hipEvent_t ev_fetch = nullptr, ev_h2d = nullptr, ev_gate = nullptr;
+    int state = 0;                // 0 free, 1 staging (open launch), 2 queued for the worker, 3 issued (ev_fetch recorded)
+    int rows = 0; int64_t nnz = 0;
+    int block = -1, lane = -1;
+    std::vector<Feed> feeds;
+    size_t next_feed = 0;         // first feed of the launch not handed out yet
+};
+
+}  // namespace
+
+struct dae_pipeline {
+    int device = 0, V = 0, H = 0, n_tracks = 0, dtype = 0, k = 0, group_rows = 0, want_scores = 0;
+    int64_t max_nnz = 0;
+    const float *W_enc = nullptr, *b_enc = nullptr, *W_dec = nullptr, *b_dec = nullptr;
+    std::vector<Lane> lanes;
+    std::vector<Slot> slots;
+    std::vector<OutBlock> blocks;
+    hipStream_t copy_stream = nullptr;    // uploads: hipMemcpyAsync on a stream that still has kernels queued blocks its caller
+                                          // until they have run (measured: 0.43 ms per launch next to the fp32 decode) -- on a
+                                          // stream of their own the uploads run ahead and the lane waits for their event
+    std::mutex mu;                // states, queue, blocks
+    std::mutex issue_mu;          // the lanes' contexts are used by one thread at a time (worker; poll's fp32 re-run)
+    std::condition_variable cv_worker, cv_caller;
+    std::deque<int> queue;        // slots waiting for the worker, in submission order
+    std::thread worker;
+    bool stop = false;
+    std::string err;
+    int err_code = 0;
+    uint64_t next_ticket = 1;
+    int open_slot = -1;           // slot of the launch being staged
+    int next_slot = 0;            // slots take the launches in ring order ...
+    int poll_slot = 0;            // ... and are polled in the same order
+    int next_lane = 0;            // lanes take the launches in turn
+    hipEvent_t last_gate = nullptr;   // fp32, several lanes: the gate event of the launch issued before (dae_set_decode_gate)
+    uint64_t guard_fallbacks = 0, launches = 0;
+    uint64_t issue_ns = 0, idle_ns = 0, submit_ns = 0, wait_ns = 0;      // where the host side of the loop spends its time (dae_pipeline_times)
+};
+
+namespace {
+
+thread_local std::string g_pipe_err;
+
+// pfail: an error of THIS call (message only); pfatal: the pipeline is broken from here on (every later call returns it)
+int pfail(dae_pipeline* p, int code, const char* msg)
+{
+    if (p) p->err = msg; else g_pipe_err = msg;
+    return code;
+}
+int pfatal(dae_pipeline* p, int code, const char* msg)
+{
+    if (p && !p->err_code) { p->err = msg; p->err_code = code; }
+    return code;
+}
+
+#define PIPE_HIP(p, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            char _b[400];                                                                          \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return pfatal((p), DAE_ERR_HIP, _b);                                                   \
+        }                                                                                          \
+    } while (0)
+
+// everything of one launch, asynchronously on its lane's stream (issue_mu held)
+int issue(dae_pipeline* p, Slot& S, int dtype)
+{
+    Lane& L = p->lanes[S.lane];
+    const size_t k = (size_t)p->k;
+    PIPE_HIP(p, hipMemcpyAsync(S.d_pos, S.h_pos, (size_t)S.nnz * 2 * sizeof(int64_t), hipMemcpyHostToDevice, p->copy_stream));
+    PIPE_HIP(p, hipMemcpyAsync(S.d_val, S.h_val, (size_t)S.nnz * sizeof(float), hipMemcpyHostToDevice, p->copy_stream));
+    PIPE_HIP(p, hipEventRecord(S.ev_h2d, p->copy_stream));
+    PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_h2d, 0));
+    if (p->dtype == DAE_DTYPE_F32 && p->lanes.size() > 1) {
+        // the fp32 filter launch takes every CU, two of them in flight only queue behind each other: this launch's waits for
+        // the one issued before it (on another lane) and announces its own end.  One event per launch SLOT: re-recording a
+        // lane's event while its previous record was still pending made hipEventRecord wait for it (0.7 ms per launch).
+        (void)dae_set_decode_gate(L.ctx, p->last_gate, S.ev_gate);
+        p->last_gate = S.ev_gate;
+    }
+    int rc = dae_coo_to_csr(L.ctx, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, L.d_rp, L.d_col, L.d_cval, L.d_status);
+    if (!rc) rc = dae_seeds_from_csr(L.ctx, L.d_rp, L.d_col, S.rows, p->n_tracks, L.d_srp, L.d_scol);
+    if (!rc) rc = dae_score_topk(L.ctx, L.d_rp, L.d_col, L.d_cval, p->W_enc, p->b_enc, p->V, p->H, S.rows, dtype, p->n_tracks,
+                                 L.d_srp, L.d_scol, p->k, DAE_OUT_SCORE, L.d_score, L.d_idx);
+    if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
+    OutBlock& ob = p->blocks[S.block];
+    PIPE_HIP(p, hipMemcpyAsync(ob.idx, L.d_idx, (size_t)S.rows * k * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    if (p->want_scores)
+        PIPE_HIP(p, hipMemcpyAsync(ob.score, L.d_score, (size_t)S.rows * k * sizeof(float), hipMemcpyDeviceToHost, L.stream));
+    PIPE_HIP(p, hipMemcpyAsync(S.h_flags, L.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    if (dtype == DAE_DTYPE_BF16_EXACT) {
+        const int32_t* gw = nullptr;
+        rc = dae_exact_guard_words(L.ctx, &gw);
+        if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
+        PIPE_HIP(p, hipMemcpyAsync(S.h_flags + 1, gw, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    }
+    PIPE_HIP(p, hipEventRecord(S.ev_fetch, L.stream));
+    return DAE_OK;
+}
+
+void worker_main(dae_pipeline* p)
+{
+    (void)hipSetDevice(p->device);
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        const auto t_idle = std::chrono::steady_clock::now();
+        p->cv_worker.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+        p->idle_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_idle).count();
+        if (p->stop && p->queue.empty()) return;
+        const int si = p->queue.front();
+        p->queue.pop_front();
+        Slot& S = p->slots[si];
+        const bool broken = p->err_code != 0;
+        lk.unlock();
+        const auto t_iss = std::chrono::steady_clock::now();
+        if (!broken) {                                       // after an error: drain without touching the device
+            std::lock_guard<std::mutex> g(p->issue_mu);
+            (void)issue(p, S, p->dtype);
+        }
+        lk.lock();
+        p->issue_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_iss).count();
+        S.state = 3;
+        ++p->launches;
+        p->cv_caller.notify_all();
+    }
+}
+
+// close the open launch: a result block and a lane for it, then over to the worker (caller thread, lock held)
+int close_open(dae_pipeline* p)
+{
+    if (p->open_slot < 0) return DAE_OK;
+    Slot& S = p->slots[p->open_slot];
+    int b = -1;
+    for (size_t i = 0; i < p->blocks.size(); ++i) if (p->blocks[i].refs == 0) { b = (int)i; break; }
+    if (b < 0) return pfail(p, DAE_PIPE_BUSY, "dae_pipeline: every result block is still held by the caller (dae_pipeline_release)");
+    p->blocks[b].refs = 1;                                  // the launch's own reference, dropped when its last feed went out
+    S.block = b;
+    S.lane = p->next_lane;
+    p->next_lane = (p->next_lane + 1) % (int)p->lanes.size();
+    S.state = 2;
+    S.next_feed = 0;
+    p->queue.push_back(p->open_slot);
+    p->open_slot = -1;
+    p->cv_worker.notify_one();
+    return DAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dae_pipeline_last_error(const dae_pipeline* p) { return p ? p->err.c_str() : g_pipe_err.c_str(); }
+
+int dae_pipeline_destroy(dae_pipeline* p)
+{
+    if (!p) return DAE_OK;
+    {
+        std::lock_guard<std::mutex> g(p->mu);
+        p->stop = true;
+    }
+    p->cv_worker.notify_all();
+    if (p->worker.joinable()) p->worker.join();
+    (void)hipSetDevice(p->device);
+    for (Lane& L : p->lanes) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        void* dev[] = {L.d_rp, L.d_col, L.d_status, L.d_srp, L.d_scol, L.d_idx, L.d_cval, L.d_score};
+        for (void* q : dev) if (q) (void)hipFree(q);
+    }
+    if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+    for (Slot& S : p->slots) {
+        if (S.ev_fetch) (void)hipEventDestroy(S.ev_fetch);
+        if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
+        if (S.ev_gate) (void)hipEventDestroy(S.ev_gate);
+        if (S.d_pos) (void)hipFree(S.d_pos);
+        if (S.d_val) (void)hipFree(S.d_val);
+        void* host[] = {S.h_pos, S.h_val, S.h_flags};
+        for (void* q : host) if (q) (void)hipHostFree(q);
+    }
+    for (OutBlock& b : p->blocks) {
+        if (b.idx) (void)hipHostFree(b.idx);
+        if (b.score) (void)hipHostFree(b.score);
+    }
+    delete p;
+    return DAE_OK;
+}
+
+int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                        int V, int H, int n_tracks, int dtype, int k, int group_rows, int64_t max_nnz, int lanes,
+                        int want_scores, int result_blocks, dae_pipeline** out)
+{
+    if (!out) return pfail(nullptr, DAE_ERR_ARG, "out is null");
+    if (!W_enc || !b_enc || !W_dec || !b_dec) return pfail(nullptr, DAE_ERR_ARG, "null pointer");
+    if (V <= 0 || H <= 0 || n_tracks <= 0 || n_tracks > V || k < 1 || k > DAE_MAX_K || group_rows < 1 || group_rows > 16384 ||
+        max_nnz < 1 || max_nnz >= ((int64_t)1 << 31) || lanes < 1 || lanes > 8)
+        return pfail(nullptr, DAE_ERR_ARG, "dae_pipeline_create: bad shape / sizes");
+    if (dtype != DAE_DTYPE_F32 && dtype != DAE_DTYPE_BF16 && dtype != DAE_DTYPE_BF16_EXACT)
+        return pfail(nullptr, DAE_ERR_ARG, "dae_pipeline_create: unknown dtype");
+    const int n_slots = 2 * lanes + 2;                       // launches staged, queued, running or waiting to be polled
+    if (result_blocks < n_slots) result_blocks = n_slots;
+    dae_pipeline* p = new dae_pipeline();
+    p->device = device; p->V = V; p->H = H; p->n_tracks = n_tracks; p->dtype = dtype; p->k = k; p->group_rows = group_rows;
+    p->max_nnz = max_nnz; p->want_scores = want_scores ? 1 : 0;
+    p->W_enc = W_enc; p->b_enc = b_enc; p->W_dec = W_dec; p->b_dec = b_dec;
+    p->lanes.resize(lanes);
+    p->slots.resize(n_slots);
+    p->blocks.resize(result_blocks);
+    auto bail = [&](int rc, const char* msg) { const std::string m(msg); dae_pipeline_destroy(p); g_pipe_err = m; return rc; };
+    if (hipSetDevice(device) != hipSuccess) return bail(DAE_ERR_HIP, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(DAE_ERR_HIP, "stream creation failed");
+    const size_t rows = (size_t)group_rows, nz = (size_t)max_nnz, kk = (size_t)k;
+    for (int i = 0; i < lanes; ++i) {
+        Lane& L = p->lanes[i];
+        int rc = dae_create(device, &L.ctx);
+        if (rc) return bail(rc, dae_last_error(nullptr));
+        bool ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_rp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_col), nz * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_cval), nz * sizeof(float)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_srp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_scol), nz * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_idx), rows * kk * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&L.d_score), rows * kk * sizeof(float)) == hipSuccess;
+        if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");
+        rc = dae_set_stream(L.ctx, L.stream);
+        if (!rc) rc = i == 0 ? dae_prepack_decoder(L.ctx, W_dec, b_dec, V, H, 0, V, dtype) : DAE_OK;
+        if (rc) return bail(rc, dae_last_error(L.ctx));
+        if (i == 0 && hipStreamSynchronize(L.stream) != hipSuccess) return bail(DAE_ERR_HIP, "prepack failed");
+        if (i > 0) {
+            rc = dae_share_decoder(L.ctx, p->lanes[0].ctx, dtype);
+            if (rc) return bail(rc, dae_last_error(L.ctx));
+        }
+        (void)dae_set_overlap_hint(L.ctx, lanes);
+    }
+    for (Slot& S : p->slots) {
+        bool ok = hipEventCreateWithFlags(&S.ev_fetch, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&S.ev_gate, hipEventDisableTiming) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_pos), nz * 2 * sizeof(int64_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_val), nz * sizeof(float)) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&S.h_pos), nz * 2 * sizeof(int64_t)) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&S.h_val), nz * sizeof(float)) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&S.h_flags), 4 * sizeof(int32_t)) == hipSuccess;
+        if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: pinned allocation failed");
+        S.h_flags[0] = S.h_flags[1] = 0; S.h_flags[2] = -1;
+    }
+    for (OutBlock& b : p->blocks) {
+        bool ok = hipHostMalloc(reinterpret_cast<void**>(&b.idx), rows * kk * sizeof(int32_t)) == hipSuccess &&
+                  (!want_scores || hipHostMalloc(reinterpret_cast<void**>(&b.score), rows * kk * sizeof(float)) == hipSuccess);
+        if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: pinned allocation failed");
+    }
+    for (Lane& L : p->lanes) if (hipStreamSynchronize(L.stream) != hipSuccess) return bail(DAE_ERR_HIP, "setup failed");
+    p->worker = std::thread(worker_main, p);
+    *out = p;
+    return DAE_OK;
+}
+
+int dae_pipeline_flush(dae_pipeline* p)
+{
+    if (!p) return DAE_ERR_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->err_code) return p->err_code;
+    return close_open(p);
+}
+
+int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                        int n_rows, uint64_t* ticket_out)
+{
+    if (!p) return DAE_ERR_ARG;
+    if (n_rows < 1 || n_rows > p->group_rows || nnz < 0 || nnz > p->max_nnz || (nnz > 0 && (!positions || !values)))
+        return pfail(p, DAE_ERR_ARG, "dae_pipeline_submit: a feed must fit one launch (rows <= group_rows, nnz <= max_nnz)");
+    const auto t_sub = std::chrono::steady_clock::now();
+    // a row index outside the feed would land in ANOTHER feed's rows of the launch: checked here (the device flags only
+    // what leaves the launch)
+    for (int64_t i = 0; i < nnz; ++i)
+        if (positions[2 * i] < 0 || positions[2 * i] >= n_rows)
+            return pfail(p, DAE_ERR_ARG, "dae_pipeline_submit: a row index of the feed is outside [0, n_rows)");
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->err_code) return p->err_code;
+    if (p->open_slot >= 0) {
+        Slot& O = p->slots[p->open_slot];
+        if (O.rows + n_rows > p->group_rows || O.nnz + nnz > p->max_nnz) {
+            const int rc = close_open(p);
+            if (rc) return rc;
+        }
+    }
+    if (p->open_slot < 0) {
+        // the next slot of the ring; it is free once every feed of its previous launch has been handed out
+        Slot& N = p->slots[p->next_slot];
+        if (N.state != 0) return pfail(p, DAE_PIPE_BUSY, "dae_pipeline_submit: every launch slot holds results that were not polled "
+                                                           "yet (poll before submitting more)");
+        p->open_slot = p->next_slot;
+        p->next_slot = (p->next_slot + 1) % (int)p->slots.size();
+        N.state = 1; N.rows = 0; N.nnz = 0; N.feeds.clear(); N.next_feed = 0;
+    }
+    Slot& S = p->slots[p->open_slot];
+    const int row0 = S.rows;
+    const int64_t off = S.nnz;
+    const uint64_t ticket = p->next_ticket++;
+    S.feeds.push_back(Feed{ticket, row0, n_rows});
+    S.rows += n_rows; S.nnz += nnz;
+    lk.unlock();                                            // the copy runs outside the lock (the worker never touches an open slot)
+    int64_t* dp = S.h_pos + 2 * off;
+    if (row0 == 0) {
+        memcpy(dp, positions, (size_t)nnz * 2 * sizeof(int64_t));
+    } else {
+        for (int64_t i = 0; i < nnz; ++i) { dp[2 * i] = positions[2 * i] + row0; dp[2 * i + 1] = positions[2 * i + 1]; }
+    }
+    float* dv = S.h_val + off;
+    if (values_broadcast) { const float v = values[0]; for (int64_t i = 0; i < nnz; ++i) dv[i] = v; }
+    else memcpy(dv, values, (size_t)nnz * sizeof(float));
+    if (ticket_out) *ticket_out = ticket;
+    lk.lock();
+    if (S.rows + n_rows > p->group_rows) (void)close_open(p);   // the next feed of this size would not fit: off it goes
+    p->submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_sub).count();
+    return DAE_OK;
+}
+
+int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t** idx, const float** score, int* n_rows,
+                      int* block)
+{
+    if (!p) return DAE_ERR_ARG;
+    if (!idx || !n_rows || !block) return pfail(p, DAE_ERR_ARG, "null pointer");
+    std::unique_lock<std::mutex> lk(p->mu);
+    *n_rows = 0; *idx = nullptr; *block = -1;
+    if (score) *score = nullptr;
+    Slot& S = p->slots[p->poll_slot];
+    if (S.state == 0) return p->err_code;                    // nothing pending (0 rows), or the worker's error
+    if (S.state == 1) {
+        if (!wait) return DAE_OK;
+        const int rc = close_open(p);                        // the caller waits for a launch that is still open: close it
+        if (rc) return rc;
+    }
+    if (S.state == 2) {
+        if (!wait) return DAE_OK;
+        p->cv_caller.wait(lk, [&] { return S.state == 3; });
+    }
+    if (p->err_code) return p->err_code;
+    if (S.next_feed == 0) {                                  // first feed of the launch: its results have to be here
+        lk.unlock();
+        if (!wait) {
+            const hipError_t q = hipEventQuery(S.ev_fetch);
+            if (q == hipErrorNotReady) return DAE_OK;
+            if (q != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(q)); }
+        } else {
+            const auto t_w = std::chrono::steady_clock::now();
+            const hipError_t e = hipEventSynchronize(S.ev_fetch);
+            p->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_w).count();
+            if (e != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(e)); }
+        }
+        if (S.h_flags[0] != 0) {
+            lk.lock();
+            return pfatal(p, DAE_ERR_ARG, "dae_pipeline: a feed of the launch holds a column index out of range");
+        }
+        if (p->dtype == DAE_DTYPE_BF16_EXACT && S.h_flags[1] != 0) {
+            // BOUND GUARD (include/dae_hip.h dae_exact_guard_read): a recomputed survivor left its promised interval, the
+            // lists of this launch are unproven -> the same launch again on the fp32 kernels, here and now (its feed is
+            // still in the slot's staging buffers; the lane's context is shared with the worker: issue_mu)
+            int rc;
+            bool ok;
+            {
+                std::lock_guard<std::mutex> g(p->issue_mu);
+                (void)hipSetDevice(p->device);
+                Lane& L = p->lanes[S.lane];
+                int32_t nv = 0, col = -1;
+                rc = dae_exact_guard_read(L.ctx, &nv, &col);       // (synchronises the lane, resets the words)
+                if (!rc && !L.has_f32) { rc = dae_prepack_decoder(L.ctx, p->W_dec, p->b_dec, p->V, p->H, 0, p->V, DAE_DTYPE_F32); L.has_f32 = !rc; }
+                if (!rc) rc = issue(p, S, DAE_DTYPE_F32);
+                ok = !rc && hipEventSynchronize(S.ev_fetch) == hipSuccess;
+            }
+            lk.lock();
+            if (!ok) return pfatal(p, rc ? rc : DAE_ERR_HIP, "dae_pipeline: the fp32 re-run after a bound-guard hit failed");
+            S.h_flags[1] = 0;
+            ++p->guard_fallbacks;
+        } else {
+            lk.lock();
+        }
+    }
+    const Feed& f = S.feeds[S.next_feed];
+    OutBlock& ob = p->blocks[S.block];
+    if (ticket) *ticket = f.ticket;
+    *idx = ob.idx + (size_t)f.row0 * p->k;
+    if (score) *score = p->want_scores ? ob.score + (size_t)f.row0 * p->k : nullptr;
+    *n_rows = f.n_rows;
+    *block = S.block;
+    ++ob.refs;                                               // the caller's reference to the block (dae_pipeline_release)
+    if (++S.next_feed == S.feeds.size()) {                   // last feed of the launch: the slot is free again
+        --ob.refs;                                           // (the launch's own reference)
+        S.state = 0; S.block = -1;
+        p->poll_slot = (p->poll_slot + 1) % (int)p->slots.size();
+    }
+    return DAE_OK;
+}
+
+int dae_pipeline_release(dae_pipeline* p, int block)
+{
+    if (!p) return DAE_ERR_ARG;
+    std::lock_guard<std::mutex> g(p->mu);
+    if (block < 0 || block >= (int)p->blocks.size() || p->blocks[block].refs <= 0)
+        return pfail(p, DAE_ERR_ARG, "dae_pipeline_release: not a block that is out");
+    --p->blocks[block].refs;
+    return DAE_OK;
+}
+
+int dae_pipeline_exact_margin(dae_pipeline* p, float scale)
+{
+    if (!p) return DAE_ERR_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->err_code) return p->err_code;
+    if (p->dtype != DAE_DTYPE_BF16_EXACT) return pfail(p, DAE_ERR_ARG, "dae_pipeline_exact_margin: not an exact_bf16 pipeline");
+    for (Slot& S : p->slots)
+        if (S.state != 0) return pfail(p, DAE_ERR_STATE, "dae_pipeline_exact_margin: feeds are in flight");
+    lk.unlock();
+    std::lock_guard<std::mutex> g(p->issue_mu);
+    (void)hipSetDevice(p->device);
+    Lane& L0 = p->lanes[0];
+    for (Lane& L : p->lanes) (void)hipStreamSynchronize(L.stream);
+    int rc = dae_set_exact_margin(L0.ctx, scale);
+    if (!rc) rc = dae_prepack_decoder(L0.ctx, p->W_dec, p->b_dec, p->V, p->H, 0, p->V, p->dtype);
+    if (rc) return pfail(p, rc, dae_last_error(L0.ctx));
+    if (hipStreamSynchronize(L0.stream) != hipSuccess) return pfatal(p, DAE_ERR_HIP, "prepack failed");
+    for (size_t i = 1; i < p->lanes.size(); ++i) {
+        rc = dae_share_decoder(p->lanes[i].ctx, L0.ctx, p->dtype);
+        if (rc) return pfail(p, rc, dae_last_error(p->lanes[i].ctx));
+    }
+    return DAE_OK;
+}
+
+int dae_pipeline_times(dae_pipeline* p, uint64_t out4[4])
+{
+    if (!p || !out4) return DAE_ERR_ARG;
+    std::lock_guard<std::mutex> g(p->mu);
+    out4[0] = p->issue_ns; out4[1] = p->idle_ns; out4[2] = p->submit_ns; out4[3] = p->wait_ns;
+    return DAE_OK;
+}
+
+int dae_pipeline_stats(dae_pipeline* p, uint64_t out3[3])
+{
+    if (!p || !out3) return DAE_ERR_ARG;
+    std::lock_guard<std::mutex> g(p->mu);
+    out3[0] = p->launches; out3[1] = p->next_ticket - 1; out3[2] = p->guard_fallbacks;
+    return DAE_OK;
+}
+
+}  // extern "C"

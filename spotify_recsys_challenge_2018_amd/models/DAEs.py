@@ -573,6 +573,15 @@ class DAE_tied:
                 yield idx, (score if want_scores else None)
             return
         dtype = self._dtype_of(dtype)
+        # THE NATIVE LOOP (default for the plain DAE): the library's own streaming pipeline (include/dae_hip.h
+        # dae_pipeline_*) -- this generator only copies feeds in and hands views of pinned result blocks out; a
+        # library-owned thread issues the launches.  `model.iter_engine = "python"` keeps the interpreter loop below
+        # (what a title model, explicit seed lists or host-built CSRs take anyway).
+        if (self.__dict__.get("iter_copies") or "async") not in ("async", "blocking"):
+            raise ValueError("iter_copies: 'async' or 'blocking'")
+        if (self.__dict__.get("iter_engine", "native") == "native" and type(self)._submit is DAE._submit and self.device_csr):
+            yield from self._recommend_iter_native(feeds, k, dtype, want_scores)
+            return
         self._ensure_packed(dtype)
         if getattr(self, "title_model", None) is not None:
             self.title_model._ensure_packed(_title_dtype(dtype))
@@ -781,6 +790,72 @@ class DAE_tied:
                 for c, _s in lanes:                          # other entry points run ungated
                     c.check(c.lib.dae_set_decode_gate(c.h, None, None))
         self._check_feed()
+
+    def _native_pipe(self, dtype, k, want_scores):
+        """The model's dae_pipeline for (dtype, k, scores wanted): created on first use, again after the weights changed."""
+        key = (int(dtype), int(k), bool(want_scores), self.n_batch)
+        gen = self.__dict__.get("_weights_gen", 0)
+        cache = self.__dict__.setdefault("_pipes", {})
+        ent = cache.get(key)
+        if ent is not None and (ent[0] != gen or ent[1].h is None):
+            ent[1].close()
+            ent = None
+        if ent is None:
+            import torch
+            self._flush_rows_adam()
+            torch.cuda.current_stream(self.device_index).synchronize()      # the weights are final before another thread reads them
+            group = self._coalesce_count(dtype) * self.n_batch
+            # three lanes: measured best in every mode (batch 256, playlists/s through the loop, 2 / 3 / 4 lanes: fp32 0.98 /
+            # 1.29 / 1.06 M, exact_bf16 4.1 / 4.8 / 4.2 M, bf16 5.3 / 6.3 / 5.6 M -- profiles/r04_notes.md)
+            lanes = int(self.__dict__.get("n_lanes") or 3)
+            pipe = _lib.Pipeline(self.weights["encoder_h"], self.biases["encoder_b"], self.weights["decoder_h"],
+                                 self.biases["decoder_b"], self.n_tracks, dtype=dtype, k=k, group_rows=group,
+                                 max_nnz=max(1 << 18, group * 1024), lanes=lanes, want_scores=want_scores,
+                                 device_index=self.device_index)
+            ent = cache[key] = (gen, pipe)
+        return ent[1]
+
+    def _recommend_iter_native(self, feeds, k, dtype, want_scores):
+        pipe = self._native_pipe(dtype, k, want_scores)
+        key = (int(dtype), int(k), bool(want_scores), self.n_batch)
+
+        rows_out = []                # rows each pending feed asked for (a feed is fed as the graph's n_batch rows, DAEs.py:34)
+
+        def out(r):
+            n = rows_out.pop(0)
+            return r[0][:n], (r[1][:n] if want_scores else None)
+        clean = False
+        try:
+            for f in feeds:
+                x_positions, x_ones, seeds, n_rows = f[:4]
+                n = self.n_batch if n_rows is None else int(n_rows)
+                if not (isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT) or len(f) > 4 or n > self.n_batch:
+                    pipe.flush()                                 # a feed the pipeline does not take: in order, through recommend()
+                    while pipe.pending:
+                        yield out(pipe.poll(True))
+                    idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
+                    yield idx, (score if want_scores else None)
+                    continue
+                while not pipe.submit(x_positions, x_ones, self.n_batch):      # every lane full: hand the oldest lists out first
+                    yield out(pipe.poll(True))
+                rows_out.append(n)
+                while True:                                      # ... and whatever else is ready, without waiting
+                    r = pipe.poll(False)
+                    if r is None:
+                        break
+                    yield out(r)
+            pipe.flush()
+            while pipe.pending:
+                yield out(pipe.poll(True))
+            clean = True
+        except _lib.DaeError as e:
+            if "out of range" in str(e) or "outside" in str(e):
+                raise ValueError(str(e))
+            raise
+        finally:
+            if not clean:        # an error, or a consumer that stopped early: feeds may be queued -- this pipeline is not reused
+                self.__dict__.get("_pipes", {}).pop(key, None)
+                pipe.close()
 
     def _coalesce_count(self, dtype=None):
         """Feeds per launch of the streamed loop.  fp32 decode (the device is the limit): the count (<= 8, <= 1024 rows)

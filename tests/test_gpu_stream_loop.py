@@ -13,8 +13,9 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("dtype,B", [("f32", 256), ("bf16", 256), ("f32", 150), ("f32", 250), ("exact_bf16", 256), ("exact_bf16", 150)])
-def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
+def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B, engine):
     """7 feeds (short ones among them) through the streamed loop: coalesced 4 or 5 to a launch (256 / 250 -> 4, the
     reference's challenge batch of 150 -> 5), launches alternating between two contexts."""
     nt, na, H, k = 20000, 4000, 256, 500
@@ -28,6 +29,7 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B):
         save = str(tmp_path / "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
         n_tracks = nt; initval = path
     m = DAE(C()); m.fit()
+    m.iter_engine = engine              # "native": the library's dae_pipeline; "python": the interpreter loop of round 3
     batches = [make_playlists(B, nt, na, seed=10 + s) for s in range(7)]           # odd count: the lanes end unevenly
     rows = [B, B, 100, B, 1, B, 37]                                                # short last batches of a file
     assert m._coalesce_count() == {256: 4, 250: 4, 150: 5}[B]
@@ -92,6 +94,7 @@ def test_recommend_iter_hands_out_leased_pinned_blocks(tmp_path):
         save = str(tmp_path / "unused"); batch = B; n_input = nt + na; hidden = H; lr = 0.005; reg_lambda = 0.0
         n_tracks = nt; initval = path
     m = DAE(C()); m.fit()
+    m.iter_engine = "python"            # (the pool belongs to the interpreter loop; the native loop lends result blocks: below)
     batches = [make_playlists(B, nt, na, seed=30 + s) for s in range(6)]
     want = [m.recommend(p, o, s, k=k) for p, o, s in batches]
     feeds = [(p, o, SEEDS_FROM_INPUT, B) for p, o, _s in batches] * 4
@@ -112,6 +115,73 @@ def test_recommend_iter_hands_out_leased_pinned_blocks(tmp_path):
     assert pool.out == 0 and sum(len(v) for v in pool.free.values()) > 0
     again = list(m.recommend_iter(feeds[:6], k=k))                # served from the free lists
     assert all(np.array_equal(a[0], b[0]) for a, b in zip(again, want))
+
+
+def test_native_pipeline_orders_lends_and_recovers(tmp_path):
+    """dae_pipeline_* directly (include/dae_hip.h): feeds of different sizes come back in submission order with the lists
+    dae_score_topk gives each alone; results are views of pinned blocks that go back when the arrays die and are copied when
+    the caller hoards them; a feed with an index out of range is an error and not a silent skip; the exact mode's bound guard
+    (forged margin) makes the pipeline re-score the launch in fp32 -- the lists stay the fp32 lists."""
+    import gc
+    import torch
+    nt, na, H, k = 9000, 1500, 128, 200
+    V = nt + na
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=6, bias="zipf", n_tracks=nt)
+    W_dec = (W_dec * 40).astype(np.float32)
+    dev = [torch.from_numpy(a).cuda() for a in (W_enc, b_enc, W_dec, b_dec)]
+    path = str(tmp_path / "init.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        save = str(tmp_path / "unused"); batch = 64; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
+        n_tracks = nt; initval = path
+    m = DAE(C()); m.fit()
+    sizes = [64, 17, 64, 1, 40, 64, 64, 5, 64, 33, 64, 64]
+    batches = [make_playlists(n, nt, na, seed=50 + i) for i, n in enumerate(sizes)]
+    want = [m.recommend(p, o, SEEDS_FROM_INPUT, k=k, n_rows=n, dtype="f32") for (p, o, _s), n in zip(batches, sizes)]
+    for dtype in (_lib.DAE_DTYPE_F32, _lib.DAE_DTYPE_BF16_EXACT):
+        pipe = _lib.Pipeline(*dev, nt, dtype=dtype, k=k, group_rows=160, max_nnz=1 << 16, lanes=2, want_scores=True, result_blocks=7)
+        got = []
+        for (p, o, _s), n in zip(batches, sizes):
+            while not pipe.submit(p, o, n):
+                got.append(pipe.poll(True))
+        pipe.flush()
+        while pipe.pending:
+            got.append(pipe.poll(True))
+        assert len(got) == len(want) and pipe.poll(True) is None
+        for (gi, gs), (wi, ws) in zip(got, want):
+            assert gi.shape == wi.shape and np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        st = pipe.stats()
+        assert st["feeds"] == len(sizes) and 0 < st["launches"] < len(sizes) and st["guard_fallbacks"] == 0
+        assert len(pipe._held) <= pipe.max_held          # hoarded results were copied, not lent
+        del got, gi, gs
+        gc.collect()
+        assert not pipe._held
+        if dtype == _lib.DAE_DTYPE_BF16_EXACT:
+            pipe.exact_margin(1e-3)                       # forged bound: the guard fires, the launch is re-scored in fp32
+            for (p, o, _s), n in zip(batches[:4], sizes[:4]):
+                assert pipe.submit(p, o, n)
+            pipe.flush()
+            again = [pipe.poll(True, copy=True) for _ in range(4)]
+            assert pipe.stats()["guard_fallbacks"] >= 1
+            for (gi, gs), (wi, ws) in zip(again, want):
+                assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        # a column out of range: the launch reports it
+        bad = np.array([[0, 1], [1, V + 5]], np.int64)
+        assert pipe.submit(bad, np.ones(2, np.float32), 2)
+        with pytest.raises(_lib.DaeError):
+            pipe.poll(True)
+        pipe.close()
+        # a row outside the feed is refused at submit, and the pipeline lives on
+        pipe = _lib.Pipeline(*dev, nt, dtype=dtype, k=k, group_rows=160, max_nnz=1 << 16, lanes=2)
+        with pytest.raises(_lib.DaeError):
+            pipe.submit(np.array([[7, 1]], np.int64), np.ones(1, np.float32), 2)
+        p0, o0, _ = batches[0]
+        assert pipe.submit(p0, o0, 64)
+        gi, gs = pipe.poll(True)
+        assert np.array_equal(gi, want[0][0])
+        pipe.close()
 
 
 def test_clock_probe_reads_a_plausible_engine_clock():
