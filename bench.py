@@ -109,15 +109,31 @@ def _probe_tensorflow():
         return None if isinstance(e, ImportError) else "import failed: %r" % (e,)
 
 
+def _src_sha(name):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "spotify_recsys_challenge_2018_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def _pmc_json(fname, source_file):
+    """A committed summary of rocprofv3 --pmc passes (scripts/pmc_summarise.py), only while the kernel source it was measured
+    on is the file in the tree (the summary carries sha256[:16] of the .hip file; a changed kernel voids its counters)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
+    except Exception:
+        return {}
+    want = (tj.get("kernel_source_sha256_16") or {}).get(source_file)
+    return tj if (want is not None and want == _src_sha(source_file)) else {}
+
+
 def _pmc_traffic(key, kernel):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes, only if they were taken on this kernel."""
     if key is None:
         return None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_decode.json"))).get(key, {})
-        return tj.get("hbm_bytes_per_launch") if tj.get("kernel") == kernel else None
-    except Exception:
-        return None
+    tj = _pmc_json("traffic_decode.json", "decode_f32.hip").get(key, {})
+    return tj.get("hbm_bytes_per_launch") if tj.get("kernel") == kernel else None
 
 
 def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_artists, H, B, k, dist_name):
@@ -712,10 +728,9 @@ def main():
     kern_avg_ms = kern_ms / max(kern_n, 1)
     achieved_tflops = flop_per_launch / (kern_avg_ms * 1e-3) / 1e12 if kern_avg_ms > 0 else 0.0
     traffic, pmc_mfma = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_decode.json")
-    if os.path.exists(tpath) and world == 1 and args.batch_per_gpu == 256 and not sim:
+    if world == 1 and args.batch_per_gpu == 256 and not sim:
         try:
-            tj = json.load(open(tpath)).get("bf16" if lowp else "f32", {})
+            tj = _pmc_json("traffic_decode.json", "decode_f32.hip").get("bf16" if lowp else "f32", {})
             # PMC passes are separate rocprofv3 runs (scripts/gpu_pmc_traffic.sh); the figure is quoted only when it
             # was collected for the kernel this run timed
             traffic = tj.get("hbm_bytes_per_launch") if tj.get("kernel") == ctx.profile_kernel() else None
@@ -889,10 +904,9 @@ def main():
                                           "distinct_rows_bytes": int(np.unique(colU).size) * 4 * H,
                                           "note": "ids uniform over the vocabulary (worst case for locality)"}
         del hU, dU
-    tpath_e = os.path.join(ROOT, "profiles", "traffic_encode.json")
-    if os.path.exists(tpath_e):
-        try:                                  # PMC passes of scripts/gpu_pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE per launch)
-            te = json.load(open(tpath_e))
+    if True:
+        try:                                  # PMC passes of scripts/gpu_pmc_round4.sh (FETCH_SIZE x2 + WRITE_SIZE per launch)
+            te = _pmc_json("traffic_encode.json", "encode.hip")
             roofline_encode["traffic"] = te.get("step_batch", {}).get("hbm_bytes_per_launch")
             roofline_encode["kernel"] = te.get("step_batch", {}).get("kernel", roofline_encode["kernel"])
             for key in ("large_batch", "uniform_ids"):
@@ -929,7 +943,8 @@ def main():
     }
     if roofline.get("traffic") is not None:
         roofline["traffic_source"] = ("profiles/traffic_decode.json: FETCH_SIZE x 2 + WRITE_SIZE of this kernel from separate "
-                                      "rocprofv3 --pmc passes (scripts/gpu_pmc_round3.sh), not counters of this run")
+                                      "rocprofv3 --pmc passes (scripts/gpu_pmc_round4.sh), not counters of this run; quoted only while "
+                                      "sha256 of csrc/decode_f32.hip equals the one stamped into that file")
     if sharded:
         # what the collectives of this run really spanned (n_gpus above is WORLD_SIZE from the launcher's environment)
         coll = {"world": dist.get_world_size(), "backend": dist.get_backend(), "exchange": args.exchange}

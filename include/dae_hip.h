@@ -123,7 +123,7 @@ int dae_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, 
  * (main_challenge.py:76-88 `seed` = the track ids x_positions feeds; main_train.py:64-89 `test_seed` likewise): the
  * columns < n_tracks of every row of the input CSR, as a CSR (seed_row_ptr [B+1], seed_col with room for
  * row_ptr[B] entries; sorted and unique per row because the input rows are).  Saves the host the list handling and
- * two uploads per batch.  B <= 16384. */
+ * two uploads per batch.  Any B (slabs of 16384 rows inside). */
 int dae_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
                        int32_t* seed_row_ptr, int32_t* seed_col);
 

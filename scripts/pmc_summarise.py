@@ -6,7 +6,6 @@ import collections
 import csv
 import json
 import os
-import subprocess
 import sys
 
 root = sys.argv[1]
@@ -43,15 +42,23 @@ def find(d, sub):
     return None, {}
 
 
-try:
-    sha = subprocess.check_output(["git", "-C", os.path.dirname(root), "rev-parse", "--short", "HEAD"], text=True).strip()
-except Exception:
-    sha = os.environ.get("DAE_GIT_SHA", "unknown")
+def src_sha(name):
+    """sha256[:16] of a kernel source file as it is on the box that ran the passes: bench.py quotes a counter figure only
+    while the file it was measured on is the file in the tree (no hand-stamped commit ids)."""
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return hashlib.sha256(open(os.path.join(here, "spotify_recsys_challenge_2018_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+sha = {n: src_sha(n) for n in ("decode_f32.hip", "refine.hip", "encode.hip", "train.hip", "dae_internal.h")}
 dec = {"source": "rocprofv3 --kernel-trace --pmc <set>, one pass per counter set (scripts/gpu_pmc_round3.sh): bench.py "
                  "--streams 1 --steps 6, default workload (B=256, V=170000, H=256); raw CSVs profiles/%s_pmc_*.csv" % PFX,
        "fetch_correction": "hbm_bytes_per_launch = FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half) + "
-                           "WRITE_SIZE; counters are KB", "git": sha}
-enc = {"source": dec["source"], "fetch_correction": dec["fetch_correction"], "git": sha}
+                           "WRITE_SIZE; counters are KB", "kernel_source_sha256_16": sha}
+enc = {"source": dec["source"], "fetch_correction": dec["fetch_correction"], "kernel_source_sha256_16": sha}
 for cfg, ksub, peak_mops in (("f32", "decode_f32_h256_filter_kernel", "SQ_INSTS_VALU_MFMA_MOPS_F32"),
                              ("bf16", "decode_bf16_h256_filter_kernel", "SQ_INSTS_VALU_MFMA_MOPS_BF16")):
     f = per_kernel(os.path.join(root, "%s_pmc_%s_fetch.csv" % (PFX, cfg)))
@@ -102,6 +109,22 @@ for key, sub in (("exact_refine", "exact_refine"), ("exact_filter", "decode_bf16
         fetch, write = mean(fd.get("FETCH_SIZE", [0])), mean(wd.get("WRITE_SIZE", [0]))
         dec[key] = {"kernel": short_name(kn), "launches": len(fd.get("FETCH_SIZE", [])), "fetch_size_kb": round(fetch, 1),
                     "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
+# the training step's HBM-bound launches (scripts/bench_train.py --default under --pmc)
+f = per_kernel(os.path.join(root, "%s_pmc_train_fetch.csv" % PFX))
+w = per_kernel(os.path.join(root, "%s_pmc_train_write.csv" % PFX))
+trn = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python scripts/bench_train.py --default",
+       "fetch_correction": dec["fetch_correction"], "kernel_source_sha256_16": sha}
+for key, sub in (("grad_wdec_adam", "grad_wdec_t_kernel"), ("loss_forward", "decode_loss_rowmajor_bf16_kernel"),
+                 ("grad_hidden", "grad_hidden_kernel"), ("adam_rows_apply", "adam_rows_kernel<1>"), ("adam_rows_begin", "adam_rows_kernel<0>")):
+    kn, fd = find(f, sub)
+    _, wd = find(w, sub)
+    if kn:
+        fetch, write = mean(fd.get("FETCH_SIZE", [0])), mean(wd.get("WRITE_SIZE", [0]))
+        trn[key] = {"kernel": short_name(kn), "launches": len(fd.get("FETCH_SIZE", [])), "fetch_size_kb": round(fetch, 1),
+                    "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
+if len(trn) > 3:
+    json.dump(trn, open(os.path.join(root, "traffic_train.json"), "w"), indent=1)
+    print(json.dumps(trn, indent=1))
 json.dump(dec, open(os.path.join(root, "traffic_decode.json"), "w"), indent=1)
 json.dump(enc, open(os.path.join(root, "traffic_encode.json"), "w"), indent=1)
 print(json.dumps(dec, indent=1))

@@ -305,12 +305,12 @@ constexpr int SEED_MAX_ROWS = 16384;
 __global__ __launch_bounds__(1024) void seeds_from_csr_kernel(const int32_t* __restrict__ row_ptr,
                                                               const int32_t* __restrict__ col, int B, int n_tracks,
                                                               int32_t* __restrict__ seed_row_ptr,
-                                                              int32_t* __restrict__ seed_col)
+                                                              int32_t* __restrict__ seed_col, const int32_t* base)
 {
     extern __shared__ int s_off[];                                // [B + 1]
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int carry = 0;
+    int carry = base ? *base : 0;                                 // a later slab of a long batch continues the offsets
     for (int r0 = 0; r0 < B; r0 += 1024) {
         const int r = r0 + tid;
         int cnt = 0;
@@ -362,15 +362,20 @@ __global__ __launch_bounds__(256) void seeds_copy_kernel(const int32_t* __restri
 int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
                               int32_t* seed_row_ptr, int32_t* seed_col)
 {
-    if (B > SEED_MAX_ROWS) return dae_fail(ctx, DAE_ERR_ARG, "seeds_from_csr: %d rows (max %d)", B, SEED_MAX_ROWS);
     static const char attr_key = 0;          // (B + 1) offsets in LDS: above 64 KiB from B = 16 383 on
     if (dae_first_use(ctx, &attr_key))
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&seeds_from_csr_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)((SEED_MAX_ROWS + 1) * sizeof(int))));
-    hipLaunchKernelGGL(seeds_from_csr_kernel, dim3(1), dim3(1024), (size_t)(B + 1) * sizeof(int), ctx->stream, row_ptr,
-                       col, B, n_tracks, seed_row_ptr, seed_col);
-    DAE_CHECK_LAUNCH(ctx, "seeds_from_csr_kernel");
+    // any number of rows, in slabs of SEED_MAX_ROWS: a slab's offsets start where the one before ended (seed_row_ptr[r0],
+    // read on the device: the launches are stream-ordered)
+    for (int r0 = 0; r0 < B || r0 == 0; r0 += SEED_MAX_ROWS) {
+        const int nb = B - r0 < SEED_MAX_ROWS ? B - r0 : SEED_MAX_ROWS;
+        hipLaunchKernelGGL(seeds_from_csr_kernel, dim3(1), dim3(1024), (size_t)(nb + 1) * sizeof(int), ctx->stream, row_ptr + r0,
+                           col, nb, n_tracks, seed_row_ptr + r0, seed_col, r0 ? seed_row_ptr + r0 : nullptr);
+        DAE_CHECK_LAUNCH(ctx, "seeds_from_csr_kernel");
+        if (B <= SEED_MAX_ROWS) break;
+    }
     if (B > 0) {
         hipLaunchKernelGGL(seeds_copy_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, row_ptr, col, B, seed_row_ptr,
                            seed_col);
