@@ -181,9 +181,9 @@ int dae_exact_bounds(dae_ctx* ctx, float* eps_out);
  * The ranking values that reach main_challenge.py:26-36's argsort are fp32 either way: the guard protects the SET. */
 int dae_exact_guard_read(dae_ctx* ctx, int32_t* violations, int32_t* column);
 int dae_exact_guard_words(dae_ctx* ctx, const int32_t** words_dev);
-/* How selective the filter was (the exact mode's rate depends on it, its results never): since the last read, summed over
- * the refine launches of this context, out3 = {rows refined, candidates the bf16 filter launch left for them, candidates
- * recomputed in fp32 after the narrowing step}.  Synchronises the ctx stream; resets the sums. */
+/* How selective the filter was (the exact mode's rate depends on it, its results never): of the LAST exact scoring launch
+ * of this context, out3 = {rows refined, candidates the bf16 filter launch left for them (sum over the rows), candidates
+ * recomputed in fp32 after the narrowing step (sum)}.  Synchronises the ctx stream. */
 int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3]);
 
 /* Factor on every eps_c computed by the NEXT dae_prepack_decoder(DAE_DTYPE_BF16_EXACT) of this context (default 1).

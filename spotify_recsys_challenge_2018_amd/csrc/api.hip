@@ -42,7 +42,7 @@ int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes)
     return DAE_OK;
 }
 
-constexpr size_t DAE_GUARD_BYTES = 2 * sizeof(int) + 3 * sizeof(uint64_t);   // {violations, column} + {rows, candidates, recomputed}
+constexpr size_t DAE_GUARD_BYTES = 2 * sizeof(int);   // {violations, column}
 
 namespace {
 
@@ -149,7 +149,7 @@ int dae_destroy(dae_ctx* ctx)
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
-                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
+                       &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -365,11 +365,13 @@ int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3])
     if (!ctx) return DAE_ERR_ARG;
     if (!out3) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
     out3[0] = out3[1] = out3[2] = 0;
-    if (!ctx->guard.p) return DAE_OK;
-    char* st = static_cast<char*>(ctx->guard.p) + 2 * sizeof(int);
-    DAE_HIP_CHECK(ctx, hipMemcpyAsync(out3, st, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    DAE_HIP_CHECK(ctx, hipMemsetAsync(st, 0, 3 * sizeof(uint64_t), ctx->stream));
+    const int n = ctx->refstat_rows;
+    if (!ctx->refstat.p || n <= 0) return DAE_OK;
+    std::vector<int> h((size_t)2 * n);
+    DAE_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), ctx->refstat.p, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     DAE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    out3[0] = (uint64_t)n;
+    for (int r = 0; r < n; ++r) { out3[1] += (uint64_t)h[2 * r]; out3[2] += (uint64_t)h[2 * r + 1]; }
     return DAE_OK;
 }
 
@@ -617,7 +619,10 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
         if (rc) return rc;
         uint2* rf = static_cast<uint2*>(ctx->refined.p);
         int* rf_cnt = reinterpret_cast<int*>(rf + (size_t)g.Bpad * DAE_REFINED_CAP);
-        rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr, rf, rf_cnt, DAE_REFINED_CAP);
+        rc = dae_reserve(ctx, ctx->refstat, (size_t)g.Bpad * 2 * sizeof(int));
+        if (rc) return rc;
+        ctx->refstat_rows = B;
+        rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr, rf, rf_cnt, DAE_REFINED_CAP, static_cast<int*>(ctx->refstat.p));
         if (rc) return rc;
         dae_pair_group gr{rf, rf_cnt, 0, DAE_REFINED_CAP, 0, 1, 0};
         return dae_launch_topk_pairs(ctx, gr, g1, ta);

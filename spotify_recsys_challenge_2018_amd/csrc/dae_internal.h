@@ -116,6 +116,7 @@ struct dae_ctx {
     int overlap_hint = 0;      // dae_set_overlap_hint: other batches are in flight on other streams -> kernel shapes that share CUs
     dae_buf row_bad;           // DAE_DTYPE_BF16_EXACT via dae_decode_topk: [Bpad] int32, 1 = the caller's hidden row leaves [0, 1]
     dae_buf refined;           // DAE_DTYPE_BF16_EXACT: [Bpad][DAE_REFINED_CAP] (fp32 logit, column) pairs + [Bpad] counts (refine.hip)
+    dae_buf refstat; int refstat_rows = 0;   // DAE_DTYPE_BF16_EXACT: [rows][2] {candidates, recomputed} of the last refine launch
     dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
 
@@ -397,4 +398,5 @@ struct dae_exact_src {
 // out / out_cnt / out_cap (nullable): per row a compact list [out_cap] of the survivors' (fp32 logit, column) pairs and its
 // length; rows that fit get it filled and their g1 lists emptied (counts zeroed), the others are refined in place
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
-                            const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0);
+                            const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0,
+                            int* stat = nullptr);

@@ -39,6 +39,7 @@ struct RefineP {
     dae_exact_src x;
     const int32_t* seed_row_ptr; int k;
     uint2* out; int* out_cnt; int out_cap;        // compact output lists [row][out_cap] + counts (see the header comment)
+    int* stat;                                    // nullable: [B][2] {candidates, recomputed} of this launch
     long long* stamps;                            // experiments build: stage stamps of workgroup 0 (DAE_DBG_R)
 };
 
@@ -88,6 +89,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     const int total = seg_prefix[nseg];
     if (total == 0) {
         if (tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
+        if (tid == 0 && p.stat) { p.stat[2 * row] = 0; p.stat[2 * row + 1] = 0; }
         return;
     }
     const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
@@ -320,11 +322,12 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             p.x.guard[1] = colv;
         }
     };
-    // statistics of the context (dae_exact_stats_read): rows refined, candidates the filter launch left, candidates recomputed
-    if (tid == 0 && p.x.guard) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.x.guard + 2);
-        atomicAdd(st + 0, 1ull); atomicAdd(st + 1, (unsigned long long)total);
-        if (!staged) atomicAdd(st + 2, (unsigned long long)n_kept);      // (narrowed rows add their count when it is known)
+    // statistics of the launch (dae_exact_stats_read): per row, the candidates the filter launch left and the candidates
+    // recomputed -- PLAIN stores into the row's own slots (three device-scope atomics per row on shared words cost the launch
+    // 7 of its 27 us: 256 workgroups queueing on one address)
+    if (tid == 0 && p.stat) {
+        p.stat[2 * row] = total;
+        if (!staged) p.stat[2 * row + 1] = n_kept;                // (narrowed rows store their count when it is known)
     }
     // the row's per-workgroup lists are empty from here on (compact), its own list holds n_kept entries
     auto finish_compact = [&](int n_written) {
@@ -420,7 +423,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         }
     }
     RSTAMP(6)                                                    // recomputed
-    if (tid == 0 && p.x.guard) atomicAdd(reinterpret_cast<unsigned long long*>(p.x.guard + 2) + 2, (unsigned long long)n_out);
+    if (tid == 0 && p.stat) p.stat[2 * row + 1] = n_out;
     if (compact) finish_compact(n_out);
     RSTAMP(7)
 }
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 }  // namespace
 
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
-                            const int32_t* seed_row_ptr, uint2* out, int* out_cnt, int out_cap)
+                            const int32_t* seed_row_ptr, uint2* out, int* out_cnt, int out_cap, int* stat)
 {
     if (B <= 0) return DAE_OK;
     if (g1.nseg > RF_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
@@ -444,6 +447,7 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     RefineP p;
     p.base = const_cast<uint2*>(g1.base); p.cnt = const_cast<int*>(g1.cnt); p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;
     p.cnt_seg_stride = g1.cnt_seg_stride; p.nseg = g1.nseg; p.x = x; p.seed_row_ptr = seed_row_ptr; p.k = k;
+    p.stat = stat;
     p.out = (out && out_cnt && out_cap > 0) ? out : nullptr; p.out_cnt = p.out ? out_cnt : nullptr; p.out_cap = p.out ? out_cap : 0;
     if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
