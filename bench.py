@@ -60,8 +60,9 @@ def parse():
                          "the bf16 GEMM as a filter + fp32 recomputation of the survivors (north_star: the fp32 lists, bit for bit)")
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: each has its own library context and HIP stream, so the "
-                         "latency-bound kernels of one batch overlap the decode of the other.  Default: 2 for f32 (a third "
-                         "only stretches the fp32 MFMA launches), 3 for bf16 (short launches that leave the CUs room)")
+                         "latency-bound kernels of one batch overlap the decode of the other.  Default: 3 for f32 (gated: the "
+                         "dominant launches take turns; round 4 measured 1.32 / 1.39 / 1.38 M playlists/s at 2 / 3 / 4), 4 for the "
+                         "bf16 modes (short launches that leave the CUs room)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the sharded code path (RCCL all-gather + merge) even at world size 1")
     ap.add_argument("--sim-world", type=int, default=0,
@@ -430,7 +431,8 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
     k = 0
     for name, dt, fz, ra in (("f32", _lib.DAE_DTYPE_F32, False, False), ("bf16_gemms", _lib.DAE_DTYPE_BF16, False, False),
                              ("bf16_gemms_decoder_adam_in_kernel", _lib.DAE_DTYPE_BF16, H % 128 == 0, False),
-                             ("model_default_bf16", _lib.DAE_DTYPE_BF16, H % 128 == 0, True)):
+                             ("model_default_bf16", _lib.DAE_DTYPE_BF16, H % 128 == 0, True),
+                             ("model_default_f32", _lib.DAE_DTYPE_F32, H % 128 == 0, True)):
         ctx.set_train_dtype(dt)
         fuse[0] = fz
         n_t = 20
@@ -482,6 +484,17 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
     rows[0] = None
     ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 0))
     ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
+    # the step's largest kernels against their own roofs: rocprofv3 averages of the committed profiles (scripts/gpu_round4.sh,
+    # scripts/train_top3.py), quoted only for this shape and while csrc/train.hip is the file they were measured on
+    try:
+        tk = json.load(open(os.path.join(ROOT, "profiles", "r04_train_top3.json")))
+        if tk.get("shape") == [B, V, H] and tk.get("train_hip_sha256_16") == _src_sha("train.hip"):
+            for name in ("f32", "bf16_gemms", "model_default_bf16"):
+                if name in row and name in tk:
+                    row[name]["top_kernels"] = tk[name]
+            row["top_kernels_source"] = tk.get("source")
+    except Exception:
+        pass
     row["note"] = ("NOT the headline.  model_default_bf16 is the step models/DAEs.py runs with train_dtype = bf16 (decoder Adam in "
                    "the gradient kernel, rows-Adam on the encoder: bit-identical parameters, no HBM passes over rows without "
                    "gradient); scripts/bench_epoch.py times that loop with the reader and the device CSR builds")
@@ -564,7 +577,7 @@ def main():
             c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
 
     lowp = args.dtype in ("bf16", "exact_bf16")          # the GEMM launches run on bf16 operands
-    n_str = args.streams if args.streams > 0 else (4 if lowp else 2)
+    n_str = args.streams if args.streams > 0 else (4 if lowp else 3)       # fp32: three gated batches in flight (r04: 1.39 M against 1.32 M with two)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     ctx = ctxs[0]
