@@ -577,7 +577,8 @@ def main():
             c.prepack_decoder(d_Wd, d_bd, col_lo, col_hi, dtype=dt)
 
     lowp = args.dtype in ("bf16", "exact_bf16")          # the GEMM launches run on bf16 operands
-    n_str = args.streams if args.streams > 0 else (4 if lowp else 3)       # fp32: three gated batches in flight (r04: 1.39 M against 1.32 M with two)
+    n_str = args.streams if args.streams > 0 else (4 if lowp else (2 if sharded else 3))    # fp32: three gated batches in flight (r04: 1.39 M
+    # against 1.32 M with two); a vocabulary shard keeps two (--sim-world 8: 0.249 ms per rank step with two, 0.269 ms with three)
     ctxs = [_lib.Context(local_rank) for _ in range(n_str)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_str)]
     ctx = ctxs[0]
