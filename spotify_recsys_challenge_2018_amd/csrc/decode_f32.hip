@@ -1298,11 +1298,23 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int cg = p.col_lo + t[nt] * 32 + 4 * hi;
+                        // two neighbouring values that both pass leave as ONE 16-byte store: in the hottest tiles of the
+                        // bias-ordered list nearly every value passes, and their 16 scattered 8-byte stores per lane and row
+                        // block made those tiles cost 21 k cycles against 4 k (profiles/r03_notes.md) -- the launch's tail
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            if (m[nt] & (1u << reg))
-                                dst[at++] = make_uint2(__float_as_uint(acc[nt][rb][reg]),
-                                                       (unsigned)(cg + (reg & 3) + 8 * (reg >> 2)));
+                        for (int reg = 0; reg < 16; reg += 2) {
+                            const unsigned two = (m[nt] >> reg) & 3u;
+                            const uint2 e0 = make_uint2(__float_as_uint(acc[nt][rb][reg]), (unsigned)(cg + (reg & 3) + 8 * (reg >> 2)));
+                            const uint2 e1 = make_uint2(__float_as_uint(acc[nt][rb][reg + 1]),
+                                                        (unsigned)(cg + ((reg + 1) & 3) + 8 * ((reg + 1) >> 2)));
+                            if (two == 3u) {
+                                *reinterpret_cast<uint4*>(dst + at) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+                                at += 2;
+                            } else if (two == 1u) {
+                                dst[at++] = e0;
+                            } else if (two == 2u) {
+                                dst[at++] = e1;
+                            }
                         }
                     }
                 }
