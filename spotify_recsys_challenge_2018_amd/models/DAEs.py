@@ -553,6 +553,16 @@ class DAE_tied:
         score, idx, _ev = self._submit(x_positions, x_ones, seeds, k, dtype, side_stream=False)
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
         self._check_feed()
+        if dtype == _lib.DAE_DTYPE_BF16_EXACT and type(self)._submit is DAE._submit:
+            # the exact mode's BOUND GUARD (include/dae_hip.h dae_exact_guard_read): a recomputed survivor outside the interval
+            # the bf16 filter promised means the lists of this call are unproven -- the same call again on the fp32 kernels
+            n_bad, col = self.ctx.exact_guard_read()
+            if n_bad:
+                import warnings
+                warnings.warn("exact_bf16: the bound guard fired (%d survivors, e.g. column %d): this batch is re-scored with "
+                              "the fp32 kernels" % (n_bad, col))
+                self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
+                return self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=_lib.DAE_DTYPE_F32)
         return res
 
     def recommend_iter(self, feeds, k=500, dtype=None, want_scores=True):
