@@ -32,7 +32,7 @@ import numpy as np
 # Four batches in flight need four hardware queues of their own: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES (default
 # 4, one of them taken by the null stream) and streams that share a queue serialise (bf16 row: 5.9 -> 8.5 M playlists/s).
 # Read by the runtime when it initialises, i.e. before torch is imported below.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -165,8 +165,10 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
     row = {"unit": "playlists/s", "what": _drivers_loop_row.__doc__.split("\n\n")[0].replace("\n    ", " "),
            "feeds_per_launch": {}}
     first = {}
-    for name, reps in (("f32", 25), ("exact_bf16", 60), ("bf16", 60)):
-        for i_, (idx_, _s) in enumerate(m.recommend_iter(feeds(3), k=k, want_scores=False, dtype=name)):
+    for name, reps, warm in (("f32", 40, 5), ("exact_bf16", 120, 15), ("bf16", 120, 15)):
+        # warm-up: ~0.3 s of the same loop (the row follows seconds of host-only work: the device is back at its sustained
+        # state before the timed pass, as for the headline's prime phase)
+        for i_, (idx_, _s) in enumerate(m.recommend_iter(feeds(warm), k=k, want_scores=False, dtype=name)):
             if i_ == 0:
                 first[name] = idx_.copy()
         torch.cuda.synchronize()
@@ -178,8 +180,9 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
         row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B}
         row["feeds_per_launch"][name] = m._coalesce_count(m._dtype_of(name))
     row["exact_bf16"]["identical_to_fp32_lists"] = bool(np.array_equal(first["f32"], first["exact_bf16"]))
+    row["engine"] = "native (dae_pipeline_*: a library-owned thread issues the launches; models/DAEs.py recommend_iter)"
     row["note"] = ("NOT the headline: host feeds in, host lists out (indices only; seeds = the playlist's own tracks, cut "
-                   "out of the input on the device).  scripts/bench_shim.py is the longer version")
+                   "out of the input on the device).  scripts/bench_loop.py is the longer version (both engines, lane counts)")
     return row
 
 

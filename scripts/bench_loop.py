@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spotify_recsys_challenge_2018_amd.models.DAEs import DAE, SEEDS_FROM_INPUT          # noqa: E402
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights   # noqa: E402
@@ -43,8 +43,8 @@ def main():
             for nl in lanes:
                 m.n_lanes = nl or None
                 m.__dict__.pop("_pipes", None)
-                for _ in m.recommend_iter(feeds(2), k=500, want_scores=False, dtype=mode):
-                    pass
+                for _ in m.recommend_iter(feeds(40 if mode == "f32" else 120), k=500, want_scores=False, dtype=mode):
+                    pass                                          # (~0.3 s: the device at its sustained state, as bench.py's prime phase)
                 torch.cuda.synchronize()
                 reps = 100 if mode == "f32" else 300
                 t0 = time.perf_counter()
