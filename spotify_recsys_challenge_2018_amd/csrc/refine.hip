@@ -40,6 +40,7 @@ struct RefineP {
     const int32_t* seed_row_ptr; int k;
     uint2* out; int* out_cnt; int out_cap;        // compact output lists [row][out_cap] + counts (see the header comment)
     int* stat;                                    // nullable: [B][2] {candidates, recomputed} of this launch
+    int stage_cap;                                // candidates of a row the staging area holds (the launch's dynamic LDS)
     long long* stamps;                            // experiments build: stage stamps of workgroup 0 (DAE_DBG_R)
 };
 
@@ -110,7 +111,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     unsigned* skey = reinterpret_cast<unsigned*>(rf_dyn);         // staged bounds as order-preserving keys
     float taup = bad ? __builtin_inff() : -__builtin_inff();
     unsigned ktau = 0u;                                          // its key (narrowed rows)
-    const bool staged = !bad && total <= RF_STAGE && total > need + (need >> 1);   // narrowing pays when it can drop a third
+    const bool staged = !bad && total <= p.stage_cap && total > need + (need >> 1);   // narrowing pays when it can drop a third
     int n_kept = bad ? 0 : total;
     if (staged) {
         // the candidates' bounds as order-preserving KEYS, staged by segment: wave w takes segments w, w + RF_WAVES, ...,
@@ -469,16 +470,25 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
         }
     }
 #endif
-    size_t dyn = (size_t)RF_STAGE * sizeof(float);
-    if (dyn < (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float)) dyn = (size_t)8 * 64 * RF_ROWSTRIDE * sizeof(float);
+    // Many rows per CU (>= 3 at 768 rows): the 256-thread shape with HALF the staging area -- 57 KB of LDS and ~100 registers,
+    // so two or three rows share a CU and one's memory round trips (counts, pairs, decoder rows) hide under another's
+    // arithmetic; a row is latency-bound on its own (batch 1024: 60 -> see profiles/r04_notes.md).  Rows with more candidates
+    // than the smaller area holds are recomputed without narrowing (slower, same bits).
+    const bool many = B >= 768;
+    const bool slim = ctx->overlap_hint || many;
+    p.stage_cap = many ? RF_STAGE / 2 : RF_STAGE;
+    size_t dyn = (size_t)p.stage_cap * sizeof(float);
+    const size_t tb = (size_t)(slim ? 4 : 8) * 64 * RF_ROWSTRIDE * sizeof(float);
+    if (dyn < tb) dyn = tb;
     static const char key = 0;
     if (dae_first_use(ctx, &key)) {
+        const int mx = (int)((size_t)RF_STAGE * sizeof(float));
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_slim_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     }
-    if (ctx->overlap_hint)
+    if (slim)
         hipLaunchKernelGGL(exact_refine_slim_kernel, dim3(B), dim3(256), dyn, ctx->stream, p);
     else
         hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(512), dyn, ctx->stream, p);
