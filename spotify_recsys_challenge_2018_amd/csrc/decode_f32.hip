@@ -1132,6 +1132,11 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     // ring as soon as the ids are here and the tile has been handed to LDS -- it streams from HBM while the workgroup
     // meets.  The straight order (tile, barrier, thresholds, ids, W) was one more dependent trip to memory before the
     // first MFMA; keeping the tile's registers live across the ring's loads made the compiler park them in scratch.
+    // WHICH groups a wave decodes: its first two by position (wave w: the w-th and the (NW + w)-th group of the workgroup's
+    // share {bir + m nb_rg}), every further one CLAIMED from a counter in LDS, two groups ahead of its use.  A wave that
+    // drew one of the hottest tiles of the bias-ordered list (nearly every value passes: 16 - 20 k cycles of appends against
+    // 4 k for an ordinary tile, stage stamps DAE_DBG_F) then simply takes fewer tiles, instead of setting the end of the
+    // launch with the static share it had before (42 k cycles against 32 k for a workgroup without a hot tile).
     int t[NT], u[NT];                                            // tiles of this / the next group (uniform)
     int tv0[NT], tv1[NT];
     const bool has = grp0 < n_grp;
@@ -1151,6 +1156,8 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
+    int* claim = reinterpret_cast<int*>(ltau + R_TILE);          // next unclaimed group of the workgroup (in units of nb_rg)
+    if (tid == 0) *claim = 2 * NW;
     {
         const float4* hsrc = p.hp + (size_t)rg * n_h4;
 #pragma unroll
@@ -1200,9 +1207,16 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
 
-    for (int grp = grp0; grp < n_grp; grp += n_ws) {
-        const int gn = grp + n_ws < n_grp ? grp + n_ws : grp;
-        const int gnn = gn + n_ws < n_grp ? gn + n_ws : gn;
+    int g_nxt = grp0 + n_ws;
+    int n_done = 0;
+    for (int grp = grp0; grp < n_grp;) {
+        int g_nn;
+        {
+            int n2 = 0;
+            if (lane == 0) n2 = atomicAdd(claim, 1);
+            g_nn = __builtin_amdgcn_readfirstlane(n2) * p.nb_rg + bir;
+        }
+        const int gnn = g_nn < n_grp ? g_nn : grp;                // (a group that exists: its tile id is read, never used)
         int wv[NT];
         const uint4 *cur[NT], *nxt[NT];
 #pragma unroll
@@ -1322,7 +1336,9 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { t[nt] = u[nt]; u[nt] = __builtin_amdgcn_readfirstlane(wv[nt]); }
-        FSTAMP(3 + (grp - grp0) / n_ws)                          // tile (group) done, epilogue included
+        FSTAMP(3 + (n_done < 9 ? n_done : 9))                    // tile (group) done, epilogue included
+        ++n_done;
+        grp = g_nxt; g_nxt = g_nn;
     }
     FSTAMP(13)
     __syncthreads();
@@ -2256,7 +2272,7 @@ int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, cons
             }
         }
 #endif
-        const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * (sizeof(int) + sizeof(float));
+        const size_t lds = (size_t)(g.R_TILE / 32) * 64 * 16 * sizeof(float4) + (size_t)g.R_TILE * (sizeof(int) + sizeof(float)) + 16;     // (+ the claim counter)
         static const char attr_set_key = 0;
         if (dae_first_use(ctx, &attr_set_key)) {
             DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_filter_kernel<1, 4, 8, 8>),
