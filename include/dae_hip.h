@@ -54,7 +54,8 @@ typedef struct dae_ctx dae_ctx;
  * fp32 fmaf chain before they are ranked.  Accepted by dae_prepack_decoder (bf16 image + bounds + a row-major fp32
  * copy of the decoder rows), dae_score_topk and dae_decode_topk.  Precondition of the bound: hidden activations in
  * [0, 1] (sigmoid outputs, DAEs.py:66-67) -- always true in dae_score_topk; a row passed to dae_decode_topk that
- * violates it returns no recommendations (idx -1, score -inf).  Not available with dae_set_score_mix. */
+ * violates it returns no recommendations (idx -1, score -inf).  Not available with dae_set_score_mix: the title mix
+ * has its own exact entry point, dae_mix_topk_exact. */
 #define DAE_DTYPE_BF16_EXACT 2
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -417,6 +418,26 @@ int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, flo
 int dae_decode_mix_term(dae_ctx* ctx, const float* h, int B, int H, int dtype, const float* row_scale, int n_cols,
                         float* outT, int64_t ldT);
 int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, const float* w_title);
+
+/* DAE_DTYPE_BF16_EXACT for the title mix: the top-k of y = sigmoid(z_title) * w_title + sigmoid(z_dae) * w_playlist
+ * (DAEs.py:176-181; what main_challenge.py:80-90 ranks for every titled batch) BIT-IDENTICAL to the fp32 path above
+ * (dae_decode_mix_term + dae_set_score_mix + dae_decode_topk, or dae_mix_scores + dae_topk_dense), with both vocabulary-
+ * wide GEMMs on v_mfma_f32_32x32x16_bf16: one launch decodes each 32-column tile against the hidden rows of BOTH scorers
+ * on bounds of the two logits (sample: lower bounds -> threshold; filter: upper bounds -> candidates), and the candidates'
+ * logits are recomputed with the canonical fp32 chains and mixed with dae_mix_scores' operations before they are ranked.
+ * No [B, V] matrix and no transposed term.  Called on the TITLE scorer's context; `dae` is the DAE's.  Both must hold
+ * their weights prepacked with DAE_DTYPE_BF16_EXACT over the same columns [0, V) (DAE: hidden 256; title: Output_W^T in
+ * rows of 448), and be bound to the same stream.  feat [B][ld_feat]: title features (dae_title_features; any finite
+ * values -- the bound scales with the row's largest |feature|), h [B][ld_h]: the DAE's fp32 hidden rows (dae_encode),
+ * w_title / w_playlist [B] in [0, 1] (DAEs.py:159-162).  Rows that violate a precondition return no recommendations
+ * (idx -1).  The bound guard of the plain exact mode covers both GEMMs: dae_exact_guard_read / _words on the title
+ * context; a row with more than 8192 candidates also counts there (column -2).  guard_out (nullable, DEVICE int32[2]):
+ * receives the guard words {violations so far, a violating column} in stream order, for a fetch alongside the lists --
+ * a count that grew since the previous launch's means THIS launch is not to be trusted (re-score it with
+ * DAE_DTYPE_F32).  out_score holds y.  B <= 4096. */
+int dae_mix_topk_exact(dae_ctx* title_ctx, dae_ctx* dae, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h,
+                       int B, const float* w_title, const float* w_playlist, int n_tracks, const int32_t* seed_row_ptr,
+                       const int32_t* seed_col, int k, float* out_score, int32_t* out_idx, int32_t* guard_out);
 
 /* Training of the title variables (main_train.py:214-221 feeds the playlist as x AND y, titles_use = 1; the DAE
  * arrays are constants, DAEs.py:165-171).  The caller runs the forward pieces -- dae_encode (dropout on) +

@@ -19,7 +19,7 @@ EXPORTS = [
     "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
     "dae_pipeline_create", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_flush", "dae_pipeline_poll",
@@ -97,6 +97,7 @@ def load():
     lib.dae_mix_scores.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, c_int, c_int]
     lib.dae_decode_mix_term.argtypes = [vp, vp, c_int, c_int, c_int, vp, c_int, vp, c_i64]
     lib.dae_set_score_mix.argtypes = [vp, vp, c_i64, c_int, vp]
+    lib.dae_mix_topk_exact.argtypes = [vp, vp, vp, c_i64, vp, c_i64, c_int, vp, vp, c_int, vp, vp, c_int, vp, vp, vp]
     lib.dae_row_sums.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp]
     lib.dae_title_loss_backward.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, c_int, c_int, c_int,
                                             vp, c_int, vp, vp, vp, vp, vp]
@@ -348,6 +349,15 @@ class Context:
         """dae_decode_topk on this context ranks sigmoid(.) * w_title[r] + mixT[c, r] until cleared (no arguments)."""
         self.check(self.lib.dae_set_score_mix(self.h, _ptr(mixT), int(mixT.stride(0)) if mixT is not None else 0,
                                               int(mixT.shape[0]) if mixT is not None else 0, _ptr(w_title)))
+
+    def mix_topk_exact(self, dae_ctx, feat, h, w_title, w_playlist, n_tracks, seed_row_ptr, seed_col, k, out_score, out_idx,
+                       guard_out=None):
+        """On the title scorer's context: top-k of the title mix, bit-identical to the fp32 path, both GEMMs on bf16
+        operands (dae_mix_topk_exact; both contexts prepacked with DAE_DTYPE_BF16_EXACT and bound to the same stream)."""
+        B = h.shape[0]
+        self.check(self.lib.dae_mix_topk_exact(self.h, dae_ctx.h, _ptr(feat), int(feat.stride(0)), _ptr(h), int(h.stride(0)),
+                                               int(B), _ptr(w_title), _ptr(w_playlist), int(n_tracks), _ptr(seed_row_ptr),
+                                               _ptr(seed_col), int(k), _ptr(out_score), _ptr(out_idx), _ptr(guard_out)))
 
     def topk_merge(self, cand_logit, cand_idx, out_score, out_idx, out_kind=DAE_OUT_SCORE):
         G, B, k = cand_logit.shape

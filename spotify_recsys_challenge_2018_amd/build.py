@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdae_hip.so")
-SOURCES = ["api.hip", "encode.hip", "decode_f32.hip", "topk.hip", "refine.hip", "train.hip", "csr.hip", "title.hip", "pipeline.hip"]
+SOURCES = ["api.hip", "encode.hip", "decode_f32.hip", "topk.hip", "refine.hip", "mixexact.hip", "train.hip", "csr.hip", "title.hip", "pipeline.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -42,7 +42,6 @@ int dae_reserve(dae_ctx* ctx, dae_buf& b, size_t bytes)
     return DAE_OK;
 }
 
-constexpr size_t DAE_GUARD_BYTES = 2 * sizeof(int);   // {violations, column}
 
 namespace {
 
@@ -145,12 +144,13 @@ int dae_destroy(dae_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (dae_packed* pk : {&ctx->pk_f32, &ctx->pk_bf16})
-        if (pk->borrowed) pk->W = pk->bias = pk->bias16 = pk->bias16_lo = pk->bias16_hi = pk->eps = pk->W32 = dae_buf{};
+        if (pk->borrowed) pk->W = pk->bias = pk->bias16 = pk->bias16_lo = pk->bias16_hi = pk->eps = pk->W32 = pk->mix_alpha = pk->mix_beta = pk->mix16_lo = pk->mix16_hi = dae_buf{};
     dae_buf* bufs[] = {&ctx->pk_f32.W, &ctx->pk_f32.bias, &ctx->pk_bf16.W, &ctx->pk_bf16.bias, &ctx->pk_f32.order, &ctx->pk_bf16.order, &ctx->pk_bf16.bias16, &ctx->pk_f32.ident, &ctx->pk_bf16.ident,
                        &ctx->h_packed, &ctx->sample, &ctx->tau, &ctx->sample_top, &ctx->cand,
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
-                       &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32};
+                       &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -290,7 +290,7 @@ int dae_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const f
 static void unborrow(dae_packed& pk)
 {
     if (!pk.borrowed) return;
-    pk.W = pk.bias = pk.bias16 = pk.bias16_lo = pk.bias16_hi = pk.eps = pk.W32 = dae_buf{};
+    pk.W = pk.bias = pk.bias16 = pk.bias16_lo = pk.bias16_hi = pk.eps = pk.W32 = pk.mix_alpha = pk.mix_beta = pk.mix16_lo = pk.mix16_hi = dae_buf{};
     pk.borrowed = false; pk.valid = false; pk.exact = false; pk.order_nrank = -1;
 }
 
@@ -308,7 +308,7 @@ int dae_share_decoder(dae_ctx* dst, const dae_ctx* src, int dtype)
     if (!dp.borrowed) {                                    // drop the own image of this slot (after its last use)
         hipError_t e = hipStreamSynchronize(dst->stream);
         if (e != hipSuccess) return dae_fail(dst, DAE_ERR_HIP, "sync: %s", hipGetErrorString(e));
-        for (dae_buf* b : {&dp.W, &dp.bias, &dp.bias16, &dp.bias16_lo, &dp.bias16_hi, &dp.eps, &dp.W32})
+        for (dae_buf* b : {&dp.W, &dp.bias, &dp.bias16, &dp.bias16_lo, &dp.bias16_hi, &dp.eps, &dp.W32, &dp.mix_alpha, &dp.mix_beta, &dp.mix16_lo, &dp.mix16_hi})
             if (b->p) { (void)hipFree(b->p); dst->scratch_total -= b->bytes; *b = dae_buf{}; }
     }
     const dae_buf order = dp.order, ident = dp.ident;      // the tile lists stay this context's own (small, built lazily)
@@ -847,6 +847,32 @@ int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, c
     if (!ctx) return DAE_ERR_ARG;
     if ((mixT == nullptr) != (w_title == nullptr)) return dae_fail(ctx, DAE_ERR_ARG, "mixT and w_title go together");
     ctx->mixT = mixT; ctx->mix_ld = ld; ctx->mix_w = w_title; ctx->mix_ncols = mixT ? n_cols : 0;
+    return DAE_OK;
+}
+
+int dae_mix_topk_exact(dae_ctx* title_ctx, dae_ctx* dae_ctx_, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h,
+                       int B, const float* w_title, const float* w_playlist, int n_tracks, const int32_t* seed_row_ptr,
+                       const int32_t* seed_col, int k, float* out_score, int32_t* out_idx, int32_t* guard_out)
+{
+    if (!title_ctx) return DAE_ERR_ARG;
+    if (!dae_ctx_ || dae_ctx_ == title_ctx) return dae_fail(title_ctx, DAE_ERR_ARG, "dae_mix_topk_exact: needs the DAE's context");
+    if (title_ctx->device != dae_ctx_->device) return dae_fail(title_ctx, DAE_ERR_ARG, "dae_mix_topk_exact: contexts on different devices");
+    if (!feat || !h || !w_title || !w_playlist) return dae_fail(title_ctx, DAE_ERR_ARG, "null pointer");
+    if (B < 0 || n_tracks <= 0) return dae_fail(title_ctx, DAE_ERR_ARG, "bad shape B=%d n_tracks=%d", B, n_tracks);
+    int rc = check_topk_args(title_ctx, DAE_DTYPE_BF16_EXACT, k, seed_row_ptr, seed_col, out_score, out_idx);
+    if (rc) return rc;
+    if (title_ctx->mixT) return dae_fail(title_ctx, DAE_ERR_STATE, "dae_mix_topk_exact takes the DAE's hidden rows itself: clear dae_set_score_mix");
+    rc = dae_mix_topk_exact_impl(title_ctx, dae_ctx_, feat, ld_feat, h, ld_h, B, w_title, w_playlist, n_tracks, seed_row_ptr,
+                                 seed_col, k, out_score, out_idx);
+    if (rc) return rc;
+    if (guard_out) {                                       // the guard words as they stand after this launch, in stream order
+        if (!title_ctx->guard.p) {                         // (B == 0: nothing ran yet)
+            rc = dae_reserve(title_ctx, title_ctx->guard, DAE_GUARD_BYTES);
+            if (rc) return rc;
+            DAE_HIP_CHECK(title_ctx, hipMemsetAsync(title_ctx->guard.p, 0, DAE_GUARD_BYTES, title_ctx->stream));
+        }
+        DAE_HIP_CHECK(title_ctx, hipMemcpyAsync(guard_out, title_ctx->guard.p, DAE_GUARD_BYTES, hipMemcpyDeviceToDevice, title_ctx->stream));
+    }
     return DAE_OK;
 }
 

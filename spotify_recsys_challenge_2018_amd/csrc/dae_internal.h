@@ -23,6 +23,7 @@ constexpr int DAE_MAX_K = 1024;   // largest top-k supported
 constexpr int DAE_NUM_CU = 256;   // MI355X
 constexpr int DAE_NUM_XCD = 8;
 constexpr int DAE_REFINED_CAP = 4096;   // survivors per row the exact mode's compact lists hold (more: refined in place)
+constexpr size_t DAE_GUARD_BYTES = 2 * sizeof(int);   // a context's guard words {violations, a violating column}
 
 struct dae_buf {
     void* p = nullptr;
@@ -53,6 +54,10 @@ struct dae_packed {            // one prepacked decoder image
     dae_buf eps;               // [ntiles*32] fp32, zero padded; then one more float: the maximum (eps_max)
     dae_buf bias16_lo, bias16_hi;   // [ntiles][64] uint4, as bias16
     dae_buf W32;               // [col_hi - col_lo][H] fp32 row-major
+    // the same image as the TITLE side of the exact title mix (mixexact.hip): hidden rows with entries in [-F_r, F_r],
+    // |z32 - z16| <= F_r alpha_c + beta_c; the bias fragments carry b -+ beta in k-slots 0..2 and -+alpha (bf16) in slot 3
+    dae_buf mix_alpha, mix_beta;    // [ntiles*32] fp32 (alpha: the bf16 value the fragments hold)
+    dae_buf mix16_lo, mix16_hi;     // [ntiles][64] uint4
 };
 
 struct dae_rowgeom {        // how B rows are cut into row groups for the decode kernels
@@ -119,6 +124,7 @@ struct dae_ctx {
     dae_buf refstat; int refstat_rows = 0;   // DAE_DTYPE_BF16_EXACT: [rows][2] {candidates, recomputed} of the last refine launch
     dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
+    dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -346,6 +352,13 @@ int dae_launch_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, i
                                    float kp, uint32_t seed, float* g_emb, float* g_conv_w, float* g_conv_b);
 int dae_launch_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_t, float* dae_score, int64_t ld_d,
                           const float* w_title, const float* w_playlist, int B, int ncols);
+
+// mixexact.hip (DAE_DTYPE_BF16_EXACT under the title mix)
+int dae_launch_mix_title_bounds(dae_ctx* ctx, const float* W, const float* b, int H, int Hp, int col_lo, int col_hi,
+                                int ntiles, dae_packed& pk);
+int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h, int B,
+                            const float* w_title, const float* w_playlist, int n_tracks, const int32_t* seed_row_ptr,
+                            const int32_t* seed_col, int k, float* out_score, int32_t* out_idx);
 
 // topk.hip
 struct dae_dense_src {      // element p of row r = logits[r*ld + p], p in [0,n)

@@ -2020,6 +2020,9 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
                            static_cast<uint4*>(pk.bias16_hi.p), ctx->exact_margin);
         DAE_CHECK_LAUNCH(ctx, "exact_bounds_kernel");
         DAE_HIP_CHECK(ctx, hipMemcpyAsync(pk.W32.p, W + (size_t)col_lo * H, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        // the same image read as the title side of the exact title mix: row-scaled bounds (mixexact.hip)
+        rc = dae_launch_mix_title_bounds(ctx, W, b, H, Hp, col_lo, col_hi, ntiles, pk);
+        if (rc) return rc;
         pk.exact = true;
     }
     pk.valid = true;

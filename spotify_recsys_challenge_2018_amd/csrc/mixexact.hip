@@ -1,0 +1,714 @@
+// mixexact.hip -- DAE_DTYPE_BF16_EXACT under the title mix (`--challenge` with titles: main_challenge.py:80-90 of the
+// reference always scores through DAE_title, DAEs.py:153-181):
+//
+//     y[r, c] = sigmoid(z_t[r, c]) * w_title[r] + sigmoid(z_d[r, c]) * w_playlist[r]                      (DAEs.py:180)
+//     z_d = h[r, :] . W_dec[c, :] + b_dec[c]            (hidden 256: the frozen DAE, DAEs.py:165-171)
+//     z_t = feat[r, :] . Output_W[:, c] + Output_b[c]   (400 title features in rows of 448, Char_CNN.py:64-72)
+//
+// The fp32 path runs both vocabulary-wide GEMMs on v_mfma_f32_32x32x2_f32 (the canonical fmaf chains) and ranks y.  Here
+// BOTH run on v_mfma_f32_32x32x16_bf16 in ONE launch per pass -- a wave decodes a 32-column tile against a row group's
+// hidden rows of both scorers (704 k values, two accumulator sets) -- on BOUNDS of the two logits, and only the survivors are
+// recomputed in fp32:
+//   sample launch (MODE 1): biases shifted DOWN by the bounds -> lower bounds l of y over the head of the bias-ordered tile
+//          list; their maxima over groups of 4 columns go to the threshold kernel (tau_select_kernel, topk.hip), whose tau is
+//          a valid lower bound of the row's k-th largest rankable non-seed y;
+//   filter launch (MODE 0): biases shifted UP -> upper bounds; every (row, column) whose upper bound reaches tau is listed
+//          with the two upper logits (u_t, u_d);
+//   refine launch: recomputes z_t, z_d of every listed column with the canonical chains and mixes them with the operations of
+//          mix_scores_kernel (title.hip) in their order: the value the fp32 path ranks; tests it against the promise
+//          (bound guard, as refine.hip) and leaves one compact (y, column) list per row for the selection kernel.
+// BOUNDS.  DAE side: hidden rows lie in [0, 1], eps_c of exact_bounds_kernel (decode_f32.hip) as in the plain exact mode.
+// Title side: the features are ReLU maxima, not confined to [0, 1]; with F_r = max_k |feat[r][k]| every term of that
+// derivation that is linear in the hidden row scales by F_r:
+//     |z16_t - z32_t| <= F_r alpha_c + beta_c,
+//     alpha_c = (1 + 2^-8) d_c + 2^-9 n_c + A16 (1 + 2^-8)(n_c + d_c) + A32 n_c,   beta_c = (1.01 A16 + A32 + 2^-23) |b_c|
+// (d_c, n_c, A16, A32 as there; both inflated for the feedback of the shift through the accumulation).  The shift itself
+// goes through the matrix pipe like the bias: k-slot 3 of the tile's bias fragment holds +-alpha_c (bf16, rounded up), k-slot
+// 3 of the row's "ones" fragment holds F_r (bf16, rounded up), slots 0..2 the three-term split of b_c +- beta_c.
+// The canonical sigmoid is monotone only to one unit in the last place (920 one-ulp inversions among the 2.2 10^9 floats of
+// [-88, 88], checked exhaustively), so mixed bounds are widened by 2^-20 relative before they are compared.
+#include <climits>
+
+#include "dae_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) { return __builtin_bit_cast(bf16x8, u); }
+
+constexpr int MX_RB = 3;            // row blocks of 32 playlists per row group: 96 rows x 704 k x 2 B = 132 KiB of LDS
+constexpr int MX_NW = 8;            // waves per workgroup (two per SIMD: one's epilogue under the other's MFMAs)
+constexpr int MX_QR = 8;            // W ring depth (steps)
+constexpr int MX_REF_CAP = 8192;    // survivors per row the refine launch's compact lists hold
+
+// the mixed score with the operations of mix_scores_kernel (title.hip) / the fp32 mix epilogue (decode_f32.hip), in their order
+__device__ __forceinline__ float mixf(float zt, float zd, float wt, float wp)
+{
+    const float ts = dae_sigmoidf(zt) * wt;
+    const float pd = dae_sigmoidf(zd) * wp;
+    return ts + pd;
+}
+__device__ __forceinline__ float widen_up(float y) { return fmaf(y, 0x1p-20f, y); }       // y >= 0
+__device__ __forceinline__ float widen_dn(float y) { return fmaf(y, -0x1p-20f, y); }
+
+struct MixP {
+    const uint4* WqD; const uint4* WqT;          // bf16 images [tile][NS][64] of the two scorers (same tiles: column 32 t + i)
+    const uint4* biasD; const uint4* biasT;      // [tile][64] bias fragments: the lower or the upper shift
+    const uint4* hp;                             // hidden rows of both scorers [n_rg][NSD + NST][RB][64] (mix_pack_kernel)
+    const unsigned* fhat;                        // [Bpad] bf16 bits of F_r, rounded up
+    const float* w_t; const float* w_p;          // [B]
+    const float* tau;                            // [B] (filter)
+    const int* list; int n_items;                // tiles of this launch
+    int n_valid_col;                             // rankable columns (the images start at column 0)
+    int B, n_rg, nb_rg, Bpad;
+    uint4* cand; int* cand_cnt; int cap;         // filter: [bir][Bpad][cap] entries (u_t, u_d, column, 0) + [bir][Bpad] counts
+    float* samp; int64_t ld_s;                   // sample: [B][ld_s] maxima of 4-column groups, element item * 8 + 4 hi + qd
+};
+
+template <int NSD, int NST, int RB, int QR, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
+{
+    constexpr int NS = NSD + NST, R_TILE = RB * 32, NTH = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+
+    // the workgroups that walk the same tiles for different row groups sit on one XCD (decode_f32.hip)
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+
+    constexpr int n_h4 = RB * 64 * NS;
+    constexpr int PER = (n_h4 + NTH - 1) / NTH;
+    constexpr int CH = PER < 8 ? PER : 8;
+    const int n_items = p.n_items;
+    const int n_ws = p.nb_rg * NW;
+    const int it0 = wave * p.nb_rg + bir;
+    const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
+
+    // a wave's tiles: its first two by position, every further one claimed from a counter in LDS (decode_f32.hip)
+    const bool has = it0 < n_items;
+    const int tv0 = p.list[has ? it0 : 0];
+    const int tv1 = p.list[has ? (it0 + n_ws < n_items ? it0 + n_ws : it0) : 0];
+    float tau_g[(R_TILE + NTH - 1) / NTH];
+#pragma unroll
+    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
+        const int i = e * NTH + tid;
+        tau_g[e] = (MODE == 0 && i < R_TILE && rg * R_TILE + i < p.B) ? p.tau[rg * R_TILE + i] : __builtin_inff();
+    }
+    int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
+    float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
+    int* claim = reinterpret_cast<int*>(ltau + R_TILE);
+    if (tid == 0) *claim = 2 * NW;
+    {
+        const uint4* hsrc = p.hp + (size_t)rg * n_h4;
+        uint4* l4 = reinterpret_cast<uint4*>(lds4);
+#pragma unroll
+        for (int e0 = 0; e0 < PER; e0 += CH) {
+            uint4 hv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = (e0 + e) * NTH + tid;
+                hv[e] = hsrc[i < n_h4 ? i : n_h4 - 1];
+            }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const int i = (e0 + e) * NTH + tid;
+                if (e0 + e < PER && i < n_h4) l4[i] = hv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
+        const int i = e * NTH + tid;
+        if (i < R_TILE) { lcnt[i] = 0; ltau[i] = tau_g[e]; }
+    }
+    // per lane: the mixing weights and the row's feature bound of its RB rows
+    float wt_r[RB], wp_r[RB];
+    unsigned oy[RB];                                              // .y of the title side's "ones" fragment (k-slots 2, 3)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rg * R_TILE + rb * 32 + j;
+        const bool in = row < p.B;
+        wt_r[rb] = in ? p.w_t[row] : 0.0f;
+        wp_r[rb] = in ? p.w_p[row] : 0.0f;
+        oy[rb] = hi == 0 ? (0x3F80u | ((in ? p.fhat[row] : 0u) << 16)) : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int t = __builtin_amdgcn_readfirstlane(tv0), u = __builtin_amdgcn_readfirstlane(tv1);
+    // step sg of tile x: the DAE image's steps first, then the title image's
+    auto wsrc = [&](int x, int sg) -> const uint4* {
+        return sg < NSD ? p.WqD + ((size_t)x * NSD + sg) * 64 + lane : p.WqT + ((size_t)x * NST + (sg - NSD)) * 64 + lane;
+    };
+    uint4 wq[QR];
+    uint4 cb[2][RB];
+    uint4 bfD = p.biasD[(size_t)t * 64 + lane], bfT = p.biasT[(size_t)t * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < QR; ++k) wq[k] = *wsrc(t, k);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    float tau_r[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) tau_r[rb] = ltau[rb * 32 + j];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
+    const uint4 onesD = hi == 0 ? make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+
+    int g_nxt = it0 + n_ws;
+    for (int it = it0; it < n_items;) {
+        int g_nn;
+        {
+            int n2 = 0;
+            if (lane == 0) n2 = atomicAdd(claim, 1);
+            g_nn = __builtin_amdgcn_readfirstlane(n2) * p.nb_rg + bir;
+        }
+        const int wv = p.list[g_nn < n_items ? g_nn : it];       // consumed at the end of this tile
+
+        f32x16 accD[RB], accT[RB];
+        {
+            f32x16 zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
+            const uint4 bd = bfD, bt = bfT;
+            bfD = p.biasD[(size_t)u * 64 + lane];
+            bfT = p.biasT[(size_t)u * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                accD[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bd), as_bf16x8(onesD), zero, 0, 0, 0);
+                const uint4 ot = hi == 0 ? make_uint4(0x3F803F80u, oy[rb], 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+                accT[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bt), as_bf16x8(ot), zero, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sn = (s + 1) % NS;
+            const uint4 a = wq[s % QR];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                if (s < NSD)
+                    accD[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(cb[s & 1][rb]), accD[rb], 0, 0, 0);
+                else
+                    accT[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(cb[s & 1][rb]), accT[rb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                cb[(s + 1) & 1][rb] = ldsq[(sn * RB + rb) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wq[s % QR] = (s + QR < NS) ? *wsrc(t, s + QR) : *wsrc(u, s + QR - NS);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue: lane = playlist j of row block rb; register reg is column 32 t + 4 hi + (reg & 3) + 8 (reg >> 2)
+        if (MODE == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float tv = tau_r[rb];
+                float mT = accT[rb][0], mD = accD[rb][0];
+#pragma unroll
+                for (int reg = 1; reg < 16; ++reg) { mT = fmaxf(mT, accT[rb][reg]); mD = fmaxf(mD, accD[rb][reg]); }
+                // (the pair of maxima bounds every pair of the lane's 16 columns: most tiles stop here)
+                if (widen_up(widen_up(mixf(mT, mD, wt_r[rb], wp_r[rb]))) >= tv) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int lc = t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
+                        const float y = widen_up(mixf(accT[rb][reg], accD[rb][reg], wt_r[rb], wp_r[rb]));
+                        if (y >= tv && lc < p.n_valid_col) m |= 1u << reg;
+                    }
+                    if (m) {
+                        int at = atomicAdd(&lcnt[rb * 32 + j], __popc(m));
+                        uint4* dst = p.cand + ((size_t)bir * p.Bpad + rg * R_TILE + rb * 32 + j) * (size_t)p.cap;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            if (m & (1u << reg))
+                                dst[at++] = make_uint4(__float_as_uint(accT[rb][reg]), __float_as_uint(accD[rb][reg]),
+                                                       (unsigned)(t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2)), 0u);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = rg * R_TILE + rb * 32 + j;
+                float o[4];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    float mx = -__builtin_inff();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lc = t * 32 + 4 * hi + e + 8 * qd;
+                        const float y = widen_dn(mixf(accT[rb][4 * qd + e], accD[rb][4 * qd + e], wt_r[rb], wp_r[rb]));
+                        if (lc < p.n_valid_col) mx = fmaxf(mx, y);
+                    }
+                    o[qd] = mx;
+                }
+                if (row < p.B)
+                    *reinterpret_cast<float4*>(p.samp + (size_t)row * p.ld_s + (size_t)it * 8 + 4 * hi) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        t = u; u = __builtin_amdgcn_readfirstlane(wv);
+        it = g_nxt; g_nxt = g_nn;
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (int i = tid; i < R_TILE; i += NTH) p.cand_cnt[(size_t)bir * p.Bpad + rg * R_TILE + i] = lcnt[i];
+    }
+}
+
+// ---- the title image's row-scaled bounds (see the header) ---------------------------------------------------------------
+// One 256-thread workgroup per 32-column tile, 8 threads per column (as exact_bounds_kernel).  alpha_hat[c]: the bf16
+// value (as a float) the fragments carry; beta[c]: the shift folded into the bias split.
+__device__ __forceinline__ uint4 mix_bias_fragment(float bv, unsigned slot3)
+{
+    const unsigned e0 = dae_bf16_rne(bv);
+    const float r1 = bv - __uint_as_float(e0 << 16);
+    const unsigned e1 = dae_bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(e1 << 16);
+    const unsigned e2 = dae_bf16_rne(r2);
+    return make_uint4(e0 | (e1 << 16), e2 | (slot3 << 16), 0u, 0u);
+}
+
+__global__ __launch_bounds__(256) void mix_title_bounds_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                               int H, int Hp, int col_lo, int col_hi, int ntiles,
+                                                               float* __restrict__ alpha_hat, float* __restrict__ beta,
+                                                               uint4* __restrict__ frag_lo, uint4* __restrict__ frag_hi,
+                                                               float margin)
+{
+    const int tid = threadIdx.x;
+    const int c = tid >> 3, part = tid & 7;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int v = col_lo + t * 32 + c;
+        double n = 0.0, d = 0.0;
+        if (v < col_hi) {
+            const float* row = W + (size_t)v * H;
+            for (int k = part; k < H; k += 8) {
+                const float w = row[k];
+                const float w16 = __uint_as_float(dae_bf16_rne(w) << 16);
+                n += fabs((double)w);
+                d += fabs((double)w16 - (double)w);
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 8; sh <<= 1) { n += __shfl_xor(n, sh); d += __shfl_xor(d, sh); }
+        if (part == 0) {
+            float a_f = 0.0f, be_f = 0.0f, lo_f = 0.0f, hi_f = 0.0f;
+            unsigned a16 = 0u;
+            if (v < col_hi) {
+                const double bv = (double)b[v], ab = fabs(bv);
+                const double A16 = (double)(Hp + 16) * 0x1p-22;
+                const double A32 = (double)(H + 2) * 0x1p-24 * (1.0 + 0x1p-10);
+                const double up = 1.0 + 0x1p-8;               // bf16(f) <= F_r (1 + 2^-8); bf16(F_r) and bf16(alpha) round up
+                double al = up * d + 0x1p-9 * n + A16 * up * (n + d) + A32 * n;
+                double be = (1.01 * A16 + A32 + 0x1p-23) * ab;
+                al = al * (1.0 + 4.0 * A16 * up * up) * (1.0 + 1e-6) + 1e-30;      // the shift feeds back through the accumulation
+                be = be * (1.0 + 4.0 * A16) * (1.0 + 1e-6) + 0x1p-23 * be + 1e-30;
+                al *= (double)margin; be *= (double)margin;   // dae_set_exact_margin (< 1 voids the bound: the guard's test hook)
+                a_f = (float)al;
+                if ((double)a_f < al) a_f = __uint_as_float(__float_as_uint(a_f) + 1u);
+                a16 = (__float_as_uint(a_f) + 0xFFFFu) >> 16;                     // bf16, rounded up (a_f > 0)
+                a_f = __uint_as_float(a16 << 16);
+                be_f = (float)be;
+                if ((double)be_f < be) be_f = __uint_as_float(__float_as_uint(be_f) + 1u);
+                const double lo = bv - (double)be_f, hi = bv + (double)be_f;
+                lo_f = (float)lo; if ((double)lo_f > lo) lo_f = nextafterf(lo_f, -__builtin_inff());
+                hi_f = (float)hi; if ((double)hi_f < hi) hi_f = nextafterf(hi_f, __builtin_inff());
+            }
+            alpha_hat[t * 32 + c] = a_f;
+            beta[t * 32 + c] = be_f;
+            frag_lo[t * 64 + c] = v < col_hi ? mix_bias_fragment(lo_f, a16 | 0x8000u) : make_uint4(0u, 0u, 0u, 0u);
+            frag_hi[t * 64 + c] = v < col_hi ? mix_bias_fragment(hi_f, a16) : make_uint4(0u, 0u, 0u, 0u);
+            frag_lo[t * 64 + 32 + c] = make_uint4(0u, 0u, 0u, 0u);
+            frag_hi[t * 64 + 32 + c] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+// ---- per row: F_r (bf16, rounded up) and whether the bound's preconditions hold -----------------------------------------
+// one wave per row.  row_bad[r] = 1: a DAE hidden entry outside [0, 1], a feature that is not finite, or a mixing weight
+// outside [0, 1] -- such rows return no recommendations (idx -1), as in the plain exact mode
+__global__ __launch_bounds__(256) void mix_rowprep_kernel(const float* __restrict__ h, int64_t ld_h, int HD,
+                                                          const float* __restrict__ feat, int64_t ld_f, int HT,
+                                                          const float* __restrict__ w_t, const float* __restrict__ w_p,
+                                                          int B, int Bpad, unsigned* __restrict__ fhat, int* __restrict__ row_bad)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Bpad) return;
+    float mx = 0.0f;
+    bool bad = false;
+    if (row < B) {
+        for (int k = lane; k < HT; k += 64) {
+            const float f = fabsf(feat[(size_t)row * ld_f + k]);
+            bad = bad || !(f <= 3.0e38f);
+            mx = fmaxf(mx, f);
+        }
+        for (int k = lane; k < HD; k += 64) {
+            const float x = h[(size_t)row * ld_h + k];
+            bad = bad || !(x >= 0.0f && x <= 1.0f);
+        }
+        const float a = w_t[row], c = w_p[row];
+        bad = bad || !(a >= 0.0f && a <= 1.0f) || !(c >= 0.0f && c <= 1.0f);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const bool any_bad = __any(bad);
+    if (lane == 0) {
+        fhat[row] = mx > 0.0f ? (__float_as_uint(mx) + 0xFFFFu) >> 16 : 0u;
+        row_bad[row] = any_bad ? 1 : 0;
+    }
+}
+
+// hidden rows of both scorers in B-operand order: out uint4 index = ((rg * NS + s) * RB + rb) * 64 + lane holds the bf16 of
+// h[r][16 s + 8 hi + 0..7] (s < NSD) or feat[r][16 (s - NSD) + 8 hi + 0..7], r = (rg RB + rb) 32 + j  (zero outside)
+__global__ __launch_bounds__(256) void mix_pack_kernel(const float* __restrict__ h, int64_t ld_h, int HD,
+                                                       const float* __restrict__ feat, int64_t ld_f, int HT,
+                                                       int B, int NSD, int NS, int RB, int n_rg, uint4* __restrict__ hp)
+{
+    const size_t total = (size_t)n_rg * NS * RB * 64;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int lane = (int)(o & 63);
+        size_t x = o >> 6;
+        const int rb = (int)(x % RB); x /= RB;
+        const int s = (int)(x % NS);
+        const int rg = (int)(x / NS);
+        const int hi = lane >> 5, jj = lane & 31;
+        const int r = (rg * RB + rb) * 32 + jj;
+        const bool dae = s < NSD;
+        const float* src = dae ? h + (size_t)r * ld_h : feat + (size_t)r * ld_f;
+        const int k0 = 16 * (dae ? s : s - NSD) + 8 * hi;
+        const int Hs = dae ? HD : HT;
+        unsigned e[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e[c] = dae_bf16_rne((r < B && k0 + c < Hs) ? src[k0 + c] : 0.0f);
+        hp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+}
+
+// ---- refine: the survivors' fp32 scores ------------------------------------------------------------------------------
+constexpr int MR_THREADS = 256, MR_WAVES = 4, MR_DEPTH = 4;
+constexpr int MR_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (refine.hip)
+constexpr int MR_MAX_SEG = 1024;
+
+struct MixRefP {
+    const uint4* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
+    const float* hD; int64_t ld_hD; int HD; const float* W32D; const float* biasD; const float* epsD;
+    const float* hT; int64_t ld_hT; int HT; const float* W32T; const float* biasT; const float* alphaT; const float* betaT;
+    const unsigned* fhat; const float* w_t; const float* w_p; const int* row_bad;
+    uint2* out; int* out_cnt; int out_cap;
+    int* guard;                        // {violations, a violating column}
+    int* stat;                         // [B][2] {candidates, recomputed}
+};
+
+// One group of 64 candidates, a lane each: the canonical chain acc = fmaf(hrow[k], W32[rowidx][k], acc), k = 0 .. H-1, from
+// +0 (oracle orc_decode; what v_mfma_f32_32x32x2_f32 performs in the fp32 kernels).  The rows are fetched quad-wise -- the
+// 4 lanes of a quad read 64 contiguous bytes of one row per instruction -- and handed to their lanes through the wave's
+// LDS buffer; the hidden factors travel by v_readlane (refine.hip rescore_group, which this restates for two scorers).
+// H % 16 == 0; hrow zero beyond H up to the next multiple of 64.
+template <int DEPTH>
+__device__ __forceinline__ float mix_chain64(const float* __restrict__ W32, int H, const float* hrow, float* tbuf, int lane, int rowidx)
+{
+    const int Q = lane >> 2, q = lane & 3;
+    const int H16 = H >> 4;
+    const float4* rp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = __shfl(rowidx, 4 * Q + i);
+        rp[i] = reinterpret_cast<const float4*>(W32 + (size_t)ci * H) + q;
+    }
+    float4 v[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[d][i] = d < H16 ? rp[i][4 * d] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc = 0.0f;
+    constexpr int U = DEPTH < 4 ? 4 : DEPTH;
+    for (int j0 = 0; j0 < H16; j0 += U) {
+        float hq[U / 4];
+#pragma unroll
+        for (int c = 0; c < U / 4; ++c) hq[c] = hrow[16 * j0 + 64 * c + lane];
+#pragma unroll
+        for (int dd = 0; dd < U; ++dd) {
+            const int jb = j0 + dd;
+            const int d = dd & (DEPTH - 1);
+            if (jb < H16) {                                       // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * MR_ROWSTRIDE + 4 * q) = v[d][i];
+                __builtin_amdgcn_wave_barrier();
+                const int jn = jb + DEPTH;
+                if (jn < H16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
+                }
+                float4 w[4];
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) w[tq] = *reinterpret_cast<const float4*>(tbuf + lane * MR_ROWSTRIDE + 4 * tq);
+                __builtin_amdgcn_wave_barrier();
+                const int hc = (int)__float_as_uint(hq[dd >> 2]);
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) {
+                    const int l0 = 16 * (dd & 3) + 4 * tq;
+                    acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0)), w[tq].x, acc);
+                    acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 1)), w[tq].y, acc);
+                    acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 2)), w[tq].z, acc);
+                    acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_readlane(hc, l0 + 3)), w[tq].w, acc);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// two floats further from the value than the rounded subtraction / addition left it
+__device__ __forceinline__ float two_down(float x) { return dae_okey_inv(dae_okey(x) - 2u); }
+
+__global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP p)
+{
+    __shared__ int seg_prefix[MR_MAX_SEG + 2];
+    __shared__ float hrowD[1024];
+    __shared__ float hrowT[1024];
+    __shared__ __attribute__((aligned(16))) float tb[MR_WAVES * 64 * MR_ROWSTRIDE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const int nseg = p.nseg;
+    const bool bad = p.row_bad && p.row_bad[row] != 0;
+    for (int s = tid; s < nseg; s += MR_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
+    if (tid == 0) seg_prefix[0] = 0;
+    for (int i = tid; i < 1024; i += MR_THREADS) {
+        hrowD[i] = i < p.HD ? p.hD[(size_t)row * p.ld_hD + i] : 0.0f;
+        hrowT[i] = i < p.HT ? p.hT[(size_t)row * p.ld_hT + i] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int carry = 0;
+        for (int b0 = 0; b0 < nseg; b0 += 64) {
+            const int i = b0 + tid;
+            int v = i < nseg ? seg_prefix[i + 1] : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d);
+                if (tid >= d) v += o;
+            }
+            if (i < nseg) seg_prefix[i + 1] = v + carry;
+            carry += __shfl(v, 63);
+        }
+    }
+    __syncthreads();
+    const int total = seg_prefix[nseg];
+    if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = bad ? 0 : total; }
+    if (bad || total == 0 || total > p.out_cap) {
+        if (tid == 0) {
+            p.out_cnt[row] = 0;
+            // more survivors than the row's list holds: the launch cannot vouch for this row -- counted like a bound failure
+            // (the callers then re-score the launch with the fp32 kernels)
+            if (!bad && total > p.out_cap) { atomicAdd(p.guard, 1); p.guard[1] = -2; }
+        }
+        return;
+    }
+    auto offset_of = [&](int e) -> int64_t {
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_prefix[mid] <= e) lo = mid; else hi = mid;
+        }
+        return (int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]);
+    };
+    float* tbuf = tb + wave * (64 * MR_ROWSTRIDE);
+    const float wt = p.w_t[row], wp = p.w_p[row];
+    const float F = __uint_as_float(p.fhat[row] << 16);
+    uint2* orow = p.out + (size_t)row * p.out_cap;
+    const int gstep = MR_WAVES * 64;
+    uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+    int g0 = wave * 64;
+    if (g0 < total) pr = p.base[offset_of(g0 + lane < total ? g0 + lane : g0)];
+    for (; g0 < total; g0 += gstep) {
+        const int e = g0 + lane;
+        const bool in = e < total;
+        const uint4 cur = pr;
+        const int gn = g0 + gstep;
+        if (gn < total) pr = p.base[offset_of(gn + lane < total ? gn + lane : gn)];      // the next group's entries, under this group's rows
+        const int col = (int)cur.z;
+        const float zT = mix_chain64<MR_DEPTH>(p.W32T, p.HT, hrowT, tbuf, lane, col) + p.biasT[col];
+        const float zD = mix_chain64<MR_DEPTH>(p.W32D, p.HD, hrowD, tbuf, lane, col) + p.biasD[col];
+        const float y = mixf(zT, zD, wt, wp);
+        if (in) {
+            // BOUND GUARD: the filter launch promised u - width <= z32 <= u for both logits of every listed column
+            const float uT = __uint_as_float(cur.x), uD = __uint_as_float(cur.y);
+            const float wdT = 2.0f * fmaf(p.alphaT[col], F, p.betaT[col]) * 1.000001f;
+            const float wdD = 2.0f * p.epsD[col] * 1.000001f;
+            const bool ok = zT <= uT && zT >= two_down(uT - wdT) && zD <= uD && zD >= two_down(uD - wdD);
+            if (!ok) { atomicAdd(p.guard, 1); p.guard[1] = col; }
+            orow[e] = make_uint2(__float_as_uint(y), (unsigned)col);
+        }
+    }
+    if (tid == 0) p.out_cnt[row] = total;
+}
+
+}  // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+int dae_launch_mix_title_bounds(dae_ctx* ctx, const float* W, const float* b, int H, int Hp, int col_lo, int col_hi,
+                                int ntiles, dae_packed& pk)
+{
+    int rc = dae_reserve(ctx, pk.mix_alpha, (size_t)ntiles * 32 * sizeof(float));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, pk.mix_beta, (size_t)ntiles * 32 * sizeof(float));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, pk.mix16_lo, (size_t)ntiles * 64 * sizeof(uint4));
+    if (rc) return rc;
+    rc = dae_reserve(ctx, pk.mix16_hi, (size_t)ntiles * 64 * sizeof(uint4));
+    if (rc) return rc;
+    const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
+    hipLaunchKernelGGL(mix_title_bounds_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, Hp, col_lo, col_hi, ntiles,
+                       static_cast<float*>(pk.mix_alpha.p), static_cast<float*>(pk.mix_beta.p),
+                       static_cast<uint4*>(pk.mix16_lo.p), static_cast<uint4*>(pk.mix16_hi.p), ctx->exact_margin);
+    DAE_CHECK_LAUNCH(ctx, "mix_title_bounds_kernel");
+    return DAE_OK;
+}
+
+int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h, int B,
+                            const float* w_title, const float* w_playlist, int n_tracks, const int32_t* seed_row_ptr,
+                            const int32_t* seed_col, int k, float* out_score, int32_t* out_idx)
+{
+    constexpr int NSD = 16, NST = 28, RB = MX_RB, NW = MX_NW, QR = MX_QR, NS = NSD + NST, R_TILE = RB * 32;
+    dae_packed& pt = tc->pk_bf16;
+    dae_packed& pd = dc->pk_bf16;
+    if (!pt.valid || !pt.exact || !pd.valid || !pd.exact)
+        return dae_fail(tc, DAE_ERR_STATE, "both contexts need their weights prepacked with DAE_DTYPE_BF16_EXACT");
+    if (pd.Hp != NSD * 16 || pt.Hp != NST * 16 || pd.H != pd.Hp || (pt.H & 15))
+        return dae_fail(tc, DAE_ERR_ARG, "the exact title mix is built for hidden 256 (DAE) and 448-wide feature rows "
+                        "(got %d and %d): use DAE_DTYPE_F32", pd.H, pt.H);
+    if (pt.col_lo != 0 || pd.col_lo != 0 || pt.col_hi != pd.col_hi)
+        return dae_fail(tc, DAE_ERR_ARG, "both images must hold the same columns, starting at 0");
+    if (B <= 0) return DAE_OK;
+    if (B > 4096) return dae_fail(tc, DAE_ERR_ARG, "at most 4096 rows per call (got %d)", B);
+    hipStream_t st = tc->stream;
+    int rc;
+    const int n_valid_col = n_tracks < pt.col_hi ? n_tracks : pt.col_hi;
+    const int ntr = (n_valid_col + 31) / 32;                      // tiles with rankable columns
+    if (ntr <= 0) return dae_fail(tc, DAE_ERR_ARG, "no rankable column");
+
+    // geometry: 96-row groups; the workgroups of a row group in multiples of the XCD count
+    const int n_rg = (B + R_TILE - 1) / R_TILE;
+    const int Bpad = n_rg * R_TILE;
+    int nb = (DAE_NUM_CU / n_rg) / DAE_NUM_XCD * DAE_NUM_XCD;
+    if (nb < DAE_NUM_XCD) nb = DAE_NUM_XCD;
+    while (nb > DAE_NUM_XCD && (nb - DAE_NUM_XCD) * NW >= ntr) nb -= DAE_NUM_XCD;     // small images: no workgroups without a tile
+    const int grid = n_rg * nb;
+
+    // tiles by their largest DAE bias (the popularity prior): the head of the list is the threshold sample
+    // (an eighth of the tiles, in whole rounds of 64, at least 256)
+    int n_samp = (ntr / 8) / 64 * 64;
+    if (n_samp < 256) n_samp = 256;
+    if (n_samp > ntr) n_samp = ntr;
+    if (dc->stream != st) return dae_fail(tc, DAE_ERR_STATE, "both contexts must be bound to the same stream");
+    if (!(pd.order.p && pd.order_nrank == n_valid_col && pd.ntiles <= 8192)) {      // (the bias order does not depend on the sample size)
+        rc = dae_launch_tile_order(dc, pd, n_valid_col, n_samp, 1);
+        if (rc) return dae_fail(tc, rc, "%s", dc->err.c_str());
+    }
+    const int* order = static_cast<const int*>(pd.order.p);
+
+    // per row: F_r, preconditions; the packed hidden rows
+    rc = dae_reserve(tc, tc->row_bad, (size_t)Bpad * sizeof(int)); if (rc) return rc;
+    rc = dae_reserve(tc, tc->mix_fhat, (size_t)Bpad * sizeof(unsigned)); if (rc) return rc;
+    rc = dae_reserve(tc, tc->h_packed16, (size_t)n_rg * NS * RB * 64 * sizeof(uint4)); if (rc) return rc;
+    tc->h16_geom_key = -1;                                       // (the buffer no longer holds a plain image's pad region)
+    hipLaunchKernelGGL(mix_rowprep_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, h, ld_h, pd.H, feat, ld_feat, pt.H,
+                       w_title, w_playlist, B, Bpad, static_cast<unsigned*>(tc->mix_fhat.p), static_cast<int*>(tc->row_bad.p));
+    DAE_CHECK_LAUNCH(tc, "mix_rowprep_kernel");
+    {
+        const size_t total = (size_t)n_rg * NS * RB * 64;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4 * DAE_NUM_CU) blocks = 4 * DAE_NUM_CU;
+        hipLaunchKernelGGL(mix_pack_kernel, dim3(blocks), dim3(256), 0, st, h, ld_h, pd.H, feat, ld_feat, pt.H, B, NSD, NS, RB,
+                           n_rg, static_cast<uint4*>(tc->h_packed16.p));
+        DAE_CHECK_LAUNCH(tc, "mix_pack_kernel");
+    }
+
+    MixP p;
+    memset(&p, 0, sizeof(p));
+    p.WqD = static_cast<const uint4*>(pd.W.p); p.WqT = static_cast<const uint4*>(pt.W.p);
+    p.hp = static_cast<const uint4*>(tc->h_packed16.p);
+    p.fhat = static_cast<const unsigned*>(tc->mix_fhat.p);
+    p.w_t = w_title; p.w_p = w_playlist;
+    p.n_valid_col = n_valid_col;
+    p.B = B; p.n_rg = n_rg; p.nb_rg = nb; p.Bpad = Bpad;
+    const size_t lds = (size_t)RB * 64 * NS * sizeof(uint4) + (size_t)R_TILE * 8 + 16;
+    auto kf = mix_bf16_kernel<NSD, NST, RB, QR, NW, 0>;
+    auto ks = mix_bf16_kernel<NSD, NST, RB, QR, NW, 1>;
+    static const char attr_key = 0;
+    if (dae_first_use(tc, &attr_key)) {
+        DAE_HIP_CHECK(tc, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DAE_HIP_CHECK(tc, hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+
+    // ---- sample: lower bounds over the head of the list -> tau
+    const int64_t ld_s = (int64_t)n_samp * 8;
+    rc = dae_reserve(tc, tc->gmax, (size_t)Bpad * ld_s * sizeof(float)); if (rc) return rc;
+    rc = dae_reserve(tc, tc->tau, (size_t)Bpad * sizeof(float)); if (rc) return rc;
+    p.biasD = static_cast<const uint4*>(pd.bias16_lo.p); p.biasT = static_cast<const uint4*>(pt.mix16_lo.p);
+    p.list = order; p.n_items = n_samp;
+    p.samp = static_cast<float*>(tc->gmax.p); p.ld_s = ld_s;
+    hipLaunchKernelGGL(ks, dim3(grid), dim3(NW * 64), lds, st, p);
+    DAE_CHECK_LAUNCH(tc, "mix_bf16_kernel<sample>");
+    rc = dae_reserve(tc, tc->sample_top, (size_t)Bpad * (sizeof(uint2) + sizeof(int))); if (rc) return rc;
+    rc = dae_launch_tau_select(tc, p.samp, ld_s, (int)ld_s, p.samp, 0, 0, order, 0, B, k, seed_row_ptr,
+                               static_cast<float*>(tc->tau.p), static_cast<uint2*>(tc->sample_top.p), 1,
+                               reinterpret_cast<int*>(static_cast<uint2*>(tc->sample_top.p) + Bpad));        // (no sample list: count 0)
+    if (rc) return rc;
+
+    // ---- filter: upper bounds over every rankable tile
+    const int cap = ((ntr + nb - 1) / nb) * 32;
+    rc = dae_reserve(tc, tc->cand, (size_t)nb * Bpad * cap * sizeof(uint4)); if (rc) return rc;
+    rc = dae_reserve(tc, tc->cand_cnt, (size_t)nb * Bpad * sizeof(int)); if (rc) return rc;
+    p.biasD = static_cast<const uint4*>(pd.bias16_hi.p); p.biasT = static_cast<const uint4*>(pt.mix16_hi.p);
+    p.list = order; p.n_items = ntr;
+    p.tau = static_cast<const float*>(tc->tau.p);
+    p.cand = static_cast<uint4*>(tc->cand.p); p.cand_cnt = static_cast<int*>(tc->cand_cnt.p); p.cap = cap;
+    p.samp = nullptr; p.ld_s = 0;
+    hipLaunchKernelGGL(kf, dim3(grid), dim3(NW * 64), lds, st, p);
+    DAE_CHECK_LAUNCH(tc, "mix_bf16_kernel<filter>");
+
+    // ---- refine + selection
+    if (!tc->guard.p) {
+        rc = dae_reserve(tc, tc->guard, DAE_GUARD_BYTES); if (rc) return rc;
+        DAE_HIP_CHECK(tc, hipMemsetAsync(tc->guard.p, 0, DAE_GUARD_BYTES, st));
+    }
+    rc = dae_reserve(tc, tc->refined, (size_t)Bpad * MX_REF_CAP * sizeof(uint2) + (size_t)Bpad * sizeof(int)); if (rc) return rc;
+    uint2* rf = static_cast<uint2*>(tc->refined.p);
+    int* rf_cnt = reinterpret_cast<int*>(rf + (size_t)Bpad * MX_REF_CAP);
+    rc = dae_reserve(tc, tc->refstat, (size_t)Bpad * 2 * sizeof(int)); if (rc) return rc;
+    tc->refstat_rows = B;
+    MixRefP r;
+    memset(&r, 0, sizeof(r));
+    r.base = p.cand; r.cnt = p.cand_cnt; r.seg_stride = (int64_t)Bpad * cap; r.row_stride = cap; r.cnt_seg_stride = Bpad; r.nseg = nb;
+    r.hD = h; r.ld_hD = ld_h; r.HD = pd.H; r.W32D = static_cast<const float*>(pd.W32.p);
+    r.biasD = static_cast<const float*>(pd.bias.p); r.epsD = static_cast<const float*>(pd.eps.p);
+    r.hT = feat; r.ld_hT = ld_feat; r.HT = pt.H; r.W32T = static_cast<const float*>(pt.W32.p);
+    r.biasT = static_cast<const float*>(pt.bias.p);
+    r.alphaT = static_cast<const float*>(pt.mix_alpha.p); r.betaT = static_cast<const float*>(pt.mix_beta.p);
+    r.fhat = p.fhat; r.w_t = w_title; r.w_p = w_playlist; r.row_bad = static_cast<const int*>(tc->row_bad.p);
+    r.out = rf; r.out_cnt = rf_cnt; r.out_cap = MX_REF_CAP;
+    r.guard = static_cast<int*>(tc->guard.p); r.stat = static_cast<int*>(tc->refstat.p);
+    if (nb > MR_MAX_SEG) return dae_fail(tc, DAE_ERR_ARG, "too many candidate segments (%d)", nb);
+    hipLaunchKernelGGL(mix_refine_kernel, dim3(B), dim3(MR_THREADS), 0, st, r);
+    DAE_CHECK_LAUNCH(tc, "mix_refine_kernel");
+
+    dae_topk_args ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.B = B; ta.k = k;
+    ta.bitmap_base = 0; ta.bitmap_n = n_valid_col;
+    ta.seed_row_ptr = seed_row_ptr; ta.seed_col = seed_col;
+    ta.out_kind = DAE_OUT_LOGIT;                                 // the mixed score is a probability already: it goes out as it is
+    ta.out_score = out_score; ta.out_idx = out_idx;
+    dae_pair_group gr{rf, rf_cnt, 0, MX_REF_CAP, 0, 1, 0};
+    dae_pair_group g_none{nullptr, nullptr, 0, 0, 0, 0, 0};
+    return dae_launch_topk_pairs(tc, gr, g_none, ta);
+}

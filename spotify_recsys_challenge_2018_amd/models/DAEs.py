@@ -28,10 +28,16 @@ from .. import _lib
 _DECODE_DTYPES = {"f32": _lib.DAE_DTYPE_F32, "bf16": _lib.DAE_DTYPE_BF16, "exact_bf16": _lib.DAE_DTYPE_BF16_EXACT}
 
 
-def _title_dtype(dtype):
-    """Title-mixed launches rank a MIXED score, which the exact mode's bound does not cover: they run the fp32 kernels
-    (the lists exact_bf16 promises are the fp32 lists)."""
-    return _lib.DAE_DTYPE_F32 if dtype == _lib.DAE_DTYPE_BF16_EXACT else dtype
+def _title_dtype(dtype, model=None):
+    """Arithmetic of a title-mixed launch.  exact_bf16 has its own two-GEMM path (dae_mix_topk_exact, csrc/mixexact.hip)
+    built for the shipped shapes -- DAE hidden 256, title feature rows of 448; any other model runs its titled launches
+    on the fp32 kernels (the lists exact_bf16 promises are the fp32 lists either way)."""
+    if dtype != _lib.DAE_DTYPE_BF16_EXACT:
+        return dtype
+    tm = getattr(model, "title_model", None)
+    if (tm is not None and model.n_hidden == 256 and tm.ld == 448 and not getattr(model, "title_exact_off", False)):
+        return dtype
+    return _lib.DAE_DTYPE_F32
 
 
 class _Placeholder:
@@ -594,9 +600,9 @@ class DAE_tied:
             return
         self._ensure_packed(dtype)
         if getattr(self, "title_model", None) is not None:
-            self.title_model._ensure_packed(_title_dtype(dtype))
-            if _title_dtype(dtype) != dtype:
-                self._ensure_packed(_title_dtype(dtype))     # titled launches of an exact_bf16 model run the fp32 kernels
+            self.title_model._ensure_packed(_title_dtype(dtype, self))
+            if _title_dtype(dtype, self) != dtype:
+                self._ensure_packed(_title_dtype(dtype, self))     # shapes without the exact title mix: fp32 kernels
         self.ctx.bind_stream()
         fs = self.__dict__.get("_fetch_stream")
         if fs is None:
@@ -719,6 +725,12 @@ class DAE_tied:
             if blocking:                                    # (score, idx, done event): a blocking copy on the fetch stream
                 score_, idx_, ev_, n_fetch, rws, nt_ = t
                 fs.wait_event(ev_)
+                if getattr(idx_, "_mix_guard", None) is not None:          # exact title mix: see DAE_title._mix_guard_fired
+                    ev_.synchronize()
+                    redo = self._mix_guard_fired(idx_, k)
+                    if redo is not None:
+                        score_, idx_ = redo
+                        fs.wait_stream(torch.cuda.current_stream(self.device_index))
                 with torch.cuda.stream(fs):
                     idx_.record_stream(fs)
                     i_h = idx_[:n_fetch].cpu().numpy()
@@ -1266,13 +1278,25 @@ class DAE_title(DAE):
         import torch
         tm = self.title_model
         tm.ctx.bind_stream()
-        dtype = _title_dtype(dtype)
+        dtype = _title_dtype(dtype, self)
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
         csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
         h = torch.empty((nb, self.n_hidden), dtype=torch.float32, device=dev)
         self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h)
         w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb)
+        if dtype == _lib.DAE_DTYPE_BF16_EXACT:
+            # both GEMMs on bf16 operands in one launch per pass, the survivors recomputed in fp32 (csrc/mixexact.hip)
+            feat = tm.features(titles, nb, side_stream_of=self if side_stream else None)
+            d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, n_rows=nb)
+            score = torch.empty((nb, k), dtype=torch.float32, device=dev)
+            idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
+            gw = torch.empty(2, dtype=torch.int32, device=dev)
+            tm.ctx.mix_topk_exact(self.ctx, feat, h, w_t, w_p, self.n_tracks, d_srp, d_sc, k, score, idx, guard_out=gw)
+            ev = torch.cuda.current_stream(self.device_index).record_event()
+            # the guard words travel with the lists; what a re-scoring in fp32 needs, should they have moved
+            idx._mix_guard = (gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows))
+            return score, idx, ev
         nt32 = min((self.n_tracks + 31) // 32 * 32, self.n_input)
         y1T = torch.empty((nt32, nb), dtype=torch.float32, device=dev)
         self.ctx.decode_mix_term(h, w_p, self.n_tracks, y1T, dtype=dtype)
@@ -1288,6 +1312,28 @@ class DAE_title(DAE):
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
+    def _mix_guard_fired(self, idx, k):
+        """A launch of the exact title mix whose guard words moved is not trusted (a recomputed logit left the interval
+        the bf16 launch promised for it, or a row overflowed its candidate list): -> (score, idx) of the same feed through
+        the fp32 kernels, or None when the launch stands."""
+        tag = getattr(idx, "_mix_guard", None)
+        if tag is None:
+            return None
+        gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows) = tag
+        n_bad, col = (int(v) for v in gw.cpu())
+        if n_bad == self.__dict__.get("_mix_guard_seen", 0):
+            return None
+        self._mix_guard_seen = n_bad
+        import warnings
+        warnings.warn("exact_bf16 title mix: the bound guard fired (column %d): this launch is re-scored with the fp32 "
+                      "kernels" % col)
+        self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
+        self._ensure_packed(_lib.DAE_DTYPE_F32)
+        self.title_model._ensure_packed(_lib.DAE_DTYPE_F32)
+        score, idx2, _ev = self._submit(x_positions, x_ones, seeds, k, _lib.DAE_DTYPE_F32, False, titles, titles_use,
+                                        n_rows=n_rows)
+        return score, idx2
+
     def recommend(self, x_positions, x_ones, seeds, k=500, n_rows=None, dtype=None, titles=None, titles_use=None):
         """Top-k of the MIXED score (DAEs.py:176-181 + main_challenge.py:26-41) without either [batch, n_input] matrix
         (see `_submit`).  Same operations in the same order as `mixed_scores` + dae_topk_dense, hence the same bits
@@ -1299,12 +1345,15 @@ class DAE_title(DAE):
         if self._score_shard is not None:
             raise _lib.DaeError("title-mixed batches are not vocabulary-sharded: run --challenge with titles on one "
                                 "GPU per process group (playlist partitioning), or without the title variables")
-        dtype = _title_dtype(self._dtype_of(dtype))
+        dtype = _title_dtype(self._dtype_of(dtype), self)
         self._ensure_packed(dtype)
         self.title_model._ensure_packed(dtype)
         self.ctx.bind_stream()
         score, idx, _ev = self._submit(x_positions, x_ones, seeds, k, dtype, False, titles, titles_use)
         n_rows = self.n_batch if n_rows is None else n_rows
+        redo = self._mix_guard_fired(idx, k)
+        if redo is not None:
+            score, idx = redo
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()
         self._check_feed()
         return res

@@ -175,6 +175,11 @@ class Char_CNN:
             self.ctx.bind_stream()
             self.ctx.prepack_decoder(self.p["Output_WT"], self.p["Output_b"], 0, self.output_dim, dtype)
             self._packed.add(dtype)
+            # "bf16" and "exact_bf16" share the context's bf16 image: the exact prepack serves both, a plain one drops the bounds
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT:
+                self._packed.add(_lib.DAE_DTYPE_BF16)
+            elif dtype == _lib.DAE_DTYPE_BF16:
+                self._packed.discard(_lib.DAE_DTYPE_BF16_EXACT)
 
     def score(self, titles, n_rows, keep_prob=1.0, seed=0):
         """`model_title.output`: sigmoid(features . Output_W + Output_b) as a dense [n_rows, n_output] CUDA tensor."""

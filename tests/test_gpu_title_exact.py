@@ -1,0 +1,189 @@
+"""GPU (-m gpu): DAE_DTYPE_BF16_EXACT under the title mix (dae_mix_topk_exact, csrc/mixexact.hip) -- what `--challenge`
+ranks for every titled batch (reference main_challenge.py:80-90, DAEs.py:153-181).  The bar is the exact mode's: the lists
+(indices AND score bits) of the fp32 title path, which tests/test_gpu_title.py pins to the oracle's ranking rule on the
+numpy restatement of the mix."""
+import pickle
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import title_numpy as tn
+from spotify_recsys_challenge_2018_amd import _lib
+from spotify_recsys_challenge_2018_amd.models.DAEs import DAE_title, SEEDS_FROM_INPUT
+from spotify_recsys_challenge_2018_amd.models.title_models import get_model
+from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
+
+pytestmark = pytest.mark.gpu
+FS = [3, 5, 7, 9]
+
+
+def _conf(n_tracks=2000, n_input=2300, batch=24):
+    class Conf:
+        hidden = 256; lr = 0.01; reg_lambda = 0.0
+        char_emb = 50; strmaxlen = 25; charsize = 41; char_model = 'Char_CNN'; filter_num = 100; filter_size = FS
+        save = "/tmp/_title_unused"; initval = "NULL"
+    c = Conf()
+    c.batch = batch; c.n_input = n_input; c.n_output = n_input; c.n_tracks = n_tracks
+    return c
+
+
+def _titles(B, seed=0):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(0, 41, (B, 25))
+    for r in range(B):
+        t[r, int(rng.integers(0, 26)):] = -1
+    t[0, :] = -1                                       # an empty title
+    return t
+
+
+def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.0, out_scale=1.0):
+    W_enc, b_enc, W_dec, b_dec = make_weights(conf.n_input, conf.hidden, seed=1, bias=bias, n_tracks=conf.n_tracks)
+    W_dec = (W_dec * np.float32(w_scale)).astype(np.float32)
+    p = tmp_path / ("w_dae_%s_%g" % (bias, w_scale))
+    with open(p, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+    conf.DAEval = str(p)
+    mt = get_model(conf)
+    host = tn.make_params(41, 50, FS, 100, conf.n_output, seed=title_seed)
+    if feat_scale != 1.0:                              # features far outside [0, 1]: the bound scales with the row's largest
+        for i in range(len(FS)):
+            host["Conv_W%d" % i] = (host["Conv_W%d" % i] * np.float32(feat_scale)).astype(np.float32)
+    if out_scale != 1.0:
+        host["Output_W"] = (host["Output_W"] * np.float32(out_scale)).astype(np.float32)
+    mt.fit(host)
+    m = DAE_title(conf, mt)
+    m.fit()
+    return m
+
+
+def _same(a, b):
+    (ia, sa), (ib, sb) = a, b
+    assert np.array_equal(ia, ib)
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+
+
+def _feed(conf, seed, empty_rows=()):
+    pos, ones, seeds = make_playlists(conf.batch, conf.n_tracks, conf.n_input - conf.n_tracks, seed=seed)
+    if len(empty_rows):                                # title-only playlists: w_playlist = 0, w_title = 1 (challenge category 1)
+        keep = ~np.isin(pos[:, 0], np.asarray(empty_rows))
+        pos = pos[keep]
+        ones = ones[keep] if np.ndim(ones) and len(ones) == len(keep) else ones
+        seeds = [[] if r in empty_rows else s for r, s in enumerate(seeds)]
+    return pos, ones, seeds
+
+
+@pytest.mark.parametrize("bias,w_scale,feat_scale,out_scale", [("zipf", 1.0, 1.0, 1.0), ("zeros", 1.0, 1.0, 1.0),
+                                                                 ("zipf", 40.0, 1.0, 1.0), ("zipf", 1.0, 25.0, 1.0),
+                                                                 ("zipf", 1.0, 4.0, 30.0)])
+def test_exact_title_mix_returns_the_fp32_lists(tmp_path, bias, w_scale, feat_scale, out_scale):
+    conf = _conf()
+    m = _model(tmp_path, conf, bias, w_scale, feat_scale=feat_scale, out_scale=out_scale)
+    tm = m.title_model
+    for trial, k in enumerate((100, 500, 37)):
+        pos, ones, seeds = _feed(conf, 5 + trial, empty_rows=(2, 11) if trial != 1 else ())
+        titles = _titles(conf.batch, seed=6 + trial)
+        use = (np.arange(conf.batch) % 3 != trial).astype(np.float32)      # every third row has no title
+        use[2] = 1.0
+        want = m.recommend(pos, ones, seeds, k=k, titles=titles, titles_use=use, dtype="f32")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                  # a guard fallback would hide a broken bound
+            got = m.recommend(pos, ones, seeds, k=k, titles=titles, titles_use=use, dtype="exact_bf16")
+        _same(got, want)
+        st = tm.ctx.exact_stats_read()
+        assert st["rows"] == conf.batch and st["candidates_per_row"] >= min(k, 1)      # the two-GEMM launches ran
+        assert tm.ctx.exact_guard_read()[0] == 0
+    assert not getattr(m, "_guard_fallbacks", 0)
+
+
+def test_exact_title_mix_streamed_and_coalesced(tmp_path):
+    """The drivers' loop: 5 feeds of 150 rows in one 750-row launch (8 row groups of 96), a vocabulary of 1 400 tiles;
+    rows with and without titles, short feeds, a feed without any title (the plain exact path)."""
+    conf = _conf(n_tracks=40000, n_input=45000, batch=150)
+    m = _model(tmp_path, conf)
+    m.decode_dtype = _lib.DAE_DTYPE_BF16_EXACT
+    B = conf.batch
+    feeds, want = [], []
+    for i in range(7):
+        pos, ones, _s = make_playlists(B, conf.n_tracks, conf.n_input - conf.n_tracks, seed=20 + i)
+        titles = _titles(B, seed=30 + i)
+        use = (np.arange(B) % 3 != i % 3).astype(np.float32)
+        if i == 3:
+            use[:] = 0.0
+        n = [B, B, 7, B, B, 1, 119][i]
+        seeds = [[] for _ in range(B)]
+        for r, c in np.asarray(pos):
+            if c < conf.n_tracks:
+                seeds[int(r)].append(int(c))
+        seeds = [sorted(set(s)) for s in seeds]
+        feeds.append((pos, ones, SEEDS_FROM_INPUT, n, [list(t) for t in titles], use))
+        want.append(m.recommend(pos, ones, seeds, k=500, n_rows=n, titles=titles, titles_use=use, dtype="f32"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = list(m.recommend_iter(feeds, k=500))
+    assert len(got) == 7
+    for g, w in zip(got, want):
+        _same(g, w)
+    assert m.title_model.ctx.exact_stats_read()["rows"] > 0
+    assert not getattr(m, "_guard_fallbacks", 0)
+
+
+def test_exact_title_mix_guard_and_fallback(tmp_path):
+    """A forged bound (dae_set_exact_margin < 1 on either context) makes recomputed logits leave their intervals: the guard
+    counts them, `recommend` and the streamed loop re-score the launch with the fp32 kernels and say so."""
+    conf = _conf()
+    m = _model(tmp_path, conf)
+    pos, ones, seeds = _feed(conf, 5)
+    titles = _titles(conf.batch, seed=6)
+    use = np.ones(conf.batch, np.float32)
+    want = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="f32")
+    for which in ("title", "dae"):
+        ctx = m.title_model.ctx if which == "title" else m.ctx
+        ctx.set_exact_margin(1e-3)
+        if which == "title":
+            m.title_model._packed_dirty = True
+        else:
+            m._mark_dirty()
+        with pytest.warns(UserWarning, match="bound guard"):
+            got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
+        _same(got, want)
+        assert m._guard_fallbacks >= 1
+        ctx.set_exact_margin(1.0)
+        m.title_model._packed_dirty = True
+        m._mark_dirty()
+    n0 = m._guard_fallbacks
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got, want)
+    assert m._guard_fallbacks == n0
+    # a wider bound (margin > 1) only lists more candidates
+    m.title_model.ctx.set_exact_margin(8.0)
+    m.title_model._packed_dirty = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got, want)
+
+
+def test_exact_title_mix_other_shapes_run_fp32(tmp_path):
+    """Hidden sizes the two-GEMM kernel is not built for: exact_bf16 still returns the fp32 lists (on the fp32 kernels), and
+    the C entry point says why it refuses."""
+    conf = _conf()
+    conf.hidden = 64
+    m = _model(tmp_path, conf)
+    pos, ones, seeds = _feed(conf, 5)
+    titles = _titles(conf.batch, seed=6)
+    use = np.ones(conf.batch, np.float32)
+    _same(m.recommend(pos, ones, seeds, k=50, titles=titles, titles_use=use, dtype="exact_bf16"),
+          m.recommend(pos, ones, seeds, k=50, titles=titles, titles_use=use, dtype="f32"))
+    import torch
+    tm = m.title_model
+    m._ensure_packed(_lib.DAE_DTYPE_BF16_EXACT)
+    tm._ensure_packed(_lib.DAE_DTYPE_BF16_EXACT)
+    dev = m.weights["encoder_h"].device
+    feat = torch.zeros((4, tm.ld), device=dev); h = torch.zeros((4, 64), device=dev)
+    w = torch.ones(4, device=dev)
+    sc = torch.empty((4, 10), device=dev); ix = torch.empty((4, 10), dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.DaeError, match="hidden 256"):
+        tm.ctx.mix_topk_exact(m.ctx, feat, h, w, w, conf.n_tracks, None, None, 10, sc, ix)
