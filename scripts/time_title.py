@@ -9,6 +9,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spotify_recsys_challenge_2018_amd import _lib as _l   # noqa: E402
+if os.environ.get("DAE_LIB_AB"):       # A/B against another build of the library
+    _l.LIB_PATH = os.environ["DAE_LIB_AB"]
 from spotify_recsys_challenge_2018_amd.models.DAEs import DAE_title, SEEDS_FROM_INPUT   # noqa: E402
 from spotify_recsys_challenge_2018_amd.models.title_models import get_model   # noqa: E402
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights   # noqa: E402
@@ -47,6 +50,9 @@ def main():
     torch.cuda.synchronize()
     ds = (time.perf_counter() - t0) / n
     print("titled recommend_iter %s: %.3f ms per batch of 150 = %.0f playlists/s" % (mode, ds * 1e3, 150 / ds))
+    if mode == "exact_bf16":
+        print("  last launch:", m.title_model.ctx.exact_stats_read(), "guard", m.title_model.ctx.exact_guard_read(),
+              "fallbacks", getattr(m, "_guard_fallbacks", 0))
 
 
 if __name__ == "__main__":

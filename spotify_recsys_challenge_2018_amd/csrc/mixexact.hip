@@ -12,11 +12,19 @@
 //   sample launch (MODE 1): biases shifted DOWN by the bounds -> lower bounds l of y over the head of the bias-ordered tile
 //          list; their maxima over groups of 4 columns go to the threshold kernel (tau_select_kernel, topk.hip), whose tau is
 //          a valid lower bound of the row's k-th largest rankable non-seed y;
-//   filter launch (MODE 0): biases shifted UP -> upper bounds; every (row, column) whose upper bound reaches tau is listed
-//          with the two upper logits (u_t, u_d);
-//   refine launch: recomputes z_t, z_d of every listed column with the canonical chains and mixes them with the operations of
-//          mix_scores_kernel (title.hip) in their order: the value the fp32 path ranks; tests it against the promise
-//          (bound guard, as refine.hip) and leaves one compact (y, column) list per row for the selection kernel.
+//   filter launch (MODE 0): biases shifted UP -> upper logits (u_t, u_d); a column is listed with them when its upper bound
+//          can reach tau.  The test needs no sigmoid and no division: with E = exp(-z),
+//              w_t / (1 + E_t) + w_p / (1 + E_d) >= tau   <=>   w_t (1 + E_d) + w_p (1 + E_t) >= tau (1 + E_t)(1 + E_d),
+//          two v_exp_f32 and a handful of multiply-adds per element, compared with 2^-15 of slack (mix_can_reach).  The
+//          lane's pair of MAXIMA over its 16 columns takes the test first: most (row block, tile) pairs of the low-bias
+//          tiles stop there.  (The canonical sigmoid in the epilogue -- ~35 VALU instructions, twice per element -- made the
+//          launch VALU-bound at 316 us for 750 rows; two logit thresholds per row, u_t >= thT or u_d >= thD, cost 3
+//          instructions but list EVERY column when one scorer is a flat background, e.g. an untrained title model.)
+//   refine launch, one workgroup per row: (1) the mixed bounds [l, u] of every listed column, densely (a lane per
+//          candidate); the need-th largest l is a threshold tau' that `need` columns provably reach, so only columns with
+//          u >= tau' can be among the k best; (2) those are recomputed: z_t, z_d with the canonical chains, mixed with the
+//          operations of mix_scores_kernel (title.hip) in their order -- the value the fp32 path ranks -- tested against the
+//          promise (bound guard, as refine.hip) and left as one compact (y, column) list per row for the selection kernel.
 // BOUNDS.  DAE side: hidden rows lie in [0, 1], eps_c of exact_bounds_kernel (decode_f32.hip) as in the plain exact mode.
 // Title side: the features are ReLU maxima, not confined to [0, 1]; with F_r = max_k |feat[r][k]| every term of that
 // derivation that is linear in the hidden row scales by F_r:
@@ -51,6 +59,30 @@ __device__ __forceinline__ float mixf(float zt, float zd, float wt, float wp)
 }
 __device__ __forceinline__ float widen_up(float y) { return fmaf(y, 0x1p-20f, y); }       // y >= 0
 __device__ __forceinline__ float widen_dn(float y) { return fmaf(y, -0x1p-20f, y); }
+// The threshold sample evaluates every element, so it takes the hardware's exp2 / rcp (1 ulp each) instead of the canonical
+// polynomial (4 instructions against ~35): within 6.1e-6 relative of the canonical value for every finite logit (the
+// argument's rounding, |z| log2(e) 2^-24 <= 7.6e-6 in the exponent, dominates), hence a lower bound after 2^-15 relative.
+__device__ __forceinline__ float sig_fast(float z)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
+}
+// Can w_t sigmoid(z_t) + w_p sigmoid(z_d) reach tau?  True whenever the canonical mixed value, widened by 2^-20, does (the
+// caller passes tau (1 - 2^-17)); false only with 2^-15 of room.  With E = exp(-z) (v_exp_f32: 1 ulp, its argument's
+// rounding <= 6e-6 relative in E; arguments capped at 2^60, which only raises the left side's share):
+//     w_t / (1 + E_t) + w_p / (1 + E_d) >= tau  <=>  w_t (1 + E_d) + w_p (1 + E_t) >= tau (1 + E_t)(1 + E_d)
+__device__ __forceinline__ bool mix_can_reach(float zt, float zd, float wt, float wp, float tau)
+{
+    const float et = 1.0f + __builtin_amdgcn_exp2f(fminf(zt * -1.44269504088896341f, 60.0f));
+    const float ed = 1.0f + __builtin_amdgcn_exp2f(fminf(zd * -1.44269504088896341f, 60.0f));
+    const float lhs = fmaf(wp, et, wt * ed);
+    const float rhs = (tau * et) * ed;
+    return fmaf(lhs, 0x1p-15f, lhs) >= rhs;
+}
+__device__ __forceinline__ float mix_fast_dn(float zt, float zd, float wt, float wp)
+{
+    const float y = sig_fast(zt) * wt + sig_fast(zd) * wp;
+    return fmaf(y, -0x1p-15f, y);
+}
 
 struct MixP {
     const uint4* WqD; const uint4* WqT;          // bf16 images [tile][NS][64] of the two scorers (same tiles: column 32 t + i)
@@ -95,11 +127,14 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
     const bool has = it0 < n_items;
     const int tv0 = p.list[has ? it0 : 0];
     const int tv1 = p.list[has ? (it0 + n_ws < n_items ? it0 + n_ws : it0) : 0];
-    float tau_g[(R_TILE + NTH - 1) / NTH];
-#pragma unroll
-    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
-        const int i = e * NTH + tid;
-        tau_g[e] = (MODE == 0 && i < R_TILE && rg * R_TILE + i < p.B) ? p.tau[rg * R_TILE + i] : __builtin_inff();
+    // filter: the row's threshold (rows beyond B list nothing)
+    static_assert(R_TILE <= NTH, "one thread per row");
+    float tau_g = __builtin_inff();
+    if (MODE == 0 && tid < R_TILE && rg * R_TILE + tid < p.B) {
+        const float tau = p.tau[rg * R_TILE + tid];
+        // the compared bound is widened by 2^-20 and rounded twice; tau <= 0 (or -inf: fewer than `need` sample values,
+        // or NaN): every column passes
+        tau_g = tau > 0.0f ? tau * (1.0f - 0x1p-17f) : 0.0f;
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
@@ -123,11 +158,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
             }
         }
     }
-#pragma unroll
-    for (int e = 0; e < (R_TILE + NTH - 1) / NTH; ++e) {
-        const int i = e * NTH + tid;
-        if (i < R_TILE) { lcnt[i] = 0; ltau[i] = tau_g[e]; }
-    }
+    if (tid < R_TILE) { lcnt[tid] = 0; ltau[tid] = tau_g; }
     // per lane: the mixing weights and the row's feature bound of its RB rows
     float wt_r[RB], wp_r[RB];
     unsigned oy[RB];                                              // .y of the title side's "ones" fragment (k-slots 2, 3)
@@ -207,18 +238,17 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
         if (MODE == 0) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const float tv = tau_r[rb];
+                const float tv = tau_r[rb], wt = wt_r[rb], wp = wp_r[rb];
                 float mT = accT[rb][0], mD = accD[rb][0];
 #pragma unroll
                 for (int reg = 1; reg < 16; ++reg) { mT = fmaxf(mT, accT[rb][reg]); mD = fmaxf(mD, accD[rb][reg]); }
-                // (the pair of maxima bounds every pair of the lane's 16 columns: most tiles stop here)
-                if (widen_up(widen_up(mixf(mT, mD, wt_r[rb], wp_r[rb]))) >= tv) {
+                // (the pair of maxima bounds every pair of the lane's 16 columns)
+                if (mix_can_reach(mT, mD, wt, wp, tv)) {
                     unsigned m = 0;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int lc = t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
-                        const float y = widen_up(mixf(accT[rb][reg], accD[rb][reg], wt_r[rb], wp_r[rb]));
-                        if (y >= tv && lc < p.n_valid_col) m |= 1u << reg;
+                        if (mix_can_reach(accT[rb][reg], accD[rb][reg], wt, wp, tv) && lc < p.n_valid_col) m |= 1u << reg;
                     }
                     if (m) {
                         int at = atomicAdd(&lcnt[rb * 32 + j], __popc(m));
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int lc = t * 32 + 4 * hi + e + 8 * qd;
-                        const float y = widen_dn(mixf(accT[rb][4 * qd + e], accD[rb][4 * qd + e], wt_r[rb], wp_r[rb]));
+                        const float y = mix_fast_dn(accT[rb][4 * qd + e], accD[rb][4 * qd + e], wt_r[rb], wp_r[rb]);
                         if (lc < p.n_valid_col) mx = fmaxf(mx, y);
                     }
                     o[qd] = mx;
@@ -390,16 +420,19 @@ __global__ __launch_bounds__(256) void mix_pack_kernel(const float* __restrict__
     }
 }
 
-// ---- refine: the survivors' fp32 scores ------------------------------------------------------------------------------
-constexpr int MR_THREADS = 256, MR_WAVES = 4, MR_DEPTH = 4;
+// ---- refine: bounds of every candidate, the ones that can still be among the k best recomputed in fp32 -------------------
+constexpr int MR_THREADS = 512, MR_WAVES = 8, MR_DEPTH = 4;
 constexpr int MR_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (refine.hip)
 constexpr int MR_MAX_SEG = 1024;
+constexpr int MR_STAGE = 12288;        // candidates of a row whose two keys fit LDS
+constexpr int MR_BINS = 2048;
 
 struct MixRefP {
     const uint4* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
     const float* hD; int64_t ld_hD; int HD; const float* W32D; const float* biasD; const float* epsD;
     const float* hT; int64_t ld_hT; int HT; const float* W32T; const float* biasT; const float* alphaT; const float* betaT;
     const unsigned* fhat; const float* w_t; const float* w_p; const int* row_bad;
+    const int32_t* seed_row_ptr; int k;
     uint2* out; int* out_cnt; int out_cap;
     int* guard;                        // {violations, a violating column}
     int* stat;                         // [B][2] {candidates, recomputed}
@@ -465,7 +498,7 @@ __device__ __forceinline__ float mix_chain64(const float* __restrict__ W32, int 
     return acc;
 }
 
-// two floats further from the value than the rounded subtraction / addition left it
+// two floats further from the value than the rounded subtraction left it
 __device__ __forceinline__ float two_down(float x) { return dae_okey_inv(dae_okey(x) - 2u); }
 
 __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP p)
@@ -473,14 +506,22 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     __shared__ int seg_prefix[MR_MAX_SEG + 2];
     __shared__ float hrowD[1024];
     __shared__ float hrowT[1024];
-    __shared__ __attribute__((aligned(16))) float tb[MR_WAVES * 64 * MR_ROWSTRIDE];
+    __shared__ __attribute__((aligned(16))) float tb[MR_WAVES * 64 * MR_ROWSTRIDE];      // the waves' buffers; before: the histogram
+    // (static LDS beyond 64 KiB compiles, but its arrays then overlap at run time: the two key arrays are the launch's
+    // dynamic LDS, as refine.hip's staging area)
+    extern __shared__ __attribute__((aligned(16))) unsigned mr_dyn[];
+    unsigned* kl = mr_dyn;                       // keys of the lower bounds; afterwards the survivors' flat indices
+    unsigned* ku = mr_dyn + MR_STAGE;            // keys of the upper bounds
+    __shared__ unsigned cnts[32];
+    __shared__ int s_n;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
     const int nseg = p.nseg;
     const bool bad = p.row_bad && p.row_bad[row] != 0;
     for (int s = tid; s < nseg; s += MR_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
-    if (tid == 0) seg_prefix[0] = 0;
+    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
+    if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
     for (int i = tid; i < 1024; i += MR_THREADS) {
         hrowD[i] = i < p.HD ? p.hD[(size_t)row * p.ld_hD + i] : 0.0f;
         hrowT[i] = i < p.HT ? p.hT[(size_t)row * p.ld_hT + i] : 0.0f;
@@ -502,16 +543,130 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     }
     __syncthreads();
     const int total = seg_prefix[nseg];
-    if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = bad ? 0 : total; }
-    if (bad || total == 0 || total > p.out_cap) {
-        if (tid == 0) {
-            p.out_cnt[row] = 0;
-            // more survivors than the row's list holds: the launch cannot vouch for this row -- counted like a bound failure
-            // (the callers then re-score the launch with the fp32 kernels)
-            if (!bad && total > p.out_cap) { atomicAdd(p.guard, 1); p.guard[1] = -2; }
-        }
+    auto give_up = [&](int code) {
+        // a row the launch cannot vouch for (more candidates than its buffers hold): counted like a bound failure -- the
+        // callers then re-score the launch with the fp32 kernels
+        if (tid == 0) { p.out_cnt[row] = 0; atomicAdd(p.guard, 1); p.guard[1] = code; }
+    };
+    if (bad || total == 0) {
+        if (tid == 0) { p.out_cnt[row] = 0; if (p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; } }
         return;
     }
+    if (total > MR_STAGE) {
+        if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; }
+        give_up(-2);
+        return;
+    }
+    const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
+    const float wt = p.w_t[row], wp = p.w_p[row];
+    const float F = __uint_as_float(p.fhat[row] << 16);
+
+    // ---- 1. the mixed bounds of every candidate, as order-preserving keys: wave w takes the segments w, w + 8, ...
+    unsigned kmx = 0u, kmn = 0xFFFFFFFFu;
+    for (int sg = wave; sg < nseg; sg += MR_WAVES) {
+        const int b0 = seg_prefix[sg], cn = seg_prefix[sg + 1] - b0;
+        const uint4* sp = p.base + ((int64_t)sg * p.seg_stride + (int64_t)row * p.row_stride);
+        // (hipcc's loop vectorizer pairs the iterations i, i + 64 of this per-lane loop and the paired body leaves wrong
+        // lower bounds in kl for segments of more than 64 entries -- found with a device-side recomputation; off here)
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int i = lane; i < cn; i += 64) {
+            const uint4 en = sp[i];
+            const int col = (int)en.z;
+            const float uT = __uint_as_float(en.x), uD = __uint_as_float(en.y);
+            const float wdT = 2.0f * fmaf(p.alphaT[col], F, p.betaT[col]) * 1.000001f;
+            const float wdD = 2.0f * p.epsD[col] * 1.000001f;
+            const float up = widen_up(mixf(uT, uD, wt, wp));
+            const float lo = widen_dn(mixf(two_down(uT - wdT), two_down(uD - wdD), wt, wp));
+            const unsigned a = dae_okey(lo);
+            kl[b0 + i] = a;
+            ku[b0 + i] = dae_okey(up);
+            kmx = a > kmx ? a : kmx; kmn = a < kmn ? a : kmn;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned a = __shfl_xor(kmx, d), b = __shfl_xor(kmn, d);
+        kmx = a > kmx ? a : kmx; kmn = b < kmn ? b : kmn;
+    }
+    if (lane == 0) { atomicMax(&cnts[0], kmx); atomicMin(&cnts[1], kmn); }
+    unsigned* hist = reinterpret_cast<unsigned*>(tb);
+    for (int i = tid; i < MR_BINS; i += MR_THREADS) hist[i] = 0u;
+    __syncthreads();
+
+    // ---- 2. tau': the need-th largest lower bound (to a 2048-bin histogram over [min, max] of the row's keys and one pass
+    // for the smallest key of the selected bin, as refine.hip): `need` distinct columns provably reach it
+    unsigned P = 0u;                                             // key of tau' (0: everything survives)
+    if (total > need) {
+        const unsigned kmin = cnts[1], kmax = cnts[0];
+        const float scale = 2047.999f / ((float)(kmax - kmin) + 1.0f);
+        auto bin_of = [&](unsigned key) -> int {
+            const unsigned bq = (unsigned)((float)(key - kmin) * scale);
+            return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
+        };
+        for (int i = tid; i < total; i += MR_THREADS) atomicAdd(&hist[bin_of(kl[i])], 1u);
+        __syncthreads();
+        constexpr int BPT = MR_BINS / MR_THREADS;
+        const int top = MR_BINS - 1 - BPT * tid;
+        unsigned hc[BPT], own = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) { hc[e] = hist[top - e]; own += hc[e]; }
+        unsigned incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) cnts[8 + wave] = incl;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int w = 0; w < wave; ++w) pre += cnts[8 + w];
+        incl += pre;
+        const unsigned excl = incl - own;
+        if (excl < (unsigned)need && (unsigned)need <= incl) {
+            unsigned run = excl;
+            bool done = false;
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) {
+                if (!done && run + hc[e] >= (unsigned)need) { cnts[2] = (unsigned)(top - e); done = true; }
+                run += hc[e];
+            }
+        }
+        __syncthreads();
+        const int Bsel = (int)cnts[2];
+        unsigned kb = 0xFFFFFFFFu;
+        for (int i = tid; i < total; i += MR_THREADS) {
+            const unsigned key = kl[i];
+            if (bin_of(key) == Bsel) kb = key < kb ? key : kb;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(kb, d); kb = o < kb ? o : kb; }
+        if (lane == 0 && kb != 0xFFFFFFFFu) atomicMin(&cnts[3], kb);
+        __syncthreads();
+        if (cnts[3] != 0xFFFFFFFFu) P = cnts[3];
+    }
+    __syncthreads();                                             // (the last reads of kl and of the histogram)
+
+    // ---- 3. the survivors: upper bound >= tau'.  Their flat indices take kl's place.
+    int* surv = reinterpret_cast<int*>(kl);
+    for (int c0 = 0; c0 < total; c0 += MR_THREADS) {
+        const int i = c0 + tid;
+        const bool keep = i < total && ku[i] >= P;
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int b = 0;
+            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
+            b = __shfl(b, leader);
+            // (slot b + rank <= i always: the list never overtakes the keys still to be read -- and kl is dead anyway)
+            if (keep) surv[b + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = n; }
+    if (n > p.out_cap) { give_up(-3); return; }
+
+    // ---- 4. recompute the survivors
     auto offset_of = [&](int e) -> int64_t {
         int lo = 0, hi = nseg;
         while (hi - lo > 1) {
@@ -521,19 +676,17 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         return (int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]);
     };
     float* tbuf = tb + wave * (64 * MR_ROWSTRIDE);
-    const float wt = p.w_t[row], wp = p.w_p[row];
-    const float F = __uint_as_float(p.fhat[row] << 16);
     uint2* orow = p.out + (size_t)row * p.out_cap;
     const int gstep = MR_WAVES * 64;
     uint4 pr = make_uint4(0u, 0u, 0u, 0u);
     int g0 = wave * 64;
-    if (g0 < total) pr = p.base[offset_of(g0 + lane < total ? g0 + lane : g0)];
-    for (; g0 < total; g0 += gstep) {
+    if (g0 < n) pr = p.base[offset_of(surv[g0 + lane < n ? g0 + lane : g0])];
+    for (; g0 < n; g0 += gstep) {
         const int e = g0 + lane;
-        const bool in = e < total;
+        const bool in = e < n;
         const uint4 cur = pr;
         const int gn = g0 + gstep;
-        if (gn < total) pr = p.base[offset_of(gn + lane < total ? gn + lane : gn)];      // the next group's entries, under this group's rows
+        if (gn < n) pr = p.base[offset_of(surv[gn + lane < n ? gn + lane : gn])];       // the next group's entries, under this group's rows
         const int col = (int)cur.z;
         const float zT = mix_chain64<MR_DEPTH>(p.W32T, p.HT, hrowT, tbuf, lane, col) + p.biasT[col];
         const float zD = mix_chain64<MR_DEPTH>(p.W32D, p.HD, hrowD, tbuf, lane, col) + p.biasD[col];
@@ -548,7 +701,7 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             orow[e] = make_uint2(__float_as_uint(y), (unsigned)col);
         }
     }
-    if (tid == 0) p.out_cnt[row] = total;
+    if (tid == 0) p.out_cnt[row] = n;
 }
 
 }  // namespace
@@ -643,6 +796,12 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     const size_t lds = (size_t)RB * 64 * NS * sizeof(uint4) + (size_t)R_TILE * 8 + 16;
     auto kf = mix_bf16_kernel<NSD, NST, RB, QR, NW, 0>;
     auto ks = mix_bf16_kernel<NSD, NST, RB, QR, NW, 1>;
+#ifdef DAE_EXPERIMENTS
+    static const int qr_env = dae_exp_env("DAE_MIX_QR") ? atoi(dae_exp_env("DAE_MIX_QR")) : 0;      // A/B: W ring depth
+    if (qr_env == 12) { kf = mix_bf16_kernel<NSD, NST, RB, 12, NW, 0>; ks = mix_bf16_kernel<NSD, NST, RB, 12, NW, 1>; }
+    if (qr_env == 16) { kf = mix_bf16_kernel<NSD, NST, RB, 16, NW, 0>; ks = mix_bf16_kernel<NSD, NST, RB, 16, NW, 1>; }
+    if (qr_env == 4) { kf = mix_bf16_kernel<NSD, NST, RB, 4, NW, 0>; ks = mix_bf16_kernel<NSD, NST, RB, 4, NW, 1>; }
+#endif
     static const char attr_key = 0;
     if (dae_first_use(tc, &attr_key)) {
         DAE_HIP_CHECK(tc, hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -695,10 +854,15 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     r.biasT = static_cast<const float*>(pt.bias.p);
     r.alphaT = static_cast<const float*>(pt.mix_alpha.p); r.betaT = static_cast<const float*>(pt.mix_beta.p);
     r.fhat = p.fhat; r.w_t = w_title; r.w_p = w_playlist; r.row_bad = static_cast<const int*>(tc->row_bad.p);
+    r.seed_row_ptr = seed_row_ptr; r.k = k;
     r.out = rf; r.out_cnt = rf_cnt; r.out_cap = MX_REF_CAP;
     r.guard = static_cast<int*>(tc->guard.p); r.stat = static_cast<int*>(tc->refstat.p);
     if (nb > MR_MAX_SEG) return dae_fail(tc, DAE_ERR_ARG, "too many candidate segments (%d)", nb);
-    hipLaunchKernelGGL(mix_refine_kernel, dim3(B), dim3(MR_THREADS), 0, st, r);
+    static const char ref_key = 0;
+    if (dae_first_use(tc, &ref_key))
+        DAE_HIP_CHECK(tc, hipFuncSetAttribute(reinterpret_cast<const void*>(mix_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(2 * MR_STAGE * sizeof(unsigned))));
+    hipLaunchKernelGGL(mix_refine_kernel, dim3(B), dim3(MR_THREADS), 2 * MR_STAGE * sizeof(unsigned), st, r);
     DAE_CHECK_LAUNCH(tc, "mix_refine_kernel");
 
     dae_topk_args ta;
