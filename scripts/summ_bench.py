@@ -20,6 +20,10 @@ for path in sys.argv[1:]:
                 print("   ", k, kk, {a: b.get("value") for a, b in v.items() if isinstance(b, dict) and "value" in b} or v.get("value"))
     if "drivers_loop" in d:
         print("    loop", {a: b.get("value") for a, b in d["drivers_loop"].items() if isinstance(b, dict) and "value" in b})
+    if "titled" in d:
+        t = d["titled"]
+        print("    titled", {a: b.get("value") for a, b in t.items() if isinstance(b, dict) and "value" in b} or t,
+              {a: b for a, b in (t.get("exact_bf16") or {}).items() if a != "value" and a != "feeds"})
     if "training_step" in d:
         print("    train", {a: b.get("ms_per_step") for a, b in d["training_step"].items() if isinstance(b, dict)})
     if "phases" in d:

@@ -726,8 +726,10 @@ class DAE_tied:
                 score_, idx_, ev_, n_fetch, rws, nt_ = t
                 fs.wait_event(ev_)
                 if getattr(idx_, "_mix_guard", None) is not None:          # exact title mix: see DAE_title._mix_guard_fired
-                    ev_.synchronize()
-                    redo = self._mix_guard_fired(idx_, k)
+                    with torch.cuda.stream(fs):                             # (on the compute stream the copy would wait for the NEXT launch too)
+                        idx_._mix_guard[0].record_stream(fs)
+                        words = idx_._mix_guard[0].cpu()
+                    redo = self._mix_guard_fired(idx_, k, words)
                     if redo is not None:
                         score_, idx_ = redo
                         fs.wait_stream(torch.cuda.current_stream(self.device_index))
@@ -1312,7 +1314,7 @@ class DAE_title(DAE):
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
-    def _mix_guard_fired(self, idx, k):
+    def _mix_guard_fired(self, idx, k, words=None):
         """A launch of the exact title mix whose guard words moved is not trusted (a recomputed logit left the interval
         the bf16 launch promised for it, or a row overflowed its candidate list): -> (score, idx) of the same feed through
         the fp32 kernels, or None when the launch stands."""
@@ -1320,7 +1322,7 @@ class DAE_title(DAE):
         if tag is None:
             return None
         gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows) = tag
-        n_bad, col = (int(v) for v in gw.cpu())
+        n_bad, col = (int(v) for v in (gw.cpu() if words is None else words))
         if n_bad == self.__dict__.get("_mix_guard_seen", 0):
             return None
         self._mix_guard_seen = n_bad
