@@ -96,6 +96,7 @@ struct MixP {
     int B, n_rg, nb_rg, Bpad;
     uint4* cand; int* cand_cnt; int cap;         // filter: [bir][Bpad][cap] entries (u_t, u_d, column, 0) + [bir][Bpad] counts
     float* samp; int64_t ld_s;                   // sample: [B][ld_s] maxima of 4-column groups, element item * 8 + 4 hi + qd
+    int exp_mode;                                // experiments build: 1 = no epilogue at all, 2 = the maxima's test only
 };
 
 template <int NSD, int NST, int RB, int QR, int NW, int MODE>
@@ -235,6 +236,14 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
         }
 
         // ---- epilogue: lane = playlist j of row block rb; register reg is column 32 t + 4 hi + (reg & 3) + 8 (reg >> 2)
+#ifdef DAE_EXPERIMENTS
+        if (p.exp_mode == 1) {
+            float sink = 0.0f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) sink += accT[rb][0] + accD[rb][5];
+            if (sink == 123.456f) p.cand_cnt[0] = 1;
+        } else
+#endif
         if (MODE == 0) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -243,6 +252,9 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
 #pragma unroll
                 for (int reg = 1; reg < 16; ++reg) { mT = fmaxf(mT, accT[rb][reg]); mD = fmaxf(mD, accD[rb][reg]); }
                 // (the pair of maxima bounds every pair of the lane's 16 columns)
+#ifdef DAE_EXPERIMENTS
+                if (p.exp_mode == 2) { if (mix_can_reach(mT, mD, wt, wp, tv) && tv == 123.456f) p.cand_cnt[0] = 1; continue; }
+#endif
                 if (mix_can_reach(mT, mD, wt, wp, tv)) {
                     unsigned m = 0;
 #pragma unroll
@@ -797,6 +809,8 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     auto kf = mix_bf16_kernel<NSD, NST, RB, QR, NW, 0>;
     auto ks = mix_bf16_kernel<NSD, NST, RB, QR, NW, 1>;
 #ifdef DAE_EXPERIMENTS
+    static const int exp_mode = dae_exp_env("DAE_MIX_EXP") ? atoi(dae_exp_env("DAE_MIX_EXP")) : 0;   // stage bisection of the filter launch
+    p.exp_mode = exp_mode;
     static const int qr_env = dae_exp_env("DAE_MIX_QR") ? atoi(dae_exp_env("DAE_MIX_QR")) : 0;      // A/B: W ring depth
     if (qr_env == 12) { kf = mix_bf16_kernel<NSD, NST, RB, 12, NW, 0>; ks = mix_bf16_kernel<NSD, NST, RB, 12, NW, 1>; }
     if (qr_env == 16) { kf = mix_bf16_kernel<NSD, NST, RB, 16, NW, 0>; ks = mix_bf16_kernel<NSD, NST, RB, 16, NW, 1>; }

@@ -662,15 +662,21 @@ class DAE_tied:
                 rows = [nb if f[3] is None else f[3] for f in buf]
                 feed = (P, O, seeds, None)
                 if any(len(f) > 4 for f in buf):           # DAE_title feeds: titles / titles_use, one entry per row
-                    pad = [-1] * self.title_model.input_len
-                    titles, use = [], []
-                    for f in buf:
-                        t = [] if len(f) <= 4 or f[4] is None else [pad if x is None else x for x in f[4]]
-                        u = [] if len(f) <= 5 or f[5] is None else [float(x) for x in np.asarray(f[5]).reshape(-1)]
-                        u = (u + [0.0] * len(t))[:len(t)]
-                        titles += list(t)[:nb] + [pad] * (nb - min(len(t), nb))
-                        use += u[:nb] + [0.0] * (nb - min(len(u), nb))
-                    feed = feed + (titles, np.asarray(use, np.float32))
+                    L_ = self.title_model.input_len
+                    pad = [-1] * L_
+                    titles = np.full((len(buf) * nb, L_), -1, np.int32)        # (one array per launch: 750 Python lists cost the
+                    use = np.zeros(len(buf) * nb, np.float32)                   #  upload a conversion of their own)
+                    for i, f in enumerate(buf):
+                        t = [] if len(f) <= 4 or f[4] is None else f[4]
+                        nt = min(len(t), nb)
+                        if nt:
+                            if not isinstance(t, np.ndarray):
+                                t = [pad if x is None else x for x in t[:nt]]
+                            titles[i * nb:i * nb + nt] = np.asarray(t, np.int64).reshape(-1, L_)[:nt]
+                        if len(f) > 5 and f[5] is not None:
+                            u = np.asarray(f[5], np.float32).reshape(-1)[:nt]        # (no title, no use)
+                            use[i * nb:i * nb + len(u)] = u
+                    feed = feed + (titles, use)
                 return feed, rows, len(buf) * nb
             def titled(f):
                 return len(f) > 5 and f[5] is not None and bool(np.any(np.asarray(f[5])))
@@ -1184,7 +1190,7 @@ class DAE_title(DAE):
         rows = np.repeat(np.arange(self.n_batch), np.diff(rp))
         return np.bincount(rows, weights=v.astype(np.float64), minlength=self.n_batch).astype(np.float32)
 
-    def _mix_weights(self, csr, titles_use, input_keep_prob=1.0, seed=0, side_stream=False, n_rows=None):
+    def _mix_weights(self, csr, titles_use, input_keep_prob=1.0, seed=0, side_stream=False, n_rows=None, u_dev=None):
         """DAEs.py:159-162 on the device: x_count = row_sum(x) * input_keep_prob; w_title = u / (u + x_count + 1e-10),
         w_playlist = x_count / (same) -- fp32 operations in the reference's order.  -> (w_title, w_playlist) [n_batch]."""
         import torch
@@ -1195,10 +1201,13 @@ class DAE_title(DAE):
         P = _lib._ptr
         self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(rp), P(c), P(v), nb, float(input_keep_prob),
                                                  int(seed), P(s)))
-        u = np.zeros(nb, np.float32)
-        tu = np.asarray(titles_use, np.float32).reshape(-1)
-        u[:len(tu)] = tu[:nb]
-        u = self._to_dev(u, torch.float32, side_stream)
+        if u_dev is None:
+            u = np.zeros(nb, np.float32)
+            tu = np.asarray(titles_use, np.float32).reshape(-1)
+            u[:len(tu)] = tu[:nb]
+            u = self._to_dev(u, torch.float32, side_stream)
+        else:
+            u = u_dev                                         # staged with the feed (`_stage_titled`)
         x_count = s * float(np.float32(input_keep_prob))
         deno = u + x_count + 1e-10
         return (u / deno).contiguous(), (x_count / deno).contiguous()
@@ -1269,6 +1278,52 @@ class DAE_title(DAE):
         self._check_feed()
         return cost
 
+    def _stage_titled(self, x_positions, x_ones, titles, titles_use, nb):
+        """The streamed loop's upload of a titled launch: feed positions / values, titles and titles_use through ONE pinned
+        block and ONE asynchronous copy on the copy stream (four blocking copies from pageable memory were 0.25 ms of
+        the host's ~1 ms per launch, with the GPU's share at 0.55 ms).  -> (d_pos, d_val, d_titles [nb, L] int32, d_use [nb])."""
+        import torch
+        pos, vals = self._feed_arrays(x_positions, x_ones)
+        L = self.title_model.input_len
+        t = np.full((nb, L), -1, np.int32)
+        src = np.asarray(titles, np.int64).reshape(-1, L) if len(titles) else np.zeros((0, L), np.int64)
+        t[:min(len(src), nb)] = src[:nb]
+        u = np.zeros(nb, np.float32)
+        tu = np.asarray(titles_use, np.float32).reshape(-1)
+        u[:min(len(tu), nb)] = tu[:nb]
+        n, nv = max(pos.shape[0], 1), max(vals.size, 1)
+        parts = [(pos if pos.shape[0] else np.zeros((1, 2), np.int64), n * 16), (vals if vals.size else np.zeros(1, np.float32), nv * 4),
+                 (t, nb * L * 4), (u, nb * 4)]
+        offs, total = [], 0
+        for _a, nbytes in parts:
+            offs.append(total)
+            total += (nbytes + 15) // 16 * 16
+        ring = self.__dict__.setdefault("_title_ring", [{} for _ in range(4)])
+        slot = ring[self.__dict__.get("_title_ring_at", 0) % len(ring)]
+        self._title_ring_at = self.__dict__.get("_title_ring_at", 0) + 1
+        if slot.get("busy") is not None:
+            slot["busy"].synchronize()                           # its previous upload left the block long ago
+        pin = _pinned(slot, "blk", total, torch.uint8)
+        host = pin.numpy()
+        for (a, nbytes), o in zip(parts, offs):
+            host[o:o + nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        dev = torch.device("cuda", self.device_index)
+        cs = self.__dict__.get("_copy_stream")
+        if cs is None:
+            cs = self._copy_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(self.device_index)
+        with torch.cuda.stream(cs):
+            d = torch.empty(total, dtype=torch.uint8, device=dev)
+            d.copy_(pin[:total], non_blocking=True)
+            slot["busy"] = ev = cs.record_event()
+        cur.wait_event(ev)
+        d.record_stream(cur)
+        d_pos = d[offs[0]:offs[0] + n * 16].view(torch.int64).view(n, 2)[:pos.shape[0]]
+        d_val = d[offs[1]:offs[1] + nv * 4].view(torch.float32)
+        d_t = d[offs[2]:offs[2] + nb * L * 4].view(torch.int32).view(nb, L)
+        d_u = d[offs[3]:offs[3] + nb * 4].view(torch.float32)
+        return d_pos, d_val, d_t, d_u
+
     def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
                 n_rows=None):
         """One batch enqueued, nothing fetched (`n_rows`: rows of a launch that coalesces several feeds).  Without titles in use the mix reduces to the plain DAE (w_playlist is
@@ -1283,13 +1338,18 @@ class DAE_title(DAE):
         dtype = _title_dtype(dtype, self)
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
+        d_titles = d_use = None
+        if side_stream and self.device_csr:                   # the streamed loop: one pinned block, one asynchronous copy
+            d_pos, d_val, d_titles, d_use = self._stage_titled(x_positions, x_ones, titles, titles_use, nb)
+            csr = self._upload_csr(None, None, n_rows=nb, staged=(d_pos, d_val, None))
+        else:
+            csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
         h = torch.empty((nb, self.n_hidden), dtype=torch.float32, device=dev)
         self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h)
-        w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb)
+        w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb, u_dev=d_use)
         if dtype == _lib.DAE_DTYPE_BF16_EXACT:
             # both GEMMs on bf16 operands in one launch per pass, the survivors recomputed in fp32 (csrc/mixexact.hip)
-            feat = tm.features(titles, nb, side_stream_of=self if side_stream else None)
+            feat = tm.features(titles, nb, side_stream_of=self if side_stream else None, d_titles=d_titles)
             d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, n_rows=nb)
             score = torch.empty((nb, k), dtype=torch.float32, device=dev)
             idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
@@ -1302,7 +1362,7 @@ class DAE_title(DAE):
         nt32 = min((self.n_tracks + 31) // 32 * 32, self.n_input)
         y1T = torch.empty((nt32, nb), dtype=torch.float32, device=dev)
         self.ctx.decode_mix_term(h, w_p, self.n_tracks, y1T, dtype=dtype)
-        feat = tm.features(titles, nb, side_stream_of=self if side_stream else None)
+        feat = tm.features(titles, nb, side_stream_of=self if side_stream else None, d_titles=d_titles)
         d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, n_rows=nb)
         score = torch.empty((nb, k), dtype=torch.float32, device=dev)
         idx = torch.empty((nb, k), dtype=torch.int32, device=dev)

@@ -151,12 +151,12 @@ class Char_CNN:
             return side_stream_of._to_dev(t, torch.int32, side_stream=True)
         return torch.from_numpy(t).to(torch.device("cuda", self.device_index))
 
-    def features(self, titles, n_rows, keep_prob=1.0, seed=0, keep_for_backward=False, side_stream_of=None):
+    def features(self, titles, n_rows, keep_prob=1.0, seed=0, keep_for_backward=False, side_stream_of=None, d_titles=None):
         """Char_CNN.py:23-63 -> feat [n_rows, ld] (CUDA); with keep_for_backward also (argmax, raw)."""
         import torch
         self.ctx.bind_stream()
         dev = self.p["conv_w"].device
-        d_t = self._titles_dev(titles, n_rows, side_stream_of)
+        d_t = self._titles_dev(titles, n_rows, side_stream_of) if d_titles is None else d_titles    # (staged with the feed)
         feat = torch.empty((n_rows, self.ld), dtype=torch.float32, device=dev)
         arg = torch.empty((n_rows, self.n_feat), dtype=torch.int32, device=dev) if keep_for_backward else None
         raw = torch.empty((n_rows, self.n_feat), dtype=torch.float32, device=dev) if keep_for_backward else None
