@@ -32,7 +32,7 @@ import numpy as np
 # Four batches in flight need four hardware queues of their own: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES (default
 # 4, one of them taken by the null stream) and streams that share a queue serialise (bf16 row: 5.9 -> 8.5 M playlists/s).
 # Read by the runtime when it initialises, i.e. before torch is imported below.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")     # (16 left the drivers_loop row's lanes sharing queues with the other rows' contexts)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -165,9 +165,10 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
     row = {"unit": "playlists/s", "what": _drivers_loop_row.__doc__.split("\n\n")[0].replace("\n    ", " "),
            "feeds_per_launch": {}}
     first = {}
-    for name, reps, warm in (("f32", 40, 5), ("exact_bf16", 120, 15), ("bf16", 120, 15)):
-        # warm-up: ~0.3 s of the same loop (the row follows seconds of host-only work: the device is back at its sustained
-        # state before the timed pass, as for the headline's prime phase)
+    for name, reps, warm in (("f32", 150, 60), ("exact_bf16", 500, 200), ("bf16", 600, 250)):
+        # warm-up: ~0.4 s of the same loop (the row follows seconds of host-only work: the device is back at its sustained
+        # state before the timed pass, as for the headline's prime phase; with 30 ms of warm-up the fp32 loop measured
+        # 0.9 - 1.07 M playlists/s here against 1.31 M in scripts/bench_loop.py); the timed pass runs ~1 s
         for i_, (idx_, _s) in enumerate(m.recommend_iter(feeds(warm), k=k, want_scores=False, dtype=name)):
             if i_ == 0:
                 first[name] = idx_.copy()

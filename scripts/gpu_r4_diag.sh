@@ -1,7 +1,7 @@
 # round 4 diagnostic: the exact mode on hard models (rates, candidates per row, per-kernel times)
 # usage: bash scripts/gpu_r4_diag.sh   (on the GPU box; writes gpurun_out/r4diag_*)
 cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=32
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_exact.py -x -q 2>&1 | tail -5
 run() {  # tag, env..., -- args

@@ -1,7 +1,7 @@
 # Round-4 session on the GPU box: the JSON lines and rocprofv3 kernel stats quoted in DESIGN.md / profiles/r04_notes.md
 # (copy gpurun_out/r04_* into profiles/ afterwards).  usage: bash scripts/gpu_round4.sh [quick]
 cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=32
 o=gpurun_out; mkdir -p $o
 python bench.py > $o/r04_bench_default.json 2> $o/err_default.txt
 python bench.py --dtype bf16 --no-train-row --no-cpu-baseline > $o/r04_bench_bf16.json 2> $o/err_bf16.txt

@@ -1,5 +1,5 @@
 # A/B of the exact title mix's kernels (experiments build): kernel times per variant
-export GPU_MAX_HW_QUEUES=16
+export GPU_MAX_HW_QUEUES=32
 R=${GRAFT_REPO_ROOT:-$PWD}
 export DAE_LIB_AB=$R/scripts/probe/libdae_hip_exp.so
 for v in "$@"; do
