@@ -229,7 +229,7 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
                 yield b_
     row = {"unit": "playlists/s", "what": _titled_row.__doc__.split("\n\n")[0].replace("\n    ", " "), "batch": B}
     lists = {}
-    for name, reps, warm in (("f32", 10, 3), ("exact_bf16", 30, 5)):
+    for name, reps, warm in (("f32", 60, 15), ("exact_bf16", 250, 60)):
         got = list(m.recommend_iter(feeds(warm), k=k, want_scores=True, dtype=name))
         lists[name] = got[:len(batches)]
         torch.cuda.synchronize()

@@ -157,6 +157,23 @@ def test_exact_title_mix_guard_and_fallback(tmp_path):
         got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
     _same(got, want)
     assert m._guard_fallbacks == n0
+    # the streamed loop: the guard words travel with each launch's lists; a launch whose words moved is re-scored in fp32
+    m.ctx.set_exact_margin(1e-3)
+    m._mark_dirty()
+    feeds = [(pos, ones, SEEDS_FROM_INPUT, conf.batch, [list(t) for t in titles], use)] * 7
+    own = [sorted(set(int(c) for r, c in np.asarray(pos) if r == row and c < conf.n_tracks)) for row in range(conf.batch)]
+    want_own = m.recommend(pos, ones, own, k=100, titles=titles, titles_use=use, dtype="f32")
+    with pytest.warns(UserWarning, match="bound guard"):
+        got_all = list(m.recommend_iter(feeds, k=100, dtype="exact_bf16"))
+    assert len(got_all) == 7
+    for g in got_all:
+        _same(g, want_own)
+    m.ctx.set_exact_margin(1.0)
+    m._mark_dirty()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for g in m.recommend_iter(feeds[:2], k=100, dtype="exact_bf16"):
+            _same(g, want_own)
     # a wider bound (margin > 1) only lists more candidates
     m.title_model.ctx.set_exact_margin(8.0)
     m.title_model._packed_dirty = True
