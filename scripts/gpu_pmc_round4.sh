@@ -31,4 +31,14 @@ tpass() {  # set-name counter
 }
 tpass fetch FETCH_SIZE
 tpass write WRITE_SIZE
+# the exact title mix (dae_mix_topk_exact): the two-GEMM filter launch and the refine launch, 750 rows per launch
+mpass() {  # set-name counter
+  d=/tmp/pmc4_title_$1; rm -rf $d
+  timeout 400 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $d -o p -- python $GRAFT_REPO_ROOT/scripts/time_title.py exact_bf16 20 > $d.log 2>&1
+  echo "pass title/$1 rc=$?"
+  f=$(find $d -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f $GRAFT_REPO_ROOT/gpurun_out/r04_pmc_title_$1.csv
+}
+mpass fetch FETCH_SIZE
+mpass write WRITE_SIZE
 python $GRAFT_REPO_ROOT/scripts/pmc_summarise.py $GRAFT_REPO_ROOT/gpurun_out r04

@@ -37,6 +37,12 @@ bash scripts/gpu_kprof.sh r04_train_default 14 python $GRAFT_REPO_ROOT/scripts/b
 SCALE=40 bash scripts/gpu_kprof.sh r04_exact_x40 7 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zipf exact 1
 bash scripts/gpu_kprof.sh r04_exact_zeros 7 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zeros exact 1
 TRAINED=1500 bash scripts/gpu_kprof.sh r04_exact_trained 16 python $GRAFT_REPO_ROOT/scripts/time_modes.py 256 zipf exact 1
+# the reference's real --challenge path (every batch title-mixed), per kernel: fp32 / both GEMMs bf16 / exact_bf16
+bash scripts/gpu_kprof.sh r04_title_f32 8 python $GRAFT_REPO_ROOT/scripts/time_title.py f32
+bash scripts/gpu_kprof.sh r04_title_bf16 8 python $GRAFT_REPO_ROOT/scripts/time_title.py bf16
+bash scripts/gpu_kprof.sh r04_title_exact 12 python $GRAFT_REPO_ROOT/scripts/time_title.py exact_bf16
+(python scripts/time_title.py f32 200; python scripts/time_title.py bf16 200; python scripts/time_title.py exact_bf16 400) 2>&1 | grep -v amdgpu > $o/r04_title_loop.log
+cat $o/r04_title_loop.log
 # the drivers' loop per engine (scripts/bench_loop.py)
 (python scripts/bench_loop.py 256 native,python; python scripts/bench_loop.py 150 native,python) 2>&1 | grep playlists | cut -c1-90 > $o/r04_bench_loop.log
 cat $o/r04_bench_loop.log

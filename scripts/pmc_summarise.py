@@ -125,6 +125,22 @@ for key, sub in (("grad_wdec_adam", "grad_wdec_t_kernel"), ("loss_forward", "dec
 if len(trn) > 3:
     json.dump(trn, open(os.path.join(root, "traffic_train.json"), "w"), indent=1)
     print(json.dumps(trn, indent=1))
+# the exact title mix (scripts/time_title.py exact_bf16 under --pmc): 750 rows per launch, 140 000 rankable columns
+f = per_kernel(os.path.join(root, "%s_pmc_title_fetch.csv" % PFX))
+w = per_kernel(os.path.join(root, "%s_pmc_title_write.csv" % PFX))
+ttl = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python scripts/time_title.py exact_bf16 20",
+       "fetch_correction": dec["fetch_correction"], "kernel_source_sha256_16": dict(sha, **{"mixexact.hip": src_sha("mixexact.hip")})}
+for key, sub in (("mix_filter", "mix_bf16_kernel<16, 28, 3, 8, 8, 0>"), ("mix_sample", "mix_bf16_kernel<16, 28, 3, 8, 8, 1>"),
+                 ("mix_refine", "mix_refine_kernel"), ("title_features", "title_features_mfma_kernel")):
+    kn, fd = find(f, sub)
+    _, wd = find(w, sub)
+    if kn:
+        fetch, write = mean(fd.get("FETCH_SIZE", [0])), mean(wd.get("WRITE_SIZE", [0]))
+        ttl[key] = {"kernel": short_name(kn), "launches": len(fd.get("FETCH_SIZE", [])), "fetch_size_kb": round(fetch, 1),
+                    "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024)}
+if len(ttl) > 3:
+    json.dump(ttl, open(os.path.join(root, "traffic_title.json"), "w"), indent=1)
+    print(json.dumps(ttl, indent=1))
 json.dump(dec, open(os.path.join(root, "traffic_decode.json"), "w"), indent=1)
 json.dump(enc, open(os.path.join(root, "traffic_encode.json"), "w"), indent=1)
 print(json.dumps(dec, indent=1))

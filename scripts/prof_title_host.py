@@ -10,8 +10,8 @@ for _ in m.recommend_iter([feed] * 10, k=500, dtype=mode, want_scores=False):
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in m.recommend_iter([feed] * 40, k=500, dtype=mode, want_scores=False):
+for _ in m.recommend_iter([feed] * 200, k=500, dtype=mode, want_scores=False):
     pass
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
+pstats.Stats(pr).sort_stats(sys.argv[2] if len(sys.argv) > 2 else "cumulative").print_stats(40)
