@@ -83,6 +83,11 @@ __device__ __forceinline__ float mix_fast_dn(float zt, float zd, float wt, float
     const float y = sig_fast(zt) * wt + sig_fast(zd) * wp;
     return fmaf(y, -0x1p-15f, y);
 }
+__device__ __forceinline__ float mix_fast_up(float zt, float zd, float wt, float wp)
+{
+    const float y = sig_fast(zt) * wt + sig_fast(zd) * wp;
+    return fmaf(y, 0x1p-15f, y);
+}
 
 struct MixP {
     const uint4* WqD; const uint4* WqT;          // bf16 images [tile][NS][64] of the two scorers (same tiles: column 32 t + i)
@@ -433,10 +438,10 @@ __global__ __launch_bounds__(256) void mix_pack_kernel(const float* __restrict__
 }
 
 // ---- refine: bounds of every candidate, the ones that can still be among the k best recomputed in fp32 -------------------
-constexpr int MR_THREADS = 512, MR_WAVES = 8, MR_DEPTH = 4;
+constexpr int MR_THREADS = 1024, MR_WAVES = 16, MR_DEPTH = 4;
 constexpr int MR_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (refine.hip)
 constexpr int MR_MAX_SEG = 1024;
-constexpr int MR_STAGE = 12288;        // candidates of a row whose two keys fit LDS
+constexpr int MR_STAGE = 8192;         // candidates of a row whose two keys fit LDS (next to the 16 waves' 80 KiB of buffers)
 constexpr int MR_BINS = 2048;
 
 struct MixRefP {
@@ -448,6 +453,7 @@ struct MixRefP {
     uint2* out; int* out_cnt; int out_cap;
     int* guard;                        // {violations, a violating column}
     int* stat;                         // [B][2] {candidates, recomputed}
+    long long* stamps;                 // experiments build: stage stamps of row 0's workgroup (DAE_DBG_MR)
 };
 
 // One group of 64 candidates, a lane each: the canonical chain acc = fmaf(hrow[k], W32[rowidx][k], acc), k = 0 .. H-1, from
@@ -513,6 +519,13 @@ __device__ __forceinline__ float mix_chain64(const float* __restrict__ W32, int 
 // two floats further from the value than the rounded subtraction left it
 __device__ __forceinline__ float two_down(float x) { return dae_okey_inv(dae_okey(x) - 2u); }
 
+// (No per-thread strided loop of this kernel is left to hipcc's loop vectorizer: see the note at the staging loop's
+// predecessor in profiles/r04_notes.md, item 11d.)
+#ifdef DAE_EXPERIMENTS
+#define MSTAMP(i) if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_readcyclecounter();
+#else
+#define MSTAMP(i)
+#endif
 __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP p)
 {
     __shared__ int seg_prefix[MR_MAX_SEG + 2];
@@ -531,9 +544,11 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     const int row = blockIdx.x;
     const int nseg = p.nseg;
     const bool bad = p.row_bad && p.row_bad[row] != 0;
+#pragma clang loop vectorize(disable) interleave(disable)
     for (int s = tid; s < nseg; s += MR_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
     if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
     if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
+#pragma clang loop vectorize(disable) interleave(disable)
     for (int i = tid; i < 1024; i += MR_THREADS) {
         hrowD[i] = i < p.HD ? p.hD[(size_t)row * p.ld_hD + i] : 0.0f;
         hrowT[i] = i < p.HT ? p.hT[(size_t)row * p.ld_hT + i] : 0.0f;
@@ -555,6 +570,7 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     }
     __syncthreads();
     const int total = seg_prefix[nseg];
+    MSTAMP(0)
     auto give_up = [&](int code) {
         // a row the launch cannot vouch for (more candidates than its buffers hold): counted like a bound failure -- the
         // callers then re-score the launch with the fp32 kernels
@@ -573,26 +589,49 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     const float wt = p.w_t[row], wp = p.w_p[row];
     const float F = __uint_as_float(p.fhat[row] << 16);
 
-    // ---- 1. the mixed bounds of every candidate, as order-preserving keys: wave w takes the segments w, w + 8, ...
+    // ---- 1. the mixed bounds of every candidate, as order-preserving keys.  Flat over the row's candidates, four per thread
+    // and round with their loads issued together: the entry first, then the three bound terms of its column -- two trips to
+    // memory per round.  (A wave per segment, 64 entries at a time, made every 64 entries two DEPENDENT trips: 16 of them
+    // per wave and row.)
+    auto offset_of = [&](int e) -> int64_t {
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_prefix[mid] <= e) lo = mid; else hi = mid;
+        }
+        return (int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]);
+    };
     unsigned kmx = 0u, kmn = 0xFFFFFFFFu;
-    for (int sg = wave; sg < nseg; sg += MR_WAVES) {
-        const int b0 = seg_prefix[sg], cn = seg_prefix[sg + 1] - b0;
-        const uint4* sp = p.base + ((int64_t)sg * p.seg_stride + (int64_t)row * p.row_stride);
-        // (hipcc's loop vectorizer pairs the iterations i, i + 64 of this per-lane loop and the paired body leaves wrong
-        // lower bounds in kl for segments of more than 64 entries -- found with a device-side recomputation; off here)
-#pragma clang loop vectorize(disable) interleave(disable)
-        for (int i = lane; i < cn; i += 64) {
-            const uint4 en = sp[i];
-            const int col = (int)en.z;
-            const float uT = __uint_as_float(en.x), uD = __uint_as_float(en.y);
-            const float wdT = 2.0f * fmaf(p.alphaT[col], F, p.betaT[col]) * 1.000001f;
-            const float wdD = 2.0f * p.epsD[col] * 1.000001f;
-            const float up = widen_up(mixf(uT, uD, wt, wp));
-            const float lo = widen_dn(mixf(two_down(uT - wdT), two_down(uD - wdD), wt, wp));
-            const unsigned a = dae_okey(lo);
-            kl[b0 + i] = a;
-            ku[b0 + i] = dae_okey(up);
-            kmx = a > kmx ? a : kmx; kmn = a < kmn ? a : kmn;
+    constexpr int MR_U = 4;
+    for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS) {
+        uint4 en[MR_U];
+#pragma unroll
+        for (int q = 0; q < MR_U; ++q) {
+            const int i = c0 + q * MR_THREADS + tid;
+            en[q] = p.base[offset_of(i < total ? i : 0)];
+        }
+        float al[MR_U], be[MR_U], ep[MR_U];
+#pragma unroll
+        for (int q = 0; q < MR_U; ++q) {
+            const int col = (int)en[q].z;
+            al[q] = p.alphaT[col]; be[q] = p.betaT[col]; ep[q] = p.epsD[col];
+        }
+#pragma unroll
+        for (int q = 0; q < MR_U; ++q) {
+            const int i = c0 + q * MR_THREADS + tid;
+            const float uT = __uint_as_float(en[q].x), uD = __uint_as_float(en[q].y);
+            const float wdT = 2.0f * fmaf(al[q], F, be[q]) * 1.000001f;
+            const float wdD = 2.0f * ep[q] * 1.000001f;
+            // (the narrowing only needs bounds of the canonical value: the hardware's exp2 / rcp, 2^-15 wider -- 4 canonical
+            // sigmoids per candidate were 24 k of the row's 88 k cycles)
+            const float up = mix_fast_up(uT, uD, wt, wp);
+            const float lo = mix_fast_dn(two_down(uT - wdT), two_down(uD - wdD), wt, wp);
+            if (i < total) {
+                const unsigned a = dae_okey(lo);
+                kl[i] = a;
+                ku[i] = dae_okey(up);
+                kmx = a > kmx ? a : kmx; kmn = a < kmn ? a : kmn;
+            }
         }
     }
 #pragma unroll
@@ -600,8 +639,10 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         const unsigned a = __shfl_xor(kmx, d), b = __shfl_xor(kmn, d);
         kmx = a > kmx ? a : kmx; kmn = b < kmn ? b : kmn;
     }
+    MSTAMP(1)
     if (lane == 0) { atomicMax(&cnts[0], kmx); atomicMin(&cnts[1], kmn); }
     unsigned* hist = reinterpret_cast<unsigned*>(tb);
+#pragma clang loop vectorize(disable) interleave(disable)
     for (int i = tid; i < MR_BINS; i += MR_THREADS) hist[i] = 0u;
     __syncthreads();
 
@@ -615,6 +656,7 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             const unsigned bq = (unsigned)((float)(key - kmin) * scale);
             return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
         };
+#pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < total; i += MR_THREADS) atomicAdd(&hist[bin_of(kl[i])], 1u);
         __syncthreads();
         constexpr int BPT = MR_BINS / MR_THREADS;
@@ -646,6 +688,7 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         __syncthreads();
         const int Bsel = (int)cnts[2];
         unsigned kb = 0xFFFFFFFFu;
+#pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < total; i += MR_THREADS) {
             const unsigned key = kl[i];
             if (bin_of(key) == Bsel) kb = key < kb ? key : kb;
@@ -658,6 +701,7 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     }
     __syncthreads();                                             // (the last reads of kl and of the histogram)
 
+    MSTAMP(2)
     // ---- 3. the survivors: upper bound >= tau'.  Their flat indices take kl's place.
     int* surv = reinterpret_cast<int*>(kl);
     for (int c0 = 0; c0 < total; c0 += MR_THREADS) {
@@ -677,16 +721,9 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     const int n = s_n;
     if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = n; }
     if (n > p.out_cap) { give_up(-3); return; }
+    MSTAMP(3)
 
     // ---- 4. recompute the survivors
-    auto offset_of = [&](int e) -> int64_t {
-        int lo = 0, hi = nseg;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (seg_prefix[mid] <= e) lo = mid; else hi = mid;
-        }
-        return (int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]);
-    };
     float* tbuf = tb + wave * (64 * MR_ROWSTRIDE);
     uint2* orow = p.out + (size_t)row * p.out_cap;
     const int gstep = MR_WAVES * 64;
@@ -713,8 +750,10 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             orow[e] = make_uint2(__float_as_uint(y), (unsigned)col);
         }
     }
+    MSTAMP(4)
     if (tid == 0) p.out_cnt[row] = n;
 }
+#undef MSTAMP
 
 }  // namespace
 
@@ -872,12 +911,27 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     r.out = rf; r.out_cnt = rf_cnt; r.out_cap = MX_REF_CAP;
     r.guard = static_cast<int*>(tc->guard.p); r.stat = static_cast<int*>(tc->refstat.p);
     if (nb > MR_MAX_SEG) return dae_fail(tc, DAE_ERR_ARG, "too many candidate segments (%d)", nb);
+#ifdef DAE_EXPERIMENTS
+    static const bool dbg_mr = dae_exp_env("DAE_DBG_MR") != nullptr;
+    static long long* mr_stamps = nullptr;
+    static int mr_calls = 0;
+    if (dbg_mr) { if (!mr_stamps) (void)hipMalloc(&mr_stamps, 8 * 8); r.stamps = mr_stamps; }
+#endif
     static const char ref_key = 0;
     if (dae_first_use(tc, &ref_key))
         DAE_HIP_CHECK(tc, hipFuncSetAttribute(reinterpret_cast<const void*>(mix_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)(2 * MR_STAGE * sizeof(unsigned))));
     hipLaunchKernelGGL(mix_refine_kernel, dim3(B), dim3(MR_THREADS), 2 * MR_STAGE * sizeof(unsigned), st, r);
     DAE_CHECK_LAUNCH(tc, "mix_refine_kernel");
+#ifdef DAE_EXPERIMENTS
+    if (dbg_mr && (++mr_calls % 4) == 0) {
+        long long hst[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hst, mr_stamps, sizeof(hst), hipMemcpyDeviceToHost);
+        fprintf(stderr, "MIX_REFINE row0 cycles: bounds %lld | threshold %lld | list %lld | recompute %lld\n", hst[1] - hst[0], hst[2] - hst[1],
+                hst[3] - hst[2], hst[4] - hst[3]);
+    }
+#endif
 
     dae_topk_args ta;
     memset(&ta, 0, sizeof(ta));
