@@ -431,7 +431,7 @@ int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, c
  * values -- the bound scales with the row's largest |feature|), h [B][ld_h]: the DAE's fp32 hidden rows (dae_encode),
  * w_title / w_playlist [B] in [0, 1] (DAEs.py:159-162).  Rows that violate a precondition return no recommendations
  * (idx -1).  The bound guard of the plain exact mode covers both GEMMs: dae_exact_guard_read / _words on the title
- * context; a row with more than 8192 candidates also counts there (column -2).  guard_out (nullable, DEVICE int32[2]):
+ * context; a row with more than 8192 columns left to recompute also counts there (column -3).  guard_out (nullable, DEVICE int32[2]):
  * receives the guard words {violations so far, a violating column} in stream order, for a fetch alongside the lists --
  * a count that grew since the previous launch's means THIS launch is not to be trusted (re-score it with
  * DAE_DTYPE_F32).  out_score holds y.  B <= 4096. */

@@ -19,7 +19,8 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 
 def build(B=150, nt=140000, na=30000, H=256):
     V = nt + na
-    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias=os.environ.get("BIAS", "zipf"), n_tracks=nt)
+    W_dec = (W_dec * np.float32(float(os.environ.get("SCALE", "1")))).astype(np.float32)
     path = "/tmp/_title_dae.pkl"
     with open(path, "wb") as f:
         pickle.dump([W_enc, W_dec, b_enc, b_dec], f)

@@ -580,11 +580,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         if (tid == 0) { p.out_cnt[row] = 0; if (p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; } }
         return;
     }
-    if (total > MR_STAGE) {
-        if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; }
-        give_up(-2);
-        return;
-    }
     const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
     const float wt = p.w_t[row], wp = p.w_p[row];
     const float F = __uint_as_float(p.fhat[row] << 16);
@@ -601,9 +596,9 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         }
         return (int64_t)lo * p.seg_stride + (int64_t)row * p.row_stride + (e - seg_prefix[lo]);
     };
-    unsigned kmx = 0u, kmn = 0xFFFFFFFFu;
     constexpr int MR_U = 4;
-    for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS) {
+    // body(i, key of l, key of u) for every candidate i of the round starting at c0
+    auto bounds_round = [&](int c0, auto body) {
         uint4 en[MR_U];
 #pragma unroll
         for (int q = 0; q < MR_U; ++q) {
@@ -622,17 +617,19 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             const float uT = __uint_as_float(en[q].x), uD = __uint_as_float(en[q].y);
             const float wdT = 2.0f * fmaf(al[q], F, be[q]) * 1.000001f;
             const float wdD = 2.0f * ep[q] * 1.000001f;
-            // (the narrowing only needs bounds of the canonical value: the hardware's exp2 / rcp, 2^-15 wider -- 4 canonical
-            // sigmoids per candidate were 24 k of the row's 88 k cycles)
+            // (the narrowing only needs bounds of the canonical value: the hardware's exp2 / rcp, 2^-15 wider)
             const float up = mix_fast_up(uT, uD, wt, wp);
             const float lo = mix_fast_dn(two_down(uT - wdT), two_down(uD - wdD), wt, wp);
-            if (i < total) {
-                const unsigned a = dae_okey(lo);
-                kl[i] = a;
-                ku[i] = dae_okey(up);
-                kmx = a > kmx ? a : kmx; kmn = a < kmn ? a : kmn;
-            }
+            body(i, i < total, dae_okey(lo), dae_okey(up));
         }
+    };
+    const bool staged = total <= MR_STAGE;                        // both keys of every candidate fit LDS
+    unsigned kmx = 0u, kmn = 0xFFFFFFFFu;
+    if (staged) {
+        for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS)
+            bounds_round(c0, [&](int i, bool in, unsigned a, unsigned u) {
+                if (in) { kl[i] = a; ku[i] = u; kmx = a > kmx ? a : kmx; kmn = a < kmn ? a : kmn; }
+            });
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -649,16 +646,8 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     // ---- 2. tau': the need-th largest lower bound (to a 2048-bin histogram over [min, max] of the row's keys and one pass
     // for the smallest key of the selected bin, as refine.hip): `need` distinct columns provably reach it
     unsigned P = 0u;                                             // key of tau' (0: everything survives)
-    if (total > need) {
-        const unsigned kmin = cnts[1], kmax = cnts[0];
-        const float scale = 2047.999f / ((float)(kmax - kmin) + 1.0f);
-        auto bin_of = [&](unsigned key) -> int {
-            const unsigned bq = (unsigned)((float)(key - kmin) * scale);
-            return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
-        };
-#pragma clang loop vectorize(disable) interleave(disable)
-        for (int i = tid; i < total; i += MR_THREADS) atomicAdd(&hist[bin_of(kl[i])], 1u);
-        __syncthreads();
+    // the bin that holds the need-th largest key of the histogram, counted from the top (block-uniform, via cnts[2])
+    auto select_bin = [&](int need_) -> int {                     // (cnts[5]: how many keys lie in the bins above it)
         constexpr int BPT = MR_BINS / MR_THREADS;
         const int top = MR_BINS - 1 - BPT * tid;
         unsigned hc[BPT], own = 0;
@@ -676,17 +665,78 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         for (int w = 0; w < wave; ++w) pre += cnts[8 + w];
         incl += pre;
         const unsigned excl = incl - own;
-        if (excl < (unsigned)need && (unsigned)need <= incl) {
+        if (excl < (unsigned)need_ && (unsigned)need_ <= incl) {
             unsigned run = excl;
             bool done = false;
 #pragma unroll
             for (int e = 0; e < BPT; ++e) {
-                if (!done && run + hc[e] >= (unsigned)need) { cnts[2] = (unsigned)(top - e); done = true; }
+                if (!done && run + hc[e] >= (unsigned)need_) { cnts[2] = (unsigned)(top - e); cnts[5] = run; done = true; }
                 run += hc[e];
             }
         }
         __syncthreads();
-        const int Bsel = (int)cnts[2];
+        return (int)cnts[2];
+    };
+    int* surv = reinterpret_cast<int*>(kl);                       // the survivors' flat indices (the staged path: in kl's place)
+    auto append = [&](bool keep, int i) {                         // (whole waves call this)
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+            const int leader = __ffsll((long long)bal) - 1;
+            int b = 0;
+            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
+            b = __shfl(b, leader);
+            const int at = b + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < 2 * MR_STAGE) surv[at] = i;          // (beyond out_cap <= 2 MR_STAGE the row gives up below)
+        }
+    };
+    if (!staged) {
+        // STREAMED (a flat DAE bias: the threshold sample says little and a row lists tens of thousands of columns): nothing
+        // is staged.  Pass A: histogram of the lower bounds over FIXED bins (1/32 of an octave of y between 2^-40 and 1),
+        // A2 inside the bin holding the need-th largest; the lower edge of the sub-bin found is tau'.  Pass B: the bounds
+        // again, survivors listed.
+        constexpr unsigned K0 = 0x80000000u | 0x2B800000u;        // key of 2^-40
+        auto fbin = [&](unsigned key) -> int {
+            if (key < K0) return 0;
+            const unsigned bq = (key - K0) >> 18;
+            return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
+        };
+        for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS)
+            bounds_round(c0, [&](int, bool in, unsigned a, unsigned) { if (in) atomicAdd(&hist[fbin(a)], 1u); });
+        __syncthreads();
+        if (total > need) {
+            const int Bsel = select_bin(need);
+            P = Bsel > 0 ? K0 + ((unsigned)Bsel << 18) : 0u;
+            if (Bsel > 0 && Bsel < MR_BINS - 1) {
+                // ... refined: with a flat bias thousands of bounds share that bin (2 % of y wide).  Pass A2: the keys of the
+                // selected bin alone, in 2048 sub-bins of 128 key units (1.5e-5 of y)
+                const int need2 = need - (int)cnts[5];
+                __syncthreads();                                  // (everybody has read cnts[5] and the histogram)
+#pragma clang loop vectorize(disable) interleave(disable)
+                for (int i = tid; i < MR_BINS; i += MR_THREADS) hist[i] = 0u;
+                __syncthreads();
+                const unsigned e0 = P;
+                for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS)
+                    bounds_round(c0, [&](int, bool in, unsigned a, unsigned) {
+                        if (in && fbin(a) == Bsel) atomicAdd(&hist[(a - e0) >> 7], 1u);
+                    });
+                __syncthreads();
+                const int B2 = select_bin(need2);
+                P = e0 + ((unsigned)B2 << 7);
+            }
+        }
+        for (int c0 = 0; c0 < total; c0 += MR_U * MR_THREADS)
+            bounds_round(c0, [&](int i, bool in, unsigned, unsigned u) { append(in && u >= P, i); });
+    } else if (total > need) {
+        const unsigned kmin = cnts[1], kmax = cnts[0];
+        const float scale = 2047.999f / ((float)(kmax - kmin) + 1.0f);
+        auto bin_of = [&](unsigned key) -> int {
+            const unsigned bq = (unsigned)((float)(key - kmin) * scale);
+            return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
+        };
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int i = tid; i < total; i += MR_THREADS) atomicAdd(&hist[bin_of(kl[i])], 1u);
+        __syncthreads();
+        const int Bsel = select_bin(need);
         unsigned kb = 0xFFFFFFFFu;
 #pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < total; i += MR_THREADS) {
@@ -703,18 +753,10 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
 
     MSTAMP(2)
     // ---- 3. the survivors: upper bound >= tau'.  Their flat indices take kl's place.
-    int* surv = reinterpret_cast<int*>(kl);
-    for (int c0 = 0; c0 < total; c0 += MR_THREADS) {
-        const int i = c0 + tid;
-        const bool keep = i < total && ku[i] >= P;
-        const unsigned long long bal = __ballot(keep);
-        if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            int b = 0;
-            if (lane == leader) b = atomicAdd(&s_n, __popcll(bal));
-            b = __shfl(b, leader);
-            // (slot b + rank <= i always: the list never overtakes the keys still to be read -- and kl is dead anyway)
-            if (keep) surv[b + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    if (staged) {
+        for (int c0 = 0; c0 < total; c0 += MR_THREADS) {
+            const int i = c0 + tid;
+            append(i < total && ku[i] >= P, i);                   // (slot <= i: the list never overtakes the keys still to be read)
         }
     }
     __syncthreads();

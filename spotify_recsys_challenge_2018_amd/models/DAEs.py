@@ -1338,6 +1338,13 @@ class DAE_title(DAE):
         tm = self.title_model
         tm.ctx.bind_stream()
         dtype = _title_dtype(dtype, self)
+        if dtype == _lib.DAE_DTYPE_BF16_EXACT and self.__dict__.get("_mix_exact_pause", 0) > 0:
+            # rows of this model keep overflowing the refine launch's candidate buffers (a flat DAE bias: no prior for the
+            # threshold sample): the exact launches are paused for a while instead of being run and re-scored every time
+            self._mix_exact_pause -= 1
+            self._ensure_packed(_lib.DAE_DTYPE_F32)
+            tm._ensure_packed(_lib.DAE_DTYPE_F32)
+            dtype = _lib.DAE_DTYPE_F32
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
         d_titles = d_use = None
@@ -1389,11 +1396,17 @@ class DAE_title(DAE):
         gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows) = tag
         n_bad, col = (int(v) for v in (gw.cpu() if words is None else words))
         if n_bad == self.__dict__.get("_mix_guard_seen", 0):
+            self._mix_overflow_streak = 0
             return None
         self._mix_guard_seen = n_bad
+        if col in (-2, -3):                     # not a broken bound: more candidates than the refine launch holds
+            self._mix_overflow_streak = self.__dict__.get("_mix_overflow_streak", 0) + 1
+            if self._mix_overflow_streak >= 2:
+                self._mix_exact_pause = 64      # launches on the fp32 kernels before the mode is tried again
+                self._mix_overflow_streak = 0
         import warnings
-        warnings.warn("exact_bf16 title mix: the bound guard fired (column %d): this launch is re-scored with the fp32 "
-                      "kernels" % col)
+        warnings.warn("exact_bf16 title mix: the bound guard fired (%s): this launch is re-scored with the fp32 kernels"
+                      % ("a row's candidates overflow the refine launch" if col in (-2, -3) else "column %d" % col))
         self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
         self._ensure_packed(_lib.DAE_DTYPE_F32)
         self.title_model._ensure_packed(_lib.DAE_DTYPE_F32)

@@ -128,6 +128,25 @@ def test_exact_title_mix_streamed_and_coalesced(tmp_path):
     assert not getattr(m, "_guard_fallbacks", 0)
 
 
+def test_exact_title_mix_flat_bias_streams_its_candidates(tmp_path):
+    """b_dec = 0: the threshold sample has no prior to go by and a row lists more columns than the refine launch stages
+    (8 192) -- those rows take its streamed narrowing (fixed-bin histogram, two passes over the lists): same lists, no guard
+    event, no fp32 fallback."""
+    conf = _conf(n_tracks=60000, n_input=64000, batch=24)
+    m = _model(tmp_path, conf, bias="zeros")
+    pos, ones, seeds = _feed(conf, 5, empty_rows=(3,))
+    titles = _titles(conf.batch, seed=6)
+    use = np.ones(conf.batch, np.float32)
+    want = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="f32")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got, want)
+    st = m.title_model.ctx.exact_stats_read()
+    assert st["candidates_per_row"] > 8192, st                    # (else this case no longer reaches the streamed path)
+    assert m.title_model.ctx.exact_guard_read()[0] == 0 and not getattr(m, "_guard_fallbacks", 0)
+
+
 def test_exact_title_mix_guard_and_fallback(tmp_path):
     """A forged bound (dae_set_exact_margin < 1 on either context) makes recomputed logits leave their intervals: the guard
     counts them, `recommend` and the streamed loop re-score the launch with the fp32 kernels and say so."""
