@@ -455,6 +455,11 @@ int dae_mix_topk_exact(dae_ctx* title_ctx, dae_ctx* dae, const float* feat, int6
  * Then dae_adam_step on each variable. */
 int dae_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
                  float input_keep_prob, uint32_t seed, float* out);
+/* The mixing weights of DAE_title (DAEs.py:159-162) in one launch: x_count = (the row sum of dae_row_sums) * input_keep_prob,
+ * deno = titles_use + x_count + 1e-10, w_title = titles_use / deno, w_playlist = x_count / deno -- fp32 operations in the
+ * reference's order.  titles_use, w_title, w_playlist: device arrays [B]. */
+int dae_mix_weights(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B, float input_keep_prob,
+                    uint32_t seed, const float* titles_use, float* w_title, float* w_playlist);
 int dae_title_loss_backward(dae_ctx* ctx, const float* title_logits, int64_t ld_z, const float* dae_score, int64_t ld_d,
                             const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
                             const float* w_title, const float* w_playlist, int B, int V, int n_batch,

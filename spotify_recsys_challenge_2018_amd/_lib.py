@@ -19,7 +19,7 @@ EXPORTS = [
     "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_row_sums", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
     "dae_pipeline_create", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_flush", "dae_pipeline_poll",
@@ -99,6 +99,7 @@ def load():
     lib.dae_set_score_mix.argtypes = [vp, vp, c_i64, c_int, vp]
     lib.dae_mix_topk_exact.argtypes = [vp, vp, vp, c_i64, vp, c_i64, c_int, vp, vp, c_int, vp, vp, c_int, vp, vp, vp]
     lib.dae_row_sums.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp]
+    lib.dae_mix_weights.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp, vp, vp]
     lib.dae_title_loss_backward.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, c_int, c_int, c_int,
                                             vp, c_int, vp, vp, vp, vp, vp]
     lib.dae_title_conv_backward.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, ctypes.POINTER(ctypes.c_int32),

@@ -1030,6 +1030,16 @@ int dae_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const
     return dae_launch_row_sums(ctx, row_ptr, col, val, B, input_keep_prob, seed, out);
 }
 
+int dae_mix_weights(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B, float input_keep_prob,
+                    uint32_t seed, const float* titles_use, float* w_title, float* w_playlist)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!row_ptr || !titles_use || !w_title || !w_playlist) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    if (B <= 0) return DAE_OK;
+    if (!(input_keep_prob > 0.f && input_keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
+    return dae_launch_mix_weights(ctx, row_ptr, col, val, B, input_keep_prob, seed, titles_use, w_title, w_playlist);
+}
+
 int dae_title_loss_backward(dae_ctx* ctx, const float* title_logits, int64_t ld_z, const float* dae_score, int64_t ld_d,
                             const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
                             const float* w_title, const float* w_playlist, int B, int V, int n_batch,

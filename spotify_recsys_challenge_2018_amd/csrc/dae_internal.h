@@ -341,6 +341,8 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
                               int32_t* argmax, float* feat_raw);
 int dae_launch_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
                         float ikp, uint32_t seed, float* out);
+int dae_launch_mix_weights(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B, float ikp,
+                           uint32_t seed, const float* use, float* w_t, float* w_p);
 int dae_launch_title_loss_backward(dae_ctx* ctx, const float* zt, int64_t ld_z, const float* dae_score, int64_t ld_d,
                                    const int32_t* y_row_ptr, const int32_t* y_col, const float* y_val,
                                    const float* w_title, const float* w_playlist, int B, int V, int n_batch,

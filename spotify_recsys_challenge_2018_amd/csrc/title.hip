@@ -284,6 +284,38 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const int32_t* __restrict
     if (lane == 0) out[row] = s;
 }
 
+// the mixing weights of DAEs.py:159-162 in one launch: x_count = reduce_sum * input_keep_prob (the row sum as above),
+// deno = titles_use + x_count + 1e-10, w_title = titles_use / deno, w_playlist = x_count / deno -- fp32 operations in the
+// reference's order (what DAE_title._mix_weights did with five elementwise launches after dae_row_sums)
+__global__ __launch_bounds__(256) void mix_weights_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                          const float* __restrict__ val, int B, float ikp, uint32_t seed,
+                                                          const float* __restrict__ use, float* __restrict__ w_t,
+                                                          float* __restrict__ w_p)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int beg = row_ptr[row], end = row_ptr[row + 1];
+    float s = 0.0f;
+    for (int base = beg; base < end; base += 64) {
+        const int n = min(64, end - base);
+        float x = 0.0f;
+        if (lane < n) {
+            x = val[base + lane];
+            if (ikp < 1.0f)
+                x = (x / ikp) * floorf(ikp + dae_uniform(seed, 0U, (uint32_t)row, (uint32_t)col[base + lane]));
+        }
+        for (int i = 0; i < n; ++i) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+    }
+    if (lane == 0) {
+        const float u = use[row];
+        const float xc = s * ikp;
+        const float deno = (u + xc) + 1e-10f;
+        w_t[row] = u / deno;
+        w_p[row] = xc / deno;
+    }
+}
+
 __global__ __launch_bounds__(256) void title_scatter_y_kernel(const int32_t* __restrict__ row_ptr,
                                                               const int32_t* __restrict__ col,
                                                               const float* __restrict__ val, int B, int V,
@@ -453,6 +485,15 @@ int dae_launch_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col
     hipLaunchKernelGGL(row_sums_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, row_ptr, col, val, B, ikp,
                        seed, out);
     DAE_CHECK_LAUNCH(ctx, "row_sums_kernel");
+    return DAE_OK;
+}
+
+int dae_launch_mix_weights(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B, float ikp,
+                           uint32_t seed, const float* use, float* w_t, float* w_p)
+{
+    hipLaunchKernelGGL(mix_weights_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, row_ptr, col, val, B, ikp, seed, use,
+                       w_t, w_p);
+    DAE_CHECK_LAUNCH(ctx, "mix_weights_kernel");
     return DAE_OK;
 }
 

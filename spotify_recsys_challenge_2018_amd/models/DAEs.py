@@ -1199,10 +1199,7 @@ class DAE_title(DAE):
         rp, c, v = csr
         dev = rp.device
         nb = n_rows or self.n_batch
-        s = torch.empty(nb, dtype=torch.float32, device=dev)
         P = _lib._ptr
-        self.ctx.check(self.ctx.lib.dae_row_sums(self.ctx.h, P(rp), P(c), P(v), nb, float(input_keep_prob),
-                                                 int(seed), P(s)))
         if u_dev is None:
             u = np.zeros(nb, np.float32)
             tu = np.asarray(titles_use, np.float32).reshape(-1)
@@ -1210,9 +1207,12 @@ class DAE_title(DAE):
             u = self._to_dev(u, torch.float32, side_stream)
         else:
             u = u_dev                                         # staged with the feed (`_stage_titled`)
-        x_count = s * float(np.float32(input_keep_prob))
-        deno = u + x_count + 1e-10
-        return (u / deno).contiguous(), (x_count / deno).contiguous()
+        w_t = torch.empty(nb, dtype=torch.float32, device=dev)
+        w_p = torch.empty(nb, dtype=torch.float32, device=dev)
+        # one launch (dae_mix_weights: the row sums of dae_row_sums and the four elementwise operations behind them)
+        self.ctx.check(self.ctx.lib.dae_mix_weights(self.ctx.h, P(rp), P(c), P(v), nb, float(input_keep_prob), int(seed),
+                                                    P(u), P(w_t), P(w_p)))
+        return w_t, w_p
 
     def mixed_scores(self, x_positions, x_ones, titles, titles_use, input_keep_prob=1.0, title_keep_prob=1.0,
                      seed=0):
