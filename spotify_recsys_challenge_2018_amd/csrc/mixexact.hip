@@ -141,6 +141,9 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
         // the compared bound is widened by 2^-20 and rounded twice; tau <= 0 (or -inf: fewer than `need` sample values,
         // or NaN): every column passes
         tau_g = tau > 0.0f ? tau * (1.0f - 0x1p-17f) : 0.0f;
+        // a row without input and without title (the padding rows of a reader's last batch, main_challenge.py:75-78): both
+        // weights are 0, y is +0 for every column -- nothing is listed, the refine launch writes its list directly
+        if (p.w_t[rg * R_TILE + tid] == 0.0f && p.w_p[rg * R_TILE + tid] == 0.0f) tau_g = __builtin_inff();
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
@@ -449,7 +452,7 @@ struct MixRefP {
     const float* hD; int64_t ld_hD; int HD; const float* W32D; const float* biasD; const float* epsD;
     const float* hT; int64_t ld_hT; int HT; const float* W32T; const float* biasT; const float* alphaT; const float* betaT;
     const unsigned* fhat; const float* w_t; const float* w_p; const int* row_bad;
-    const int32_t* seed_row_ptr; int k;
+    const int32_t* seed_row_ptr; int k; int n_valid_col;
     uint2* out; int* out_cnt; int out_cap;
     int* guard;                        // {violations, a violating column}
     int* stat;                         // [B][2] {candidates, recomputed}
@@ -576,6 +579,15 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         // callers then re-score the launch with the fp32 kernels
         if (tid == 0) { p.out_cnt[row] = 0; atomicAdd(p.guard, 1); p.guard[1] = code; }
     };
+    if (!bad && p.w_t[row] == 0.0f && p.w_p[row] == 0.0f) {
+        // y = sigmoid(.) * 0 + sigmoid(.) * 0 = +0 for every column: the fp32 path ranks (y desc, column asc), i.e. the first
+        // k non-seed columns -- the first k + n_seeds columns cover them
+        const int nl = min(p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0), min(p.n_valid_col, p.out_cap));
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int i = tid; i < nl; i += MR_THREADS) p.out[(size_t)row * p.out_cap + i] = make_uint2(0u, (unsigned)i);
+        if (tid == 0) { p.out_cnt[row] = nl; if (p.stat) { p.stat[2 * row] = 0; p.stat[2 * row + 1] = 0; } }
+        return;
+    }
     if (bad || total == 0) {
         if (tid == 0) { p.out_cnt[row] = 0; if (p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; } }
         return;
@@ -949,7 +961,7 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     r.biasT = static_cast<const float*>(pt.bias.p);
     r.alphaT = static_cast<const float*>(pt.mix_alpha.p); r.betaT = static_cast<const float*>(pt.mix_beta.p);
     r.fhat = p.fhat; r.w_t = w_title; r.w_p = w_playlist; r.row_bad = static_cast<const int*>(tc->row_bad.p);
-    r.seed_row_ptr = seed_row_ptr; r.k = k;
+    r.seed_row_ptr = seed_row_ptr; r.k = k; r.n_valid_col = n_valid_col;
     r.out = rf; r.out_cnt = rf_cnt; r.out_cap = MX_REF_CAP;
     r.guard = static_cast<int*>(tc->guard.p); r.stat = static_cast<int*>(tc->refstat.p);
     if (nb > MR_MAX_SEG) return dae_fail(tc, DAE_ERR_ARG, "too many candidate segments (%d)", nb);

@@ -735,7 +735,7 @@ class DAE_tied:
                     with torch.cuda.stream(fs):                             # (on the compute stream the copy would wait for the NEXT launch too)
                         idx_._mix_guard[0].record_stream(fs)
                         words = idx_._mix_guard[0].cpu()
-                    redo = self._mix_guard_fired(idx_, k, words)
+                    redo = self._mix_guard_fired(idx_, k, words, score_)
                     if redo is not None:
                         score_, idx_ = redo
                         fs.wait_stream(torch.cuda.current_stream(self.device_index))
@@ -1386,7 +1386,7 @@ class DAE_title(DAE):
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
-    def _mix_guard_fired(self, idx, k, words=None):
+    def _mix_guard_fired(self, idx, k, words=None, score=None):
         """A launch of the exact title mix whose guard words moved is not trusted (a recomputed logit left the interval
         the bf16 launch promised for it, or a row overflowed its candidate list): -> (score, idx) of the same feed through
         the fp32 kernels, or None when the launch stands."""
@@ -1395,21 +1395,51 @@ class DAE_title(DAE):
             return None
         gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows) = tag
         n_bad, col = (int(v) for v in (gw.cpu() if words is None else words))
-        if n_bad == self.__dict__.get("_mix_guard_seen", 0):
+        seen = self.__dict__.get("_mix_guard_seen", 0)
+        if n_bad == seen:
             self._mix_overflow_streak = 0
             return None
         self._mix_guard_seen = n_bad
-        if col in (-2, -3):                     # not a broken bound: more candidates than the refine launch holds
-            self._mix_overflow_streak = self.__dict__.get("_mix_overflow_streak", 0) + 1
-            if self._mix_overflow_streak >= 2:
-                self._mix_exact_pause = 64      # launches on the fp32 kernels before the mode is tried again
-                self._mix_overflow_streak = 0
         import warnings
-        warnings.warn("exact_bf16 title mix: the bound guard fired (%s): this launch is re-scored with the fp32 kernels"
-                      % ("a row's candidates overflow the refine launch" if col in (-2, -3) else "column %d" % col))
-        self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
+        import torch
         self._ensure_packed(_lib.DAE_DTYPE_F32)
         self.title_model._ensure_packed(_lib.DAE_DTYPE_F32)
+        n_new = n_bad - seen
+        nb = n_rows or self.n_batch
+        if col == -3:
+            # rows whose survivors overflow the refine launch's list return no recommendations (idx -1): when every event of
+            # this launch is such a row (e.g. a title-only playlist under a flat title scorer: its scores cannot be told apart
+            # by any bound), ONLY those rows are re-scored with the fp32 kernels and patched in
+            rows = np.nonzero(idx[:nb, 0].cpu().numpy() < 0)[0]
+            use = np.asarray(titles_use, np.float32).reshape(-1)
+            if 0 < len(rows) == n_new and len(rows) <= nb // 2 and np.all(use[rows] > 0):
+                P = np.asarray(x_positions, np.int64).reshape(-1, 2)
+                sel = np.isin(P[:, 0], rows)
+                newid = np.full(nb, -1, np.int64)
+                newid[rows] = np.arange(len(rows))
+                P2 = np.stack([newid[P[sel, 0]], P[sel, 1]], 1) if sel.any() else np.zeros((0, 2), np.int64)
+                o = np.asarray(x_ones, np.float32).reshape(-1)
+                O2 = o[sel] if o.size == len(P) else o
+                seeds2 = seeds if isinstance(seeds, str) else [list(seeds[r]) if r < len(seeds) else [] for r in rows]
+                T2 = np.asarray(titles, np.int64).reshape(-1, self.title_model.input_len)[rows]
+                warnings.warn("exact_bf16 title mix: the bound guard fired (%d row(s) overflow the refine launch): those rows are "
+                              "re-scored with the fp32 kernels" % len(rows))
+                self._guard_row_fallbacks = self.__dict__.get("_guard_row_fallbacks", 0) + len(rows)
+                score2, idx2, _ev = self._submit(P2, O2, seeds2, k, _lib.DAE_DTYPE_F32, False, T2, use[rows], n_rows=len(rows))
+                rt = torch.from_numpy(rows).to(idx.device)
+                idx_n, score_n = idx.clone(), score.clone()
+                idx_n[rt] = idx2[:len(rows)]
+                score_n[rt] = score2[:len(rows)]
+                self._mix_overflow_streak = 0
+                return score_n, idx_n
+        if col in (-2, -3):                     # not a broken bound, but many rows the refine launch cannot hold: after two such
+            self._mix_overflow_streak = self.__dict__.get("_mix_overflow_streak", 0) + 1      # launches in a row the mode pauses
+            if self._mix_overflow_streak >= 2:
+                self._mix_exact_pause = 64      # launches on the fp32 kernels before it is tried again
+                self._mix_overflow_streak = 0
+        warnings.warn("exact_bf16 title mix: the bound guard fired (%s): this launch is re-scored with the fp32 kernels"
+                      % ("rows overflow the refine launch" if col in (-2, -3) else "column %d" % col))
+        self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
         score, idx2, _ev = self._submit(x_positions, x_ones, seeds, k, _lib.DAE_DTYPE_F32, False, titles, titles_use,
                                         n_rows=n_rows)
         return score, idx2
@@ -1431,7 +1461,7 @@ class DAE_title(DAE):
         self.ctx.bind_stream()
         score, idx, _ev = self._submit(x_positions, x_ones, seeds, k, dtype, False, titles, titles_use)
         n_rows = self.n_batch if n_rows is None else n_rows
-        redo = self._mix_guard_fired(idx, k)
+        redo = self._mix_guard_fired(idx, k, None, score)
         if redo is not None:
             score, idx = redo
         res = idx[:n_rows].cpu().numpy(), score[:n_rows].cpu().numpy()

@@ -37,7 +37,7 @@ def _titles(B, seed=0):
     return t
 
 
-def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.0, out_scale=1.0):
+def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.0, out_scale=1.0, flat_title=False):
     W_enc, b_enc, W_dec, b_dec = make_weights(conf.n_input, conf.hidden, seed=1, bias=bias, n_tracks=conf.n_tracks)
     W_dec = (W_dec * np.float32(w_scale)).astype(np.float32)
     p = tmp_path / ("w_dae_%s_%g" % (bias, w_scale))
@@ -51,6 +51,9 @@ def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.
             host["Conv_W%d" % i] = (host["Conv_W%d" % i] * np.float32(feat_scale)).astype(np.float32)
     if out_scale != 1.0:
         host["Output_W"] = (host["Output_W"] * np.float32(out_scale)).astype(np.float32)
+    if flat_title:                                     # a title scorer that says 0.5 for every track
+        host["Output_W"] = np.zeros_like(host["Output_W"])
+        host["Output_b"] = np.zeros_like(host["Output_b"])
     mt.fit(host)
     m = DAE_title(conf, mt)
     m.fit()
@@ -145,6 +148,33 @@ def test_exact_title_mix_flat_bias_streams_its_candidates(tmp_path):
     st = m.title_model.ctx.exact_stats_read()
     assert st["candidates_per_row"] > 8192, st                    # (else this case no longer reaches the streamed path)
     assert m.title_model.ctx.exact_guard_read()[0] == 0 and not getattr(m, "_guard_fallbacks", 0)
+
+
+def test_exact_title_mix_padding_rows_and_row_level_fallback(tmp_path):
+    """(a) The padding rows of a reader's last batch (no input, titles_use 0: main_challenge.py:75-78) have both weights 0 and
+    y = 0 everywhere: the fp32 path returns the first k columns for them, and so does the exact path, without listing a
+    candidate.  (b) A title-only playlist under a title scorer that says 0.5 for every track has 60 000 equal scores: its
+    survivors overflow the refine launch's list; only that row is re-scored with the fp32 kernels."""
+    conf = _conf(n_tracks=60000, n_input=61000, batch=24)
+    m = _model(tmp_path, conf, flat_title=True)
+    pos, ones, seeds = _feed(conf, 5, empty_rows=(3, 7, 20, 21, 22, 23))
+    titles = _titles(conf.batch, seed=6)
+    use = np.ones(conf.batch, np.float32)
+    use[20:] = 0.0                                                 # rows 20..23: padding; rows 3, 7: title only
+    titles[20:] = -1
+    want = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="f32")
+    assert np.array_equal(want[0][22], np.arange(500))
+    with pytest.warns(UserWarning, match="2 row.s. overflow"):
+        got = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got, want)
+    assert m._guard_row_fallbacks == 2 and not getattr(m, "_guard_fallbacks", 0)
+    # without the title-only rows: nothing to re-score, the padding rows still right
+    pos2, ones2, seeds2 = _feed(conf, 5, empty_rows=(20, 21, 22, 23))
+    want2 = m.recommend(pos2, ones2, seeds2, k=500, titles=titles, titles_use=use, dtype="f32")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got2 = m.recommend(pos2, ones2, seeds2, k=500, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got2, want2)
 
 
 def test_exact_title_mix_guard_and_fallback(tmp_path):
