@@ -173,6 +173,40 @@ def test_pretrain_dae_challenge_drivers_end_to_end(tmp_path, capsys):
         os.chdir(cwd)
 
 
+def test_challenge_driver_with_titles_under_exact_bf16_at_hidden_256(tmp_path, monkeypatch):
+    """The same drivers with [DAE] hidden = 256 (the shipped size): under `decode_dtype = exact_bf16` the title-mixed launches
+    of `--challenge` take dae_mix_topk_exact (both GEMMs in one bf16 launch per pass) and the result file equals the fp32
+    run's, row for row."""
+    import random
+    from spotify_recsys_challenge_2018_amd import main as cli
+    from spotify_recsys_challenge_2018_amd import _lib as L
+    work = tmp_path / "run"
+    work.mkdir()
+    ini = open(os.path.join(G, "config.ini")).read().replace("hidden = 32", "hidden = 256")
+    ini = ini.replace("[CHALLENGE]", "[CHALLENGE]\nallow_no_title = True")
+    open(work / "config.ini", "w").write(ini)
+    shutil.copytree(os.path.join(G, "data"), tmp_path / "data")
+    calls = []
+    real = L.Context.mix_topk_exact
+    monkeypatch.setattr(L.Context, "mix_topk_exact", lambda self, *a, **kw: (calls.append(1), real(self, *a, **kw))[1])
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        random.seed(0); np.random.seed(0)
+        for mode in ("--pretrain", "--dae", "--title"):
+            assert cli.main(["--dir", "run", mode]) == 0
+        assert cli.main(["--dir", "run", "--challenge"]) == 0
+        res32 = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
+        assert not calls and len(res32) == 13
+        open(work / "config.ini", "w").write(ini.replace("[BASE]", "[BASE]\ndecode_dtype = exact_bf16"))
+        assert cli.main(["--dir", "run", "--challenge"]) == 0
+        res_exact = pickle.load(open(tmp_path / "challenge_results" / "result_inorder_5to100", "rb"))
+        assert calls, "the title-mixed launches did not take the exact path"
+        assert res_exact == res32
+    finally:
+        os.chdir(cwd)
+
+
 def _step(ctx, csr, d, V, H, B, tied, ikp, kp, seed, lam):
     import torch
     P = _lib._ptr
