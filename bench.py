@@ -221,7 +221,7 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
         p_, o_ = make_playlists(B, n_tracks, n_artists, seed=300 + s_, dist=dist_name)[:2]
         t_ = rng.integers(0, 41, (B, 25)); t_[:, 18:] = -1
         u_ = np.ones(B, np.float32); u_[s_::7] = 0.0                 # a few playlists without a title, as in the challenge set
-        batches.append((p_, o_, SEEDS_FROM_INPUT, B, [list(x) for x in t_], u_))
+        batches.append((p_, o_, SEEDS_FROM_INPUT, B, t_.astype(np.int32), u_))     # titles as this build's reader hands them over: one array per batch
 
     def feeds(reps):
         for _ in range(reps):

@@ -177,6 +177,8 @@ def run(conf, model=None):
             mine = sharded or world == 1 or n_batches % world == rank
             if mine:
                 meta.append((n_seen, pid, len(seed)))
+                if getattr(reader, "last_titles", None) is not None:      # this build's reader: the same titles as arrays
+                    titles, titles_exist = reader.last_titles, reader.last_titles_use.reshape(-1, 1)
                 yield x_positions, x_ones, seed, titles, titles_exist
             n_seen += len(seed)
             n_batches += 1

@@ -217,11 +217,23 @@ class data_reader_challenge:
         self.ch_idx = 0
         self._trk, self._trk_off = _flatten([p[0] for p in self.playlists])
         self._art, self._art_off = _flatten([p[1] for p in self.playlists])
+        # the titles once more as ONE int32 array (rows padded with -1) and the has-name flags as a float array: the scoring
+        # loop takes `last_titles` / `last_titles_use` of a batch instead of converting 150 Python lists per batch (0.16 ms
+        # of a 0.6 ms launch); `next_batch` itself returns what the reference's returns
+        L = int(self.max_title_len)
+        self._titles_arr = np.full((len(self.playlists), L), -1, np.int32)
+        for i, p in enumerate(self.playlists):
+            if p[2]:
+                self._titles_arr[i, :min(len(p[2]), L)] = p[2][:L]
+        self._texist_arr = np.asarray([float(p[3][0]) for p in self.playlists], np.float32)
+        self.last_titles = self.last_titles_use = None
 
     def next_batch(self):
         n = len(self.playlists)
         stop = min(self.ch_idx + self.batch_size, n)
         order = np.arange(self.ch_idx, stop, dtype=np.int64)
+        self.last_titles = self._titles_arr[self.ch_idx:stop]
+        self.last_titles_use = self._texist_arr[self.ch_idx:stop]
         self.ch_idx = 0 if stop == n else stop                   # data_reader.py:308-311
         trk, trk_rows, trk_lens = _gather(self._trk, self._trk_off, order)
         art, art_rows, _ = _gather(self._art, self._art_off, order)

@@ -66,6 +66,11 @@ def test_data_reader_challenge_matches_reference(exp, capsys):
         assert seed == want["seed"] and titles == want["titles"]
         assert texist == want["titles_exist"] and pid == want["pid"]
         assert np.array_equal(xo, np.asarray(want["x_ones"], np.float32))
+        # this build's extra: the same titles / has-name flags as arrays (what the scoring loop uploads)
+        L = r.max_title_len
+        assert r.last_titles.shape == (len(titles), L) and r.last_titles.dtype == np.int32
+        assert [list(t[:L]) + [-1] * (L - len(t[:L])) for t in titles] == r.last_titles.tolist()
+        assert r.last_titles_use.tolist() == [float(e[0]) for e in texist]
         saw_015 |= bool(np.any(xo == np.float32(0.15)))
     assert r.ch_idx == 0
     assert saw_015, "fixture must exercise the >50-seed 0.15 weighting (data_reader.py:288-289)"
