@@ -60,6 +60,29 @@ def test_features_and_title_scores_match_numpy():
     assert sorted(back) == sorted(host) and all(np.array_equal(back[k], host[k]) for k in host)
 
 
+def test_features_of_a_large_launch_equal_the_small_launches():
+    """A launch of 601 titles (the coalesced launches of the streamed loop carry 750) equals launches of 100, bit for bit;
+    dropout draws by (row, feature).  (Two titles per workgroup -- a W piece serving two matrix instructions -- was measured
+    for such launches: 177 us against 107 us, the kernel lives on its 24 resident waves per CU; not kept.)"""
+    conf = Conf()
+    m = get_model(conf)
+    m.fit(tn.make_params(41, 50, FS, 100, conf.n_output, seed=3))
+    n = 601
+    rng = np.random.default_rng(11)
+    titles = rng.integers(0, 41, (n, 25))
+    for r in range(n):
+        titles[r, int(rng.integers(0, 26)):] = -1
+    big = m.features(titles, n).cpu().numpy()
+    small = np.concatenate([m.features(titles[a:a + 100], min(100, n - a)).cpu().numpy() for a in range(0, n, 100)])
+    assert big.shape == (n, m.ld) and np.array_equal(big.view(np.uint32), small.view(np.uint32))
+    bigd = m.features(titles, n, keep_prob=0.8, seed=5).cpu().numpy()
+    kept = bigd != 0
+    assert 0.7 < kept[:, :400][big[:, :400] != 0].mean() < 0.9
+    # (rows of a later chunk draw with their own row index: compare the first chunk only)
+    smalld = m.features(titles[:100], 100, keep_prob=0.8, seed=5).cpu().numpy()
+    assert np.array_equal(bigd[:100].view(np.uint32), smalld.view(np.uint32))
+
+
 def _fma32(a, b, c):
     """fmaf(a, b, c) for float32 arrays, exactly: the product is exact in float64 (24 + 24 bits); the sum is rounded
     to ODD in float64 (TwoSum gives its error), so the final rounding to float32 is the single rounding of the exact
