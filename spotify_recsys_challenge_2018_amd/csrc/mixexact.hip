@@ -20,11 +20,14 @@
 //          tiles stop there.  (The canonical sigmoid in the epilogue -- ~35 VALU instructions, twice per element -- made the
 //          launch VALU-bound at 316 us for 750 rows; two logit thresholds per row, u_t >= thT or u_d >= thD, cost 3
 //          instructions but list EVERY column when one scorer is a flat background, e.g. an untrained title model.)
-//   refine launch, one workgroup per row: (1) the mixed bounds [l, u] of every listed column, densely (a lane per
-//          candidate); the need-th largest l is a threshold tau' that `need` columns provably reach, so only columns with
-//          u >= tau' can be among the k best; (2) those are recomputed: z_t, z_d with the canonical chains, mixed with the
-//          operations of mix_scores_kernel (title.hip) in their order -- the value the fp32 path ranks -- tested against the
-//          promise (bound guard, as refine.hip) and left as one compact (y, column) list per row for the selection kernel.
+//   refine launch, one 1024-thread workgroup per row: (1) the mixed bounds [l, u] of every listed column, densely (a lane
+//          per candidate, hardware exp2 / rcp, 2^-15 wider); the need-th largest l is a threshold tau' that `need` columns
+//          provably reach, so only columns with u >= tau' can be among the k best -- both keys staged in LDS for rows of up
+//          to 8 192 candidates, three streamed passes with a two-level fixed-bin histogram beyond; (2) the survivors are
+//          recomputed: z_t, z_d with the canonical chains, mixed with the operations of mix_scores_kernel (title.hip) in
+//          their order -- the value the fp32 path ranks -- tested against the promise (bound guard, as refine.hip) and left
+//          as one compact (y, column) list per row for the selection kernel.  Rows with both weights 0 (no input, no title)
+//          have y = +0 everywhere: they list nothing and get the first k + n_seeds columns directly.
 // BOUNDS.  DAE side: hidden rows lie in [0, 1], eps_c of exact_bounds_kernel (decode_f32.hip) as in the plain exact mode.
 // Title side: the features are ReLU maxima, not confined to [0, 1]; with F_r = max_k |feat[r][k]| every term of that
 // derivation that is linear in the hidden row scales by F_r:
@@ -34,7 +37,8 @@
 // goes through the matrix pipe like the bias: k-slot 3 of the tile's bias fragment holds +-alpha_c (bf16, rounded up), k-slot
 // 3 of the row's "ones" fragment holds F_r (bf16, rounded up), slots 0..2 the three-term split of b_c +- beta_c.
 // The canonical sigmoid is monotone only to one unit in the last place (920 one-ulp inversions among the 2.2 10^9 floats of
-// [-88, 88], checked exhaustively), so mixed bounds are widened by 2^-20 relative before they are compared.
+// [-88, 88], checked exhaustively), so bounds of the mixed value are widened (2^-15 with the hardware's exp2 / rcp, whose
+// results lie within 6e-6 of the canonical ones) before they are compared; the guard compares LOGITS, which need none.
 #include <climits>
 
 #include "dae_internal.h"
@@ -57,8 +61,6 @@ __device__ __forceinline__ float mixf(float zt, float zd, float wt, float wp)
     const float pd = dae_sigmoidf(zd) * wp;
     return ts + pd;
 }
-__device__ __forceinline__ float widen_up(float y) { return fmaf(y, 0x1p-20f, y); }       // y >= 0
-__device__ __forceinline__ float widen_dn(float y) { return fmaf(y, -0x1p-20f, y); }
 // The threshold sample evaluates every element, so it takes the hardware's exp2 / rcp (1 ulp each) instead of the canonical
 // polynomial (4 instructions against ~35): within 6.1e-6 relative of the canonical value for every finite logit (the
 // argument's rounding, |z| log2(e) 2^-24 <= 7.6e-6 in the exponent, dominates), hence a lower bound after 2^-15 relative.
@@ -67,7 +69,7 @@ __device__ __forceinline__ float sig_fast(float z)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896341f));
 }
 // Can w_t sigmoid(z_t) + w_p sigmoid(z_d) reach tau?  True whenever the canonical mixed value, widened by 2^-20, does (the
-// caller passes tau (1 - 2^-17)); false only with 2^-15 of room.  With E = exp(-z) (v_exp_f32: 1 ulp, its argument's
+// caller passes tau (1 - 2^-17): rounding, the canonical sigmoid's <= 3 ulp and its 1-ulp inversions); false only with 2^-15 of room.  With E = exp(-z) (v_exp_f32: 1 ulp, its argument's
 // rounding <= 6e-6 relative in E; arguments capped at 2^60, which only raises the left side's share):
 //     w_t / (1 + E_t) + w_p / (1 + E_d) >= tau  <=>  w_t (1 + E_d) + w_p (1 + E_t) >= tau (1 + E_t)(1 + E_d)
 __device__ __forceinline__ bool mix_can_reach(float zt, float zd, float wt, float wp, float tau)
