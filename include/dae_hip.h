@@ -435,6 +435,19 @@ int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, c
  * receives the guard words {violations so far, a violating column} in stream order, for a fetch alongside the lists --
  * a count that grew since the previous launch's means THIS launch is not to be trusted (re-score it with
  * DAE_DTYPE_F32).  out_score holds y.  B <= 4096. */
+/* One titled launch of the drivers' loop under DAE_DTYPE_BF16_EXACT in ONE call (main_challenge.py:72-93 with DAE_title:
+ * `reader.next_batch()` -> `sess.run(model.y_pred)` -> `cand_generate`): the feed as the reader emits it (COO positions /
+ * values ON THE DEVICE, as for dae_coo_to_csr), the titles [n_rows][L] int32 and titles_use [n_rows] on the device ->
+ * dae_title_features, dae_coo_to_csr, dae_encode, dae_seeds_from_csr (seeds = the playlist's own tracks), dae_mix_weights,
+ * dae_mix_topk_exact, with the intermediates in the title context's scratch.  Same results as the calls made one by one
+ * (`DAE_title.recommend_iter` made them from Python: eight library calls and a dozen allocations, ~0.2 ms of a 0.6 ms
+ * launch).  filter_sizes: HOST array.  csr_status: device int32, as dae_coo_to_csr's. */
+int dae_title_score_exact(dae_ctx* title_ctx, dae_ctx* dae, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
+                          const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
+                          const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
+                          const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
+                          int32_t* guard_out, int32_t* csr_status);
 int dae_mix_topk_exact(dae_ctx* title_ctx, dae_ctx* dae, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h,
                        int B, const float* w_title, const float* w_playlist, int n_tracks, const int32_t* seed_row_ptr,
                        const int32_t* seed_col, int k, float* out_score, int32_t* out_idx, int32_t* guard_out);

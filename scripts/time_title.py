@@ -43,6 +43,8 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     m, feed = build()
+    if os.environ.get('TITLE_NO_COMPOSITE'):
+        m.title_no_composite = True
     if os.environ.get('TITLE_COALESCE'):
         m.coalesce = int(os.environ['TITLE_COALESCE'])
     if os.environ.get('TITLE_DEPTH'):

@@ -19,7 +19,7 @@ EXPORTS = [
     "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
     "dae_pipeline_create", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_flush", "dae_pipeline_poll",
@@ -99,6 +99,8 @@ def load():
     lib.dae_set_score_mix.argtypes = [vp, vp, c_i64, c_int, vp]
     lib.dae_mix_topk_exact.argtypes = [vp, vp, vp, c_i64, vp, c_i64, c_int, vp, vp, c_int, vp, vp, c_int, vp, vp, vp]
     lib.dae_row_sums.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp]
+    lib.dae_title_score_exact.argtypes = [vp, vp, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp,
+                                          ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_int, vp, c_int, c_int, vp, vp, vp, vp]
     lib.dae_mix_weights.argtypes = [vp, vp, vp, vp, c_int, c_f, c_u32, vp, vp, vp]
     lib.dae_title_loss_backward.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, c_int, c_int, c_int,
                                             vp, c_int, vp, vp, vp, vp, vp]
@@ -350,6 +352,17 @@ class Context:
         """dae_decode_topk on this context ranks sigmoid(.) * w_title[r] + mixT[c, r] until cleared (no arguments)."""
         self.check(self.lib.dae_set_score_mix(self.h, _ptr(mixT), int(mixT.stride(0)) if mixT is not None else 0,
                                               int(mixT.shape[0]) if mixT is not None else 0, _ptr(w_title)))
+
+    def title_score_exact(self, dae_ctx, d_pos, d_val, n_rows, V, W_enc, b_enc, d_titles, tm, d_use, n_tracks, k, out_score, out_idx,
+                          guard_out, status):
+        """One titled launch of the streamed loop in one call (dae_title_score_exact); `tm`: the Char_CNN model object."""
+        nnz = int(d_pos.shape[0])
+        bcast = 1 if (d_val.numel() == 1 and nnz != 1) else 0
+        self.check(self.lib.dae_title_score_exact(
+            self.h, dae_ctx.h, _ptr(d_pos), _ptr(d_val), bcast, nnz, int(n_rows), int(V), _ptr(W_enc), _ptr(b_enc),
+            int(W_enc.shape[1]), _ptr(d_titles), tm.input_len, _ptr(tm.p["char_embedding"]), tm.char_size, tm.embedding,
+            _ptr(tm.p["conv_w"]), _ptr(tm.p["conv_b"]), tm._fs, len(tm.filter_sizes), tm.filter_num, tm.ld, _ptr(d_use),
+            int(n_tracks), int(k), _ptr(out_score), _ptr(out_idx), _ptr(guard_out), _ptr(status)))
 
     def mix_topk_exact(self, dae_ctx, feat, h, w_title, w_playlist, n_tracks, seed_row_ptr, seed_col, k, out_score, out_idx,
                        guard_out=None):

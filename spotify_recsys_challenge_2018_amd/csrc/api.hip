@@ -150,7 +150,7 @@ int dae_destroy(dae_ctx* ctx)
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
-                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat};
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -1008,6 +1008,51 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
     if (!(keep_prob > 0.f && keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
     return dae_launch_title_features(ctx, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F,
                                      keep_prob, seed, feat, ld, argmax, feat_raw);
+}
+
+int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
+                          const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
+                          const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
+                          const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
+                          int32_t* guard_out, int32_t* csr_status)
+{
+    if (!tc) return DAE_ERR_ARG;
+    if (!dc || dc == tc) return dae_fail(tc, DAE_ERR_ARG, "dae_title_score_exact: needs the DAE's context");
+    if (!titles || !titles_use || !W_enc || !b_enc || !csr_status || (nnz > 0 && (!positions || !values)))
+        return dae_fail(tc, DAE_ERR_ARG, "null pointer");
+    if (n_rows <= 0) return DAE_OK;
+    if (nnz < 0 || nnz >= (int64_t)1 << 31 || V < 1 || H < 1 || ld_feat < n_sizes * F)
+        return dae_fail(tc, DAE_ERR_ARG, "bad shape");
+    if (dc->stream != tc->stream) return dae_fail(tc, DAE_ERR_STATE, "both contexts must be bound to the same stream");
+    const int B = n_rows;
+    // the launch's intermediates, carved out of one buffer of the title context
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+    const size_t o_rp = 0, o_col = o_rp + up((size_t)(B + 1) * 4), o_val = o_col + up(nz * 4), o_srp = o_val + up(nz * 4),
+                 o_sc = o_srp + up((size_t)(B + 1) * 4), o_h = o_sc + up(nz * 4), o_ft = o_h + up((size_t)B * H * 4),
+                 o_wt = o_ft + up((size_t)B * ld_feat * 4), o_wp = o_wt + up((size_t)B * 4), total = o_wp + up((size_t)B * 4);
+    int rc = dae_reserve(tc, tc->title_scratch, total);
+    if (rc) return rc;
+    char* base = static_cast<char*>(tc->title_scratch.p);
+    int32_t* rp = reinterpret_cast<int32_t*>(base + o_rp); int32_t* col = reinterpret_cast<int32_t*>(base + o_col);
+    float* val = reinterpret_cast<float*>(base + o_val); int32_t* srp = reinterpret_cast<int32_t*>(base + o_srp);
+    int32_t* sc = reinterpret_cast<int32_t*>(base + o_sc); float* h = reinterpret_cast<float*>(base + o_h);
+    float* feat = reinterpret_cast<float*>(base + o_ft); float* wt = reinterpret_cast<float*>(base + o_wt);
+    float* wp = reinterpret_cast<float*>(base + o_wp);
+    rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
+                            nullptr, nullptr);
+    if (rc) return rc;
+    auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
+    rc = from_dc(dae_coo_to_csr(dc, positions, values, values_broadcast, nnz, B, V, rp, col, val, csr_status));
+    if (rc) return rc;
+    rc = from_dc(dae_encode(dc, rp, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0u, h));
+    if (rc) return rc;
+    rc = from_dc(dae_seeds_from_csr(dc, rp, col, B, n_tracks, srp, sc));
+    if (rc) return rc;
+    rc = from_dc(dae_mix_weights(dc, rp, col, val, B, 1.0f, 0u, titles_use, wt, wp));
+    if (rc) return rc;
+    return dae_mix_topk_exact(tc, dc, feat, ld_feat, h, H, B, wt, wp, n_tracks, srp, sc, k, out_score, out_idx, guard_out);
 }
 
 int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,

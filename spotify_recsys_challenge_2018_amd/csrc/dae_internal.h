@@ -125,6 +125,7 @@ struct dae_ctx {
     dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
+    dae_buf title_scratch;     // dae_title_score_exact: CSR, seed lists, hidden rows, features, mixing weights of the launch
 
     // profiling of the dominant kernel
     bool prof_on = false;

@@ -1351,8 +1351,27 @@ class DAE_title(DAE):
         # (Measured and not kept: the launch's two independent preambles -- CSR build / encode / seeds / mixing weights, and the
         # title features -- on streams of their own, joined before dae_mix_topk_exact: 1.12 - 1.17 M playlists/s against
         # 1.22 M without.  The loop is bound by the host's ~0.6 ms per launch, and the fork adds events and stream switches.)
+        feat = None
         if side_stream and self.device_csr:                   # the streamed loop: one pinned block, one asynchronous copy
             d_pos, d_val, d_titles, d_use = self._stage_titled(x_positions, x_ones, titles, titles_use, nb)
+            if (dtype == _lib.DAE_DTYPE_BF16_EXACT and isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT
+                    and not self.__dict__.get("title_no_composite")):
+                # the drivers' case (seeds = the playlist's own tracks): the whole launch in ONE library call
+                # (dae_title_score_exact) -- made call by call from here it cost ~0.2 ms of Python per launch
+                score = torch.empty((nb, k), dtype=torch.float32, device=dev)
+                idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
+                gw = torch.empty(2, dtype=torch.int32, device=dev)
+                status = torch.empty(1, dtype=torch.int32, device=dev)
+                tm.ctx.title_score_exact(self.ctx, d_pos, d_val, nb, self.n_input, self.weights["encoder_h"],
+                                         self.biases["encoder_b"], d_titles, tm, d_use, self.n_tracks, k, score, idx, gw, status)
+                cur = torch.cuda.current_stream(self.device_index)
+                ev = cur.record_event()
+                pending = (self._csr_status or []) + [(status, ev)]
+                if len(pending) > 64:
+                    pending = [(self._fold_status(pending), cur.record_event())]
+                self._csr_status = pending
+                idx._mix_guard = (gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows))
+                return score, idx, ev
             csr = self._upload_csr(None, None, n_rows=nb, staged=(d_pos, d_val, None))
         else:
             csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
@@ -1361,7 +1380,8 @@ class DAE_title(DAE):
         w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb, u_dev=d_use)
         if dtype == _lib.DAE_DTYPE_BF16_EXACT:
             # both GEMMs on bf16 operands in one launch per pass, the survivors recomputed in fp32 (csrc/mixexact.hip)
-            feat = tm.features(titles, nb, side_stream_of=self if side_stream else None, d_titles=d_titles)
+            if feat is None:
+                feat = tm.features(titles, nb, side_stream_of=self if side_stream else None, d_titles=d_titles)
             d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, n_rows=nb)
             score = torch.empty((nb, k), dtype=torch.float32, device=dev)
             idx = torch.empty((nb, k), dtype=torch.int32, device=dev)

@@ -187,8 +187,9 @@ def test_challenge_driver_with_titles_under_exact_bf16_at_hidden_256(tmp_path, m
     open(work / "config.ini", "w").write(ini)
     shutil.copytree(os.path.join(G, "data"), tmp_path / "data")
     calls = []
-    real = L.Context.mix_topk_exact
+    real, real1 = L.Context.mix_topk_exact, L.Context.title_score_exact        # (the latter: the whole launch in one call)
     monkeypatch.setattr(L.Context, "mix_topk_exact", lambda self, *a, **kw: (calls.append(1), real(self, *a, **kw))[1])
+    monkeypatch.setattr(L.Context, "title_score_exact", lambda self, *a, **kw: (calls.append(1), real1(self, *a, **kw))[1])
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
