@@ -1040,9 +1040,35 @@ int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, co
     int32_t* sc = reinterpret_cast<int32_t*>(base + o_sc); float* h = reinterpret_cast<float*>(base + o_h);
     float* feat = reinterpret_cast<float*>(base + o_ft); float* wt = reinterpret_cast<float*>(base + o_wt);
     float* wp = reinterpret_cast<float*>(base + o_wp);
-    rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
-                            nullptr, nullptr);
-    if (rc) return rc;
+#ifdef DAE_EXPERIMENTS
+    // DAE_TITLE_SIDE=1: the title features on a stream of their own, beside the DAE's preamble (measured: no gain, see notes)
+    static const bool side_on = dae_exp_env("DAE_TITLE_SIDE") != nullptr;
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    if (side_on) {
+        if (!side) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            DAE_HIP_CHECK(tc, hipStreamCreateWithPriority(&side, hipStreamNonBlocking, dae_exp_env("DAE_TITLE_SIDE_PRIO") ? hi : lo));
+            DAE_HIP_CHECK(tc, hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+            DAE_HIP_CHECK(tc, hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+        }
+        DAE_HIP_CHECK(tc, hipEventRecord(ev_in, tc->stream));
+        DAE_HIP_CHECK(tc, hipStreamWaitEvent(side, ev_in, 0));
+        hipStream_t keep = tc->stream;
+        tc->stream = side;
+        rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
+                                nullptr, nullptr);
+        tc->stream = keep;
+        if (rc) return rc;
+        DAE_HIP_CHECK(tc, hipEventRecord(ev_out, side));
+    } else
+#endif
+    {
+        rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
+                                nullptr, nullptr);
+        if (rc) return rc;
+    }
     auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
     rc = from_dc(dae_coo_to_csr(dc, positions, values, values_broadcast, nnz, B, V, rp, col, val, csr_status));
     if (rc) return rc;
@@ -1052,6 +1078,9 @@ int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, co
     if (rc) return rc;
     rc = from_dc(dae_mix_weights(dc, rp, col, val, B, 1.0f, 0u, titles_use, wt, wp));
     if (rc) return rc;
+#ifdef DAE_EXPERIMENTS
+    if (side_on) DAE_HIP_CHECK(tc, hipStreamWaitEvent(tc->stream, ev_out, 0));
+#endif
     return dae_mix_topk_exact(tc, dc, feat, ld_feat, h, H, B, wt, wp, n_tracks, srp, sc, k, out_score, out_idx, guard_out);
 }
 
