@@ -391,7 +391,9 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     hipStream_t st = ctx->stream;
     int rc;
     // scratch: cnt | cursor | bptr | kcnt  (n_rows + 1 each), then t_col | t_feed | t_val | k_col | k_val
-    const size_t nr = (size_t)n_rows + 1;
+    // (n_rows + 1 rounded up to a multiple of 4: the fill of cnt | cursor | flag below is then a whole number of 16-byte
+    // words and ONE fill kernel -- 6 024 bytes for 750 rows went out as two, 5 us each on the launch's critical path)
+    const size_t nr = ((size_t)n_rows + 1 + 3) & ~(size_t)3;
     const size_t ints = 4 * nr + 4 + 5 * (size_t)(nnz > 0 ? nnz : 1);
     if ((rc = dae_reserve(ctx, ctx->csr_tmp, ints * sizeof(int)))) return rc;
     int* cnt = static_cast<int*>(ctx->csr_tmp.p);

@@ -384,13 +384,13 @@ __global__ __launch_bounds__(256) void mix_title_bounds_kernel(const float* __re
 // ---- per row: F_r (bf16, rounded up) and whether the bound's preconditions hold -----------------------------------------
 // one wave per row.  row_bad[r] = 1: a DAE hidden entry outside [0, 1], a feature that is not finite, or a mixing weight
 // outside [0, 1] -- such rows return no recommendations (idx -1), as in the plain exact mode
-__global__ __launch_bounds__(256) void mix_rowprep_kernel(const float* __restrict__ h, int64_t ld_h, int HD,
-                                                          const float* __restrict__ feat, int64_t ld_f, int HT,
-                                                          const float* __restrict__ w_t, const float* __restrict__ w_p,
-                                                          int B, int Bpad, unsigned* __restrict__ fhat, int* __restrict__ row_bad)
+__device__ __forceinline__ void mix_rowprep_body(int block, const float* __restrict__ h, int64_t ld_h, int HD,
+                                                 const float* __restrict__ feat, int64_t ld_f, int HT,
+                                                 const float* __restrict__ w_t, const float* __restrict__ w_p,
+                                                 int B, int Bpad, unsigned* __restrict__ fhat, int* __restrict__ row_bad)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = block * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
     float mx = 0.0f;
     bool bad = false;
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(256) void mix_rowprep_kernel(const float* __restric
 
 // hidden rows of both scorers in B-operand order: out uint4 index = ((rg * NS + s) * RB + rb) * 64 + lane holds the bf16 of
 // h[r][16 s + 8 hi + 0..7] (s < NSD) or feat[r][16 (s - NSD) + 8 hi + 0..7], r = (rg RB + rb) 32 + j  (zero outside)
-__global__ __launch_bounds__(256) void mix_pack_kernel(const float* __restrict__ h, int64_t ld_h, int HD,
-                                                       const float* __restrict__ feat, int64_t ld_f, int HT,
-                                                       int B, int NSD, int NS, int RB, int n_rg, uint4* __restrict__ hp)
+__device__ __forceinline__ void mix_pack_body(int block, int n_blocks, const float* __restrict__ h, int64_t ld_h, int HD,
+                                              const float* __restrict__ feat, int64_t ld_f, int HT,
+                                              int B, int NSD, int NS, int RB, int n_rg, uint4* __restrict__ hp)
 {
     const size_t total = (size_t)n_rg * NS * RB * 64;
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    for (size_t o = (size_t)block * 256 + threadIdx.x; o < total; o += (size_t)n_blocks * 256) {
         const int lane = (int)(o & 63);
         size_t x = o >> 6;
         const int rb = (int)(x % RB); x /= RB;
@@ -440,6 +440,21 @@ __global__ __launch_bounds__(256) void mix_pack_kernel(const float* __restrict__
         for (int c = 0; c < 8; ++c) e[c] = dae_bf16_rne((r < B && k0 + c < Hs) ? src[k0 + c] : 0.0f);
         hp[o] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
     }
+}
+
+// both in ONE launch (the first `prep_blocks` workgroups prepare rows, the others pack: two launches of ~5 us each sat on the
+// launch's critical path -- profiles/r04_title_timeline.txt)
+__global__ __launch_bounds__(256) void mix_prep_pack_kernel(const float* __restrict__ h, int64_t ld_h, int HD,
+                                                            const float* __restrict__ feat, int64_t ld_f, int HT,
+                                                            const float* __restrict__ w_t, const float* __restrict__ w_p, int B,
+                                                            int Bpad, unsigned* __restrict__ fhat, int* __restrict__ row_bad,
+                                                            int prep_blocks, int NSD, int NS, int RB, int n_rg,
+                                                            uint4* __restrict__ hp)
+{
+    if ((int)blockIdx.x < prep_blocks)
+        mix_rowprep_body((int)blockIdx.x, h, ld_h, HD, feat, ld_f, HT, w_t, w_p, B, Bpad, fhat, row_bad);
+    else
+        mix_pack_body((int)blockIdx.x - prep_blocks, (int)gridDim.x - prep_blocks, h, ld_h, HD, feat, ld_f, HT, B, NSD, NS, RB, n_rg, hp);
 }
 
 // ---- refine: bounds of every candidate, the ones that can still be among the k best recomputed in fp32 -------------------
@@ -880,16 +895,15 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     rc = dae_reserve(tc, tc->mix_fhat, (size_t)Bpad * sizeof(unsigned)); if (rc) return rc;
     rc = dae_reserve(tc, tc->h_packed16, (size_t)n_rg * NS * RB * 64 * sizeof(uint4)); if (rc) return rc;
     tc->h16_geom_key = -1;                                       // (the buffer no longer holds a plain image's pad region)
-    hipLaunchKernelGGL(mix_rowprep_kernel, dim3((Bpad + 3) / 4), dim3(256), 0, st, h, ld_h, pd.H, feat, ld_feat, pt.H,
-                       w_title, w_playlist, B, Bpad, static_cast<unsigned*>(tc->mix_fhat.p), static_cast<int*>(tc->row_bad.p));
-    DAE_CHECK_LAUNCH(tc, "mix_rowprep_kernel");
     {
         const size_t total = (size_t)n_rg * NS * RB * 64;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4 * DAE_NUM_CU) blocks = 4 * DAE_NUM_CU;
-        hipLaunchKernelGGL(mix_pack_kernel, dim3(blocks), dim3(256), 0, st, h, ld_h, pd.H, feat, ld_feat, pt.H, B, NSD, NS, RB,
-                           n_rg, static_cast<uint4*>(tc->h_packed16.p));
-        DAE_CHECK_LAUNCH(tc, "mix_pack_kernel");
+        const int prep_blocks = (Bpad + 3) / 4;
+        hipLaunchKernelGGL(mix_prep_pack_kernel, dim3(prep_blocks + blocks), dim3(256), 0, st, h, ld_h, pd.H, feat, ld_feat, pt.H,
+                           w_title, w_playlist, B, Bpad, static_cast<unsigned*>(tc->mix_fhat.p), static_cast<int*>(tc->row_bad.p),
+                           prep_blocks, NSD, NS, RB, n_rg, static_cast<uint4*>(tc->h_packed16.p));
+        DAE_CHECK_LAUNCH(tc, "mix_prep_pack_kernel");
     }
 
     MixP p;
