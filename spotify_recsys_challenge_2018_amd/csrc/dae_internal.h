@@ -412,7 +412,11 @@ struct dae_exact_src {
     int* guard;                                   // nullable: device {violations, a violating column} (dae_exact_guard_read)
 };
 // out / out_cnt / out_cap (nullable): per row a compact list [out_cap] of the survivors' (fp32 logit, column) pairs and its
-// length; rows that fit get it filled and their g1 lists emptied (counts zeroed), the others are refined in place
+// length; rows that fit get it filled and their g1 lists emptied (counts zeroed), the others are refined in place.
+// fused (nullable; dae_exact_refine_can_fuse): the launch ENDS the scoring call -- seeds removed, the k best of every row in
+// order to fused->out_score / out_idx, exactly what dae_launch_topk_pairs over the refined lists returns -- and the lists it
+// leaves behind are not meant to be read
+bool dae_exact_refine_can_fuse(const dae_topk_args& a);
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
                             const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0,
-                            int* stat = nullptr);
+                            int* stat = nullptr, const dae_topk_args* fused = nullptr);

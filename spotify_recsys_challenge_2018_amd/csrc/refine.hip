@@ -20,6 +20,7 @@
 //      stride: conflict-free b128 accesses both ways); 8 blocks of 16 k (32 x 16 bytes per lane) are in flight.
 // The selection kernel (topk.hip, PairSrc) then ranks the lists as it does for the other modes.
 #include "dae_internal.h"
+#include "rank_lds.h"
 
 namespace {
 
@@ -41,6 +42,13 @@ struct RefineP {
     uint2* out; int* out_cnt; int out_cap;        // compact output lists [row][out_cap] + counts (see the header comment)
     int* stat;                                    // nullable: [B][2] {candidates, recomputed} of this launch
     int stage_cap;                                // candidates of a row the staging area holds (the launch's dynamic LDS)
+    // FUSED SELECTION (round 5; k <= 512): the launch ends with the row's final list -- seeds removed, the k best in order
+    // (main_challenge.py:26-36) -- instead of handing its survivors to a selection launch that reads them back
+    int fuse;
+    dae_rank_out fo;
+    const int32_t* seed_col; int bitmap_base, bitmap_n;     // the row's seeds -> an LDS bitmap over the ranked columns
+    const float* row_min;                         // nullable: an exchanged threshold (dae_score_topk_finish)
+    int bm_off;                                   // byte offset of the seed bitmap in the dynamic LDS (behind the staging area)
     long long* stamps;                            // experiments build: stage stamps of workgroup 0 (DAE_DBG_R)
 };
 
@@ -57,7 +65,9 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     extern __shared__ __attribute__((aligned(16))) unsigned char rf_dyn[];      // staging floats, then the waves' buffers
     __shared__ int seg_prefix[RF_MAX_SEG + 2];
     __shared__ float hrow[1024];
-    __shared__ int surv_off[RF_SURV];            // flat indices of the listed candidates (before that: the narrowing's histogram)
+    // flat indices of the listed candidates (before that: the narrowing's histogram; with the fused selection the upper half
+    // holds the row's final keys -- a row that takes that path lists at most 1024 -- and the lower half the ordering's histogram)
+    __shared__ __attribute__((aligned(16))) int surv_off[RF_SURV];
     __shared__ unsigned cnts[32];
     __shared__ int s_n;
 
@@ -70,7 +80,19 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
     if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
     for (int i = tid; i < 1024; i += RF_THREADS) hrow[i] = i < p.x.H ? p.x.h[(size_t)row * p.x.ld_h + i] : 0.0f;
+    // fused selection: the row's seeds as a bitmap over the ranked columns, built HERE -- its two dependent loads (seed_row_ptr,
+    // seed_col) travel with the prologue's instead of standing in front of the ordering at the end
+    unsigned* const bitmap = reinterpret_cast<unsigned*>(rf_dyn + p.bm_off);
+    const int bm_words = p.fuse ? (p.bitmap_n + 31) >> 5 : 0;
+    const int seed_b = (p.fuse && p.seed_col) ? p.seed_row_ptr[row] : 0;
+    const int seed_e = (p.fuse && p.seed_col) ? p.seed_row_ptr[row + 1] : 0;
+    int my_seed = seed_b + tid < seed_e ? p.seed_col[seed_b + tid] : -1;
+    for (int w = tid; w < bm_words; w += RF_THREADS) bitmap[w] = 0u;
     __syncthreads();
+    for (int i = seed_b + tid; i < seed_e; i += RF_THREADS) {
+        const int pc = (i == seed_b + tid ? my_seed : p.seed_col[i]) - p.bitmap_base;
+        if (pc >= 0 && pc < p.bitmap_n) atomicOr(&bitmap[pc >> 5], 1u << (pc & 31));
+    }
     if (tid < 64) {
         int carry = 0;
         for (int b0 = 0; b0 < nseg; b0 += 64) {
@@ -91,6 +113,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     if (total == 0) {
         if (tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
         if (tid == 0 && p.stat) { p.stat[2 * row] = 0; p.stat[2 * row + 1] = 0; }
+        if (p.fuse) dae_rank_pad<RF_THREADS>(tid, row, 0u, p.fo);
         return;
     }
     const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
@@ -233,6 +256,19 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     // than the list holds (thousands of logits within 2 eps of the cut) are refined IN PLACE, as in round 3.
     const bool compact = p.out != nullptr && n_kept <= p.out_cap;
     uint2* const orow = compact ? p.out + (size_t)row * p.out_cap : nullptr;
+    // fused selection, the common case: everything that is recomputed fits the ordering stage -- the survivors' keys stay
+    // in LDS and never see global memory.  (Other rows: their lists as before, then a narrowing over them at the end.)
+    const bool fast = p.fuse && compact && n_kept <= DAE_RANK_MAX;
+    dae_u64* const fkey = reinterpret_cast<dae_u64*>(surv_off + RF_SURV / 2);
+    const float row_min = p.row_min ? p.row_min[row] : -__builtin_inff();
+    // composite key of a recomputed survivor; 0 = absent (a seed, below an exchanged threshold, -inf)
+    auto fkey_of = [&](float z, int colv) -> dae_u64 {
+        const unsigned key = dae_okey(z);
+        if (colv < 0 || z < row_min || key <= DAE_KEY_NEG_INF) return 0ull;
+        const int pc = colv - p.bitmap_base;
+        if (pc >= 0 && pc < p.bitmap_n && ((bitmap[pc >> 5] >> (pc & 31)) & 1u)) return 0ull;
+        return ((dae_u64)key << 32) | (dae_u64)(~(unsigned)colv);
+    };
 
     // ---- 2. recompute the survivors -------------------------------------------------------------------------------
     float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // (shares the staging area: see the barriers)
@@ -332,12 +368,100 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     }
     // the row's per-workgroup lists are empty from here on (compact), its own list holds n_kept entries
     auto finish_compact = [&](int n_written) {
+        if (p.fuse) return;                                       // (nobody reads the lists after this launch)
         for (int s = tid; s < nseg; s += RF_THREADS) p.cnt[(size_t)s * p.cnt_seg_stride + row] = 0;
         if (tid == 0) p.out_cnt[row] = n_written;
     };
     if (!compact && tid == 0 && p.out_cnt) p.out_cnt[row] = 0;
 
+    // ---- 3. fused selection (p.fuse): the row's k best non-seeds in order, straight to the caller's outputs -------------------
+    // n_list = entries of the row's list: keys in LDS (fast), pairs in the row's compact list, or the flat index space of its
+    // per-workgroup lists (refined in place; what failed the narrowing is marked -inf there).  The recomputation is over, so the
+    // staging area is free: [ordering buffer][bin offsets].
+    __shared__ unsigned f_cnt, f_above;
+    __shared__ int f_bin;
+    __shared__ dae_u64 f_min, f_max;
+    __shared__ unsigned f_wave_tot[RF_WAVES];
+    auto final_select = [&](int n_list) {
+        __syncthreads();                                          // the recomputation's last LDS and list accesses
+        dae_u64* sorted = reinterpret_cast<dae_u64*>(rf_dyn);     // (the staging area is free now; the bitmap sits behind it)
+        unsigned* above = reinterpret_cast<unsigned*>(sorted + DAE_RANK_MAX);
+        unsigned* fhist = reinterpret_cast<unsigned*>(surv_off);
+        unsigned c = 0;
+        if (fast) {
+            c = (unsigned)n_list;
+        } else {
+            // more survivors than the ordering stage takes (logits packed within 2 eps of the cut), or a list refined in
+            // place: topk_kernel's range-adaptive narrowing (topk.hip step 3b) over the row's list in global memory, then the
+            // collect.  Rare by construction; every pass re-reads the list.
+            auto for_keys = [&](auto f) {
+                for (int e0 = 0; e0 < n_list; e0 += RF_THREADS) {
+                    const int e = e0 + tid;
+                    dae_u64 ck = 0ull;
+                    if (e < n_list) {
+                        const uint2 pr = compact ? orow[e] : p.base[offset_of(e)];
+                        ck = fkey_of(__uint_as_float(pr.x), (int)pr.y);
+                    }
+                    f(ck);
+                }
+            };
+            if (tid == 0) { f_cnt = 0u; f_min = ~0ull; f_max = 0ull; }
+            __syncthreads();
+            {
+                unsigned cnt = 0; dae_u64 mn = ~0ull, mx = 0ull;
+                for_keys([&](dae_u64 ck) {
+                    if (ck != 0ull) { ++cnt; mn = ck < mn ? ck : mn; mx = ck > mx ? ck : mx; }
+                });
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+                mn = dae_wave_min_u64(mn); mx = dae_wave_max_u64(mx);
+                if (lane == 0 && cnt) { atomicAdd(&f_cnt, cnt); atomicMin(&f_min, mn); atomicMax(&f_max, mx); }
+            }
+            __syncthreads();
+            const unsigned m = f_cnt;
+            const unsigned k_rank = m < (unsigned)p.fo.k ? m : (unsigned)p.fo.k;
+            dae_u64 lo = f_min, hi = f_max;
+            unsigned abv = 0;                                     // keys > hi
+            if (m > (unsigned)DAE_RANK_MAX) {
+                for (int it = 0; it < 8; ++it) {
+                    int shift = 64 - 11 - __clzll((hi - lo) | 1ull);
+                    if (shift < 0) shift = 0;
+                    for (int b = tid; b < RF_BINS; b += RF_THREADS) fhist[b] = 0u;
+                    __syncthreads();
+                    for_keys([&](dae_u64 ck) {
+                        if (ck != 0ull && ck >= lo && ck <= hi) atomicAdd(&fhist[(unsigned)((ck - lo) >> shift)], 1u);
+                    });
+                    __syncthreads();
+                    dae_rank_find_bin<RF_THREADS>(fhist, f_wave_tot, tid, k_rank - abv, &f_bin, &f_above);
+                    const unsigned b = (unsigned)f_bin;
+                    const unsigned cnt_b = fhist[b];
+                    const unsigned new_abv = abv + f_above;
+                    const dae_u64 nlo = lo + ((dae_u64)b << shift);
+                    dae_u64 nhi = nlo + ((1ull << shift) - 1ull);
+                    if (nhi > hi) nhi = hi;
+                    __syncthreads();                              // fhist / f_bin consumed
+                    lo = nlo;
+                    if (new_abv + cnt_b <= (unsigned)DAE_RANK_MAX) break;      // the keys >= lo fit (unique keys: at shift 0 a bin holds one)
+                    hi = nhi;
+                    abv = new_abv;
+                }
+            }
+            if (tid == 0) f_cnt = 0u;
+            __syncthreads();
+            for_keys([&](dae_u64 ck) {
+                if (ck != 0ull && ck >= lo) {
+                    const unsigned slot = atomicAdd(&f_cnt, 1u);
+                    if (slot < (unsigned)DAE_RANK_MAX) fkey[slot] = ck;
+                }
+            });
+            __syncthreads();
+            c = f_cnt < (unsigned)DAE_RANK_MAX ? f_cnt : (unsigned)DAE_RANK_MAX;
+        }
+        dae_rank_emit<RF_THREADS>(fkey, c, sorted, fhist, above, tid, row, p.fo);
+    };
+
     if (bad) {                                                   // a row that must return nothing
+        if (p.fuse) { dae_rank_pad<RF_THREADS>(tid, row, 0u, p.fo); return; }
         if (compact) { finish_compact(0); return; }
         for (int e = tid; e < total; e += RF_THREADS) p.base[offset_of(e)].x = __float_as_uint(-__builtin_inff());
         return;
@@ -354,11 +478,13 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const float z = rescore_group((int)pr.y, in);
             guard(z, __uint_as_float(pr.x), (int)pr.y, in);
             if (in) {
-                if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
+                if (fast) fkey[e] = fkey_of(z, (int)pr.y);
+                else if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
                 else p.base[off].x = __float_as_uint(z);
             }
         }
         if (compact) finish_compact(total);
+        if (p.fuse) final_select(total);
         return;
     }
 
@@ -406,7 +532,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                 const float z = rescore_group((int)cur.y, in);
                 guard(z, __uint_as_float(cur.x), (int)cur.y, in);
                 if (in) {
-                    if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
+                    if (fast) fkey[n_out + e] = fkey_of(z, (int)cur.y);
+                    else if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
                     else p.base[off_cur].x = __float_as_uint(z);
                 }
             }
@@ -427,6 +554,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     if (tid == 0 && p.stat) p.stat[2 * row + 1] = n_out;
     if (compact) finish_compact(n_out);
     RSTAMP(7)
+    if (p.fuse) final_select(compact ? n_out : total);
+    RSTAMP(8)
 }
 
 __global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
@@ -438,8 +567,21 @@ __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 
 }  // namespace
 
+// LDS the fused selection adds BEHIND the staging area: the seed bitmap over the ranked columns (built in the prologue; the
+// ordering's buffers reuse the staging area, which holds at least DAE_RANK_MAX * 8 + DAE_RANK_BINS * 4 bytes)
+static size_t fuse_bitmap_bytes(int bitmap_n) { return (((size_t)((bitmap_n + 31) >> 5)) * 4 + 15) & ~(size_t)15; }
+constexpr size_t RF_DYN_MAX = 128 * 1024;      // dynamic LDS a refine workgroup may ask for (static: ~25 KB)
+static_assert((size_t)(RF_STAGE / 2) * sizeof(float) >= (size_t)DAE_RANK_MAX * 8 + (size_t)DAE_RANK_BINS * 4, "ordering buffers");
+
+bool dae_exact_refine_can_fuse(const dae_topk_args& a)
+{
+    return a.k <= DAE_RANK_MAX / 2 && !a.out_pairs && !a.out_tau &&
+           (size_t)RF_STAGE * sizeof(float) + fuse_bitmap_bytes(a.bitmap_n) <= RF_DYN_MAX;
+}
+
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
-                            const int32_t* seed_row_ptr, uint2* out, int* out_cnt, int out_cap, int* stat)
+                            const int32_t* seed_row_ptr, uint2* out, int* out_cnt, int out_cap, int* stat,
+                            const dae_topk_args* fa)
 {
     if (B <= 0) return DAE_OK;
     if (g1.nseg > RF_MAX_SEG) return dae_fail(ctx, DAE_ERR_ARG, "too many candidate segments (%d)", g1.nseg);
@@ -449,6 +591,14 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     p.base = const_cast<uint2*>(g1.base); p.cnt = const_cast<int*>(g1.cnt); p.seg_stride = g1.seg_stride; p.row_stride = g1.row_stride;
     p.cnt_seg_stride = g1.cnt_seg_stride; p.nseg = g1.nseg; p.x = x; p.seed_row_ptr = seed_row_ptr; p.k = k;
     p.stat = stat;
+    p.fuse = 0; p.fo = dae_rank_out{k, DAE_OUT_LOGIT, nullptr, nullptr}; p.seed_col = nullptr; p.bitmap_base = 0; p.bitmap_n = 0;
+    p.row_min = nullptr;
+    if (fa) {
+        if (!dae_exact_refine_can_fuse(*fa) || fa->k != k || fa->seed_row_ptr != seed_row_ptr)
+            return dae_fail(ctx, DAE_ERR_ARG, "exact refine: this selection cannot be fused (k=%d)", fa->k);
+        p.fuse = 1; p.fo = dae_rank_out{fa->k, fa->out_kind, fa->out_score, fa->out_idx};
+        p.seed_col = fa->seed_col; p.bitmap_base = fa->bitmap_base; p.bitmap_n = fa->bitmap_n; p.row_min = fa->row_min;
+    }
     p.out = (out && out_cnt && out_cap > 0) ? out : nullptr; p.out_cnt = p.out ? out_cnt : nullptr; p.out_cap = p.out ? out_cap : 0;
     if ((int64_t)g1.nseg * g1.seg_stride >= ((int64_t)1 << 31))
         return dae_fail(ctx, DAE_ERR_ARG, "exact refine: candidate lists too large for 32-bit offsets");
@@ -480,9 +630,12 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     size_t dyn = (size_t)p.stage_cap * sizeof(float);
     const size_t tb = (size_t)(slim ? 4 : 8) * 64 * RF_ROWSTRIDE * sizeof(float);
     if (dyn < tb) dyn = tb;
+    p.bm_off = (int)dyn;
+    if (p.fuse) dyn += fuse_bitmap_bytes(p.bitmap_n);
     static const char key = 0;
     if (dae_first_use(ctx, &key)) {
-        const int mx = (int)((size_t)RF_STAGE * sizeof(float));
+        const int mx = (int)RF_DYN_MAX;
+        static_assert(RF_DYN_MAX >= (size_t)RF_STAGE * sizeof(float), "staging area");
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_slim_kernel),
