@@ -625,7 +625,8 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
         // k <= 512: the refine launch ends the call itself -- a row's workgroup has its recomputed survivors in LDS, takes the
         // seeds out and orders the k best there (round 5: the selection launch that read them back was 10.6 / 24.0 us of the
         // step at 256 / 1024 rows); larger k keeps the two launches
-        const bool fuse = dae_exact_refine_can_fuse(ta);
+        static const bool no_fuse = dae_exp_env("DAE_RF_NOFUSE") != nullptr;                  // A/B (experiments build)
+        const bool fuse = !no_fuse && dae_exact_refine_can_fuse(ta);
         rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr, rf, rf_cnt, DAE_REFINED_CAP, static_cast<int*>(ctx->refstat.p),
                                      fuse ? &ta : nullptr);
         if (rc || fuse) return rc;

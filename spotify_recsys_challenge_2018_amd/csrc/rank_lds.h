@@ -29,6 +29,23 @@ __device__ __forceinline__ dae_u64 dae_wave_max_u64(dae_u64 v)
     return v;
 }
 
+// Wave-wide maximum / minimum of a 32-bit value on the DPP path (quad permutes and row mirrors inside the rows of 16 lanes, the
+// four row leaders through v_readlane): ~10 instructions, no LDS -- six ds_bpermute round trips (__shfl_xor) cost ~1 k cycles on
+// the last wave to finish.  EVERY lane of the wave must be active; the result is wave-uniform.
+__device__ __forceinline__ unsigned dae_wave_max_u32(unsigned v)
+{
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); v = t > v ? t : v;      // quad_perm [1,0,3,2]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); v = t > v ? t : v;      // quad_perm [2,3,0,1]
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false); v = t > v ? t : v;     // row_half_mirror
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false); v = t > v ? t : v;     // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned dae_wave_min_u32(unsigned v) { return ~dae_wave_max_u32(~v); }
+
 // rows without a single candidate: the reference's cand[:k] of an empty list, padded as topk_kernel pads short rows
 template <int NTH>
 __device__ __forceinline__ void dae_rank_pad(int tid, int row, unsigned from, const dae_rank_out& o)
@@ -79,16 +96,26 @@ __device__ __forceinline__ void dae_rank_find_bin(const unsigned* hist, unsigned
 // keys[0 .. c), c <= DAE_RANK_MAX: unique composite keys, 0 = absent.  Emits the min(k, present) largest in descending order
 // to row `row` of the outputs and pads the rest.  LDS scratch: sorted[DAE_RANK_MAX], hist[DAE_RANK_BINS],
 // above[DAE_RANK_BINS]; `keys` itself is overwritten.  Every thread of the NTH-thread workgroup calls; starts with a barrier.
+// range (nullable, LDS): {a lower bound, an upper bound} of the present keys' HIGH words ({0xFFFFFFFF, 0}: none present), kept
+// by the caller while it produced the keys -- the caller has then ALSO zeroed hist[] before the call; both save a pass and two
+// barriers here (stage stamps: 3.5 k of the ordering's 9.2 k cycles at 16 waves).
 template <int NTH>
 __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64* sorted, unsigned* hist, unsigned* above,
-                                              int tid, int row, const dae_rank_out& o)
+                                              int tid, int row, const dae_rank_out& o, const unsigned* range = nullptr,
+                                              long long* dbg = nullptr)
 {
+#ifdef DAE_EXPERIMENTS         // stage stamps of workgroup 0 (the caller's debug switch hands the buffer in)
+#define RKSTAMP(i) if (dbg && blockIdx.x == 0 && tid == 0) dbg[i] = __builtin_readcyclecounter();
+#else
+#define RKSTAMP(i)
+#endif
     constexpr int PER = DAE_RANK_MAX / NTH, BPT = DAE_RANK_BINS / NTH, NW = NTH / 64;
     __shared__ dae_u64 rk_mm[2];
     __shared__ unsigned rk_wave_tot[NW];
     __shared__ unsigned rk_total;
     const int lane = tid & 63;
     __syncthreads();                                             // keys complete; the scratch regions' last readers are done
+    RKSTAMP(0)
     dae_u64 mine[PER];
     dae_u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
@@ -97,13 +124,20 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
         mine[e] = i < c ? keys[i] : 0ull;
         if (mine[e] != 0ull) { mn = mine[e] < mn ? mine[e] : mn; mx = mine[e] > mx ? mine[e] : mx; }
     }
-    if (tid == 0) { rk_mm[0] = ~0ull; rk_mm[1] = 0ull; }
-    for (int b = tid; b < DAE_RANK_BINS; b += NTH) hist[b] = 0u;
-    __syncthreads();
-    mn = dae_wave_min_u64(mn); mx = dae_wave_max_u64(mx);
-    if (lane == 0 && mx != 0ull) { atomicMin(&rk_mm[0], mn); atomicMax(&rk_mm[1], mx); }
-    __syncthreads();
-    const dae_u64 rlo = rk_mm[0], rhi = rk_mm[1];
+    dae_u64 rlo, rhi;
+    if (range) {                                                 // (block-uniform)
+        rlo = (dae_u64)range[0] << 32;
+        rhi = range[1] ? ((dae_u64)range[1] << 32) | 0xFFFFFFFFull : 0ull;
+    } else {
+        if (tid == 0) { rk_mm[0] = ~0ull; rk_mm[1] = 0ull; }
+        for (int b = tid; b < DAE_RANK_BINS; b += NTH) hist[b] = 0u;
+        __syncthreads();
+        mn = dae_wave_min_u64(mn); mx = dae_wave_max_u64(mx);
+        if (lane == 0 && mx != 0ull) { atomicMin(&rk_mm[0], mn); atomicMax(&rk_mm[1], mx); }
+        __syncthreads();
+        rlo = rk_mm[0]; rhi = rk_mm[1];
+    }
+    RKSTAMP(1)
     if (rhi == 0ull) { dae_rank_pad<NTH>(tid, row, 0u, o); return; }       // nothing present (block-uniform)
     // bins linear in the SCORE, not in its bit pattern (topk.hip step 5a has the measurement behind this); when the scores'
     // range is degenerate -- every key shares its float -- the bit pattern of the whole key (the column breaks the ties)
@@ -129,6 +163,7 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
         mpos[e] = mine[e] != 0ull ? atomicAdd(&hist[bn], 1u) : 0u;
     }
     __syncthreads();
+    RKSTAMP(2)
     {   // above[b] = keys in bins > b
         const int top = DAE_RANK_BINS - 1 - BPT * tid;
         unsigned cb[BPT], own = 0;
@@ -149,12 +184,14 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
         if (tid == NTH - 1) rk_total = run;
     }
     __syncthreads();
+    RKSTAMP(3)
     const unsigned present = rk_total;
     const unsigned k_eff = present < (unsigned)o.k ? present : (unsigned)o.k;
 #pragma unroll
     for (int e = 0; e < PER; ++e)
         if (mine[e] != 0ull) sorted[above[mbin[e]] + mpos[e]] = mine[e];
     __syncthreads();
+    RKSTAMP(4)
     unsigned rk[PER];
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -166,11 +203,13 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
         rk[e] = rank;
     }
     // the winners in rank order through LDS, then out in rank order: thread i writes position i (whole lines per wave)
+    RKSTAMP(5)
     dae_u64* fin = keys;                                         // (every thread took its keys into registers above)
 #pragma unroll
     for (int e = 0; e < PER; ++e)
         if (rk[e] < k_eff) fin[rk[e]] = mine[e];
     __syncthreads();
+    RKSTAMP(6)
     for (unsigned i = (unsigned)tid; i < k_eff; i += NTH) {
         const dae_u64 key = fin[i];
         const float z = dae_okey_inv((unsigned)(key >> 32));
@@ -179,4 +218,6 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
         if (o.out_score) o.out_score[at] = o.out_kind == DAE_OUT_SCORE ? dae_sigmoidf(z) : z;
     }
     dae_rank_pad<NTH>(tid, row, k_eff, o);
+    RKSTAMP(7)
+#undef RKSTAMP
 }

@@ -70,6 +70,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     __shared__ __attribute__((aligned(16))) int surv_off[RF_SURV];
     __shared__ unsigned cnts[32];
     __shared__ int s_n;
+    __shared__ unsigned f_range[2];              // fused selection: {min, max} of the high words of the keys written to LDS
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row = blockIdx.x;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     RSTAMP(0)
     const bool bad = p.x.row_bad && p.x.row_bad[row] != 0;          // precondition of the bound violated: nothing survives
     for (int s = tid; s < nseg; s += RF_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
-    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
+    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; f_range[0] = 0xFFFFFFFFu; f_range[1] = 0u; }
     if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
     for (int i = tid; i < 1024; i += RF_THREADS) hrow[i] = i < p.x.H ? p.x.h[(size_t)row * p.x.ld_h + i] : 0.0f;
     // fused selection: the row's seeds as a bitmap over the ranked columns, built HERE -- its two dependent loads (seed_row_ptr,
@@ -269,6 +270,15 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         if (pc >= 0 && pc < p.bitmap_n && ((bitmap[pc >> 5] >> (pc & 31)) & 1u)) return 0ull;
         return ((dae_u64)key << 32) | (dae_u64)(~(unsigned)colv);
     };
+    // ... into slot i of the LDS list (lanes with `in`), with the range of the keys' high words kept up to date for the ordering
+    // stage: one wave reduction on the DPP path and one LDS atomic each way per group (called by WHOLE waves)
+    auto fkey_put = [&](int i, float z, int colv, bool in) {
+        const dae_u64 ck = in ? fkey_of(z, colv) : 0ull;
+        if (in) fkey[i] = ck;
+        const unsigned hi = (unsigned)(ck >> 32);
+        const unsigned mx = dae_wave_max_u32(hi), mn = dae_wave_min_u32(ck != 0ull ? hi : 0xFFFFFFFFu);
+        if (lane == 0 && mx != 0u) { atomicMin(&f_range[0], mn); atomicMax(&f_range[1], mx); }
+    };
 
     // ---- 2. recompute the survivors -------------------------------------------------------------------------------
     float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // (shares the staging area: see the barriers)
@@ -309,11 +319,22 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                     for (int i = 0; i < 4; ++i)
                         *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * RF_ROWSTRIDE + 4 * q) = v[d][i];
                     __builtin_amdgcn_wave_barrier();              // (a wave's LDS accesses execute in order; keep the compiler from moving them)
-                    const int jn = j + RF_DEPTH;
-                    if (jn < H16) {
+                    // The ring is refilled in PAIRS of blocks: a quad reads 64 contiguous bytes of its row per block, half a
+                    // 128-byte line.  Requested one block apart, the two halves of a line were two fetches from L2 -- the ~2 000
+                    // lines a CU has in flight do not survive in its 256-line L1 (stage stamps: 18 k cycles per group of 64
+                    // against 8.5 k for its bytes at 64 B per cycle).  Requested back to back, the second finds the line pending.
+                    if (dd & 1) {
+                        const int dp = (dd - 1) & dmask;
+                        const int jn0 = j - 1 + RF_DEPTH, jn1 = j + RF_DEPTH;
+                        if (jn0 < H16) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
-                    }
+                            for (int i = 0; i < 4; ++i) v[dp][i] = rp[i][4 * jn0];
+                        }
+                        if (jn1 < H16) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn1];
+                        }
+                    }                                             // (RF_DEPTH is even: every block beyond the prologue's has a partner)
                     float4 w[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(tbuf + lane * RF_ROWSTRIDE + 4 * t);
@@ -390,6 +411,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         unsigned c = 0;
         if (fast) {
             c = (unsigned)n_list;
+            for (int b = tid; b < RF_BINS; b += RF_THREADS) fhist[b] = 0u;
         } else {
             // more survivors than the ordering stage takes (logits packed within 2 eps of the cut), or a list refined in
             // place: topk_kernel's range-adaptive narrowing (topk.hip step 3b) over the row's list in global memory, then the
@@ -457,7 +479,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             __syncthreads();
             c = f_cnt < (unsigned)DAE_RANK_MAX ? f_cnt : (unsigned)DAE_RANK_MAX;
         }
-        dae_rank_emit<RF_THREADS>(fkey, c, sorted, fhist, above, tid, row, p.fo);
+        dae_rank_emit<RF_THREADS>(fkey, c, sorted, fhist, above, tid, row, p.fo, fast ? f_range : nullptr,
+                                  p.stamps ? p.stamps + 16 : nullptr);
     };
 
     if (bad) {                                                   // a row that must return nothing
@@ -475,16 +498,20 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const bool in = e < total;
             const int off = offset_of(in ? e : g0);
             const uint2 pr = p.base[off];
+            if (g0 == 0) { RSTAMP(5) }
             const float z = rescore_group((int)pr.y, in);
+            if (g0 == 0) { RSTAMP(9) }
             guard(z, __uint_as_float(pr.x), (int)pr.y, in);
-            if (in) {
-                if (fast) fkey[e] = fkey_of(z, (int)pr.y);
-                else if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
+            if (fast) fkey_put(e, z, (int)pr.y, in);
+            else if (in) {
+                if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
                 else p.base[off].x = __float_as_uint(z);
             }
         }
+        RSTAMP(6)
         if (compact) finish_compact(total);
         if (p.fuse) final_select(total);
+        RSTAMP(8)
         return;
     }
 
@@ -531,9 +558,9 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                 if (gn < n) { off = offset_of(surv_off[gn + lane < n ? gn + lane : gn]); pr = p.base[off]; }   // next group's pairs, under this group's rows
                 const float z = rescore_group((int)cur.y, in);
                 guard(z, __uint_as_float(cur.x), (int)cur.y, in);
-                if (in) {
-                    if (fast) fkey[n_out + e] = fkey_of(z, (int)cur.y);
-                    else if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
+                if (fast) fkey_put(n_out + e, z, (int)cur.y, in);
+                else if (in) {
+                    if (compact) orow[n_out + e] = make_uint2(__float_as_uint(z), cur.y);
                     else p.base[off_cur].x = __float_as_uint(z);
                 }
             }
@@ -559,6 +586,10 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
 }
 
 __global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
+// one row per CU (launches of <= 512 rows): 16 waves, so that the ~530 - 700 recomputed survivors of a row are ONE group of 64 per
+// wave -- with 8 waves the ninth group made wave 0 run two groups one after the other, and a group is a chain of memory round
+// trips (~9 us): the launch's length was that wave's
+__global__ __launch_bounds__(1024) void exact_refine_wide_kernel(const RefineP p) { refine_body<1024, 4>(p); }
 // the shape that shares a CU with another batch's filter workgroup: one wave per SIMD within the 112 registers those leave
 __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 {
@@ -572,6 +603,7 @@ __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 static size_t fuse_bitmap_bytes(int bitmap_n) { return (((size_t)((bitmap_n + 31) >> 5)) * 4 + 15) & ~(size_t)15; }
 constexpr size_t RF_DYN_MAX = 128 * 1024;      // dynamic LDS a refine workgroup may ask for (static: ~25 KB)
 static_assert((size_t)(RF_STAGE / 2) * sizeof(float) >= (size_t)DAE_RANK_MAX * 8 + (size_t)DAE_RANK_BINS * 4, "ordering buffers");
+static_assert(RF_BINS == DAE_RANK_BINS, "the narrowing's and the ordering's histograms share their LDS");
 
 bool dae_exact_refine_can_fuse(const dae_topk_args& a)
 {
@@ -608,14 +640,15 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     static long long* rbuf = nullptr;
     static int rcalls = 0;
     if (dbgR) {
-        if (!rbuf) { (void)hipMalloc(&rbuf, 16 * 8); (void)hipMemset(rbuf, 0, 16 * 8); }
+        if (!rbuf) { (void)hipMalloc(&rbuf, 32 * 8); (void)hipMemset(rbuf, 0, 32 * 8); }
         p.stamps = rbuf;
         if ((++rcalls % 100) == 0) {
-            long long h[16];
+            long long h[32];
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipMemcpy(h, rbuf, sizeof(h), hipMemcpyDeviceToHost);
             fprintf(stderr, "REFINE wg0:");
-            for (int i = 1; i < 8; ++i) if (h[i]) fprintf(stderr, " [%d]%lld", i, h[i] - h[0]);
+            for (int i = 1; i < 10; ++i) if (h[i]) fprintf(stderr, " [%d]%lld", i, h[i] - h[0]);
+            for (int i = 16; i < 24; ++i) if (h[i]) fprintf(stderr, " rk%d:%lld", i - 16, h[i] - h[0]);
             fprintf(stderr, "\n");
         }
     }
@@ -625,10 +658,17 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     // arithmetic; a row is latency-bound on its own (batch 1024: 60 -> see profiles/r04_notes.md).  Rows with more candidates
     // than the smaller area holds are recomputed without narrowing (slower, same bits).
     const bool many = B >= 768;
-    const bool slim = ctx->overlap_hint || many;
+    bool slim = ctx->overlap_hint || many;
+    int shape = slim ? 0 : 1;                                                                  // 0 slim (256), 1 (512), 2 wide (1024)
+    // fused selection, one row per CU: the wide shape, whatever the overlap hint says -- measured (profiles/r05_notes.md), four
+    // batches in flight: slim + fused 46.1 us per step, 512 threads + fused 41.9, slim + a selection launch 42.2
+    if (p.fuse && !many) shape = 2;
+    static const char* shape_env = dae_exp_env("DAE_RF_SHAPE");                               // A/B (experiments build)
+    if (shape_env) shape = atoi(shape_env);
+    slim = shape == 0;
     p.stage_cap = many ? RF_STAGE / 2 : RF_STAGE;
     size_t dyn = (size_t)p.stage_cap * sizeof(float);
-    const size_t tb = (size_t)(slim ? 4 : 8) * 64 * RF_ROWSTRIDE * sizeof(float);
+    const size_t tb = (size_t)(shape == 0 ? 4 : shape == 1 ? 8 : 16) * 64 * RF_ROWSTRIDE * sizeof(float);
     if (dyn < tb) dyn = tb;
     p.bm_off = (int)dyn;
     if (p.fuse) dyn += fuse_bitmap_bytes(p.bitmap_n);
@@ -640,9 +680,13 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
                                                hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_slim_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_wide_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     }
-    if (slim)
+    if (shape == 0)
         hipLaunchKernelGGL(exact_refine_slim_kernel, dim3(B), dim3(256), dyn, ctx->stream, p);
+    else if (shape == 2)
+        hipLaunchKernelGGL(exact_refine_wide_kernel, dim3(B), dim3(1024), dyn, ctx->stream, p);
     else
         hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(512), dyn, ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "exact_refine_kernel");
