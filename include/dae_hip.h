@@ -306,6 +306,25 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
 int dae_pipeline_destroy(dae_pipeline* p);
 int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
                         int n_rows, uint64_t* ticket_out);
+/* The TITLED loop -- what the reference's `--challenge` really runs (main_challenge.py:58-59, :72-93: every batch goes through
+ * DAE_title with `titles` / `titles_use` in the feed; DAEs.py:153-181).  create_titled: the pipeline above plus the title
+ * scorer's variables (caller-owned DEVICE arrays in the layout of dae_title_features / dae_title_score: emb [n_char][E], conv_w /
+ * conv_b back to back, filter_sizes a HOST array of n_sizes entries, Output_WT [V][ld_feat] = Output_W^T zero padded,
+ * Output_b [V]); titles are rows of L characters.  Every lane holds a second context for the title scorer on its stream.
+ * submit_titled: a feed with its titles [n_rows][L] int32 (-1 = no character) and titles_use [n_rows] (HOST arrays) -> the
+ * launch ranks y = sigmoid(z_title) * w_title + sigmoid(z_dae) * w_playlist (dae_title_score) with seeds = the playlist's own
+ * tracks.  Feeds submitted WITHOUT titles (dae_pipeline_submit) on the same pipeline rank the plain DAE logits
+ * (dae_score_topk), as `DAE_title.recommend` does for batches whose titles_use is all zero; the two kinds never share a launch.
+ * At most 4096 rows per launch.  DAE_DTYPE_BF16_EXACT: a launch under which the title context's guard words moved (a bound
+ * violated, or rows with more survivors than the refine launch lists) is re-scored with DAE_DTYPE_F32 before its lists go out;
+ * after two launches in a row with overflowing rows the mode pauses for 64 launches (they run on the fp32 kernels). */
+int dae_pipeline_create_titled(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                               int V, int H, int n_tracks, const float* emb, int n_char, int E, const float* conv_w,
+                               const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, const float* Output_WT,
+                               const float* Output_b, int ld_feat, int L, int dtype, int k, int group_rows, int64_t max_nnz,
+                               int lanes, int want_scores, int result_blocks, dae_pipeline** out);
+int dae_pipeline_submit_titled(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                               int n_rows, const int32_t* titles, const float* titles_use, uint64_t* ticket_out);
 int dae_pipeline_flush(dae_pipeline* p);
 int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t** idx, const float** score, int* n_rows,
                       int* block);
@@ -442,6 +461,15 @@ int dae_set_score_mix(dae_ctx* ctx, const float* mixT, int64_t ld, int n_cols, c
  * dae_mix_topk_exact, with the intermediates in the title context's scratch.  Same results as the calls made one by one
  * (`DAE_title.recommend_iter` made them from Python: eight library calls and a dozen allocations, ~0.2 ms of a 0.6 ms
  * launch).  filter_sizes: HOST array.  csr_status: device int32, as dae_coo_to_csr's. */
+/* dae_title_score: the same launch for any dtype -- DAE_DTYPE_BF16_EXACT as above; DAE_DTYPE_F32 / DAE_DTYPE_BF16 through the
+ * fused mix (dae_decode_mix_term on the DAE's context, dae_set_score_mix + dae_decode_topk on the title context; both hold
+ * their weights prepacked with that dtype), guard_out zeroed.  dae_title_score_exact = dae_title_score(DAE_DTYPE_BF16_EXACT). */
+int dae_title_score(dae_ctx* title_ctx, dae_ctx* dae, int dtype, const int64_t* positions, const float* values, int values_broadcast,
+                    int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
+                    const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
+                    const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
+                    const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
+                    int32_t* guard_out, int32_t* csr_status);
 int dae_title_score_exact(dae_ctx* title_ctx, dae_ctx* dae, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
                           const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,

@@ -49,14 +49,42 @@ def main():
         m.coalesce = int(os.environ['TITLE_COALESCE'])
     if os.environ.get('TITLE_DEPTH'):
         m.title_depth = int(os.environ['TITLE_DEPTH'])
+    if os.environ.get('TITLE_ENGINE'):          # native (default: dae_pipeline_create_titled) | python
+        m.iter_engine = os.environ['TITLE_ENGINE']
+    if os.environ.get('TITLE_LANES'):
+        m.n_lanes = int(os.environ['TITLE_LANES'])
     for _ in m.recommend_iter([feed] * 10, k=500, dtype=mode, want_scores=False):
         pass
+    if os.environ.get('TITLE_GC', 'freeze') == 'freeze':      # as main.py --challenge does before its loop (a full collection of
+        import gc                                                # the interpreter's heap otherwise lands in the timed loop: 35 ms)
+        gc.collect(); gc.freeze()
+    elif os.environ.get('TITLE_GC') == 'off':
+        import gc
+        gc.disable()
+    spin_us = float(os.environ.get('TITLE_CONSUMER_US', '0'))      # a consumer that works this long on every feed's lists
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    first = None
+    stamps = []
     for _ in m.recommend_iter([feed] * n, k=500, dtype=mode, want_scores=False):
-        pass
+        if first is None:
+            first = time.perf_counter() - t0
+        stamps.append(time.perf_counter())
+        if spin_us:
+            t1 = time.perf_counter()
+            while (time.perf_counter() - t1) * 1e6 < spin_us:
+                pass
+    if os.environ.get('TITLE_GAPS'):
+        d = np.diff(np.asarray(stamps)) * 1e3
+        big = np.argsort(d)[-12:]
+        print("  gaps between yields (ms): median %.3f, sum %.1f; the 12 largest at feed#:" % (np.median(d), d.sum()),
+              [(int(i), round(float(d[i]), 2)) for i in sorted(big)])
+    t_end = time.perf_counter()               # (every list is on the host when it is handed out: nothing to wait for)
     torch.cuda.synchronize()
-    ds = (time.perf_counter() - t0) / n
-    print("titled recommend_iter %s: %.3f ms per batch of 150 = %.0f playlists/s" % (mode, ds * 1e3, 150 / ds))
+    print("  device-wide synchronize after the loop: %.2f ms (not part of the rate)" % ((time.perf_counter() - t_end) * 1e3))
+    ds = (t_end - t0) / n
+    print("titled recommend_iter %s: %.3f ms per batch of 150 = %.0f playlists/s (first lists after %.2f ms)" % (mode, ds * 1e3, 150 / ds, first * 1e3))
+    for _g, pipe in m.__dict__.get("_pipes", {}).values():
+        print("  pipeline:", pipe.stats(), pipe.times())
     if mode == "exact_bf16":
         print("  last launch:", m.title_model.ctx.exact_stats_read(), "guard", m.title_model.ctx.exact_guard_read(),
               "fallbacks", getattr(m, "_guard_fallbacks", 0))

@@ -19,10 +19,10 @@ EXPORTS = [
     "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
-    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
+    "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_title_score", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
-    "dae_pipeline_create", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_flush", "dae_pipeline_poll",
+    "dae_pipeline_create", "dae_pipeline_create_titled", "dae_pipeline_destroy", "dae_pipeline_submit", "dae_pipeline_submit_titled", "dae_pipeline_flush", "dae_pipeline_poll",
     "dae_pipeline_release", "dae_pipeline_stats", "dae_pipeline_exact_margin", "dae_pipeline_times", "dae_pipeline_last_error",
 ]
 DAE_PIPE_BUSY = 1
@@ -119,6 +119,14 @@ def load():
                               ctypes.POINTER(ctypes.POINTER(ctypes.c_float)), ctypes.POINTER(c_int))
     lib.dae_pipeline_create.argtypes = [c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_int,
                                         ctypes.POINTER(vp)]
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.dae_pipeline_create_titled.argtypes = ([c_int, vp, vp, vp, vp, c_int, c_int, c_int,        # device, the DAE's arrays, V, H, n_tracks
+                                                vp, c_int, c_int, vp, vp, i32p, c_int, c_int,       # emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F
+                                                vp, vp, c_int, c_int] +                             # Output_WT, Output_b, ld_feat, L
+                                               [c_int] * 3 + [c_i64] + [c_int] * 3 + [ctypes.POINTER(vp)])
+    lib.dae_pipeline_submit_titled.argtypes = [vp, vp, vp, c_int, c_i64, c_int, vp, vp, u64p]
+    lib.dae_title_score.argtypes = [vp, vp, c_int, vp, vp, c_int, c_i64, c_int, c_int, vp, vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp,
+                                    i32p, c_int, c_int, c_int, vp, c_int, c_int, vp, vp, vp, vp]
     lib.dae_pipeline_destroy.argtypes = [vp]
     lib.dae_pipeline_submit.argtypes = [vp, vp, vp, c_int, c_i64, c_int, u64p]
     lib.dae_pipeline_flush.argtypes = [vp]
@@ -260,6 +268,7 @@ class Context:
         """Factor on every eps_c at the NEXT exact prepack (include/dae_hip.h: > 1 widens, < 1 voids the bound -- the
         guard's test hook)."""
         self.check(self.lib.dae_set_exact_margin(self.h, float(scale)))
+        self._exact_margin = float(scale)        # (models/DAEs.py hands it on to the pipelines it builds from this model)
 
     def exact_guard_read(self):
         """(violations, column) of the exact mode's bound guard since the last non-zero read; synchronises the stream."""
@@ -439,10 +448,13 @@ class Pipeline:
     `submit` / `results` from one thread."""
 
     def __init__(self, W_enc, b_enc, W_dec, b_dec, n_tracks, dtype=DAE_DTYPE_F32, k=500, group_rows=1024, max_nnz=1 << 20,
-                 lanes=2, want_scores=True, result_blocks=None, device_index=0):
+                 lanes=2, want_scores=True, result_blocks=None, device_index=0, title=None):
+        """title: a models.title_models.Char_CNN with its variables on the device -> a titled pipeline
+        (dae_pipeline_create_titled): `submit(..., titles=, titles_use=)` ranks the title-mixed score."""
         self.lib = load()
         V, H = W_enc.shape
-        self._keep = (W_enc, b_enc, W_dec, b_dec)
+        self._keep = (W_enc, b_enc, W_dec, b_dec, title)
+        self.title_len = None if title is None else int(title.input_len)
         self.k, self.want_scores, self.group_rows, self.max_nnz = int(k), bool(want_scores), int(group_rows), int(max_nnz)
         h = ctypes.c_void_p()
         n_slots = 2 * lanes + 2              # launches the pipeline holds at once (csrc/pipeline.hip)
@@ -450,9 +462,17 @@ class Pipeline:
         self._held = {}                      # result block -> claims of arrays still alive in the caller's hands
         self._closing = False
         self.max_held = n_blocks - n_slots                    # more blocks out than this: poll() copies instead of lending
-        rc = self.lib.dae_pipeline_create(int(device_index), _ptr(W_enc), _ptr(b_enc), _ptr(W_dec), _ptr(b_dec), V, H, int(n_tracks),
-                                          int(dtype), int(k), int(group_rows), int(max_nnz), int(lanes), 1 if want_scores else 0,
-                                          n_blocks, ctypes.byref(h))
+        if title is None:
+            rc = self.lib.dae_pipeline_create(int(device_index), _ptr(W_enc), _ptr(b_enc), _ptr(W_dec), _ptr(b_dec), V, H, int(n_tracks),
+                                              int(dtype), int(k), int(group_rows), int(max_nnz), int(lanes), 1 if want_scores else 0,
+                                              n_blocks, ctypes.byref(h))
+        else:
+            tm = title
+            rc = self.lib.dae_pipeline_create_titled(
+                int(device_index), _ptr(W_enc), _ptr(b_enc), _ptr(W_dec), _ptr(b_dec), V, H, int(n_tracks),
+                _ptr(tm.p["char_embedding"]), tm.char_size, tm.embedding, _ptr(tm.p["conv_w"]), _ptr(tm.p["conv_b"]), tm._fs,
+                len(tm.filter_sizes), tm.filter_num, _ptr(tm.p["Output_WT"]), _ptr(tm.p["Output_b"]), tm.ld, tm.input_len,
+                int(dtype), int(k), int(group_rows), int(max_nnz), int(lanes), 1 if want_scores else 0, n_blocks, ctypes.byref(h))
         if rc != 0:
             raise DaeError("dae_pipeline_create failed (%d): %s" % (rc, self.lib.dae_pipeline_last_error(None).decode()))
         self.h = h
@@ -463,9 +483,10 @@ class Pipeline:
             raise DaeError("dae_pipeline error %d: %s" % (rc, self.lib.dae_pipeline_last_error(self.h).decode()))
         return rc
 
-    def submit(self, positions, values, n_rows):
+    def submit(self, positions, values, n_rows, titles=None, titles_use=None):
         """positions: int64 [nnz, 2] (C-contiguous numpy), values: float32 [nnz] or one value.  -> True, or False when every
-        lane holds lists that were not fetched yet (take `results()` first)."""
+        lane holds lists that were not fetched yet (take `results()` first).  titles [n_rows, L] int32 + titles_use [n_rows]
+        (a titled pipeline): the launch ranks the title-mixed score."""
         import numpy as np
         if self._closing:
             raise DaeError("dae_pipeline: closed")
@@ -475,8 +496,18 @@ class Pipeline:
         if val.size != nnz and val.size != 1:
             raise ValueError("positions (%d) and values (%d) differ in length" % (nnz, val.size))
         t = ctypes.c_uint64()
-        rc = self._check(self.lib.dae_pipeline_submit(self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
-                                                      1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), ctypes.byref(t)))
+        if titles is not None:
+            tt = np.ascontiguousarray(titles, np.int32).reshape(-1)
+            uu = np.ascontiguousarray(titles_use, np.float32).reshape(-1)
+            if tt.size != int(n_rows) * self.title_len or uu.size != int(n_rows):
+                raise ValueError("titles must be [n_rows, %d] and titles_use [n_rows]" % self.title_len)
+            rc = self._check(self.lib.dae_pipeline_submit_titled(
+                self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
+                1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), tt.ctypes.data_as(ctypes.c_void_p),
+                uu.ctypes.data_as(ctypes.c_void_p), ctypes.byref(t)))
+        else:
+            rc = self._check(self.lib.dae_pipeline_submit(self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
+                                                          1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), ctypes.byref(t)))
         if rc == DAE_PIPE_BUSY:
             return False
         self.pending += 1

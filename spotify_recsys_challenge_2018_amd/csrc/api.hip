@@ -1016,15 +1016,16 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
                                      keep_prob, seed, feat, ld, argmax, feat_raw);
 }
 
-int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast,
-                          int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
-                          const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
-                          const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
-                          const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
-                          int32_t* guard_out, int32_t* csr_status)
+int dae_title_score(dae_ctx* tc, dae_ctx* dc, int dtype, const int64_t* positions, const float* values, int values_broadcast,
+                    int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
+                    const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
+                    const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
+                    const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
+                    int32_t* guard_out, int32_t* csr_status)
 {
     if (!tc) return DAE_ERR_ARG;
-    if (!dc || dc == tc) return dae_fail(tc, DAE_ERR_ARG, "dae_title_score_exact: needs the DAE's context");
+    if (!dc || dc == tc) return dae_fail(tc, DAE_ERR_ARG, "dae_title_score: needs the DAE's context");
+    if (!known_dtype(dtype)) return dae_fail(tc, DAE_ERR_ARG, "unknown dtype %d", dtype);
     if (!titles || !titles_use || !W_enc || !b_enc || !csr_status || (nnz > 0 && (!positions || !values)))
         return dae_fail(tc, DAE_ERR_ARG, "null pointer");
     if (n_rows <= 0) return DAE_OK;
@@ -1035,9 +1036,13 @@ int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, co
     // the launch's intermediates, carved out of one buffer of the title context
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+    // (fp32 / plain bf16: the DAE term of the track columns, transposed [column][row] -- dae_decode_mix_term)
+    const bool exact = dtype == DAE_DTYPE_BF16_EXACT;
+    const size_t nt32 = (size_t)((n_tracks + 31) / 32 * 32 < V ? (n_tracks + 31) / 32 * 32 : V);
     const size_t o_rp = 0, o_col = o_rp + up((size_t)(B + 1) * 4), o_val = o_col + up(nz * 4), o_srp = o_val + up(nz * 4),
                  o_sc = o_srp + up((size_t)(B + 1) * 4), o_h = o_sc + up(nz * 4), o_ft = o_h + up((size_t)B * H * 4),
-                 o_wt = o_ft + up((size_t)B * ld_feat * 4), o_wp = o_wt + up((size_t)B * 4), total = o_wp + up((size_t)B * 4);
+                 o_wt = o_ft + up((size_t)B * ld_feat * 4), o_wp = o_wt + up((size_t)B * 4), o_y1 = o_wp + up((size_t)B * 4),
+                 total = o_y1 + (exact ? 0 : up(nt32 * (size_t)B * 4));
     int rc = dae_reserve(tc, tc->title_scratch, total);
     if (rc) return rc;
     char* base = static_cast<char*>(tc->title_scratch.p);
@@ -1087,7 +1092,32 @@ int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, co
 #ifdef DAE_EXPERIMENTS
     if (side_on) DAE_HIP_CHECK(tc, hipStreamWaitEvent(tc->stream, ev_out, 0));
 #endif
-    return dae_mix_topk_exact(tc, dc, feat, ld_feat, h, H, B, wt, wp, n_tracks, srp, sc, k, out_score, out_idx, guard_out);
+    if (exact)
+        return dae_mix_topk_exact(tc, dc, feat, ld_feat, h, H, B, wt, wp, n_tracks, srp, sc, k, out_score, out_idx, guard_out);
+    // fp32 / plain bf16: the fused mix of dae_set_score_mix -- the DAE term transposed, then the title context's threshold path
+    // ranks sigmoid(z_title) * w_title + term (the operations and order of dae_mix_scores)
+    float* y1T = reinterpret_cast<float*>(base + o_y1);
+    rc = from_dc(dae_decode_mix_term(dc, h, B, H, dtype, wp, n_tracks, y1T, B));
+    if (rc) return rc;
+    rc = dae_set_score_mix(tc, y1T, B, (int)nt32, wt);
+    if (rc) return rc;
+    rc = dae_decode_topk(tc, feat, B, ld_feat, dtype, n_tracks, srp, sc, k, DAE_OUT_LOGIT, out_score, out_idx);
+    (void)dae_set_score_mix(tc, nullptr, 0, 0, nullptr);
+    if (rc) return rc;
+    if (guard_out) DAE_HIP_CHECK(tc, hipMemsetAsync(guard_out, 0, DAE_GUARD_BYTES, tc->stream));      // (no bound to guard)
+    return DAE_OK;
+}
+
+int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
+                          const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
+                          const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, int ld_feat,
+                          const float* titles_use, int n_tracks, int k, float* out_score, int32_t* out_idx,
+                          int32_t* guard_out, int32_t* csr_status)
+{
+    return dae_title_score(tc, dc, DAE_DTYPE_BF16_EXACT, positions, values, values_broadcast, nnz, n_rows, V, W_enc, b_enc, H, titles,
+                           L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, ld_feat, titles_use, n_tracks, k, out_score,
+                           out_idx, guard_out, csr_status);
 }
 
 int dae_mix_scores(dae_ctx* ctx, const float* title_score, int64_t ld_title, float* dae_score, int64_t ld_dae,

@@ -32,6 +32,18 @@ struct Lane {                     // a context + stream + the device buffers its
     int32_t *d_rp = nullptr, *d_col = nullptr, *d_status = nullptr, *d_srp = nullptr, *d_scol = nullptr, *d_idx = nullptr;
     float *d_cval = nullptr, *d_score = nullptr;
     bool has_f32 = false;         // (guard fallback) an fp32 image of its own
+    // titled pipelines (dae_pipeline_create_titled): the title scorer's context on the same stream, its guard words as the
+    // launch left them, the count the previous polled launch of this lane saw (the words are cumulative)
+    dae_ctx* tctx = nullptr;
+    int32_t* d_guard = nullptr;
+    int32_t guard_seen = 0;
+    bool t_has_f32 = false;
+};
+
+struct TitleW {                   // the title scorer's variables (caller-owned device arrays) and shapes
+    const float *emb = nullptr, *conv_w = nullptr, *conv_b = nullptr, *out_WT = nullptr, *out_b = nullptr;
+    int n_char = 0, E = 0, n_sizes = 0, F = 0, ld_feat = 0, L = 0;
+    std::vector<int32_t> fs;
 };
 
 struct Slot {                     // one launch from staging to its last polled feed; more slots than lanes, so that the caller
@@ -39,6 +51,12 @@ struct Slot {                     // one launch from staging to its last polled 
     float* h_val = nullptr;       // (pinned staging of the feed)
     int32_t* h_flags = nullptr;   // pinned: {csr status, guard violations, guard column}
     int64_t* d_pos = nullptr; float* d_val = nullptr;      // the feed on the device (uploaded on the copy stream, ahead of the lane)
+    int32_t* h_titles = nullptr; float* h_use = nullptr;   // titled pipelines: [group_rows][L] characters, [group_rows] titles_use
+    int32_t* d_titles = nullptr; float* d_use = nullptr;
+    int titled = 0;               // this launch ranks the title-mixed score (its feeds came through dae_pipeline_submit_titled)
+    hipEvent_t dbg_t0 = nullptr, dbg_t1 = nullptr; bool dbg_used = false;      // experiments build (DAE_DBG_PIPE)
+    int32_t seq = 0;              // the sequence word this launch's last kernel writes into h_flags[3] (the caller's wait watches it)
+    int ran_dtype = 0;            // arithmetic the launch was issued with (a paused exact mode issues DAE_DTYPE_F32)
     hipEvent_t ev_fetch = nullptr, ev_h2d = nullptr, ev_gate = nullptr;
     int state = 0;                // 0 free, 1 staging (open launch), 2 queued for the worker, 3 issued (ev_fetch recorded)
     int rows = 0; int64_t nnz = 0;
@@ -73,11 +91,24 @@ struct dae_pipeline {
     int poll_slot = 0;            // ... and are polled in the same order
     int next_lane = 0;            // lanes take the launches in turn
     hipEvent_t last_gate = nullptr;   // fp32, several lanes: the gate event of the launch issued before (dae_set_decode_gate)
-    uint64_t guard_fallbacks = 0, launches = 0;
+    uint64_t guard_fallbacks = 0, launches = 0, seq_counter = 0;
+    bool has_title = false;       // dae_pipeline_create_titled
+    TitleW tw;
+    double dbg_dev_ms = 0.0; uint64_t dbg_dev_n = 0;
+    std::vector<std::pair<int, uint64_t>> dbg_log;   // experiments build: (tag * 100 + slot, ns) host timeline
+    uint64_t dbg_ns[4] = {0, 0, 0, 0};            // experiments build: cumulative stage stamps of issue()
+    int exact_pause = 0, overflow_streak = 0;      // titled + exact: launches left on the fp32 kernels / overflow events in a row
     uint64_t issue_ns = 0, idle_ns = 0, submit_ns = 0, wait_ns = 0;      // where the host side of the loop spends its time (dae_pipeline_times)
 };
 
 namespace {
+
+#ifdef DAE_EXPERIMENTS
+#define PLOG(p, tag, slot) do { if (dae_exp_env("DAE_DBG_PIPE") && (p)->dbg_log.size() < 100000) (p)->dbg_log.emplace_back((tag) * 100 + (slot), \
+    (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count()); } while (0)
+#else
+#define PLOG(p, tag, slot)
+#endif
 
 thread_local std::string g_pipe_err;
 
@@ -103,13 +134,89 @@ int pfatal(dae_pipeline* p, int code, const char* msg)
         }                                                                                          \
     } while (0)
 
+// The caller's wait for a launch makes NO HIP call while the launch runs.  A thread inside hipEventSynchronize -- or asking
+// hipEventQuery in a loop -- slows the library thread's enqueueing down (measured on the titled loop, one lane: 0.94 ms per
+// launch = staging + issue + device + fetch one after the other, against 0.58 ms of kernels; a consumer that idled 80 us per
+// feed OUTSIDE HIP made the loop faster; profiles/r05_notes.md).
+// So the wait watches the launch's SEQUENCE WORD -- the last word flags_to_host_kernel, the last kernel of the launch, writes
+// into the slot's pinned flags -- without any HIP call, and only then takes the (completed) event for the formal ordering.
+hipError_t wait_launch(const Slot& S)
+{
+    const volatile int32_t* seq = S.h_flags + 3;
+    for (int spins = 0; *seq != S.seq; ++spins) {
+        if (spins < 200) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((spins & 1023) == 1023) {                        // (a failed launch never writes its word: ask the runtime now and then)
+            const hipError_t q = hipEventQuery(S.ev_fetch);
+            if (q != hipErrorNotReady) return q;
+        }
+    }
+    return hipEventSynchronize(S.ev_fetch);
+}
+
+// {csr status, guard violations, guard column} of a launch -> its pinned flag words
+__global__ void flags_to_host_kernel(int32_t* dst, const int32_t* status, const int32_t* guard, int32_t seq)
+{
+    if (threadIdx.x == 0) {
+        dst[0] = status[0];
+        dst[1] = guard ? guard[0] : 0;
+        dst[2] = guard ? guard[1] : -1;
+        __threadfence_system();
+        dst[3] = seq;                                            // (last: the caller's wait watches this word)
+    }
+}
+
+// fp32 images on a lane (the bound guard's fallback; a paused exact mode): the DAE's and, on a titled pipeline, the title
+// scorer's -- lane 0 re-tiles them, the other lanes borrow lane 0's (issue_mu held)
+int ensure_f32(dae_pipeline* p, int lane)
+{
+    Lane& L0 = p->lanes[0];
+    Lane& L = p->lanes[lane];
+    int rc = DAE_OK;
+    if (!L0.has_f32) {
+        rc = dae_prepack_decoder(L0.ctx, p->W_dec, p->b_dec, p->V, p->H, 0, p->V, DAE_DTYPE_F32);
+        if (rc) return pfatal(p, rc, dae_last_error(L0.ctx));
+        PIPE_HIP(p, hipStreamSynchronize(L0.stream));
+        L0.has_f32 = true;
+    }
+    if (p->has_title && !L0.t_has_f32) {
+        rc = dae_prepack_decoder(L0.tctx, p->tw.out_WT, p->tw.out_b, p->V, p->tw.ld_feat, 0, p->V, DAE_DTYPE_F32);
+        if (rc) return pfatal(p, rc, dae_last_error(L0.tctx));
+        PIPE_HIP(p, hipStreamSynchronize(L0.stream));
+        L0.t_has_f32 = true;
+    }
+    if (lane != 0 && !L.has_f32) {
+        rc = dae_share_decoder(L.ctx, L0.ctx, DAE_DTYPE_F32);
+        if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
+        L.has_f32 = true;
+    }
+    if (lane != 0 && p->has_title && !L.t_has_f32) {
+        rc = dae_share_decoder(L.tctx, L0.tctx, DAE_DTYPE_F32);
+        if (rc) return pfatal(p, rc, dae_last_error(L.tctx));
+        L.t_has_f32 = true;
+    }
+    return DAE_OK;
+}
+
 // everything of one launch, asynchronously on its lane's stream (issue_mu held)
 int issue(dae_pipeline* p, Slot& S, int dtype)
 {
     Lane& L = p->lanes[S.lane];
-    const size_t k = (size_t)p->k;
+#ifdef DAE_EXPERIMENTS         // where a launch's issue time goes (DAE_DBG_PIPE=1 prints the sums when the pipeline is destroyed)
+    static const bool dbg_pipe = dae_exp_env("DAE_DBG_PIPE") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
+    auto lap = [&](int i) {
+        if (dbg_pipe) p->dbg_ns[i] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_a).count();
+    };
+#else
+    auto lap = [&](int) {};
+#endif
     PIPE_HIP(p, hipMemcpyAsync(S.d_pos, S.h_pos, (size_t)S.nnz * 2 * sizeof(int64_t), hipMemcpyHostToDevice, p->copy_stream));
     PIPE_HIP(p, hipMemcpyAsync(S.d_val, S.h_val, (size_t)S.nnz * sizeof(float), hipMemcpyHostToDevice, p->copy_stream));
+    if (S.titled) {
+        PIPE_HIP(p, hipMemcpyAsync(S.d_titles, S.h_titles, (size_t)S.rows * p->tw.L * sizeof(int32_t), hipMemcpyHostToDevice, p->copy_stream));
+        PIPE_HIP(p, hipMemcpyAsync(S.d_use, S.h_use, (size_t)S.rows * sizeof(float), hipMemcpyHostToDevice, p->copy_stream));
+    }
     PIPE_HIP(p, hipEventRecord(S.ev_h2d, p->copy_stream));
     PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_h2d, 0));
     if (p->dtype == DAE_DTYPE_F32 && p->lanes.size() > 1) {
@@ -119,23 +226,62 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
         (void)dae_set_decode_gate(L.ctx, p->last_gate, S.ev_gate);
         p->last_gate = S.ev_gate;
     }
-    int rc = dae_coo_to_csr(L.ctx, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, L.d_rp, L.d_col, L.d_cval, L.d_status);
-    if (!rc) rc = dae_seeds_from_csr(L.ctx, L.d_rp, L.d_col, S.rows, p->n_tracks, L.d_srp, L.d_scol);
-    if (!rc) rc = dae_score_topk(L.ctx, L.d_rp, L.d_col, L.d_cval, p->W_enc, p->b_enc, p->V, p->H, S.rows, dtype, p->n_tracks,
-                                 L.d_srp, L.d_scol, p->k, DAE_OUT_SCORE, L.d_score, L.d_idx);
-    if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
+    int rc;
+    S.ran_dtype = dtype;
+#ifdef DAE_EXPERIMENTS
+    if (dbg_pipe) {                                          // device time of the launch: a timing event pair on the lane's stream
+        if (!S.dbg_t0) { (void)hipEventCreate(&S.dbg_t0); (void)hipEventCreate(&S.dbg_t1); }
+        else if (S.dbg_used) { float ms = 0.f; if (hipEventElapsedTime(&ms, S.dbg_t0, S.dbg_t1) == hipSuccess) { p->dbg_dev_ms += ms; ++p->dbg_dev_n; } }
+        (void)hipEventRecord(S.dbg_t0, L.stream);
+        S.dbg_used = true;
+    }
+#endif
+    // NO DOWNLOADS: the last kernel of a launch writes its lists straight into the launch's pinned result block (host memory
+    // the device reaches over the link: 1.5 - 4 MB of coalesced stores per launch), and a one-wave kernel leaves the launch's
+    // flags next to them.  A hipMemcpyAsync device-to-host blocks its caller until everything queued before it has run --
+    // whichever stream it is put on (measured: on the lane's stream and on a fetch stream behind an event alike): the
+    // library thread sat in those calls for the length of every launch and a second launch was never in flight
+    // (0.77 of a titled launch's 0.9 ms of issue time; profiles/r05_notes.md).
     OutBlock& ob = p->blocks[S.block];
-    PIPE_HIP(p, hipMemcpyAsync(ob.idx, L.d_idx, (size_t)S.rows * k * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
-    if (p->want_scores)
-        PIPE_HIP(p, hipMemcpyAsync(ob.score, L.d_score, (size_t)S.rows * k * sizeof(float), hipMemcpyDeviceToHost, L.stream));
-    PIPE_HIP(p, hipMemcpyAsync(S.h_flags, L.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
-    if (dtype == DAE_DTYPE_BF16_EXACT) {
-        const int32_t* gw = nullptr;
+    int32_t* const out_idx = ob.idx;
+    float* const out_score = p->want_scores ? ob.score : L.d_score;      // (scores nobody fetches stay on the device)
+    lap(0);
+    if (S.titled) {
+        // main_challenge.py:80-90 with DAE_title: the whole titled launch in one library call (api.hip dae_title_score)
+        const TitleW& t = p->tw;
+        if (dtype == DAE_DTYPE_F32) { rc = ensure_f32(p, S.lane); if (rc) return rc; }
+        rc = dae_title_score(L.tctx, L.ctx, dtype, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, p->W_enc, p->b_enc, p->H, S.d_titles, t.L,
+                             t.emb, t.n_char, t.E, t.conv_w, t.conv_b, t.fs.data(), t.n_sizes, t.F, t.ld_feat, S.d_use, p->n_tracks,
+                             p->k, out_score, out_idx, L.d_guard, L.d_status);
+        if (rc) return pfatal(p, rc, dae_last_error(L.tctx));
+        lap(1);
+    } else {
+        rc = dae_coo_to_csr(L.ctx, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, L.d_rp, L.d_col, L.d_cval, L.d_status);
+        if (!rc) rc = dae_seeds_from_csr(L.ctx, L.d_rp, L.d_col, S.rows, p->n_tracks, L.d_srp, L.d_scol);
+        if (!rc) rc = dae_score_topk(L.ctx, L.d_rp, L.d_col, L.d_cval, p->W_enc, p->b_enc, p->V, p->H, S.rows, dtype, p->n_tracks,
+                                     L.d_srp, L.d_scol, p->k, DAE_OUT_SCORE, out_score, out_idx);
+        if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
+    }
+    // The downloads go to the lane's FETCH stream, behind an event of the launch: a hipMemcpyAsync on a stream that still has
+    // kernels queued blocks its caller until they have run (as for the uploads above) -- on the lane's own stream the library
+    // thread sat in these calls for the length of the launch (0.77 ms of a titled launch's 0.9 ms issue time, stage stamps of
+    // issue(): profiles/r05_notes.md), and no second launch was in flight.  The small words first pass through one device
+    // block (flags: status, guard words), so a launch costs two or three copies.
+    const int32_t* gw = nullptr;                             // the guard words as this launch left them (titled fp32: zeros)
+    if (S.titled) {
+        gw = L.d_guard;
+    } else if (dtype == DAE_DTYPE_BF16_EXACT) {
         rc = dae_exact_guard_words(L.ctx, &gw);
         if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
-        PIPE_HIP(p, hipMemcpyAsync(S.h_flags + 1, gw, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
     }
+    S.seq = (int32_t)(++p->seq_counter & 0x7FFFFFFF) | 1;     // (never 0: the word's idle value)
+    hipLaunchKernelGGL(flags_to_host_kernel, dim3(1), dim3(64), 0, L.stream, S.h_flags, L.d_status, gw, S.seq);
+    PIPE_HIP(p, hipGetLastError());
+#ifdef DAE_EXPERIMENTS
+    if (dbg_pipe) (void)hipEventRecord(S.dbg_t1, L.stream);
+#endif
     PIPE_HIP(p, hipEventRecord(S.ev_fetch, L.stream));
+    lap(2);
     return DAE_OK;
 }
 
@@ -156,7 +302,11 @@ void worker_main(dae_pipeline* p)
         const auto t_iss = std::chrono::steady_clock::now();
         if (!broken) {                                       // after an error: drain without touching the device
             std::lock_guard<std::mutex> g(p->issue_mu);
-            (void)issue(p, S, p->dtype);
+            int dt = p->dtype;
+            if (S.titled && dt == DAE_DTYPE_BF16_EXACT && p->exact_pause > 0) { --p->exact_pause; dt = DAE_DTYPE_F32; }
+            PLOG(p, 2, si);
+            (void)issue(p, S, dt);
+            PLOG(p, 3, si);
         }
         lk.lock();
         p->issue_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_iss).count();
@@ -180,6 +330,7 @@ int close_open(dae_pipeline* p)
     p->next_lane = (p->next_lane + 1) % (int)p->lanes.size();
     S.state = 2;
     S.next_feed = 0;
+    PLOG(p, 1, p->open_slot);
     p->queue.push_back(p->open_slot);
     p->open_slot = -1;
     p->cv_worker.notify_one();
@@ -201,12 +352,38 @@ int dae_pipeline_destroy(dae_pipeline* p)
     }
     p->cv_worker.notify_all();
     if (p->worker.joinable()) p->worker.join();
+#ifdef DAE_EXPERIMENTS
+    if (dae_exp_env("DAE_DBG_PIPE"))
+        fprintf(stderr, "PIPE issue(): uploads+gate %.2f ms | + scoring calls %.2f ms | + downloads %.2f ms (cumulative, %llu launches)\n",
+                p->dbg_ns[0] / 1e6, p->dbg_ns[1] / 1e6, p->dbg_ns[2] / 1e6, (unsigned long long)p->launches);
+    if (dae_exp_env("DAE_DBG_PIPE") && p->dbg_log.size() > 400) {
+        uint64_t prev = 0;                                   // intervals between consecutive "got" events (launch completions seen by the caller)
+        fprintf(stderr, "PLOG got-intervals (us):");
+        for (const auto& e : p->dbg_log)
+            if (e.first / 100 == 4) { if (prev) fprintf(stderr, " %.0f", (e.second - prev) / 1e3); prev = e.second; }
+        fprintf(stderr, "\n");
+        {   // the events around the longest interval
+            size_t worst = 0; uint64_t wl = 0, pv = 0;
+            for (size_t i = 0; i < p->dbg_log.size(); ++i)
+                if (p->dbg_log[i].first / 100 == 4) { if (pv && i > 25 && p->dbg_log[i].second - pv > wl) { wl = p->dbg_log[i].second - pv; worst = i; } pv = p->dbg_log[i].second; }
+            const size_t a0 = worst > 14 ? worst - 14 : 0;
+            const uint64_t t0 = p->dbg_log[a0].second;
+            for (size_t i = a0; i < worst + 6 && i < p->dbg_log.size(); ++i)
+                fprintf(stderr, "PLOG %s slot %d  t=%.0f us\n", (const char*[]){"?", "staged", "issue>", "issue<", "got", "wait>", "freed"}[p->dbg_log[i].first / 100],
+                        p->dbg_log[i].first % 100, (p->dbg_log[i].second - t0) / 1e3);
+        }
+    }
+    if (dae_exp_env("DAE_DBG_PIPE") && p->dbg_dev_n)
+        fprintf(stderr, "PIPE device time per launch (event pair on the lane's stream): %.3f ms over %llu launches\n",
+                p->dbg_dev_ms / (double)p->dbg_dev_n, (unsigned long long)p->dbg_dev_n);
+#endif
     (void)hipSetDevice(p->device);
     for (Lane& L : p->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
         if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
         if (L.stream) (void)hipStreamDestroy(L.stream);
-        void* dev[] = {L.d_rp, L.d_col, L.d_status, L.d_srp, L.d_scol, L.d_idx, L.d_cval, L.d_score};
+        void* dev[] = {L.d_rp, L.d_col, L.d_status, L.d_srp, L.d_scol, L.d_idx, L.d_cval, L.d_score, L.d_guard};
         for (void* q : dev) if (q) (void)hipFree(q);
     }
     if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
@@ -216,7 +393,9 @@ int dae_pipeline_destroy(dae_pipeline* p)
         if (S.ev_gate) (void)hipEventDestroy(S.ev_gate);
         if (S.d_pos) (void)hipFree(S.d_pos);
         if (S.d_val) (void)hipFree(S.d_val);
-        void* host[] = {S.h_pos, S.h_val, S.h_flags};
+        if (S.d_titles) (void)hipFree(S.d_titles);
+        if (S.d_use) (void)hipFree(S.d_use);
+        void* host[] = {S.h_pos, S.h_val, S.h_flags, S.h_titles, S.h_use};
         for (void* q : host) if (q) (void)hipHostFree(q);
     }
     for (OutBlock& b : p->blocks) {
@@ -227,9 +406,9 @@ int dae_pipeline_destroy(dae_pipeline* p)
     return DAE_OK;
 }
 
-int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
-                        int V, int H, int n_tracks, int dtype, int k, int group_rows, int64_t max_nnz, int lanes,
-                        int want_scores, int result_blocks, dae_pipeline** out)
+static int pipeline_create(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                           int V, int H, int n_tracks, int dtype, int k, int group_rows, int64_t max_nnz, int lanes,
+                           int want_scores, int result_blocks, const TitleW* tw, dae_pipeline** out)
 {
     if (!out) return pfail(nullptr, DAE_ERR_ARG, "out is null");
     if (!W_enc || !b_enc || !W_dec || !b_dec) return pfail(nullptr, DAE_ERR_ARG, "null pointer");
@@ -244,6 +423,7 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
     p->device = device; p->V = V; p->H = H; p->n_tracks = n_tracks; p->dtype = dtype; p->k = k; p->group_rows = group_rows;
     p->max_nnz = max_nnz; p->want_scores = want_scores ? 1 : 0;
     p->W_enc = W_enc; p->b_enc = b_enc; p->W_dec = W_dec; p->b_dec = b_dec;
+    if (tw) { p->has_title = true; p->tw = *tw; }
     p->lanes.resize(lanes);
     p->slots.resize(n_slots);
     p->blocks.resize(result_blocks);
@@ -262,7 +442,6 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
                   hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_srp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_scol), nz * sizeof(int32_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_idx), rows * kk * sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_score), rows * kk * sizeof(float)) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");
         rc = dae_set_stream(L.ctx, L.stream);
@@ -274,6 +453,22 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
             if (rc) return bail(rc, dae_last_error(L.ctx));
         }
         (void)dae_set_overlap_hint(L.ctx, lanes);
+        if (tw) {
+            // the title scorer next to the DAE: its own context on the lane's stream, its "decoder" = Output_W^T / Output_b
+            // (lane 0 re-tiles it, the others borrow the image)
+            rc = dae_create(device, &L.tctx);
+            if (rc) return bail(rc, dae_last_error(nullptr));
+            if (hipMalloc(reinterpret_cast<void**>(&L.d_guard), DAE_GUARD_BYTES) != hipSuccess ||
+                hipMemsetAsync(L.d_guard, 0, DAE_GUARD_BYTES, L.stream) != hipSuccess)
+                return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");
+            rc = dae_set_stream(L.tctx, L.stream);
+            if (!rc) rc = i == 0 ? dae_prepack_decoder(L.tctx, tw->out_WT, tw->out_b, V, tw->ld_feat, 0, V, dtype)
+                                 : dae_share_decoder(L.tctx, p->lanes[0].tctx, dtype);
+            if (rc) return bail(rc, dae_last_error(L.tctx));
+            if (i == 0 && hipStreamSynchronize(L.stream) != hipSuccess) return bail(DAE_ERR_HIP, "prepack failed");
+            (void)dae_set_overlap_hint(L.tctx, lanes);
+            if (dtype == DAE_DTYPE_F32) { L.has_f32 = true; L.t_has_f32 = true; }
+        }
     }
     for (Slot& S : p->slots) {
         bool ok = hipEventCreateWithFlags(&S.ev_fetch, hipEventDisableTiming) == hipSuccess &&
@@ -284,8 +479,13 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_pos), nz * 2 * sizeof(int64_t)) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_val), nz * sizeof(float)) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_flags), 4 * sizeof(int32_t)) == hipSuccess;
+        if (ok && tw)
+            ok = hipMalloc(reinterpret_cast<void**>(&S.d_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&S.d_use), rows * sizeof(float)) == hipSuccess &&
+                 hipHostMalloc(reinterpret_cast<void**>(&S.h_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
+                 hipHostMalloc(reinterpret_cast<void**>(&S.h_use), rows * sizeof(float)) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: pinned allocation failed");
-        S.h_flags[0] = S.h_flags[1] = 0; S.h_flags[2] = -1;
+        S.h_flags[0] = S.h_flags[1] = 0; S.h_flags[2] = -1; S.h_flags[3] = 0;
     }
     for (OutBlock& b : p->blocks) {
         bool ok = hipHostMalloc(reinterpret_cast<void**>(&b.idx), rows * kk * sizeof(int32_t)) == hipSuccess &&
@@ -298,6 +498,31 @@ int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, cons
     return DAE_OK;
 }
 
+int dae_pipeline_create(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                        int V, int H, int n_tracks, int dtype, int k, int group_rows, int64_t max_nnz, int lanes,
+                        int want_scores, int result_blocks, dae_pipeline** out)
+{
+    return pipeline_create(device, W_enc, b_enc, W_dec, b_dec, V, H, n_tracks, dtype, k, group_rows, max_nnz, lanes, want_scores,
+                           result_blocks, nullptr, out);
+}
+
+int dae_pipeline_create_titled(int device, const float* W_enc, const float* b_enc, const float* W_dec, const float* b_dec,
+                               int V, int H, int n_tracks, const float* emb, int n_char, int E, const float* conv_w,
+                               const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F, const float* Output_WT,
+                               const float* Output_b, int ld_feat, int L, int dtype, int k, int group_rows, int64_t max_nnz,
+                               int lanes, int want_scores, int result_blocks, dae_pipeline** out)
+{
+    if (!emb || !conv_w || !conv_b || !filter_sizes || !Output_WT || !Output_b) return pfail(nullptr, DAE_ERR_ARG, "null pointer");
+    if (n_char < 1 || E < 1 || n_sizes < 1 || n_sizes > 16 || F < 1 || L < 1 || ld_feat < n_sizes * F || group_rows > 4096)
+        return pfail(nullptr, DAE_ERR_ARG, "dae_pipeline_create_titled: bad title shapes (a titled launch holds at most 4096 rows)");
+    TitleW tw;
+    tw.emb = emb; tw.conv_w = conv_w; tw.conv_b = conv_b; tw.out_WT = Output_WT; tw.out_b = Output_b;
+    tw.n_char = n_char; tw.E = E; tw.n_sizes = n_sizes; tw.F = F; tw.ld_feat = ld_feat; tw.L = L;
+    tw.fs.assign(filter_sizes, filter_sizes + n_sizes);
+    return pipeline_create(device, W_enc, b_enc, W_dec, b_dec, V, H, n_tracks, dtype, k, group_rows, max_nnz, lanes, want_scores,
+                           result_blocks, &tw, out);
+}
+
 int dae_pipeline_flush(dae_pipeline* p)
 {
     if (!p) return DAE_ERR_ARG;
@@ -306,10 +531,11 @@ int dae_pipeline_flush(dae_pipeline* p)
     return close_open(p);
 }
 
-int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
-                        int n_rows, uint64_t* ticket_out)
+static int submit_impl(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                       int n_rows, const int32_t* titles, const float* titles_use, uint64_t* ticket_out)
 {
     if (!p) return DAE_ERR_ARG;
+    const int titled = titles != nullptr ? 1 : 0;
     if (n_rows < 1 || n_rows > p->group_rows || nnz < 0 || nnz > p->max_nnz || (nnz > 0 && (!positions || !values)))
         return pfail(p, DAE_ERR_ARG, "dae_pipeline_submit: a feed must fit one launch (rows <= group_rows, nnz <= max_nnz)");
     const auto t_sub = std::chrono::steady_clock::now();
@@ -322,7 +548,8 @@ int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* 
     if (p->err_code) return p->err_code;
     if (p->open_slot >= 0) {
         Slot& O = p->slots[p->open_slot];
-        if (O.rows + n_rows > p->group_rows || O.nnz + nnz > p->max_nnz) {
+        // (a launch ranks EITHER the plain logits or the title-mixed score: feeds of the other kind start a new one)
+        if (O.rows + n_rows > p->group_rows || O.nnz + nnz > p->max_nnz || O.titled != titled) {
             const int rc = close_open(p);
             if (rc) return rc;
         }
@@ -334,7 +561,7 @@ int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* 
                                                            "yet (poll before submitting more)");
         p->open_slot = p->next_slot;
         p->next_slot = (p->next_slot + 1) % (int)p->slots.size();
-        N.state = 1; N.rows = 0; N.nnz = 0; N.feeds.clear(); N.next_feed = 0;
+        N.state = 1; N.rows = 0; N.nnz = 0; N.feeds.clear(); N.next_feed = 0; N.titled = titled;
     }
     Slot& S = p->slots[p->open_slot];
     const int row0 = S.rows;
@@ -352,11 +579,30 @@ int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* 
     float* dv = S.h_val + off;
     if (values_broadcast) { const float v = values[0]; for (int64_t i = 0; i < nnz; ++i) dv[i] = v; }
     else memcpy(dv, values, (size_t)nnz * sizeof(float));
+    if (titled) {
+        memcpy(S.h_titles + (size_t)row0 * p->tw.L, titles, (size_t)n_rows * p->tw.L * sizeof(int32_t));
+        memcpy(S.h_use + row0, titles_use, (size_t)n_rows * sizeof(float));
+    }
     if (ticket_out) *ticket_out = ticket;
     lk.lock();
     if (S.rows + n_rows > p->group_rows) (void)close_open(p);   // the next feed of this size would not fit: off it goes
     p->submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_sub).count();
     return DAE_OK;
+}
+
+int dae_pipeline_submit(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                        int n_rows, uint64_t* ticket_out)
+{
+    return submit_impl(p, positions, values, values_broadcast, nnz, n_rows, nullptr, nullptr, ticket_out);
+}
+
+int dae_pipeline_submit_titled(dae_pipeline* p, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                               int n_rows, const int32_t* titles, const float* titles_use, uint64_t* ticket_out)
+{
+    if (!p) return DAE_ERR_ARG;
+    if (!p->has_title) return pfail(p, DAE_ERR_STATE, "dae_pipeline_submit_titled: not a titled pipeline (dae_pipeline_create_titled)");
+    if (!titles || !titles_use) return pfail(p, DAE_ERR_ARG, "null pointer");
+    return submit_impl(p, positions, values, values_broadcast, nnz, n_rows, titles, titles_use, ticket_out);
 }
 
 int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t** idx, const float** score, int* n_rows,
@@ -382,12 +628,14 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
     if (S.next_feed == 0) {                                  // first feed of the launch: its results have to be here
         lk.unlock();
         if (!wait) {
-            const hipError_t q = hipEventQuery(S.ev_fetch);
-            if (q == hipErrorNotReady) return DAE_OK;
+            if (*(const volatile int32_t*)(S.h_flags + 3) != S.seq) return DAE_OK;      // (no HIP call while the launch runs)
+            const hipError_t q = hipEventSynchronize(S.ev_fetch);
             if (q != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(q)); }
         } else {
             const auto t_w = std::chrono::steady_clock::now();
-            const hipError_t e = hipEventSynchronize(S.ev_fetch);
+            PLOG(p, 5, p->poll_slot);
+            const hipError_t e = wait_launch(S);
+            PLOG(p, 4, p->poll_slot);
             p->wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_w).count();
             if (e != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(e)); }
         }
@@ -395,7 +643,31 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
             lk.lock();
             return pfatal(p, DAE_ERR_ARG, "dae_pipeline: a feed of the launch holds a column index out of range");
         }
-        if (p->dtype == DAE_DTYPE_BF16_EXACT && S.h_flags[1] != 0) {
+        if (S.titled && S.ran_dtype == DAE_DTYPE_BF16_EXACT && S.h_flags[1] != p->lanes[S.lane].guard_seen) {
+            // the exact title mix (dae_mix_topk_exact): the title context's guard words moved under this launch -- a recomputed
+            // logit left its promised interval (column >= 0), or rows hold more survivors than the refine launch lists (column
+            // -2 / -3: scores no bound can tell apart; such rows came back without recommendations) -> the launch again on the
+            // fp32 kernels.  Two overflow launches in a row pause the mode for 64 launches (a model whose rows keep
+            // overflowing would otherwise pay both passes every time).
+            int rc;
+            bool ok;
+            {
+                std::lock_guard<std::mutex> g(p->issue_mu);
+                (void)hipSetDevice(p->device);
+                Lane& L = p->lanes[S.lane];
+                L.guard_seen = S.h_flags[1];
+                if (S.h_flags[2] == -2 || S.h_flags[2] == -3) {
+                    if (++p->overflow_streak >= 2) { p->exact_pause = 64; p->overflow_streak = 0; }
+                } else {
+                    p->overflow_streak = 0;
+                }
+                rc = issue(p, S, DAE_DTYPE_F32);
+                ok = !rc && wait_launch(S) == hipSuccess;
+            }
+            lk.lock();
+            if (!ok) return pfatal(p, rc ? rc : DAE_ERR_HIP, "dae_pipeline: the fp32 re-run after a bound-guard hit failed");
+            ++p->guard_fallbacks;
+        } else if (!S.titled && p->dtype == DAE_DTYPE_BF16_EXACT && S.h_flags[1] != 0) {
             // BOUND GUARD (include/dae_hip.h dae_exact_guard_read): a recomputed survivor left its promised interval, the
             // lists of this launch are unproven -> the same launch again on the fp32 kernels, here and now (its feed is
             // still in the slot's staging buffers; the lane's context is shared with the worker: issue_mu)
@@ -407,15 +679,16 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
                 Lane& L = p->lanes[S.lane];
                 int32_t nv = 0, col = -1;
                 rc = dae_exact_guard_read(L.ctx, &nv, &col);       // (synchronises the lane, resets the words)
-                if (!rc && !L.has_f32) { rc = dae_prepack_decoder(L.ctx, p->W_dec, p->b_dec, p->V, p->H, 0, p->V, DAE_DTYPE_F32); L.has_f32 = !rc; }
+                if (!rc) rc = ensure_f32(p, S.lane);
                 if (!rc) rc = issue(p, S, DAE_DTYPE_F32);
-                ok = !rc && hipEventSynchronize(S.ev_fetch) == hipSuccess;
+                ok = !rc && wait_launch(S) == hipSuccess;
             }
             lk.lock();
             if (!ok) return pfatal(p, rc ? rc : DAE_ERR_HIP, "dae_pipeline: the fp32 re-run after a bound-guard hit failed");
             S.h_flags[1] = 0;
             ++p->guard_fallbacks;
         } else {
+            if (S.titled && S.ran_dtype == DAE_DTYPE_BF16_EXACT) p->overflow_streak = 0;       // (only the caller's thread touches it here)
             lk.lock();
         }
     }
@@ -429,6 +702,7 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
     ++ob.refs;                                               // the caller's reference to the block (dae_pipeline_release)
     if (++S.next_feed == S.feeds.size()) {                   // last feed of the launch: the slot is free again
         --ob.refs;                                           // (the launch's own reference)
+        PLOG(p, 6, p->poll_slot);
         S.state = 0; S.block = -1;
         p->poll_slot = (p->poll_slot + 1) % (int)p->slots.size();
     }
@@ -465,6 +739,17 @@ int dae_pipeline_exact_margin(dae_pipeline* p, float scale)
     for (size_t i = 1; i < p->lanes.size(); ++i) {
         rc = dae_share_decoder(p->lanes[i].ctx, L0.ctx, p->dtype);
         if (rc) return pfail(p, rc, dae_last_error(p->lanes[i].ctx));
+    }
+    if (p->has_title) {                                      // the title scorer's bounds as well (alpha_c, beta_c scale with the margin)
+        rc = dae_set_exact_margin(L0.tctx, scale);
+        if (!rc) rc = dae_prepack_decoder(L0.tctx, p->tw.out_WT, p->tw.out_b, p->V, p->tw.ld_feat, 0, p->V, p->dtype);
+        if (rc) return pfail(p, rc, dae_last_error(L0.tctx));
+        if (hipStreamSynchronize(L0.stream) != hipSuccess) return pfatal(p, DAE_ERR_HIP, "prepack failed");
+        for (size_t i = 1; i < p->lanes.size(); ++i) {
+            rc = dae_share_decoder(p->lanes[i].tctx, L0.tctx, p->dtype);
+            if (rc) return pfail(p, rc, dae_last_error(p->lanes[i].tctx));
+        }
+        p->exact_pause = 0; p->overflow_streak = 0;
     }
     return DAE_OK;
 }

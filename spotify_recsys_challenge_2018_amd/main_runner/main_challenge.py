@@ -203,6 +203,12 @@ def run(conf, model=None):
                 yield model.recommend(x_positions, x_ones, seed, k=500, n_rows=len(seed))[0]
 
     uris = UriTable(reader.id2uri, reader.num_tracks)
+    # one full collection now and the survivors frozen: the loop allocates a few tracked objects per batch, and the
+    # generation-2 collection they eventually trigger walks everything torch and the model loaded (33 - 38 ms measured in
+    # the middle of a 70 ms scoring loop: profiles/r05_notes.md)
+    import gc
+    gc.collect()
+    gc.freeze()
     for b_no, idx in enumerate(results()):
         first, pid, n_in_batch = meta[b_no]
         if sharded and exchange == 'allgather' and rank != 0:        # all-gather: rank 0 formats and writes

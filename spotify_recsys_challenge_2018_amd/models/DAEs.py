@@ -595,8 +595,12 @@ class DAE_tied:
         # (what a title model, explicit seed lists or host-built CSRs take anyway).
         if (self.__dict__.get("iter_copies") or "async") not in ("async", "blocking"):
             raise ValueError("iter_copies: 'async' or 'blocking'")
-        if (self.__dict__.get("iter_engine", "native") == "native" and type(self)._submit is DAE._submit and self.device_csr):
-            yield from self._recommend_iter_native(feeds, k, dtype, want_scores)
+        titled_native = (getattr(self, "title_model", None) is not None and getattr(self.title_model, "ctx", None) is not None
+                         and type(self)._submit is DAE_title._submit)
+        if (self.__dict__.get("iter_engine", "native") == "native" and self.device_csr and
+                (type(self)._submit is DAE._submit or titled_native)):
+            # (a title model: the library's titled pipeline, dae_pipeline_create_titled -- round 5)
+            yield from self._recommend_iter_native(feeds, k, _title_dtype(dtype, self) if titled_native else dtype, want_scores)
             return
         self._ensure_packed(dtype)
         if getattr(self, "title_model", None) is not None:
@@ -825,8 +829,14 @@ class DAE_tied:
 
     def _native_pipe(self, dtype, k, want_scores):
         """The model's dae_pipeline for (dtype, k, scores wanted): created on first use, again after the weights changed."""
+        tm = getattr(self, "title_model", None)
+        if tm is not None and getattr(tm, "ctx", None) is None:
+            tm = None
         key = (int(dtype), int(k), bool(want_scores), self.n_batch)
-        gen = self.__dict__.get("_weights_gen", 0)
+        # (dae_set_exact_margin on the model's contexts -- the guard's test hook -- reaches the pipeline's own images as well)
+        margins = [getattr(c, "_exact_margin", 1.0) for c in ([self.ctx] + ([] if tm is None else [tm.ctx]))]
+        margin = next((m_ for m_ in margins if m_ != 1.0), 1.0)
+        gen = (self.__dict__.get("_weights_gen", 0), None if tm is None else tm.__dict__.get("_params_gen", 0), margin)
         cache = self.__dict__.setdefault("_pipes", {})
         ent = cache.get(key)
         if ent is not None and (ent[0] != gen or ent[1].h is None):
@@ -836,14 +846,19 @@ class DAE_tied:
             import torch
             self._flush_rows_adam()
             torch.cuda.current_stream(self.device_index).synchronize()      # the weights are final before another thread reads them
-            group = self._coalesce_count(dtype) * self.n_batch
+            # (titled launches: the fp32 rule -- 5 feeds of 150 = 750 rows of the 96- / 128-row groups, as the Python loop ran them)
+            group = self._coalesce_count(dtype if tm is None else None) * self.n_batch
+            if tm is not None:
+                group = min(group, 4096)
             # three lanes: measured best in every mode (batch 256, playlists/s through the loop, 2 / 3 / 4 lanes: fp32 0.98 /
             # 1.29 / 1.06 M, exact_bf16 4.1 / 4.8 / 4.2 M, bf16 5.3 / 6.3 / 5.6 M -- profiles/r04_notes.md)
             lanes = int(self.__dict__.get("n_lanes") or 3)
             pipe = _lib.Pipeline(self.weights["encoder_h"], self.biases["encoder_b"], self.weights["decoder_h"],
                                  self.biases["decoder_b"], self.n_tracks, dtype=dtype, k=k, group_rows=group,
                                  max_nnz=max(1 << 18, group * 1024), lanes=lanes, want_scores=want_scores,
-                                 device_index=self.device_index)
+                                 device_index=self.device_index, title=tm)
+            if margin != 1.0 and dtype == _lib.DAE_DTYPE_BF16_EXACT:
+                pipe.exact_margin(margin)
             ent = cache[key] = (gen, pipe)
         return ent[1]
 
@@ -857,18 +872,35 @@ class DAE_tied:
             n = rows_out.pop(0)
             return r[0][:n], (r[1][:n] if want_scores else None)
         clean = False
+        fallbacks0 = pipe.stats()["guard_fallbacks"] if dtype == _lib.DAE_DTYPE_BF16_EXACT else 0
         try:
             for f in feeds:
                 x_positions, x_ones, seeds, n_rows = f[:4]
                 n = self.n_batch if n_rows is None else int(n_rows)
-                if not (isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT) or len(f) > 4 or n > self.n_batch:
+                titles = use = None
+                if len(f) > 5 and f[4] is not None and f[5] is not None and pipe.title_len is not None:
+                    u = np.asarray(f[5], np.float32).reshape(-1)[:self.n_batch]
+                    if u.size and np.any(u):                     # (titles_use all zero: the plain DAE, as DAE_title.recommend decides)
+                        L_ = pipe.title_len
+                        titles = np.full((self.n_batch, L_), -1, np.int32)
+                        t = f[4]
+                        nt = min(len(t), self.n_batch)
+                        if nt:
+                            if not isinstance(t, np.ndarray):
+                                t = [([-1] * L_) if x is None else x for x in t[:nt]]
+                            titles[:nt] = np.asarray(t, np.int64).reshape(-1, L_)[:nt]
+                        use = np.zeros(self.n_batch, np.float32)
+                        use[:min(u.size, nt)] = u[:nt]                                # (no title, no use)
+                unfit = len(f) > 4 and pipe.title_len is None
+                if not (isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT) or unfit or n > self.n_batch:
                     pipe.flush()                                 # a feed the pipeline does not take: in order, through recommend()
                     while pipe.pending:
                         yield out(pipe.poll(True))
-                    idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
+                    kw = {} if len(f) <= 4 else {"titles": f[4], "titles_use": f[5] if len(f) > 5 else None}
+                    idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype, **kw)
                     yield idx, (score if want_scores else None)
                     continue
-                while not pipe.submit(x_positions, x_ones, self.n_batch):      # every lane full: hand the oldest lists out first
+                while not pipe.submit(x_positions, x_ones, self.n_batch, titles, use):      # every lane full: hand the oldest lists out first
                     yield out(pipe.poll(True))
                 rows_out.append(n)
                 while True:                                      # ... and whatever else is ready, without waiting
@@ -885,6 +917,13 @@ class DAE_tied:
                 raise ValueError(str(e))
             raise
         finally:
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT and pipe.h is not None:
+                n_fb = pipe.stats()["guard_fallbacks"] - fallbacks0
+                if n_fb > 0:         # (the lists that went out are the fp32 kernels': the pipeline re-scored those launches itself)
+                    import warnings
+                    self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + n_fb
+                    warnings.warn("exact_bf16: the bound guard fired in %d launch(es) of the streamed loop: they were re-scored with "
+                                  "the fp32 kernels" % n_fb)
             if not clean:        # an error, or a consumer that stopped early: feeds may be queued -- this pipeline is not reused
                 self.__dict__.get("_pipes", {}).pop(key, None)
                 pipe.close()

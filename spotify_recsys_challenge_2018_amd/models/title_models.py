@@ -117,6 +117,7 @@ class Char_CNN:
         self.p["Output_WT"] = dev_t(wt)
         self.p["Output_b"] = dev_t(host["Output_b"])
         self._packed_dirty = True
+        self._params_gen = self.__dict__.get("_params_gen", 0) + 1      # (a cached dae_pipeline holds images of the old variables)
 
     def get_params(self):
         """Host dict under the TF variable names and shapes."""
@@ -222,6 +223,7 @@ class Char_CNN:
             ctx.check(lib.dae_adam_step(ctx.h, P(self.p[n]), P(m), P(v), P(g[n]), self.p[n].numel(),
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
         self._packed_dirty = True
+        self._params_gen = self.__dict__.get("_params_gen", 0) + 1
 
     def __str__(self):
         return '\n'.join(["Wide CNN", "Embedding Size : " + str(self.embedding),

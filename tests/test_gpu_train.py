@@ -190,6 +190,21 @@ def test_challenge_driver_with_titles_under_exact_bf16_at_hidden_256(tmp_path, m
     real, real1 = L.Context.mix_topk_exact, L.Context.title_score_exact        # (the latter: the whole launch in one call)
     monkeypatch.setattr(L.Context, "mix_topk_exact", lambda self, *a, **kw: (calls.append(1), real(self, *a, **kw))[1])
     monkeypatch.setattr(L.Context, "title_score_exact", lambda self, *a, **kw: (calls.append(1), real1(self, *a, **kw))[1])
+    # ... or, since round 5, inside the library's titled pipeline (dae_pipeline_create_titled with DAE_DTYPE_BF16_EXACT,
+    # feeds through dae_pipeline_submit_titled -> dae_title_score): recorded at the ctypes wrapper
+    real_init, real_submit = L.Pipeline.__init__, L.Pipeline.submit
+
+    def init(self, *a, **kw):
+        real_init(self, *a, **kw)
+        self._t_exact = kw.get("title") is not None and int(kw.get("dtype", 0)) == L.DAE_DTYPE_BF16_EXACT
+
+    def submit(self, positions, values, n_rows, titles=None, titles_use=None):
+        ok = real_submit(self, positions, values, n_rows, titles, titles_use)
+        if ok and titles is not None and getattr(self, "_t_exact", False):
+            calls.append(1)
+        return ok
+    monkeypatch.setattr(L.Pipeline, "__init__", init)
+    monkeypatch.setattr(L.Pipeline, "submit", submit)
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
