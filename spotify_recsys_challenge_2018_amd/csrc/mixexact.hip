@@ -42,6 +42,7 @@
 #include <climits>
 
 #include "dae_internal.h"
+#include "rank_lds.h"
 
 namespace {
 
@@ -474,6 +475,12 @@ struct MixRefP {
     int* guard;                        // {violations, a violating column}
     int* stat;                         // [B][2] {candidates, recomputed}
     long long* stamps;                 // experiments build: stage stamps of row 0's workgroup (DAE_DBG_MR)
+    // FUSED SELECTION (round 5, as refine.hip; k <= 512): the launch ends the call -- the row's seeds out, its k best mixed
+    // scores in order (main_challenge.py:26-36 on DAEs.py:180's y) to fo.out_score / out_idx; `out` then only takes the rows
+    // with more survivors than the ordering stage holds
+    int fuse;
+    dae_rank_out fo;
+    const int32_t* seed_col;
 };
 
 // One group of 64 candidates, a lane each: the canonical chain acc = fmaf(hrow[k], W32[rowidx][k], acc), k = 0 .. H-1, from
@@ -512,10 +519,19 @@ __device__ __forceinline__ float mix_chain64(const float* __restrict__ W32, int 
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * MR_ROWSTRIDE + 4 * q) = v[d][i];
                 __builtin_amdgcn_wave_barrier();
-                const int jn = jb + DEPTH;
-                if (jn < H16) {
+                // the ring is refilled in PAIRS of blocks: the two halves of a row's 128-byte line are requested back to back, so
+                // the second finds the line pending instead of fetching it again (refine.hip rescore_group has the measurement)
+                if (dd & 1) {
+                    const int dp = (dd - 1) & (DEPTH - 1);
+                    const int jn0 = jb - 1 + DEPTH, jn1 = jb + DEPTH;
+                    if (jn0 < H16) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn];
+                        for (int i = 0; i < 4; ++i) v[dp][i] = rp[i][4 * jn0];
+                    }
+                    if (jn1 < H16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn1];
+                    }
                 }
                 float4 w[4];
 #pragma unroll
@@ -564,9 +580,15 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     const int row = blockIdx.x;
     const int nseg = p.nseg;
     const bool bad = p.row_bad && p.row_bad[row] != 0;
+    // fused selection: the row's seeds are requested with the prologue's loads (one per thread in a register; playlists with
+    // more than MR_THREADS seed tracks read the rest when the bitmap is built)
+    const int seed_b = (p.fuse && p.seed_col) ? p.seed_row_ptr[row] : 0;
+    const int seed_e = (p.fuse && p.seed_col) ? p.seed_row_ptr[row + 1] : 0;
+    const int my_seed = seed_b + tid < seed_e ? p.seed_col[seed_b + tid] : -1;
+    __shared__ unsigned f_range[2];              // {min, max} of the high words of the keys written to LDS
 #pragma clang loop vectorize(disable) interleave(disable)
     for (int s = tid; s < nseg; s += MR_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
-    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; }
+    if (tid == 0) { seg_prefix[0] = 0; s_n = 0; f_range[0] = 0xFFFFFFFFu; f_range[1] = 0u; }
     if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
 #pragma clang loop vectorize(disable) interleave(disable)
     for (int i = tid; i < 1024; i += MR_THREADS) {
@@ -595,6 +617,43 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         // a row the launch cannot vouch for (more candidates than its buffers hold): counted like a bound failure -- the
         // callers then re-score the launch with the fp32 kernels
         if (tid == 0) { p.out_cnt[row] = 0; atomicAdd(p.guard, 1); p.guard[1] = code; }
+        if (p.fuse) dae_rank_pad<MR_THREADS>(tid, row, 0u, p.fo);
+    };
+    // ---- fused selection: LDS of the upper-bound keys once they are dead (after step 3; the streamed path never uses them):
+    // [keys of the ordering stage: DAE_RANK_MAX x 8 B][seed bitmap over the rankable columns: <= 24 KiB]
+    dae_u64* const fkey = reinterpret_cast<dae_u64*>(ku);
+    unsigned* const bitmap = ku + 2 * DAE_RANK_MAX;
+    const int bm_words = p.fuse ? (p.n_valid_col + 31) >> 5 : 0;
+    auto build_bitmap = [&]() {                                   // (every thread; the callers' barrier before it freed the area)
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int w = tid; w < bm_words; w += MR_THREADS) bitmap[w] = 0u;
+        __syncthreads();
+        for (int i = seed_b + tid; i < seed_e; i += MR_THREADS) {
+            const int pc = i == seed_b + tid ? my_seed : p.seed_col[i];
+            if (pc >= 0 && pc < p.n_valid_col) atomicOr(&bitmap[pc >> 5], 1u << (pc & 31));
+        }
+        __syncthreads();
+    };
+    auto fkey_of = [&](float y, int colv) -> dae_u64 {            // composite key of a score; 0 = absent (a seed, -inf)
+        const unsigned key = dae_okey(y);
+        if (colv < 0 || key <= DAE_KEY_NEG_INF) return 0ull;
+        if (colv < p.n_valid_col && ((bitmap[colv >> 5] >> (colv & 31)) & 1u)) return 0ull;
+        return ((dae_u64)key << 32) | (dae_u64)(~(unsigned)colv);
+    };
+    // the ordering stage's buffers: the waves' transposition buffers, free once the recomputation is over
+    dae_u64* const sorted = reinterpret_cast<dae_u64*>(tb);
+    unsigned* const above = reinterpret_cast<unsigned*>(sorted + DAE_RANK_MAX);
+    unsigned* const fhist = above + DAE_RANK_BINS;
+    uint2* const orow0 = p.out + (size_t)row * p.out_cap;
+    auto select_from_list = [&](int n_list) {                     // the row's list in global memory -> its final lists
+        dae_rank_select_emit<MR_THREADS>([&](auto f) {
+            for (int e0 = 0; e0 < n_list; e0 += MR_THREADS) {
+                const int e = e0 + tid;
+                dae_u64 ck = 0ull;
+                if (e < n_list) { const uint2 pr = orow0[e]; ck = fkey_of(__uint_as_float(pr.x), (int)pr.y); }
+                f(ck);
+            }
+        }, fkey, sorted, fhist, above, tid, row, p.fo);
     };
     if (!bad && p.w_t[row] == 0.0f && p.w_p[row] == 0.0f) {
         // y = sigmoid(.) * 0 + sigmoid(.) * 0 = +0 for every column: the fp32 path ranks (y desc, column asc), i.e. the first
@@ -603,10 +662,12 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
 #pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < nl; i += MR_THREADS) p.out[(size_t)row * p.out_cap + i] = make_uint2(0u, (unsigned)i);
         if (tid == 0) { p.out_cnt[row] = nl; if (p.stat) { p.stat[2 * row] = 0; p.stat[2 * row + 1] = 0; } }
+        if (p.fuse) { build_bitmap(); select_from_list(nl); }
         return;
     }
     if (bad || total == 0) {
         if (tid == 0) { p.out_cnt[row] = 0; if (p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = 0; } }
+        if (p.fuse) dae_rank_pad<MR_THREADS>(tid, row, 0u, p.fo);
         return;
     }
     const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
@@ -793,6 +854,8 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     if (tid == 0 && p.stat) { p.stat[2 * row] = total; p.stat[2 * row + 1] = n; }
     if (n > p.out_cap) { give_up(-3); return; }
     MSTAMP(3)
+    const bool fast = p.fuse && n <= DAE_RANK_MAX;               // the survivors' keys stay in LDS
+    if (p.fuse) build_bitmap();
 
     // ---- 4. recompute the survivors
     float* tbuf = tb + wave * (64 * MR_ROWSTRIDE);
@@ -818,11 +881,27 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             const float wdD = 2.0f * p.epsD[col] * 1.000001f;
             const bool ok = zT <= uT && zT >= two_down(uT - wdT) && zD <= uD && zD >= two_down(uD - wdD);
             if (!ok) { atomicAdd(p.guard, 1); p.guard[1] = col; }
-            orow[e] = make_uint2(__float_as_uint(y), (unsigned)col);
+            if (!fast) orow[e] = make_uint2(__float_as_uint(y), (unsigned)col);
+        }
+        if (fast) {                                               // (whole waves: the range of the keys by two DPP reductions)
+            const dae_u64 ck = in ? fkey_of(y, col) : 0ull;
+            if (in) fkey[e] = ck;
+            const unsigned hi = (unsigned)(ck >> 32);
+            const unsigned mx = dae_wave_max_u32(hi), mn = dae_wave_min_u32(ck != 0ull ? hi : 0xFFFFFFFFu);
+            if (lane == 0 && mx != 0u) { atomicMin(&f_range[0], mn); atomicMax(&f_range[1], mx); }
         }
     }
     MSTAMP(4)
     if (tid == 0) p.out_cnt[row] = n;
+    if (!p.fuse) return;
+    __syncthreads();                                             // the recomputation is over: its buffers become the ordering stage's
+    if (fast) {
+#pragma clang loop vectorize(disable) interleave(disable)
+        for (int b = tid; b < DAE_RANK_BINS; b += MR_THREADS) fhist[b] = 0u;
+        dae_rank_emit<MR_THREADS>(fkey, (unsigned)n, sorted, fhist, above, tid, row, p.fo, f_range);
+    } else {
+        select_from_list(n);
+    }
 }
 #undef MSTAMP
 
@@ -980,6 +1059,11 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     r.seed_row_ptr = seed_row_ptr; r.k = k; r.n_valid_col = n_valid_col;
     r.out = rf; r.out_cnt = rf_cnt; r.out_cap = MX_REF_CAP;
     r.guard = static_cast<int*>(tc->guard.p); r.stat = static_cast<int*>(tc->refstat.p);
+    // k <= 512 and a seed bitmap that fits behind the ordering keys: the refine launch ends the call (no selection launch)
+    const bool fuse = k <= DAE_RANK_MAX / 2 && ((size_t)((n_valid_col + 31) >> 5) + 2 * DAE_RANK_MAX) <= (size_t)MR_STAGE;
+    r.fuse = fuse ? 1 : 0;
+    r.fo = dae_rank_out{k, DAE_OUT_LOGIT, out_score, out_idx};   // (the mixed score is a probability already: it goes out as it is)
+    r.seed_col = seed_col;
     if (nb > MR_MAX_SEG) return dae_fail(tc, DAE_ERR_ARG, "too many candidate segments (%d)", nb);
 #ifdef DAE_EXPERIMENTS
     static const bool dbg_mr = dae_exp_env("DAE_DBG_MR") != nullptr;
@@ -1003,6 +1087,7 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     }
 #endif
 
+    if (fuse) return DAE_OK;
     dae_topk_args ta;
     memset(&ta, 0, sizeof(ta));
     ta.B = B; ta.k = k;

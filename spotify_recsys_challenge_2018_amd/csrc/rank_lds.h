@@ -221,3 +221,72 @@ __device__ __forceinline__ void dae_rank_emit(dae_u64* keys, unsigned c, dae_u64
     RKSTAMP(7)
 #undef RKSTAMP
 }
+
+// The general case: the row's candidates sit in global memory, possibly more than DAE_RANK_MAX of them.  for_keys(f) calls
+// f(key) for every candidate (0 = absent; whole workgroup, block-uniform trip count -- it may be called several times and
+// re-reads its source each time).  topk_kernel's range-adaptive narrowing (topk.hip step 3b) until the keys above the cut fit,
+// the collect into keys[], then dae_rank_emit.  Rare by construction (logits packed within the bounds' width of the cut).
+// LDS scratch as dae_rank_emit.  Starts with a barrier.
+template <int NTH, typename ForKeys>
+__device__ __forceinline__ void dae_rank_select_emit(ForKeys for_keys, dae_u64* keys, dae_u64* sorted, unsigned* hist, unsigned* above,
+                                                     int tid, int row, const dae_rank_out& o)
+{
+    __shared__ unsigned rs_cnt, rs_above;
+    __shared__ int rs_bin;
+    __shared__ dae_u64 rs_min, rs_max;
+    __shared__ unsigned rs_wave_tot[NTH / 64];
+    const int lane = tid & 63;
+    __syncthreads();
+    if (tid == 0) { rs_cnt = 0u; rs_min = ~0ull; rs_max = 0ull; }
+    __syncthreads();
+    {
+        unsigned cnt = 0; dae_u64 mn = ~0ull, mx = 0ull;
+        for_keys([&](dae_u64 ck) {
+            if (ck != 0ull) { ++cnt; mn = ck < mn ? ck : mn; mx = ck > mx ? ck : mx; }
+        });
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+        mn = dae_wave_min_u64(mn); mx = dae_wave_max_u64(mx);
+        if (lane == 0 && cnt) { atomicAdd(&rs_cnt, cnt); atomicMin(&rs_min, mn); atomicMax(&rs_max, mx); }
+    }
+    __syncthreads();
+    const unsigned m = rs_cnt;
+    const unsigned k_rank = m < (unsigned)o.k ? m : (unsigned)o.k;
+    dae_u64 lo = rs_min, hi = rs_max;
+    unsigned abv = 0;                                            // keys > hi
+    if (m > (unsigned)DAE_RANK_MAX) {
+        for (int it = 0; it < 8; ++it) {
+            int shift = 64 - 11 - __clzll((hi - lo) | 1ull);
+            if (shift < 0) shift = 0;
+            for (int b = tid; b < DAE_RANK_BINS; b += NTH) hist[b] = 0u;
+            __syncthreads();
+            for_keys([&](dae_u64 ck) {
+                if (ck != 0ull && ck >= lo && ck <= hi) atomicAdd(&hist[(unsigned)((ck - lo) >> shift)], 1u);
+            });
+            __syncthreads();
+            dae_rank_find_bin<NTH>(hist, rs_wave_tot, tid, k_rank - abv, &rs_bin, &rs_above);
+            const unsigned b = (unsigned)rs_bin;
+            const unsigned cnt_b = hist[b];
+            const unsigned new_abv = abv + rs_above;
+            const dae_u64 nlo = lo + ((dae_u64)b << shift);
+            dae_u64 nhi = nlo + ((1ull << shift) - 1ull);
+            if (nhi > hi) nhi = hi;
+            __syncthreads();                                     // hist / rs_bin consumed
+            lo = nlo;
+            if (new_abv + cnt_b <= (unsigned)DAE_RANK_MAX) break;       // the keys >= lo fit (unique keys: at shift 0 a bin holds one)
+            hi = nhi;
+            abv = new_abv;
+        }
+    }
+    if (tid == 0) rs_cnt = 0u;
+    __syncthreads();
+    for_keys([&](dae_u64 ck) {
+        if (ck != 0ull && ck >= lo) {
+            const unsigned slot = atomicAdd(&rs_cnt, 1u);
+            if (slot < (unsigned)DAE_RANK_MAX) keys[slot] = ck;
+        }
+    });
+    __syncthreads();
+    const unsigned c = rs_cnt < (unsigned)DAE_RANK_MAX ? rs_cnt : (unsigned)DAE_RANK_MAX;
+    dae_rank_emit<NTH>(keys, c, sorted, hist, above, tid, row, o);
+}

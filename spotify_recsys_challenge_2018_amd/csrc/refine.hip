@@ -399,88 +399,30 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     // n_list = entries of the row's list: keys in LDS (fast), pairs in the row's compact list, or the flat index space of its
     // per-workgroup lists (refined in place; what failed the narrowing is marked -inf there).  The recomputation is over, so the
     // staging area is free: [ordering buffer][bin offsets].
-    __shared__ unsigned f_cnt, f_above;
-    __shared__ int f_bin;
-    __shared__ dae_u64 f_min, f_max;
-    __shared__ unsigned f_wave_tot[RF_WAVES];
     auto final_select = [&](int n_list) {
         __syncthreads();                                          // the recomputation's last LDS and list accesses
         dae_u64* sorted = reinterpret_cast<dae_u64*>(rf_dyn);     // (the staging area is free now; the bitmap sits behind it)
         unsigned* above = reinterpret_cast<unsigned*>(sorted + DAE_RANK_MAX);
         unsigned* fhist = reinterpret_cast<unsigned*>(surv_off);
-        unsigned c = 0;
         if (fast) {
-            c = (unsigned)n_list;
             for (int b = tid; b < RF_BINS; b += RF_THREADS) fhist[b] = 0u;
-        } else {
-            // more survivors than the ordering stage takes (logits packed within 2 eps of the cut), or a list refined in
-            // place: topk_kernel's range-adaptive narrowing (topk.hip step 3b) over the row's list in global memory, then the
-            // collect.  Rare by construction; every pass re-reads the list.
-            auto for_keys = [&](auto f) {
-                for (int e0 = 0; e0 < n_list; e0 += RF_THREADS) {
-                    const int e = e0 + tid;
-                    dae_u64 ck = 0ull;
-                    if (e < n_list) {
-                        const uint2 pr = compact ? orow[e] : p.base[offset_of(e)];
-                        ck = fkey_of(__uint_as_float(pr.x), (int)pr.y);
-                    }
-                    f(ck);
-                }
-            };
-            if (tid == 0) { f_cnt = 0u; f_min = ~0ull; f_max = 0ull; }
-            __syncthreads();
-            {
-                unsigned cnt = 0; dae_u64 mn = ~0ull, mx = 0ull;
-                for_keys([&](dae_u64 ck) {
-                    if (ck != 0ull) { ++cnt; mn = ck < mn ? ck : mn; mx = ck > mx ? ck : mx; }
-                });
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
-                mn = dae_wave_min_u64(mn); mx = dae_wave_max_u64(mx);
-                if (lane == 0 && cnt) { atomicAdd(&f_cnt, cnt); atomicMin(&f_min, mn); atomicMax(&f_max, mx); }
-            }
-            __syncthreads();
-            const unsigned m = f_cnt;
-            const unsigned k_rank = m < (unsigned)p.fo.k ? m : (unsigned)p.fo.k;
-            dae_u64 lo = f_min, hi = f_max;
-            unsigned abv = 0;                                     // keys > hi
-            if (m > (unsigned)DAE_RANK_MAX) {
-                for (int it = 0; it < 8; ++it) {
-                    int shift = 64 - 11 - __clzll((hi - lo) | 1ull);
-                    if (shift < 0) shift = 0;
-                    for (int b = tid; b < RF_BINS; b += RF_THREADS) fhist[b] = 0u;
-                    __syncthreads();
-                    for_keys([&](dae_u64 ck) {
-                        if (ck != 0ull && ck >= lo && ck <= hi) atomicAdd(&fhist[(unsigned)((ck - lo) >> shift)], 1u);
-                    });
-                    __syncthreads();
-                    dae_rank_find_bin<RF_THREADS>(fhist, f_wave_tot, tid, k_rank - abv, &f_bin, &f_above);
-                    const unsigned b = (unsigned)f_bin;
-                    const unsigned cnt_b = fhist[b];
-                    const unsigned new_abv = abv + f_above;
-                    const dae_u64 nlo = lo + ((dae_u64)b << shift);
-                    dae_u64 nhi = nlo + ((1ull << shift) - 1ull);
-                    if (nhi > hi) nhi = hi;
-                    __syncthreads();                              // fhist / f_bin consumed
-                    lo = nlo;
-                    if (new_abv + cnt_b <= (unsigned)DAE_RANK_MAX) break;      // the keys >= lo fit (unique keys: at shift 0 a bin holds one)
-                    hi = nhi;
-                    abv = new_abv;
-                }
-            }
-            if (tid == 0) f_cnt = 0u;
-            __syncthreads();
-            for_keys([&](dae_u64 ck) {
-                if (ck != 0ull && ck >= lo) {
-                    const unsigned slot = atomicAdd(&f_cnt, 1u);
-                    if (slot < (unsigned)DAE_RANK_MAX) fkey[slot] = ck;
-                }
-            });
-            __syncthreads();
-            c = f_cnt < (unsigned)DAE_RANK_MAX ? f_cnt : (unsigned)DAE_RANK_MAX;
+            dae_rank_emit<RF_THREADS>(fkey, (unsigned)n_list, sorted, fhist, above, tid, row, p.fo, f_range,
+                                      p.stamps ? p.stamps + 16 : nullptr);
+            return;
         }
-        dae_rank_emit<RF_THREADS>(fkey, c, sorted, fhist, above, tid, row, p.fo, fast ? f_range : nullptr,
-                                  p.stamps ? p.stamps + 16 : nullptr);
+        // more survivors than the ordering stage takes (logits packed within 2 eps of the cut), or a list refined in place:
+        // the narrowing over the row's list in global memory (rank_lds.h), every pass re-reading it
+        dae_rank_select_emit<RF_THREADS>([&](auto f) {
+            for (int e0 = 0; e0 < n_list; e0 += RF_THREADS) {
+                const int e = e0 + tid;
+                dae_u64 ck = 0ull;
+                if (e < n_list) {
+                    const uint2 pr = compact ? orow[e] : p.base[offset_of(e)];
+                    ck = fkey_of(__uint_as_float(pr.x), (int)pr.y);
+                }
+                f(ck);
+            }
+        }, fkey, sorted, fhist, above, tid, row, p.fo);
     };
 
     if (bad) {                                                   // a row that must return nothing
