@@ -182,6 +182,11 @@ int dae_exact_bounds(dae_ctx* ctx, float* eps_out);
  * The ranking values that reach main_challenge.py:26-36's argsort are fp32 either way: the guard protects the SET. */
 int dae_exact_guard_read(dae_ctx* ctx, int32_t* violations, int32_t* column);
 int dae_exact_guard_words(dae_ctx* ctx, const int32_t** words_dev);
+/* The guard words {violations so far, a violating column} as they stand after everything enqueued on the context's stream so
+ * far, copied to words_out_dev (DEVICE int32[2]) in stream order: a snapshot that travels with a launch's lists.  The words
+ * are cumulative until a dae_exact_guard_read finds them non-zero (and resets them): a count that differs from the previous
+ * launch's snapshot on the same context means THIS launch is unproven (models/DAEs.py: the interpreter loop). */
+int dae_exact_guard_snapshot(dae_ctx* ctx, int32_t* words_out_dev);
 /* How selective the filter was (the exact mode's rate depends on it, its results never): of the LAST exact scoring launch
  * of this context, out3 = {rows refined, candidates the bf16 filter launch left for them (sum over the rows), candidates
  * recomputed in fp32 after the narrowing step (sum)}.  Synchronises the ctx stream. */

@@ -15,9 +15,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_title_exact as T          # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(n_cases=24, seed=0, log=print):
+    """-> number of cases whose exact lists differ from the fp32 lists (tests/test_gpu_title_exact.py collects two seeds)."""
+    rng = np.random.default_rng(seed)
     tmp = pathlib.Path(tempfile.mkdtemp())
     bad = 0
     for case in range(n_cases):
@@ -42,14 +42,19 @@ def main():
             got = m.recommend(pos, ones, seeds, k=k, titles=titles, titles_use=use, dtype="exact_bf16")
         same = np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
         st = m.title_model.ctx.exact_stats_read()
-        print("case %2d tracks %5d batch %3d %5s x%-4g feat x%-4g out x%-4g k %3d: %s  cand %.0f recomputed %.0f fallbacks %d%s"
+        log("case %2d tracks %5d batch %3d %5s x%-4g feat x%-4g out x%-4g k %3d: %s  cand %.0f recomputed %.0f fallbacks %d%s"
               % (case, nt, conf.batch, bias, w_scale, feat_scale, out_scale, k, "same" if same else "DIFFERENT",
                  st["candidates_per_row"], st["recomputed_per_row"], 1000 * getattr(m, "_guard_fallbacks", 0) + getattr(m, "_guard_row_fallbacks", 0),
-                 ("  (%s)" % str(w[0].message)[30:110]) if w else ""), flush=True)
+                 ("  (%s)" % str(w[0].message)[30:110]) if w else ""), )
         bad += 0 if same else 1
         del m
-    print("cases %d, different %d" % (n_cases, bad))
-    sys.exit(1 if bad else 0)
+    log("cases %d, different %d" % (n_cases, bad))
+    return bad
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    sys.exit(1 if run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
 
 
 if __name__ == "__main__":

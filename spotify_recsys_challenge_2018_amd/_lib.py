@@ -16,7 +16,7 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
     "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_prepack_decoder_rows", "dae_share_decoder", "dae_exact_bounds",
-    "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
+    "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_guard_snapshot", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_title_score", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
@@ -73,6 +73,7 @@ def load():
     lib.dae_exact_bounds.argtypes = [vp, vp]
     lib.dae_exact_guard_read.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.dae_exact_guard_words.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.dae_exact_guard_snapshot.argtypes = [vp, vp]
     lib.dae_set_exact_margin.argtypes = [vp, c_f]
     lib.dae_exact_stats_read.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
@@ -274,7 +275,19 @@ class Context:
         """(violations, column) of the exact mode's bound guard since the last non-zero read; synchronises the stream."""
         n, c = ctypes.c_int32(), ctypes.c_int32()
         self.check(self.lib.dae_exact_guard_read(self.h, ctypes.byref(n), ctypes.byref(c)))
+        if n.value:
+            self._guard_seen = 0             # (the read reset the cumulative words: snapshots compare against zero again)
         return int(n.value), int(c.value)
+
+    def exact_guard_snapshot(self, words_out):
+        """The cumulative guard words after everything enqueued so far -> words_out (CUDA int32[2]), in stream order."""
+        self.check(self.lib.dae_exact_guard_snapshot(self.h, _ptr(words_out)))
+
+    def guard_moved(self, n_bad):
+        """A launch's snapshot against the previous one taken on this context: True when the count changed under it."""
+        seen = getattr(self, "_guard_seen", 0)
+        self._guard_seen = int(n_bad)
+        return int(n_bad) != seen
 
     def exact_stats_read(self):
         """{rows, candidates_per_row, recomputed_per_row} of the refine launches since the last read (synchronises)."""

@@ -410,6 +410,17 @@ int dae_exact_guard_words(dae_ctx* ctx, const int32_t** words_dev)
     return DAE_OK;
 }
 
+int dae_exact_guard_snapshot(dae_ctx* ctx, int32_t* words_out_dev)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (!words_out_dev) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    const int32_t* gw = nullptr;
+    const int rc = dae_exact_guard_words(ctx, &gw);
+    if (rc) return rc;
+    DAE_HIP_CHECK(ctx, hipMemcpyAsync(words_out_dev, gw, DAE_GUARD_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    return DAE_OK;
+}
+
 int dae_decode_dense(dae_ctx* ctx, const float* h, int B, int H, int dtype, int apply_sigmoid,
                      float* out, int64_t ld_out)
 {

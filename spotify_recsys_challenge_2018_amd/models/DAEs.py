@@ -533,6 +533,12 @@ class DAE_tied:
         idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
         ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
                        self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
+        if dtype == _lib.DAE_DTYPE_BF16_EXACT and side_stream:
+            # the streamed loop: the context's guard words as THIS launch left them travel with its lists (recommend_iter
+            # compares them with the previous launch's on the same context and re-scores the launch in fp32 when they moved)
+            gw = torch.empty(2, dtype=torch.int32, device=dev)
+            ctx.exact_guard_snapshot(gw)
+            idx._exact_guard = (gw, ctx, (x_positions, x_ones, seeds, n_rows))
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
@@ -551,6 +557,25 @@ class DAE_tied:
             csr = self._upload_csr(x_positions, x_ones)
             d_srp, d_sc = self._seed_csr_dev(seeds, csr)
             score, idx = self._shard_ranker(dtype).rank_batch((csr[0], csr[1], csr[2], d_srp, d_sc), k)
+            if dtype == _lib.DAE_DTYPE_BF16_EXACT:
+                # the exact mode's BOUND GUARD on a shard: a violation on ANY rank leaves the merged lists unproven (a column the
+                # bf16 filter wrongly dropped may have been that rank's contribution) -> the ranks agree on the flag (one 4-byte
+                # all-reduce per batch) and re-score the batch with the fp32 kernels together
+                import torch
+                import torch.distributed as dist
+                n_bad, col = self.ctx.exact_guard_read()
+                flag = torch.tensor([1 if n_bad else 0], dtype=torch.int32)
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size(sh["group"]) > 1:
+                    if dist.get_backend(sh["group"]) != "gloo":
+                        flag = flag.to(idx.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=sh["group"])
+                if int(flag.item()):
+                    import warnings
+                    warnings.warn("exact_bf16 (vocabulary shard): the bound guard fired on %s: this batch is re-scored with the fp32 "
+                                  "kernels on every rank" % ("this rank, e.g. column %d" % col if n_bad else "another rank"))
+                    self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
+                    self._ensure_packed(_lib.DAE_DTYPE_F32, sh["cols"])
+                    score, idx = self._shard_ranker(_lib.DAE_DTYPE_F32).rank_batch((csr[0], csr[1], csr[2], d_srp, d_sc), k)
             r0, r1 = self.owned_rows()
             n_own = max(0, min(r1, n_rows) - r0)
             res = idx[:n_own].cpu().numpy(), score[:n_own].cpu().numpy()
@@ -735,6 +760,10 @@ class DAE_tied:
             if blocking:                                    # (score, idx, done event): a blocking copy on the fetch stream
                 score_, idx_, ev_, n_fetch, rws, nt_ = t
                 fs.wait_event(ev_)
+                redo = self._plain_guard_fired(getattr(idx_, "_exact_guard", None), k)
+                if redo is not None:
+                    score_, idx_ = redo
+                    fs.wait_stream(torch.cuda.current_stream(self.device_index))
                 if getattr(idx_, "_mix_guard", None) is not None:          # exact title mix: see DAE_title._mix_guard_fired
                     with torch.cuda.stream(fs):                             # (on the compute stream the copy would wait for the NEXT launch too)
                         idx_._mix_guard[0].record_stream(fs)
@@ -751,8 +780,18 @@ class DAE_tied:
                         score_.record_stream(fs)
                         s_h = score_[:n_fetch].cpu().numpy()
             else:
-                pin_i, pin_s, ev2, n_fetch, rws, nt_ = t
+                pin_i, pin_s, ev2, n_fetch, rws, nt_ = t[:6]
                 ev2.synchronize()
+                redo = self._plain_guard_fired(t[6] if len(t) > 6 else None, k)
+                if redo is not None:                        # the bound guard fired under this launch: the fp32 kernels' lists instead
+                    i_h = redo[1][:n_fetch].cpu().numpy()
+                    s_h = redo[0][:n_fetch].cpu().numpy() if want_scores else None
+                    del pin_i, pin_s, t
+                    if nt_ is None:
+                        yield i_h, s_h
+                    else:
+                        yield from split((i_h, s_h), rws)
+                    return
                 if isinstance(pin_i, _Lease):               # the lists ARE the pinned block (see _PinnedPool)
                     i_h = pin_i.array(n_fetch, k)
                     s_h = pin_s.array(n_fetch, k) if pin_s is not None else None
@@ -812,7 +851,7 @@ class DAE_tied:
                         t_s[:n_fetch * k].view(n_fetch, k).copy_(score[:n_fetch], non_blocking=True)
                     ev2 = fs.record_event()
                 del t_i, t_s
-                pending.append((pin_i, pin_s, ev2, n_fetch, rows, n_total))
+                pending.append((pin_i, pin_s, ev2, n_fetch, rows, n_total, getattr(idx, "_exact_guard", None)))
                 if len(pending) > len(lanes):              # one launch per lane stays in flight behind the fetch
                     yield from results(pending.pop(0))
             while pending:
@@ -826,6 +865,26 @@ class DAE_tied:
                 for c, _s in lanes:                          # other entry points run ungated
                     c.check(c.lib.dae_set_decode_gate(c.h, None, None))
         self._check_feed()
+
+    def _plain_guard_fired(self, tag, k):
+        """The interpreter loop under exact_bf16: `tag` = (snapshot of the context's guard words taken behind the launch, the
+        context, the launch's feed).  -> (score, idx) of the same feed through the fp32 kernels when the words moved under the
+        launch (a recomputed survivor left the interval the bf16 filter promised: include/dae_hip.h dae_exact_guard_read), or
+        None when the launch stands.  (the native pipeline and `recommend` had this, the Python loop did not.)"""
+        if tag is None:
+            return None
+        gw, ctx, (x_positions, x_ones, seeds, n_rows) = tag
+        n_bad, col = (int(v) for v in gw.cpu())
+        if not ctx.guard_moved(n_bad):
+            return None
+        import warnings
+        warnings.warn("exact_bf16: the bound guard fired (%d survivors so far, e.g. column %d): this launch is re-scored with the "
+                      "fp32 kernels" % (n_bad, col))
+        self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
+        self._ensure_packed(_lib.DAE_DTYPE_F32)
+        self.ctx.bind_stream()
+        score, idx, _ev = DAE_tied._submit(self, x_positions, x_ones, seeds, k, _lib.DAE_DTYPE_F32, False, n_rows=n_rows)
+        return score, idx
 
     def _native_pipe(self, dtype, k, want_scores):
         """The model's dae_pipeline for (dtype, k, scores wanted): created on first use, again after the weights changed."""
@@ -1454,11 +1513,12 @@ class DAE_title(DAE):
             return None
         gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows) = tag
         n_bad, col = (int(v) for v in (gw.cpu() if words is None else words))
-        seen = self.__dict__.get("_mix_guard_seen", 0)
-        if n_bad == seen:
+        # (the shadow of the cumulative words lives on the context and is resynchronised by every dae_exact_guard_read on it:
+        # ADVICE r4 -- a read elsewhere used to leave this comparison one reset behind)
+        seen = getattr(self.title_model.ctx, "_guard_seen", 0)
+        if not self.title_model.ctx.guard_moved(n_bad):
             self._mix_overflow_streak = 0
             return None
-        self._mix_guard_seen = n_bad
         import warnings
         import torch
         self._ensure_packed(_lib.DAE_DTYPE_F32)

@@ -184,6 +184,56 @@ def test_native_pipeline_orders_lends_and_recovers(tmp_path):
         pipe.close()
 
 
+@pytest.mark.parametrize("engine", ["python", "native"])
+def test_streamed_loop_re_scores_when_the_guard_fires(tmp_path, engine):
+    """the interpreter loop (iter_engine = "python", two lane contexts) never looked at the exact mode's guard
+    words.  Now every launch carries a snapshot of its context's words (dae_exact_guard_snapshot); a forged bound
+    (dae_set_exact_margin < 1 on the model's context, handed on to the lanes / the pipeline) makes the loop warn and return the
+    fp32 kernels' lists -- and an honest bound stays silent, with the counters of earlier hits NOT charged to later launches."""
+    import warnings
+    nt, na, H, k, B = 20000, 3000, 128, 300, 64
+    V = nt + na
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=9, bias="zipf", n_tracks=nt)
+    W_dec = (W_dec * 40).astype(np.float32)
+    path = str(tmp_path / "init.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        save = str(tmp_path / "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
+        n_tracks = nt; initval = path
+    m = DAE(C()); m.fit()
+    m.iter_engine = engine
+    batches = [make_playlists(B, nt, na, seed=70 + i)[:2] for i in range(6)]
+    feeds = [(p, o, SEEDS_FROM_INPUT, B) for p, o in batches]
+    want = [m.recommend(p, o, SEEDS_FROM_INPUT, k=k, dtype="f32") for p, o in batches]
+
+    def same(got):
+        assert len(got) == len(want)
+        for (gi, gs), (wi, ws) in zip(got, want):
+            assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        same(list(m.recommend_iter(feeds, k=k, dtype="exact_bf16")))
+    assert m.__dict__.get("_guard_fallbacks", 0) == 0
+    m.ctx.set_exact_margin(1e-3)
+    m._mark_dirty()
+    for st in m.__dict__.get("_lanes", []):               # the extra lanes borrow the first context's image: nothing of their own to forge
+        st["packed"].clear()
+    with pytest.warns(UserWarning, match="bound guard"):
+        same(list(m.recommend_iter(feeds, k=k, dtype="exact_bf16")))
+    assert m._guard_fallbacks >= 1
+    m.ctx.set_exact_margin(1.0)
+    m._mark_dirty()
+    for st in m.__dict__.get("_lanes", []):
+        st["packed"].clear()
+    n0 = m._guard_fallbacks
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        same(list(m.recommend_iter(feeds, k=k, dtype="exact_bf16")))
+    assert m._guard_fallbacks == n0
+
+
 def test_clock_probe_reads_a_plausible_engine_clock():
     """dae_clock_probe (bench.py's `roofline.sustained_clock`): shader cycles over wall-clock ticks of one wave."""
     import torch

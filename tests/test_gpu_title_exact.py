@@ -266,3 +266,56 @@ def test_exact_title_mix_other_shapes_run_fp32(tmp_path):
     sc = torch.empty((4, 10), device=dev); ix = torch.empty((4, 10), dtype=torch.int32, device=dev)
     with pytest.raises(_lib.DaeError, match="hidden 256"):
         tm.ctx.mix_topk_exact(m.ctx, feat, h, w, w, conf.n_tracks, None, None, 10, sc, ix)
+
+
+def test_exact_title_mix_full_size(tmp_path):
+    """BASELINE.json's vocabulary (V = 170 000, 140 000 rankable columns, hidden 256) and the launch of the reference's
+    `--challenge` loop as this build coalesces it -- 5 feeds of [TITLE] batch = 150 -> 750 rows, 8 row groups of 96, 4 375
+    tiles (main_challenge.py:72-93, DAEs.py:176-181): lists AND score bits of the fp32 title path, rows with and without
+    titles, a title-only playlist, no guard event (VERDICT r4 Weak #3: the small cases above stop at V = 60 000)."""
+    conf = _conf(n_tracks=140000, n_input=170000, batch=750)
+    m = _model(tmp_path, conf)
+    pos, ones, seeds = _feed(conf, 5, empty_rows=(3, 400))
+    titles = _titles(conf.batch, seed=6)
+    use = (np.arange(conf.batch) % 7 != 2).astype(np.float32)
+    use[3] = use[400] = 1.0
+    want = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="f32")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m.recommend(pos, ones, seeds, k=500, titles=titles, titles_use=use, dtype="exact_bf16")
+    _same(got, want)
+    st = m.title_model.ctx.exact_stats_read()
+    assert st["rows"] == 750 and st["candidates_per_row"] >= 500 and st["recomputed_per_row"] >= 500, st
+    assert m.title_model.ctx.exact_guard_read()[0] == 0 and not getattr(m, "_guard_fallbacks", 0)
+    assert (got[0][:, 0] >= 0).all() and (got[0] < conf.n_tracks).all()
+    # the same rows through the streamed loop (the library's titled pipeline): 5 feeds of 150 -> one launch
+    m2conf = _conf(n_tracks=140000, n_input=170000, batch=150)
+    m2conf.DAEval = conf.DAEval
+    m2 = DAE_title(m2conf, m.title_model)
+    m2.fit()
+    feeds = []
+    for i in range(5):
+        sel = (pos[:, 0] >= 150 * i) & (pos[:, 0] < 150 * (i + 1))
+        p_i = pos[sel].copy(); p_i[:, 0] -= 150 * i
+        o_i = ones[sel] if np.ndim(ones) and len(ones) == len(sel) else ones
+        feeds.append((p_i, o_i, SEEDS_FROM_INPUT, 150, titles[150 * i:150 * (i + 1)], use[150 * i:150 * (i + 1)]))
+    own = [sorted(set(int(c) for c in pos[pos[:, 0] == r, 1] if c < conf.n_tracks)) for r in range(conf.batch)]
+    want_own = m.recommend(pos, ones, own, k=500, titles=titles, titles_use=use, dtype="f32")
+    got_it = list(m2.recommend_iter(feeds, k=500, dtype="exact_bf16"))
+    assert np.array_equal(np.concatenate([g[0] for g in got_it]), want_own[0])
+    assert np.array_equal(np.concatenate([g[1] for g in got_it]).view(np.uint32), want_own[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_exact_title_mix_fuzz(seed):
+    """scripts/fuzz_title_exact.py under pytest (VERDICT r4 Weak #3): random models (bias, weight / feature / output scales),
+    vocabularies, batches, title usage and k -- the exact lists against the fp32 title path, bit for bit."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_title_exact", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_title_exact.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    bad = mod.run(n_cases=8, seed=seed, log=lines.append)
+    assert bad == 0, "\n".join(lines)
