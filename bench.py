@@ -266,6 +266,29 @@ def _settle_interpreter():
     gc.freeze()
 
 
+def _release_model(torch, m):
+    """A host-loop row is done: its pipelines (library threads, pinned blocks, lanes' contexts) and contexts go NOW, and the
+    collector sees the row's objects again (they were frozen for the timed loops).  Left to the interpreter, the titled row's
+    three lanes stayed alive into the training row and cost it 0.52 -> 0.87 ms per step (profiles/r05_notes.md)."""
+    import gc
+    try:
+        torch.cuda.synchronize()
+        for _g, pipe in list(m.__dict__.get("_pipes", {}).values()):
+            pipe.close()
+        m.__dict__.get("_pipes", {}).clear()
+        for st in m.__dict__.get("_lanes", []):
+            st["ctx"].close()
+        tm = getattr(m, "title_model", None)
+        if tm is not None and getattr(tm, "ctx", None) is not None:
+            tm.ctx.close()
+        m.ctx.close()
+    except Exception:
+        pass
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_artists, H, B, k, dist_name):
     """The same scoring THROUGH the product's loop (models/DAEs.py DAE.recommend_iter, what main.py --challenge and the
     evaluation of main.py --dae run): host feeds (COO positions as the reference's readers emit them) in, host index lists
@@ -314,6 +337,7 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
     row["engine"] = "native (dae_pipeline_*: a library-owned thread issues the launches; models/DAEs.py recommend_iter)"
     row["note"] = ("NOT the headline: host feeds in, host lists out (indices only; seeds = the playlist's own tracks, cut "
                    "out of the input on the device).  scripts/bench_loop.py is the longer version (both engines, lane counts)")
+    _release_model(torch, m)
     return row
 
 
@@ -360,8 +384,10 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
     row = {"unit": "playlists/s", "what": _titled_row.__doc__.split("\n\n")[0].replace("\n    ", " "), "batch": B}
     lists = {}
     for name, reps, warm in (("f32", 60, 15), ("exact_bf16", 250, 60)):
-        got = [(i_.copy(), s_.copy()) for i_, s_ in m.recommend_iter(feeds(warm), k=k, want_scores=True, dtype=name)][:len(batches)]
+        got = [(i_.copy(), s_.copy()) for i_, s_ in m.recommend_iter(feeds(2), k=k, want_scores=True, dtype=name)][:len(batches)]
         lists[name] = got
+        for _ in m.recommend_iter(feeds(warm), k=k, want_scores=False, dtype=name):      # (the timed loop's own pipeline: the model keeps
+            pass                                                                          #  one per (dtype, k, scores wanted))
         torch.cuda.synchronize()
         _settle_interpreter()
         t0 = time.perf_counter()
@@ -386,6 +412,7 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
     row["engine"] = "native (dae_pipeline_create_titled / _submit_titled: the titled launches on the library's own thread, 3 lanes)"
     row["note"] = ("NOT the headline: the title scorer is randomly initialised (no trained title variables ship); host feeds in, "
                    "host lists out")
+    _release_model(torch, m)
     return row
 
 
@@ -657,6 +684,7 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
         for _ in range(3):
             step(k); k += 1
         torch.cuda.synchronize()
+        _settle_interpreter()                  # (a 35 ms generation-2 collection inside 20 steps of 0.7 ms doubled this row once)
         t0 = time.perf_counter()
         for _ in range(n_t):
             step(k); k += 1

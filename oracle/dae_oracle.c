@@ -176,7 +176,10 @@ void orc_decode_bf16(const float* h, const float* W_dec, const float* b_dec, int
 /* ------------------------------------------------------------------------------------------------
  * rank -- main_challenge.py:28-36 / metrics.py:59-68: argsort descending, remove the seed tracks,
  * keep k (=500).  numpy's argsort tie order is unspecified; the canonical rule is
- * (logit desc, column index asc).  Ranking on the LOGIT is ranking on the exact sigmoid.
+ * (logit desc, column index asc).  Ranking on the LOGIT is ranking on the EXACT sigmoid; it REFINES -- it does not
+ * equal -- the order of fp32 sigmoid outputs the reference sorts: equal outputs (a saturated plateau at 1.0f) are
+ * told apart by their logits, and orc_sigmoidf above is monotone only to one unit in the last place (920 one-ulp
+ * inversions in [-88, 88]), so at such a pair the two orders disagree.  tests/test_gpu_rank_seam.py pins both.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { uint32_t key; int32_t idx; float logit; } cand_t;
 

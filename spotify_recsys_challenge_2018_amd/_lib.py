@@ -455,6 +455,18 @@ class _Block:
             pass
 
 
+_live_pipelines = None          # weak set of open pipelines: closed at interpreter exit, BEFORE the HIP runtime tears down
+
+
+def _close_pipelines_at_exit():
+    for p in list(_live_pipelines or ()):
+        try:
+            p._held = {}
+            p.close()
+        except Exception:
+            pass
+
+
 class Pipeline:
     """The drivers' loop inside the library (include/dae_hip.h dae_pipeline_*): host feeds in, host top-k lists out; a
     library-owned thread issues the launches on `lanes` contexts.  The weights are CUDA tensors the caller keeps alive.
@@ -490,6 +502,15 @@ class Pipeline:
             raise DaeError("dae_pipeline_create failed (%d): %s" % (rc, self.lib.dae_pipeline_last_error(None).decode()))
         self.h = h
         self.pending = 0                     # feeds submitted and not yet yielded
+        # a pipeline owns a library thread and streams: it must be gone before the runtime is (a destructor running HIP calls
+        # during interpreter teardown is undefined -- ADVICE r4)
+        global _live_pipelines
+        if _live_pipelines is None:
+            import atexit
+            import weakref
+            _live_pipelines = weakref.WeakSet()
+            atexit.register(_close_pipelines_at_exit)
+        _live_pipelines.add(self)
 
     def _check(self, rc):
         if rc < 0:

@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(con
     for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
 
     int g_nxt = grp0 + n_ws;
-    int n_done = 0;
+    [[maybe_unused]] int n_done = 0;                            // (the stage stamps of the experiments build count tiles with it)
     for (int grp = grp0; grp < n_grp;) {
         int g_nn;
         {

@@ -555,8 +555,8 @@ __device__ __forceinline__ float mix_chain64(const float* __restrict__ W32, int 
 // two floats further from the value than the rounded subtraction left it
 __device__ __forceinline__ float two_down(float x) { return dae_okey_inv(dae_okey(x) - 2u); }
 
-// (No per-thread strided loop of this kernel is left to hipcc's loop vectorizer: see the note at the staging loop's
-// predecessor in profiles/r04_notes.md, item 11d.)
+// (The library is built with -fno-vectorize: hipcc's loop vectorizer miscompiled this kernel's per-lane staging loop in round 4 --
+// spotify_recsys_challenge_2018_amd/build.py, scripts/probe/vec_repro.hip.)
 #ifdef DAE_EXPERIMENTS
 #define MSTAMP(i) if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_readcyclecounter();
 #else
@@ -586,11 +586,9 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     const int seed_e = (p.fuse && p.seed_col) ? p.seed_row_ptr[row + 1] : 0;
     const int my_seed = seed_b + tid < seed_e ? p.seed_col[seed_b + tid] : -1;
     __shared__ unsigned f_range[2];              // {min, max} of the high words of the keys written to LDS
-#pragma clang loop vectorize(disable) interleave(disable)
     for (int s = tid; s < nseg; s += MR_THREADS) seg_prefix[s + 1] = p.cnt[(size_t)s * p.cnt_seg_stride + row];
     if (tid == 0) { seg_prefix[0] = 0; s_n = 0; f_range[0] = 0xFFFFFFFFu; f_range[1] = 0u; }
     if (tid < 32) cnts[tid] = (tid == 1 || tid == 3) ? 0xFFFFFFFFu : 0u;      // [1], [3]: minima
-#pragma clang loop vectorize(disable) interleave(disable)
     for (int i = tid; i < 1024; i += MR_THREADS) {
         hrowD[i] = i < p.HD ? p.hD[(size_t)row * p.ld_hD + i] : 0.0f;
         hrowT[i] = i < p.HT ? p.hT[(size_t)row * p.ld_hT + i] : 0.0f;
@@ -625,7 +623,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     unsigned* const bitmap = ku + 2 * DAE_RANK_MAX;
     const int bm_words = p.fuse ? (p.n_valid_col + 31) >> 5 : 0;
     auto build_bitmap = [&]() {                                   // (every thread; the callers' barrier before it freed the area)
-#pragma clang loop vectorize(disable) interleave(disable)
         for (int w = tid; w < bm_words; w += MR_THREADS) bitmap[w] = 0u;
         __syncthreads();
         for (int i = seed_b + tid; i < seed_e; i += MR_THREADS) {
@@ -659,7 +656,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
         // y = sigmoid(.) * 0 + sigmoid(.) * 0 = +0 for every column: the fp32 path ranks (y desc, column asc), i.e. the first
         // k non-seed columns -- the first k + n_seeds columns cover them
         const int nl = min(p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0), min(p.n_valid_col, p.out_cap));
-#pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < nl; i += MR_THREADS) p.out[(size_t)row * p.out_cap + i] = make_uint2(0u, (unsigned)i);
         if (tid == 0) { p.out_cnt[row] = nl; if (p.stat) { p.stat[2 * row] = 0; p.stat[2 * row + 1] = 0; } }
         if (p.fuse) { build_bitmap(); select_from_list(nl); }
@@ -729,7 +725,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     MSTAMP(1)
     if (lane == 0) { atomicMax(&cnts[0], kmx); atomicMin(&cnts[1], kmn); }
     unsigned* hist = reinterpret_cast<unsigned*>(tb);
-#pragma clang loop vectorize(disable) interleave(disable)
     for (int i = tid; i < MR_BINS; i += MR_THREADS) hist[i] = 0u;
     __syncthreads();
 
@@ -801,7 +796,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
                 // selected bin alone, in 2048 sub-bins of 128 key units (1.5e-5 of y)
                 const int need2 = need - (int)cnts[5];
                 __syncthreads();                                  // (everybody has read cnts[5] and the histogram)
-#pragma clang loop vectorize(disable) interleave(disable)
                 for (int i = tid; i < MR_BINS; i += MR_THREADS) hist[i] = 0u;
                 __syncthreads();
                 const unsigned e0 = P;
@@ -823,12 +817,10 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
             const unsigned bq = (unsigned)((float)(key - kmin) * scale);
             return (int)(bq < (unsigned)(MR_BINS - 1) ? bq : (unsigned)(MR_BINS - 1));
         };
-#pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < total; i += MR_THREADS) atomicAdd(&hist[bin_of(kl[i])], 1u);
         __syncthreads();
         const int Bsel = select_bin(need);
         unsigned kb = 0xFFFFFFFFu;
-#pragma clang loop vectorize(disable) interleave(disable)
         for (int i = tid; i < total; i += MR_THREADS) {
             const unsigned key = kl[i];
             if (bin_of(key) == Bsel) kb = key < kb ? key : kb;
@@ -896,7 +888,6 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
     if (!p.fuse) return;
     __syncthreads();                                             // the recomputation is over: its buffers become the ordering stage's
     if (fast) {
-#pragma clang loop vectorize(disable) interleave(disable)
         for (int b = tid; b < DAE_RANK_BINS; b += MR_THREADS) fhist[b] = 0u;
         dae_rank_emit<MR_THREADS>(fkey, (unsigned)n, sorted, fhist, above, tid, row, p.fo, f_range);
     } else {

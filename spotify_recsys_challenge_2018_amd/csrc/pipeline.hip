@@ -83,6 +83,7 @@ struct dae_pipeline {
     std::deque<int> queue;        // slots waiting for the worker, in submission order
     std::thread worker;
     bool stop = false;
+    std::mutex err_mu;            // err / err_code: written by the library thread and by the caller, read by dae_pipeline_last_error
     std::string err;
     int err_code = 0;
     uint64_t next_ticket = 1;
@@ -115,14 +116,25 @@ thread_local std::string g_pipe_err;
 // pfail: an error of THIS call (message only); pfatal: the pipeline is broken from here on (every later call returns it)
 int pfail(dae_pipeline* p, int code, const char* msg)
 {
-    if (p) p->err = msg; else g_pipe_err = msg;
+    if (p) { std::lock_guard<std::mutex> g(p->err_mu); p->err = msg; } else g_pipe_err = msg;
     return code;
 }
 int pfatal(dae_pipeline* p, int code, const char* msg)
 {
-    if (p && !p->err_code) { p->err = msg; p->err_code = code; }
+    if (p) {
+        std::lock_guard<std::mutex> g(p->err_mu);
+        if (!p->err_code) { p->err = msg; p->err_code = code; }
+    }
     return code;
 }
+
+// the calling thread's current device, put back when the call returns: the pipeline's entry points select ITS device for
+// their HIP calls, and a multi-GPU process must not find its device changed behind its back
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 #define PIPE_HIP(p, expr)                                                                          \
     do {                                                                                           \
@@ -341,7 +353,16 @@ int close_open(dae_pipeline* p)
 
 extern "C" {
 
-const char* dae_pipeline_last_error(const dae_pipeline* p) { return p ? p->err.c_str() : g_pipe_err.c_str(); }
+const char* dae_pipeline_last_error(const dae_pipeline* p)
+{
+    if (!p) return g_pipe_err.c_str();
+    thread_local std::string copy;                           // (the library thread may replace p->err at any time)
+    {
+        std::lock_guard<std::mutex> g(const_cast<dae_pipeline*>(p)->err_mu);
+        copy = p->err;
+    }
+    return copy.c_str();
+}
 
 int dae_pipeline_destroy(dae_pipeline* p)
 {
@@ -352,6 +373,7 @@ int dae_pipeline_destroy(dae_pipeline* p)
     }
     p->cv_worker.notify_all();
     if (p->worker.joinable()) p->worker.join();
+    DeviceGuard dev_guard(p->device);
 #ifdef DAE_EXPERIMENTS
     if (dae_exp_env("DAE_DBG_PIPE"))
         fprintf(stderr, "PIPE issue(): uploads+gate %.2f ms | + scoring calls %.2f ms | + downloads %.2f ms (cumulative, %llu launches)\n",
@@ -377,7 +399,6 @@ int dae_pipeline_destroy(dae_pipeline* p)
         fprintf(stderr, "PIPE device time per launch (event pair on the lane's stream): %.3f ms over %llu launches\n",
                 p->dbg_dev_ms / (double)p->dbg_dev_n, (unsigned long long)p->dbg_dev_n);
 #endif
-    (void)hipSetDevice(p->device);
     for (Lane& L : p->lanes) {
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
@@ -428,7 +449,8 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
     p->slots.resize(n_slots);
     p->blocks.resize(result_blocks);
     auto bail = [&](int rc, const char* msg) { const std::string m(msg); dae_pipeline_destroy(p); g_pipe_err = m; return rc; };
-    if (hipSetDevice(device) != hipSuccess) return bail(DAE_ERR_HIP, "hipSetDevice failed");
+    DeviceGuard dev_guard(device);
+    { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) return bail(DAE_ERR_HIP, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(DAE_ERR_HIP, "stream creation failed");
     const size_t rows = (size_t)group_rows, nz = (size_t)max_nnz, kk = (size_t)k;
     for (int i = 0; i < lanes; ++i) {
@@ -653,7 +675,7 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
             bool ok;
             {
                 std::lock_guard<std::mutex> g(p->issue_mu);
-                (void)hipSetDevice(p->device);
+                DeviceGuard dev_guard(p->device);
                 Lane& L = p->lanes[S.lane];
                 L.guard_seen = S.h_flags[1];
                 if (S.h_flags[2] == -2 || S.h_flags[2] == -3) {
@@ -675,7 +697,7 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
             bool ok;
             {
                 std::lock_guard<std::mutex> g(p->issue_mu);
-                (void)hipSetDevice(p->device);
+                DeviceGuard dev_guard(p->device);
                 Lane& L = p->lanes[S.lane];
                 int32_t nv = 0, col = -1;
                 rc = dae_exact_guard_read(L.ctx, &nv, &col);       // (synchronises the lane, resets the words)
@@ -729,7 +751,7 @@ int dae_pipeline_exact_margin(dae_pipeline* p, float scale)
         if (S.state != 0) return pfail(p, DAE_ERR_STATE, "dae_pipeline_exact_margin: feeds are in flight");
     lk.unlock();
     std::lock_guard<std::mutex> g(p->issue_mu);
-    (void)hipSetDevice(p->device);
+    DeviceGuard dev_guard(p->device);
     Lane& L0 = p->lanes[0];
     for (Lane& L : p->lanes) (void)hipStreamSynchronize(L.stream);
     int rc = dae_set_exact_margin(L0.ctx, scale);

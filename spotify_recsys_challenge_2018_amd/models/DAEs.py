@@ -903,6 +903,11 @@ class DAE_tied:
             ent = None
         if ent is None:
             import torch
+            # one pipeline at a time per model: each holds (2 lanes + 2) staging slots of pinned + device memory and a dozen
+            # result blocks -- a caller that alternates dtypes pays a re-creation, not half a gigabyte of pinned memory
+            for key_, (_g, old) in list(cache.items()):
+                old.close()
+                cache.pop(key_, None)
             self._flush_rows_adam()
             torch.cuda.current_stream(self.device_index).synchronize()      # the weights are final before another thread reads them
             # (titled launches: the fp32 rule -- 5 feeds of 150 = 750 rows of the 96- / 128-row groups, as the Python loop ran them)
@@ -951,6 +956,9 @@ class DAE_tied:
                         use = np.zeros(self.n_batch, np.float32)
                         use[:min(u.size, nt)] = u[:nt]                                # (no title, no use)
                 unfit = len(f) > 4 and pipe.title_len is None
+                if not unfit:                                    # a feed larger than a launch slot: through recommend(), not a DaeError
+                    nnz_f = int(np.shape(x_positions)[0]) if np.ndim(x_positions) == 2 else len(x_positions)
+                    unfit = nnz_f > pipe.max_nnz
                 if not (isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT) or unfit or n > self.n_batch:
                     pipe.flush()                                 # a feed the pipeline does not take: in order, through recommend()
                     while pipe.pending:
