@@ -31,6 +31,8 @@ def main():
         save = "/tmp/_loop_unused"; batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
         n_tracks = nt; initval = path
     m = DAE(C()); m.fit()
+    if os.environ.get("COALESCE"):       # A/B: feeds per launch (model.coalesce)
+        m.coalesce = int(os.environ["COALESCE"])
     batches = [make_playlists(B, nt, na, seed=200 + s)[:2] for s in range(8)]
 
     def feeds(reps):

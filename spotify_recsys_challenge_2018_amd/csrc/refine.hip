@@ -50,6 +50,11 @@ struct RefineP {
     const float* row_min;                         // nullable: an exchanged threshold (dae_score_topk_finish)
     int bm_off;                                   // byte offset of the seed bitmap in the dynamic LDS (behind the staging area)
     long long* stamps;                            // experiments build: stage stamps of workgroup 0 (DAE_DBG_R)
+    // SHARED RECOMPUTATION (round 5, launches of many rows): exact_rescore_shared_kernel ran before this launch and left the
+    // fp32 logit in place of the bound u for every candidate of the rows that are recomputed WITHOUT narrowing (`staged` false
+    // below: the same predicate there) -- such rows only read their pairs back and order them
+    int pre;
+    int B;
 };
 
 #ifdef DAE_EXPERIMENTS
@@ -441,9 +446,10 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
             const int off = offset_of(in ? e : g0);
             const uint2 pr = p.base[off];
             if (g0 == 0) { RSTAMP(5) }
-            const float z = rescore_group((int)pr.y, in);
+            // (p.pre: recomputed and guarded by exact_rescore_shared_kernel, a decoder row fetched once for 32 playlists)
+            const float z = p.pre ? __uint_as_float(pr.x) : rescore_group((int)pr.y, in);
             if (g0 == 0) { RSTAMP(9) }
-            guard(z, __uint_as_float(pr.x), (int)pr.y, in);
+            if (!p.pre) guard(z, __uint_as_float(pr.x), (int)pr.y, in);
             if (fast) fkey_put(e, z, (int)pr.y, in);
             else if (in) {
                 if (compact) orow[e] = make_uint2(__float_as_uint(z), pr.y);
@@ -525,6 +531,307 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
     RSTAMP(7)
     if (p.fuse) final_select(compact ? n_out : total);
     RSTAMP(8)
+}
+
+// ---- shared recomputation: one decoder row for 32 playlists ------------------------------------------------------------------
+// A row's workgroup above fetches every survivor's decoder row (1 KiB) for ONE playlist: 534 KiB per playlist through a CU's
+// L1, a lane-owned chain of 256 v_readlane + v_fma pairs per candidate.  With one row per CU that is the launch's length
+// (~18 us); with many rows per CU the launch grows with rows x candidates -- 2 048 rows: 149 us against 109 for the filter
+// launch that decodes the whole vocabulary.  But the rows of a launch mostly want the SAME decoder rows (the popular head of
+// the vocabulary: on the bench model every playlist has the same 534 candidates, on a trained one most of them), and the
+// canonical chain acc = fmaf(h[k], W[c][k], acc), k ascending, is what v_mfma_f32_32x32x2_f32 performs for 32 columns x 32
+// playlists at a time (the fp32 kernels of decode_f32.hip: A = W, B = h, MFMA (g, e) takes k = 8 g + 2 e + hi).  So, for
+// launches of many rows, BEFORE the per-row launch:
+//   workgroup (segment s, group of 32 playlists): the candidates the filter workgroup s listed for those rows -> the UNION of
+//   their columns (an LDS hash table, dense ranks by a scan) -> per tile of 32 union columns the 128 MFMAs over the group's
+//   hidden rows (LDS, B-operand order) with the columns' decoder rows straight from the row-major fp32 copy -> a table
+//   z[union column][playlist] in LDS -> every candidate takes its own logit (+ bias: the same fp32 addition), is tested
+//   against the filter's promise (the bound guard, as above) and REPLACES its bound u in the list.
+// Only rows that the per-row launch would recompute without narrowing (same predicate); it then orders what it reads back.
+// A decoder row is fetched once per (segment, 32 playlists) instead of once per playlist; columns of the union that a
+// playlist did not list are computed for it and ignored (the matrix pipe is idle in this launch anyway).  Bits: identical --
+// the same instruction, operand order and k order as the fp32 path's logits, which the lane-owned fmaf chain reproduces.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int RS_ROWS = 32;            // playlists per workgroup (one MFMA row block)
+constexpr int RS_PR = 128;             // candidates per playlist and round
+constexpr int RS_PMAX = RS_ROWS * RS_PR;
+constexpr int RS_HASH = 2 * RS_PMAX;   // slots of the union's hash table (load <= 1/2)
+constexpr int RS_UPASS = 128;          // union columns per pass: one tile of 32 per wave
+constexpr int RS_ZLD = 33;             // row stride of the z table (floats): conflict-free both ways
+constexpr int RS_MAXH = 256;           // hidden sizes the kernel takes (H % 8 == 0): 32 KiB of hidden rows in LDS
+constexpr int RS_MAXSEG = 32;          // segments (filter workgroups' lists) one workgroup takes
+static_assert(RS_HASH == 8192, "the hash below keeps 13 bits");
+
+struct SharedP {
+    uint2* base; const int* cnt; int64_t seg_stride, row_stride, cnt_seg_stride; int nseg;
+    dae_exact_src x;
+    const int32_t* seed_row_ptr; int k, B, stage_cap;
+    int segb, nblk;                    // segments per workgroup, workgroups per group of 32 playlists
+    long long* stamps;                 // experiments build: stage stamps of workgroup 0 (DAE_DBG_S)
+};
+#ifdef DAE_EXPERIMENTS
+#define SSTAMP(i) if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_readcyclecounter();
+#else
+#define SSTAMP(i)
+#endif
+
+// grid = nblk x groups of 32 playlists, ~one workgroup per CU: the launch is a chain of memory round trips (counts -> pairs ->
+// decoder rows), so a workgroup takes as many segments as give its four waves a tile each.  (Half the tables and two workgroups
+// per CU: 20.4 us against 22 alone at 1 024 rows, 8.8 against 9.0 M playlists/s with four batches in flight.)
+// GT > 0: hidden = 8 GT known at compile time -- the chain's loop has no branches, so the ring's waits are exact counts (with a
+// run-time bound hipcc waits for EVERY load in flight at each step: 30 k cycles per tile against 9 k)
+template <int GT>
+__global__ __launch_bounds__(256, 1) void exact_rescore_shared_kernel(const SharedP p)
+{
+    __shared__ __attribute__((aligned(16))) float4 hB[(RS_MAXH / 8) * 64];    // [g][lane = hi 32 + j] {e = 0..3}: h[row j][8 g + 2 e + hi]
+    __shared__ float zt[RS_UPASS * RS_ZLD];
+    __shared__ unsigned hkey[RS_HASH];             // column + 1 (0: empty); after the scan: the column's rank in the union
+    __shared__ int ucol[RS_PMAX];                  // union columns by rank
+    __shared__ unsigned short pslot[RS_PMAX];      // hash slot of pair (j, q) of this round
+    __shared__ int r_pre[RS_ROWS][RS_MAXSEG + 1];  // per playlist: prefix of its counts over the workgroup's segments
+    __shared__ int r_tot[RS_ROWS];
+    __shared__ int s_wtot[4], s_maxc;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+    const int blk = blockIdx.x % p.nblk, grp = blockIdx.x / p.nblk;
+    const int s0 = blk * p.segb;
+    const int ns = p.nseg - s0 < p.segb ? p.nseg - s0 : p.segb;       // segments of this workgroup (>= 1 by the launcher)
+    const int row0 = grp * RS_ROWS;
+    const int H = GT > 0 ? 8 * GT : p.x.H, G8 = GT > 0 ? GT : (H >> 3);
+
+    // ---- which rows take part, and how many candidates the workgroup's segments hold for them --------------------------------
+    SSTAMP(0)
+    if (tid < RS_ROWS) r_tot[tid] = 0;
+    if (tid == 0) s_maxc = 0;
+    {
+        uint4* hk4 = reinterpret_cast<uint4*>(hkey);
+#pragma unroll
+        for (int i = 0; i < RS_HASH / 4 / 256; ++i) hk4[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    {
+        // (every load of the prologue is requested before the first is used: counts in fours, then the hidden rows)
+        const int j = tid & 31, part = tid >> 5;
+        const int row = row0 + j;
+        const int rowc = row < p.B ? row : p.B - 1;
+        float4 v0[4], v1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                  // the group's hidden rows (rows beyond the batch: zeros below)
+            const int g = part + 8 * i;
+            const float4* src = reinterpret_cast<const float4*>(p.x.h + (size_t)rowc * p.x.ld_h) + 2 * (g < G8 ? g : 0);
+            v0[i] = src[0]; v1[i] = src[1];
+        }
+        int sum = 0;
+        for (int sg0 = part; sg0 < p.nseg; sg0 += 32) {
+            int c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sg = sg0 + 8 * i;
+                c[i] = p.cnt[(size_t)(sg < p.nseg ? sg : 0) * p.cnt_seg_stride + rowc];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sg = sg0 + 8 * i;
+                if (sg < p.nseg && row < p.B) {
+                    sum += c[i];
+                    if (sg >= s0 && sg < s0 + ns) r_pre[j][sg - s0 + 1] = c[i];
+                }
+            }
+        }
+        if (sum) atomicAdd(&r_tot[j], sum);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = part + 8 * i;
+            const bool ok = row < p.B && g < G8;
+            hB[g * 64 + j] = ok ? make_float4(v0[i].x, v0[i].z, v1[i].x, v1[i].z) : make_float4(0.f, 0.f, 0.f, 0.f);        // hi 0: k = 8 g + 0, 2, 4, 6
+            hB[g * 64 + 32 + j] = ok ? make_float4(v0[i].y, v0[i].w, v1[i].y, v1[i].w) : make_float4(0.f, 0.f, 0.f, 0.f);   // hi 1: k = 8 g + 1, 3, 5, 7
+        }
+    }
+    __syncthreads();
+    if (tid < RS_ROWS) {
+        const int row = row0 + tid;
+        bool act = false;
+        if (row < p.B) {
+            const int total = r_tot[tid];
+            const bool bad = p.x.row_bad && p.x.row_bad[row] != 0;
+            const int need = p.k + (p.seed_row_ptr ? p.seed_row_ptr[row + 1] - p.seed_row_ptr[row] : 0);
+            const bool staged = !bad && total <= p.stage_cap && total > need + (need >> 1);      // (refine_body's predicate)
+            act = !bad && !staged && total > 0;
+        }
+        int run = 0;
+        r_pre[tid][0] = 0;
+        for (int i = 1; i <= ns; ++i) { run += act ? r_pre[tid][i] : 0; r_pre[tid][i] = run; }
+        if (run) atomicMax(&s_maxc, run);
+    }
+    __syncthreads();
+    const int maxc = s_maxc;
+    SSTAMP(1)
+    if (maxc == 0) return;
+    for (int r0 = 0; r0 < maxc; r0 += RS_PR) {
+        // ---- the round's pairs -> the union of their columns ------------------------------------------------------------------
+        // (a thread's 16 pairs, then their bias and bound, are requested together: one memory round trip each, not sixteen)
+        constexpr int NPT = RS_PMAX / 256;
+        uint2 pr[NPT]; int off[NPT]; float pb[NPT], pe[NPT];
+        {
+            // pair -> (segment, position): the segment by COUNTING the prefix entries at or below the flat index -- for all of
+            // a thread's pairs together, one independent LDS read each per segment (a search per pair is a chain of them)
+            int sgn[NPT], en[NPT], tot[NPT];
+#pragma unroll
+            for (int n = 0; n < NPT; ++n) {
+                const int pid = tid + 256 * n;
+                sgn[n] = 0; en[n] = r0 + (pid % RS_PR); tot[n] = r_pre[pid / RS_PR][ns];
+            }
+            for (int i = 1; i < ns; ++i) {
+#pragma unroll
+                for (int n = 0; n < NPT; ++n) sgn[n] += r_pre[(tid + 256 * n) / RS_PR][i] <= en[n];
+            }
+#pragma unroll
+            for (int n = 0; n < NPT; ++n) {
+                const int j = (tid + 256 * n) / RS_PR;
+                off[n] = en[n] < tot[n] ? (int)((int64_t)(s0 + sgn[n]) * p.seg_stride + (int64_t)(row0 + j) * p.row_stride +
+                                                (en[n] - r_pre[j][sgn[n]])) : -1;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NPT; ++n) pr[n] = p.base[off[n] >= 0 ? off[n] : 0];          // (unconditional: no branch between the loads)
+#pragma unroll
+        for (int n = 0; n < NPT; ++n) {
+            const int ci = off[n] >= 0 ? (int)pr[n].y - p.x.col_lo : 0;
+            pb[n] = p.x.bias[ci];
+            pe[n] = p.x.eps[ci];
+        }
+        // insert: every first attempt goes out before any answer is looked at; what collided probes on
+        unsigned sl[NPT], old[NPT];
+#pragma unroll
+        for (int n = 0; n < NPT; ++n) {
+            sl[n] = (pr[n].y * 2654435761u) >> 19;                             // 13 bits: RS_HASH = 8192 slots
+            old[n] = off[n] >= 0 ? atomicCAS(&hkey[sl[n]], 0u, pr[n].y + 1u) : 0u;
+        }
+#pragma unroll
+        for (int n = 0; n < NPT; ++n) {
+            if (off[n] >= 0) {
+                const unsigned key = pr[n].y + 1u;
+                unsigned o = old[n], s_ = sl[n];
+                while (o != 0u && o != key) {
+                    s_ = (s_ + 1u) & (unsigned)(RS_HASH - 1);
+                    o = atomicCAS(&hkey[s_], 0u, key);
+                }
+                pslot[tid + 256 * n] = (unsigned short)s_;
+            }
+        }
+        __syncthreads();
+        if (r0 == 0) { SSTAMP(2) }
+        // dense ranks: thread t owns RS_HASH / 256 consecutive slots
+        constexpr int SPT = RS_HASH / 256;
+        unsigned kv_[SPT];
+        {
+            const uint4* hk4 = reinterpret_cast<const uint4*>(hkey) + tid * (SPT / 4);
+#pragma unroll
+            for (int e = 0; e < SPT / 4; ++e) { const uint4 q4 = hk4[e]; kv_[4 * e] = q4.x; kv_[4 * e + 1] = q4.y; kv_[4 * e + 2] = q4.z; kv_[4 * e + 3] = q4.w; }
+        }
+        int own = 0;
+#pragma unroll
+        for (int e = 0; e < SPT; ++e) own += kv_[e] != 0u;
+        int incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int pre = incl - own;
+        for (int w = 0; w < wave; ++w) pre += s_wtot[w];
+        const int U = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        if (own) {
+#pragma unroll
+            for (int e = 0; e < SPT; ++e) {
+                const unsigned kv = kv_[e];
+                if (kv != 0u) { ucol[pre] = (int)(kv - 1u); hkey[tid * SPT + e] = (unsigned)pre; ++pre; }
+            }
+        }
+        __syncthreads();
+        if (r0 == 0) { SSTAMP(3) if (p.stamps && blockIdx.x == 0 && tid == 0) p.stamps[8] = U; }
+
+        for (int u0 = 0; u0 < U; u0 += RS_UPASS) {
+            // ---- one tile of 32 union columns per wave: the canonical chains of 32 x 32 (column, playlist) pairs -------------
+            const int t0 = u0 + 32 * wave;
+            if (t0 < U) {                                                      // wave-uniform
+                const int ui = t0 + (lane & 31);
+                const int colv = ucol[ui < U ? ui : U - 1];
+                const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * H);
+                // lane (i, hi) fetches k = 8 g + 4 hi .. + 3 of its column's row -- ONE 16-byte load per lane and group, 32 bytes per
+                // row and instruction (both halves fetching the row's 32 bytes and selecting took twice the instructions, and the
+                // launch was bound by the address unit: 32 rows per instruction) -- and v_permlane32_swap hands each half the
+                // k it multiplies: MFMA e takes k = 8 g + 2 e + hi
+                constexpr int QD = 8;                                          // k-groups of 8 in flight
+                const float4* wq = wr + hi;
+                float4 wv[QD];
+#pragma unroll
+                for (int d = 0; d < QD; ++d)
+                    if (GT > 0 || d < G8) wv[d] = wq[2 * d];
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int g = 0; g < (GT > 0 ? GT : RS_MAXH / 8); ++g) {
+                    if (GT > 0 || g < G8) {                                    // wave-uniform (H < 256: the chain ends at H)
+                        const float4 w = wv[g % QD];
+                        if (GT > 0 ? (g + QD < GT) : (g + QD < G8)) wv[g % QD] = wq[2 * (g + QD)];
+                        const float4 b = hB[g * 64 + lane];
+                        __builtin_amdgcn_sched_barrier(0);                     // the refill stays AHEAD of this group's MFMAs (hipcc sinks it to its use)
+                        // lower half holds k = 0..3 of the group, upper half k = 4..7: swap(x, y) -> {k0 | k1}, {k4 | k5}; swap(z, w) -> {k2 | k3}, {k6 | k7}
+                        const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.x), __float_as_uint(w.y), false, false);
+                        const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(w.z), __float_as_uint(w.w), false, false);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(s01[0]), b.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(s23[0]), b.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(s01[1]), b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(s23[1]), b.w, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // lane (j, hi), register r: column (r & 3) + 8 (r >> 2) + 4 hi of the tile, playlist j
+                const int j = lane & 31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zt[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi) * RS_ZLD + j] = acc[r];
+            }
+            if (r0 == 0 && u0 == 0) { SSTAMP(4) }
+            __syncthreads();
+            if (r0 == 0 && u0 == 0) { SSTAMP(5) }
+            // ---- every pair of the round whose column sits in this pass takes its logit ---------------------------------------
+#pragma unroll
+            for (int n = 0; n < NPT; ++n) {
+                if (off[n] >= 0) {
+                    const int pid = tid + 256 * n;
+                    const int rk = (int)hkey[pslot[pid]] - u0;
+                    if (rk >= 0 && rk < RS_UPASS) {
+                        const int colv = (int)pr[n].y;
+                        const float z = zt[rk * RS_ZLD + pid / RS_PR] + pb[n];
+                        if (p.x.guard) {                                       // the bound guard (refine_body)
+                            const float u = __uint_as_float(pr[n].x);
+                            const float e2 = 2.0f * pe[n] * 1.000001f;
+                            const float lo = dae_okey_inv(dae_okey(u - e2) - 2u);
+                            if (!(z <= u && z >= lo)) {
+                                atomicAdd(p.x.guard, 1);
+                                p.x.guard[1] = colv;
+                            }
+                        }
+                        p.base[off[n]].x = __float_as_uint(z);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (r0 + RS_PR < maxc) {
+            uint4* hk4 = reinterpret_cast<uint4*>(hkey);
+#pragma unroll
+            for (int i = 0; i < RS_HASH / 4 / 256; ++i) hk4[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
+        if (r0 == 0) { SSTAMP(6) }
+    }
+    SSTAMP(7)
 }
 
 __global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
@@ -609,6 +916,47 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     if (shape_env) shape = atoi(shape_env);
     slim = shape == 0;
     p.stage_cap = many ? RF_STAGE / 2 : RF_STAGE;
+    // launches of many rows: the rows that are recomputed without narrowing get their logits from the shared recomputation
+    // (exact_rescore_shared_kernel: a decoder row fetched once per 32 playlists, the chains on the matrix pipe) first
+    bool shared = many && (x.H & 7) == 0 && x.H <= RS_MAXH;
+    static const char* shared_env = dae_exp_env("DAE_RF_SHARED");                             // A/B (experiments build)
+    if (shared_env) shared = atoi(shared_env) != 0 && (x.H & 7) == 0 && x.H <= RS_MAXH;
+    p.pre = shared ? 1 : 0; p.B = B;
+    if (shared) {
+        SharedP sp;
+        sp.base = p.base; sp.cnt = p.cnt; sp.seg_stride = p.seg_stride; sp.row_stride = p.row_stride;
+        sp.cnt_seg_stride = p.cnt_seg_stride; sp.nseg = p.nseg; sp.x = x; sp.seed_row_ptr = seed_row_ptr; sp.k = k; sp.B = B;
+        sp.stage_cap = p.stage_cap;
+        const int ngrp = (B + RS_ROWS - 1) / RS_ROWS;
+        int nblk = DAE_NUM_CU / ngrp;                                      // ~ one workgroup per CU
+        if (nblk < 1) nblk = 1;
+        if (nblk > p.nseg) nblk = p.nseg;
+        int segb = (p.nseg + nblk - 1) / nblk;
+        if (segb > RS_MAXSEG) segb = RS_MAXSEG;
+        nblk = (p.nseg + segb - 1) / segb;
+        sp.segb = segb; sp.nblk = nblk;
+        sp.stamps = nullptr;
+#ifdef DAE_EXPERIMENTS
+        static const bool dbgS = dae_exp_env("DAE_DBG_S") != nullptr;
+        static long long* sbuf = nullptr;
+        static int scalls = 0;
+        if (dbgS) {
+            if (!sbuf) { (void)hipMalloc(&sbuf, 16 * 8); (void)hipMemset(sbuf, 0, 16 * 8); }
+            sp.stamps = sbuf;
+            if ((++scalls % 100) == 0) {
+                long long h[16];
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpy(h, sbuf, sizeof(h), hipMemcpyDeviceToHost);
+                fprintf(stderr, "SHARED wg0 (grid %d x %d, segb %d):", ngrp, nblk, segb);
+                for (int i = 1; i < 8; ++i) fprintf(stderr, " [%d]%lld", i, h[i] - h[0]);
+                fprintf(stderr, " U=%lld\n", h[8]);
+            }
+        }
+#endif
+        if (x.H == 256) hipLaunchKernelGGL(exact_rescore_shared_kernel<32>, dim3((unsigned)(ngrp * nblk)), dim3(256), 0, ctx->stream, sp);
+        else hipLaunchKernelGGL(exact_rescore_shared_kernel<0>, dim3((unsigned)(ngrp * nblk)), dim3(256), 0, ctx->stream, sp);
+        DAE_CHECK_LAUNCH(ctx, "exact_rescore_shared_kernel");
+    }
     size_t dyn = (size_t)p.stage_cap * sizeof(float);
     const size_t tb = (size_t)(shape == 0 ? 4 : shape == 1 ? 8 : 16) * 64 * RF_ROWSTRIDE * sizeof(float);
     if (dyn < tb) dyn = tb;

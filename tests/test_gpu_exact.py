@@ -382,3 +382,55 @@ def test_recommend_re_scores_in_fp32_when_the_guard_fires(tmp_path):
         got = m.recommend(pos, ones, SEEDS_FROM_INPUT, k=k, dtype="exact_bf16")
     assert m._guard_fallbacks == 1
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+
+
+# ---- round 5: launches of many rows (>= 768) -- the shared recomputation (refine.hip exact_rescore_shared_kernel) ----------
+@pytest.mark.parametrize("V,nt,H,B,k,bias,dist,scale", [
+    (20000, 17000, 256, 800, 500, "zipf", "zipf", 1.0),       # popularity-dominated: the rows share their candidates
+    (9000, 8000, 128, 1000, 100, "zeros", "uniform", 40.0),   # rows rank the columns differently: large unions, several passes
+    (6000, 6000, 64, 777, 500, "zipf", "zipf", 1.0),          # hidden < 256: the chains end at H; a ragged last group of rows
+    (7000, 5000, 72, 800, 300, "zipf", "zipf", 1.0),          # H % 8 == 0, not a multiple of 32
+    (5000, 4000, 36, 900, 200, "zipf", "zipf", 1.0),          # H % 8 != 0: the per-row recomputation, many rows
+])
+def test_exact_many_rows_are_the_fp32_oracle_bit_for_bit(V, nt, H, B, k, bias, dist, scale):
+    """Launches of >= 768 rows recompute the survivors 32 playlists at a time on the fp32 matrix pipe (one fetch of a decoder
+    row per 32 playlists) before the per-row ordering: the same lists and scores as the oracle, guard silent."""
+    import torch
+    c = _lib.Context(0)
+    try:
+        p = _problem(V, nt, H, B, bias=bias, dist=dist, scale=scale)
+        c.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+        score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+        idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+        sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+        for _ in range(2):
+            c.score_topk(_dev(p["rp"]), _dev(p["col"]), _dev(p["val"]), _dev(p["W_enc"]), _dev(p["b_enc"]), nt,
+                         _dev(p["srp"]), _dev(sc), k, score, idx, dtype=EX)
+        s_ref, i_ref = oracle.score_batch(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"], p["W_dec"], p["b_dec"], V, nt,
+                                          p["srp"], p["sc"], k)
+        _check(idx.cpu().numpy(), score.cpu().numpy(), i_ref, s_ref)
+        assert c.exact_guard_read() == (0, -1)
+        st = c.exact_stats_read()
+        assert st["candidates_per_row"] >= st["recomputed_per_row"] > 0
+    finally:
+        c.close()
+
+
+def test_forged_bound_is_detected_in_a_launch_of_many_rows():
+    """The bound guard of the shared recomputation: forged bounds are counted there as in the per-row launch."""
+    import torch
+    c = _lib.Context(0)
+    try:
+        V, nt, H, B, k = 30000, 26000, 256, 800, 500
+        p = _problem(V, nt, H, B, bias="zipf", scale=40.0)
+        c.set_exact_margin(1e-3)
+        c.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+        score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+        idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+        sc = p["sc"] if p["sc"].size else np.zeros(1, np.int32)
+        c.score_topk(_dev(p["rp"]), _dev(p["col"]), _dev(p["val"]), _dev(p["W_enc"]), _dev(p["b_enc"]), nt,
+                     _dev(p["srp"]), _dev(sc), k, score, idx, dtype=EX)
+        n, col = c.exact_guard_read()
+        assert n > 0 and 0 <= col < nt
+    finally:
+        c.close()
