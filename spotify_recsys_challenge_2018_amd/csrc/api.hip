@@ -150,7 +150,7 @@ int dae_destroy(dae_ctx* ctx)
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
-                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch};
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -497,6 +497,23 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
         rc = dae_launch_tile_order(ctx, pkm, nrank, n_samp, S);
         if (rc) return rc;
         order = static_cast<const int*>(pkm.order.p);
+        // bf16 launches whose sample takes several rounds of the phase-A workgroups (many rows: few workgroups per row group): the
+        // sample re-dealt so that a workgroup's tiles of a round come from different popularity bands (decode_f32.hip
+        // tile_band_kernel); the list is this context's, rebuilt when the order or the geometry changes
+        static const bool no_band = dae_exp_env("DAE_NO_BAND") != nullptr;                    // A/B (experiments build)
+        const int n_ws_s = g.nb_rg * g.waves;
+        if (dtype == DAE_DTYPE_BF16 && n_samp > n_ws_s && !no_band) {
+            const void* band_was = ctx->tile_band.p;
+            rc = dae_reserve(ctx, ctx->tile_band, (size_t)ntiles * sizeof(int));
+            if (rc) return rc;
+            if (ctx->tile_band.p != band_was) ctx->band_gen = -1;
+            if (ctx->band_gen != pkm.order_gen || ctx->band_nsamp != n_samp || ctx->band_nbrg != g.nb_rg || ctx->band_waves != g.waves) {
+                rc = dae_launch_tile_band(ctx, order, ntiles, n_samp, g.nb_rg, g.waves, static_cast<int*>(ctx->tile_band.p));
+                if (rc) return rc;
+                ctx->band_gen = pkm.order_gen; ctx->band_nsamp = n_samp; ctx->band_nbrg = g.nb_rg; ctx->band_waves = g.waves;
+            }
+            order = static_cast<const int*>(ctx->tile_band.p);
+        }
     }
     dae_tileset tsA{n_samp, fused ? S : 1, fused ? 3 : 0, order};
     float* gmax = nullptr;

@@ -46,6 +46,7 @@ struct dae_packed {            // one prepacked decoder image
     dae_buf ident;             // [ntiles] int32: 0, 1, 2, ... (the tile list of "all tiles")
     int order_nrank = -1;      // rankable columns the order was built for (-1: none)
     int order_nsamp = -1;
+    long long order_gen = 0;   // process-wide stamp of the last rebuild of `order` (what a context's band list was cut from)
     // DAE_DTYPE_BF16_EXACT (bf16 image only; decode_f32.hip exact_bounds_kernel): per column c a rigorous bound
     // eps_c >= |z32(r, c) - z16(r, c)| for every hidden row with entries in [0, 1], the bias fragments of
     // b - eps (phase A: lower bounds of the fp32 logits) and b + eps (filter: upper bounds), and a row-major fp32
@@ -126,6 +127,8 @@ struct dae_ctx {
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
     dae_buf title_scratch;     // dae_title_score_exact: CSR, seed lists, hidden rows, features, mixing weights of the launch
+    // the bias-ordered tile list with its sample RE-DEALT for a launch geometry (dae_launch_tile_band): which order it was cut from
+    dae_buf tile_band; long long band_gen = -1; int band_nsamp = 0, band_nbrg = 0, band_waves = 0;
 
     // profiling of the dominant kernel
     bool prof_on = false;
@@ -258,6 +261,9 @@ int dae_launch_tile_iota(dae_ctx* ctx, int* dst, int ntiles);      // dst[i] = i
 // (re)build pk.order for `nrank` rankable columns; the first n_samp entries are the threshold sample
 int dae_filter_block_tiles(const dae_rowgeom& g, int n_items, int dtype, int Hp, bool mixed = false);
 int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, int S);
+// band[0 .. n_samp): the sample of `order` dealt to the phase-A launch's slots so that the tiles ONE workgroup decodes in a round
+// (item = round * nb_rg * waves + wave * nb_rg + bir) come from `waves` different popularity bands; band[n_samp ..) = order
+int dae_launch_tile_band(dae_ctx* ctx, const int* order, int ntiles, int n_samp, int nb_rg, int waves, int* band);
 
 struct dae_tileset {        // which wave tiles a decode launch walks
     int n_items;            // number of tiles in the set

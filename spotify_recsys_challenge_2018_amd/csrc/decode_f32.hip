@@ -24,6 +24,7 @@
 //     W tile hits that XCD's L2 instead of HBM.
 #include <climits>
 
+#include <atomic>
 #include "dae_internal.h"
 
 namespace {
@@ -1723,6 +1724,31 @@ __global__ __launch_bounds__(256) void tile_iota_kernel(int n, int* __restrict__
 
 // fallback for images of more than ORDER_MAX_TILES tiles (and the DAE_SAMPLE=strided experiment):
 // every S-th tile first, then the others
+// The threshold sample re-dealt for a launch of several ROUNDS (dae_launch_tile_band).  Phase A takes, per (row, position in the
+// tile), the maximum over the `waves` tiles a workgroup decodes together in a round; the threshold is the (k + seeds)-th largest
+// of these maxima, so two winners in one group cost one of them.  Item i of the sample goes to round i / n_ws, wave (i % n_ws) /
+// nb_rg, workgroup i % nb_rg: with ONE round the group's tiles sit nb_rg places apart in the bias order (128 at batch 256) --
+// different popularity bands; with ten rounds (2 048 rows: 16 workgroups per row group) they sit 16 apart, round 0 is the 64 most
+// popular tiles in 16 groups of 4, ~550 winners share 512 maxima, the threshold drops into the next round's maxima and 1 155
+// candidates per row pass instead of 534.  Here wave w's items (all rounds, all workgroups) take the w-th band of the order.
+__global__ __launch_bounds__(256) void tile_band_kernel(const int* __restrict__ order, int ntiles, int n_samp, int nb_rg,
+                                                        int waves, int* __restrict__ band)
+{
+    const int n_ws = nb_rg * waves;
+    const int R = n_samp / n_ws, rem_last = n_samp - R * n_ws;
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < ntiles; it += gridDim.x * 256) {
+        if (it >= n_samp) { band[it] = order[it]; continue; }
+        const int round = it / n_ws, rem = it - round * n_ws, w = rem / nb_rg, bir = rem - w * nb_rg;
+        int rank = round * nb_rg + bir;                       // items of wave w in front of this one: every lower (round, bir) exists
+        for (int wp = 0; wp < w; ++wp) {                      // + all items of the waves before it
+            int last = rem_last - wp * nb_rg;
+            last = last < 0 ? 0 : (last > nb_rg ? nb_rg : last);
+            rank += R * nb_rg + last;
+        }
+        band[it] = order[rank];
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_order_strided_kernel(int ntiles, int n_samp, int S,
                                                                  int* __restrict__ order)
 {
@@ -2097,6 +2123,17 @@ int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, i
     }
     DAE_CHECK_LAUNCH(ctx, "tile_order_kernel");
     pk.order_nrank = nrank; pk.order_nsamp = n_samp;
+    static std::atomic<long long> gen{0};
+    pk.order_gen = ++gen;
+    return DAE_OK;
+}
+
+int dae_launch_tile_band(dae_ctx* ctx, const int* order, int ntiles, int n_samp, int nb_rg, int waves, int* band)
+{
+    if (ntiles <= 0) return DAE_OK;
+    hipLaunchKernelGGL(tile_band_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, ctx->stream, order, ntiles, n_samp, nb_rg,
+                       waves, band);
+    DAE_CHECK_LAUNCH(ctx, "tile_band_kernel");
     return DAE_OK;
 }
 
