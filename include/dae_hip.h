@@ -419,6 +419,17 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
                        const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F,
                        float keep_prob, uint32_t seed, float* feat, int64_t ld, int32_t* argmax, float* feat_raw);
 
+/* A FROZEN title scorer's convolutions as a table (scoring: main_challenge.py:80-90 runs Char_CNN.py:23-62 with fixed
+ * variables on every batch).  Titles are rows of character ids, so the inner sum of the convolution over the embedding has
+ * only fs x (n_char + 1) distinct terms per filter: T[d][c][f] = sum_e emb[c][e] Conv_W[d][e][f].  After this call,
+ * dae_title_features / dae_title_score on this context, called with THESE emb / conv_w arrays, keep_prob = 1 and no argmax /
+ * feat_raw, sum fs table entries per (position, filter) instead of fs x E products -- the same real number in another
+ * summation order (a different fp32 rounding; the title path is specified to a tolerance, as TF's conv2d has no documented
+ * order).  The caller calls it again after the variables changed, or with emb = NULL to drop the table (training does:
+ * calls with keep_prob < 1 or argmax never use it). */
+int dae_title_prepack_features(dae_ctx* ctx, const float* emb, int n_char, int E, const float* conv_w,
+                               const int32_t* filter_sizes, int n_sizes, int F);
+
 /* DAEs.py:180: dae_score[r, c] = title_score[r, c] * w_title[r] + dae_score[r, c] * w_playlist[r] over the first
  * ncols columns; the weights are DAEs.py:159-162 (x_count = row_sum * input_keep_prob; u / (u + x_count + 1e-10),
  * x_count / (u + x_count + 1e-10)), computed by the caller from the feed. */

@@ -18,7 +18,7 @@ EXPORTS = [
     "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_prepack_decoder_rows", "dae_share_decoder", "dae_exact_bounds",
     "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_guard_snapshot", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
-    "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features",
+    "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features", "dae_title_prepack_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_title_score", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
     "dae_adam_rows_begin", "dae_adam_rows_apply", "dae_adam_rows_flush", "dae_set_enc_grad_prezeroed",
     "dae_arm_decoder_adam", "dae_set_decode_gate", "dae_set_overlap_hint",
@@ -95,6 +95,7 @@ def load():
         [vp, vp] + [vp] * 3 + [vp] * 4 + [c_int] * 5 + [c_f, c_f, c_u32, c_f] + [vp] * 4)
     lib.dae_title_features.argtypes = [vp, vp, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(ctypes.c_int32),
                                        c_int, c_int, c_f, c_u32, vp, c_i64, vp, vp]
+    lib.dae_title_prepack_features.argtypes = [vp, vp, c_int, c_int, vp, ctypes.POINTER(ctypes.c_int32), c_int, c_int]
     lib.dae_mix_scores.argtypes = [vp, vp, c_i64, vp, c_i64, vp, vp, c_int, c_int]
     lib.dae_decode_mix_term.argtypes = [vp, vp, c_int, c_int, c_int, vp, c_int, vp, c_i64]
     lib.dae_set_score_mix.argtypes = [vp, vp, c_i64, c_int, vp]

@@ -150,7 +150,7 @@ int dae_destroy(dae_ctx* ctx)
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
-                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band};
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band, &ctx->title_tab};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -1042,6 +1042,14 @@ int dae_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const 
     if (!(keep_prob > 0.f && keep_prob <= 1.f)) return dae_fail(ctx, DAE_ERR_ARG, "keep probability must be in (0,1]");
     return dae_launch_title_features(ctx, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F,
                                      keep_prob, seed, feat, ld, argmax, feat_raw);
+}
+
+int dae_title_prepack_features(dae_ctx* ctx, const float* emb, int n_char, int E, const float* conv_w,
+                               const int32_t* filter_sizes, int n_sizes, int F)
+{
+    if (!ctx) return DAE_ERR_ARG;
+    if (emb && (!conv_w || !filter_sizes)) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
+    return dae_launch_title_table(ctx, emb, n_char, E, conv_w, filter_sizes, n_sizes, F);
 }
 
 int dae_title_score(dae_ctx* tc, dae_ctx* dc, int dtype, const int64_t* positions, const float* values, int values_broadcast,

@@ -127,6 +127,10 @@ struct dae_ctx {
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
     dae_buf title_scratch;     // dae_title_score_exact: CSR, seed lists, hidden rows, features, mixing weights of the launch
+    // dae_title_prepack_features (title.hip): the convolutions of a FROZEN title scorer as a table over (filter size, offset,
+    // character) -- which variables it was built from
+    dae_buf title_tab; const float* ttab_emb = nullptr; const float* ttab_w = nullptr; int ttab_nchar = 0, ttab_E = 0, ttab_F = 0,
+        ttab_nsizes = 0; int ttab_fs[8] = {0};
     // the bias-ordered tile list with its sample RE-DEALT for a launch geometry (dae_launch_tile_band): which order it was cut from
     dae_buf tile_band; long long band_gen = -1; int band_nsamp = 0, band_nbrg = 0, band_waves = 0;
 
@@ -346,6 +350,8 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
                               int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
                               int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
                               int32_t* argmax, float* feat_raw);
+int dae_launch_title_table(dae_ctx* ctx, const float* emb, int n_char, int E, const float* conv_w, const int32_t* filter_sizes,
+                           int n_sizes, int F);
 int dae_launch_row_sums(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B,
                         float ikp, uint32_t seed, float* out);
 int dae_launch_mix_weights(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, const float* val, int B, float ikp,

@@ -486,6 +486,8 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
             rc = dae_set_stream(L.tctx, L.stream);
             if (!rc) rc = i == 0 ? dae_prepack_decoder(L.tctx, tw->out_WT, tw->out_b, V, tw->ld_feat, 0, V, dtype)
                                  : dae_share_decoder(L.tctx, p->lanes[0].tctx, dtype);
+            // (the scorer is frozen for the life of the pipeline: its convolutions as a table, dae_title_prepack_features)
+            if (!rc) rc = dae_title_prepack_features(L.tctx, tw->emb, tw->n_char, tw->E, tw->conv_w, tw->fs.data(), tw->n_sizes, tw->F);
             if (rc) return bail(rc, dae_last_error(L.tctx));
             if (i == 0 && hipStreamSynchronize(L.stream) != hipSuccess) return bail(DAE_ERR_HIP, "prepack failed");
             (void)dae_set_overlap_hint(L.tctx, lanes);

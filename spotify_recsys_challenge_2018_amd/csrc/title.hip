@@ -242,6 +242,77 @@ __global__ __launch_bounds__(NW * 64) void title_features_mfma_kernel(const Titl
     for (int fi = nf + tid; fi < p.ld; fi += NW * 64) p.feat[(size_t)row * p.ld + fi] = 0.0f;
 }
 
+// ---- a FROZEN scorer's convolutions as a table (dae_title_prepack_features) --------------------------------------------------
+// Scoring (`--challenge`, main_challenge.py:80-90) runs the title scorer with fixed variables on ~10^4 batches.  A title is a
+// row of CHARACTER IDS (41 of them + padding, spotify_reader.py:36), so the convolution's inner sum over the embedding,
+//     conv[pos][f] = b[f] + sum_d sum_e emb[t[pos + d]][e] W[d][e][f],
+// has only fs x (n_char + 1) distinct inner terms per filter: T[d][c][f] = sum_e emb[c][e] W[d][e][f] (the fmaf chain over e
+// from +0; padding and out-of-range ids: the zero row).  With the table conv[pos][f] = b[f] + T[0][t[pos]][f] + ... (d
+// ascending) costs fs additions instead of fs x E multiply-adds: 24 x 42 x 100 floats = 403 KB, resident in L2, built in
+// microseconds; 750 titles: 106 us of fp32 MFMA (title_features_mfma_kernel) -> a few us of table reads.
+// ARITHMETIC: the same real number as the chain kernels above, summed in another order (e first, then d) -- a different fp32
+// rounding of it, as any other order would be (TF's conv2d has no documented order: the title path is compared with the
+// reference restatement to a TOLERANCE, oracle/title_numpy.py; tests/test_gpu_title.py bounds the two orders against each
+// other).  Used ONLY for inference calls (keep_prob = 1, no argmax / raw features wanted) on a context whose table was built
+// from the very arrays the call passes; training keeps the chains.  fp32 and exact_bf16 title scoring read the same features,
+// so their lists stay bit-identical to each other.
+__global__ __launch_bounds__(128) void title_table_build_kernel(const float* __restrict__ emb, int n_char, int E,
+                                                                const float* __restrict__ Wd, int F, float* __restrict__ T)
+{
+    // blockIdx.x = d * (n_char + 1) + c of ONE filter size (Wd = its [fs][E][F] weights, T = its [fs][n_char + 1][F] table)
+    const int nc1 = n_char + 1;
+    const int d = blockIdx.x / nc1, c = blockIdx.x - d * nc1;
+    for (int f = threadIdx.x; f < F; f += 128) {
+        float acc = 0.0f;
+        if (c < n_char)
+            for (int e = 0; e < E; ++e) acc = fmaf(emb[(size_t)c * E + e], Wd[((size_t)d * E + e) * F + f], acc);
+        T[(size_t)blockIdx.x * F + f] = acc;
+    }
+}
+
+constexpr int TT_PMAX = 32;        // window positions per filter size (the MFMA kernel's bound as well)
+__global__ __launch_bounds__(256) void title_features_table_kernel(const TitleP p, const float* __restrict__ T)
+{
+    __shared__ int ts[T_MAX_LEN + TT_PMAX];           // the title's table rows (ids; padding / invalid -> the zero row), zero-row padded
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nc1 = p.n_char + 1;
+    for (int i = tid; i < T_MAX_LEN + TT_PMAX; i += 256) {
+        int t = p.n_char;
+        if (i < p.L) { const int v = p.titles[(size_t)row * p.L + i]; if (v >= 0 && v < p.n_char) t = v; }
+        ts[i] = t;
+    }
+    __syncthreads();
+    const int nf = p.n_sizes * p.F;
+    for (int fi = tid; fi < nf; fi += 256) {
+        const int i = fi / p.F, f = fi - i * p.F;
+        const int fs = p.fs[i];
+        const int P = p.L - fs + 1;                   // 1 .. 32 (the launcher checks)
+        int t_off = 0;
+        for (int q = 0; q < i; ++q) t_off += p.fs[q] * nc1 * p.F;
+        const float* Tf = T + t_off + f;
+        const float b = p.conv_b[fi];
+        float acc[TT_PMAX];
+#pragma unroll
+        for (int pos = 0; pos < TT_PMAX; ++pos) acc[pos] = b;
+        for (int d = 0; d < fs; ++d) {                // d ascending; the 32 positions' reads are independent of each other
+            const float* Td = Tf + (size_t)d * nc1 * p.F;
+            // (only the size's own P positions are fetched: the launch is bound by the table bytes it pulls through L1)
+#pragma unroll
+            for (int pos = 0; pos < TT_PMAX; ++pos)
+                if (pos < P) acc[pos] += Td[(size_t)ts[pos + d] * p.F];
+        }
+        float best = 0.0f;                            // ReLU, then the first maximum over the positions
+        bool first = true;
+#pragma unroll
+        for (int pos = 0; pos < TT_PMAX; ++pos) {
+            const float a = acc[pos] > 0.0f ? acc[pos] : 0.0f;
+            if (pos < P && (first || a > best)) { best = a; first = false; }
+        }
+        p.feat[(size_t)row * p.ld + fi] = best;
+    }
+    for (int fi = nf + tid; fi < p.ld; fi += 256) p.feat[(size_t)row * p.ld + fi] = 0.0f;
+}
+
 // y = title * w_title[row] + dae * w_playlist[row], written over the dae scores (DAEs.py:180)
 __global__ __launch_bounds__(256) void mix_scores_kernel(const float* __restrict__ ts, int64_t ld_t,
                                                          float* __restrict__ ds, int64_t ld_d,
@@ -555,6 +626,34 @@ int dae_launch_title_conv_backward(dae_ctx* ctx, const int32_t* titles, int B, i
     return DAE_OK;
 }
 
+// emb == nullptr: drop the table (the variables are about to change)
+int dae_launch_title_table(dae_ctx* ctx, const float* emb, int n_char, int E, const float* conv_w, const int32_t* filter_sizes,
+                           int n_sizes, int F)
+{
+    ctx->ttab_emb = nullptr; ctx->ttab_w = nullptr;
+    if (!emb) return DAE_OK;
+    if (n_sizes < 1 || n_sizes > T_MAX_SIZES || n_char < 1 || E < 1 || E > T_MAX_EMB || F < 1)
+        return dae_fail(ctx, DAE_ERR_ARG, "dae_title_prepack_features: bad shape");
+    size_t total = 0;
+    for (int i = 0; i < n_sizes; ++i) {
+        if (filter_sizes[i] < 1 || filter_sizes[i] > T_MAX_LEN) return dae_fail(ctx, DAE_ERR_ARG, "filter size %d", filter_sizes[i]);
+        total += (size_t)filter_sizes[i] * (n_char + 1) * F;
+    }
+    int rc = dae_reserve(ctx, ctx->title_tab, total * sizeof(float));
+    if (rc) return rc;
+    size_t t_off = 0, w_off = 0;
+    for (int i = 0; i < n_sizes; ++i) {
+        const int fs = filter_sizes[i];
+        hipLaunchKernelGGL(title_table_build_kernel, dim3((unsigned)(fs * (n_char + 1))), dim3(128), 0, ctx->stream, emb, n_char, E,
+                           conv_w + w_off, F, static_cast<float*>(ctx->title_tab.p) + t_off);
+        DAE_CHECK_LAUNCH(ctx, "title_table_build_kernel");
+        t_off += (size_t)fs * (n_char + 1) * F; w_off += (size_t)fs * E * F;
+        ctx->ttab_fs[i] = fs;
+    }
+    ctx->ttab_emb = emb; ctx->ttab_w = conv_w; ctx->ttab_nchar = n_char; ctx->ttab_E = E; ctx->ttab_F = F; ctx->ttab_nsizes = n_sizes;
+    return DAE_OK;
+}
+
 int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L, const float* emb, int n_char,
                               int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes,
                               int n_sizes, int F, float kp, uint32_t seed, float* feat, int64_t ld,
@@ -567,6 +666,21 @@ int dae_launch_title_features(dae_ctx* ctx, const int32_t* titles, int B, int L,
     int fs_min = L, fs_max = 1;
     for (int i = 0; i < n_sizes; ++i) { fs_min = p.fs[i] < fs_min ? p.fs[i] : fs_min; fs_max = p.fs[i] > fs_max ? p.fs[i] : fs_max; }
     const int p_max = L - fs_min + 1;                 // most window positions of any size
+    // inference on a context that holds the table of exactly these variables (dae_title_prepack_features): fs additions per
+    // (position, filter) instead of fs x E multiply-adds
+    static const bool no_table = dae_exp_env("DAE_TITLE_NO_TABLE") != nullptr;                // A/B (experiments build)
+    if (ctx->title_tab.p && ctx->ttab_emb == emb && ctx->ttab_w == conv_w && ctx->ttab_nchar == n_char && ctx->ttab_E == E &&
+        ctx->ttab_F == F && ctx->ttab_nsizes == n_sizes && kp == 1.0f && !argmax && !feat_raw && p_max >= 1 && p_max <= TT_PMAX &&
+        !no_table) {
+        bool same = true;
+        for (int i = 0; i < n_sizes; ++i) same = same && ctx->ttab_fs[i] == p.fs[i];
+        if (same) {
+            hipLaunchKernelGGL(title_features_table_kernel, dim3(B), dim3(256), 0, ctx->stream, p,
+                               static_cast<const float*>(ctx->title_tab.p));
+            DAE_CHECK_LAUNCH(ctx, "title_features_table_kernel");
+            return DAE_OK;
+        }
+    }
     static const bool generic = dae_exp_env("DAE_TITLE_GENERIC") != nullptr;          // A/B against the first kernel
     bool even_k = true;
     for (int i = 0; i < n_sizes; ++i) even_k = even_k && ((p.fs[i] * E) % 2 == 0);

@@ -1374,7 +1374,7 @@ class DAE_title(DAE):
         deno = u + x_count + 1e-10
         w_t, w_p = (u / deno).contiguous(), (x_count / deno).contiguous()
         # title forward, keeping what the backward pass needs
-        tm._ensure_packed()
+        tm._ensure_packed(features_table=False)
         feat, d_titles, arg, raw = tm.features(titles, self.n_batch, title_keep_prob, seed, keep_for_backward=True)
         zt = torch.empty((self.n_batch, self.n_input), dtype=torch.float32, device=dev)
         tm.ctx.decode_dense(feat, zt, apply_sigmoid=False)

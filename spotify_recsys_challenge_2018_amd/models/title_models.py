@@ -118,6 +118,7 @@ class Char_CNN:
         self.p["Output_b"] = dev_t(host["Output_b"])
         self._packed_dirty = True
         self._params_gen = self.__dict__.get("_params_gen", 0) + 1      # (a cached dae_pipeline holds images of the old variables)
+        self._drop_features_table()
 
     def get_params(self):
         """Host dict under the TF variable names and shapes."""
@@ -152,10 +153,29 @@ class Char_CNN:
             return side_stream_of._to_dev(t, torch.int32, side_stream=True)
         return torch.from_numpy(t).to(torch.device("cuda", self.device_index))
 
+    def _ensure_features_table(self):
+        """Inference with the variables as they are NOW: the convolutions as a table over (filter size, offset, character)
+        (dae_title_prepack_features) -- rebuilt whenever the variables changed since it was made."""
+        if self.__dict__.get("_ftab_gen") != self._params_gen:
+            P = _lib._ptr
+            self.ctx.bind_stream()
+            self.ctx.check(self.ctx.lib.dae_title_prepack_features(
+                self.ctx.h, P(self.p["char_embedding"]), self.char_size, self.embedding, P(self.p["conv_w"]), self._fs,
+                len(self.filter_sizes), self.filter_num))
+            self._ftab_gen = self._params_gen
+
+    def _drop_features_table(self):
+        """The variables are about to change (a training step, set_params): no call may read the old table."""
+        if self.__dict__.get("_ftab_gen") is not None and getattr(self, "ctx", None) is not None and self.ctx.h:
+            self.ctx.check(self.ctx.lib.dae_title_prepack_features(self.ctx.h, None, 0, 0, None, None, 0, 0))
+        self._ftab_gen = None
+
     def features(self, titles, n_rows, keep_prob=1.0, seed=0, keep_for_backward=False, side_stream_of=None, d_titles=None):
         """Char_CNN.py:23-63 -> feat [n_rows, ld] (CUDA); with keep_for_backward also (argmax, raw)."""
         import torch
         self.ctx.bind_stream()
+        if keep_prob == 1.0 and not keep_for_backward:
+            self._ensure_features_table()
         dev = self.p["conv_w"].device
         d_t = self._titles_dev(titles, n_rows, side_stream_of) if d_titles is None else d_titles    # (staged with the feed)
         feat = torch.empty((n_rows, self.ld), dtype=torch.float32, device=dev)
@@ -168,7 +188,9 @@ class Char_CNN:
             float(keep_prob), int(seed), P(feat), self.ld, P(arg), P(raw)))
         return (feat, d_t, arg, raw) if keep_for_backward else feat
 
-    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32):
+    def _ensure_packed(self, dtype=_lib.DAE_DTYPE_F32, features_table=True):
+        if features_table:                   # (scoring; a training step passes False: its forward keeps argmax / raw features)
+            self._ensure_features_table()
         if self._packed_dirty:
             self._packed = set()
             self._packed_dirty = False
@@ -224,6 +246,7 @@ class Char_CNN:
                                         self.learning_rate, 0.9, 0.999, 1e-8, self._step))
         self._packed_dirty = True
         self._params_gen = self.__dict__.get("_params_gen", 0) + 1
+        self._drop_features_table()
 
     def __str__(self):
         return '\n'.join(["Wide CNN", "Embedding Size : " + str(self.embedding),

@@ -83,6 +83,39 @@ def test_features_of_a_large_launch_equal_the_small_launches():
     assert np.array_equal(bigd[:100].view(np.uint32), smalld.view(np.uint32))
 
 
+def test_table_features_follow_the_variables_and_agree_with_the_chains():
+    """Inference calls (keep_prob = 1, nothing kept for a backward pass) read the convolutions from a table over (filter
+    size, offset, character) -- dae_title_prepack_features: the same sums in another order.  They stay within a few ulps of
+    the fmaf-chain kernels (which training keeps), equal the float64 restatement to the same tolerance, and follow the
+    variables: after set_params the table is rebuilt, after a drop the chains answer."""
+    conf = Conf()
+    m = get_model(conf)
+    host = tn.make_params(41, 50, FS, 100, conf.n_output, seed=3)
+    m.fit(host)
+    titles = _titles(conf.batch, seed=4)
+    titles[2, :] = np.arange(25) % 41                                  # a full-length title: every window position live
+    tab = m.features(titles, conf.batch).cpu().numpy()[:, :400]
+    assert m._ftab_gen == m._params_gen                                # the table path ran
+    chain = m.features(titles, conf.batch, keep_for_backward=True)[0].cpu().numpy()[:, :400]
+    scale = max(1.0, float(np.abs(chain).max()))
+    assert np.max(np.abs(tab - chain)) <= 4e-6 * scale
+    assert np.array_equal(tab == 0, chain == 0) or np.max(np.abs(tab - chain)[(tab == 0) != (chain == 0)]) <= 4e-6 * scale
+    assert np.max(np.abs(tab - tn.features(titles, host, FS))) <= 1e-5
+    # other variables: the table follows
+    host2 = tn.make_params(41, 50, FS, 100, conf.n_output, seed=8)
+    m.set_params(host2)
+    assert m._ftab_gen is None
+    tab2 = m.features(titles, conf.batch).cpu().numpy()[:, :400]
+    assert np.max(np.abs(tab2 - tn.features(titles, host2, FS))) <= 1e-5
+    assert np.max(np.abs(tab2 - tab)) > 1e-3
+    # dropped: the same call answers with the chains, bit for bit what the backward-keeping call returns
+    m._drop_features_table()
+    m._ensure_features_table = lambda: None
+    again = m.features(titles, conf.batch).cpu().numpy()[:, :400]
+    chain2 = m.features(titles, conf.batch, keep_for_backward=True)[0].cpu().numpy()[:, :400]
+    assert np.array_equal(again.view(np.uint32), chain2.view(np.uint32))
+
+
 def _fma32(a, b, c):
     """fmaf(a, b, c) for float32 arrays, exactly: the product is exact in float64 (24 + 24 bits); the sum is rounded
     to ODD in float64 (TwoSum gives its error), so the final rounding to float32 is the single rounding of the exact
