@@ -48,7 +48,7 @@ def main():
                 for _ in m.recommend_iter(feeds(40 if mode == "f32" else 120), k=500, want_scores=False, dtype=mode):
                     pass                                          # (~0.3 s: the device at its sustained state, as bench.py's prime phase)
                 torch.cuda.synchronize()
-                reps = 100 if mode == "f32" else 300
+                reps = (100 if mode == "f32" else 300) * int(os.environ.get("REPS_X", "1"))      # REPS_X=4: a loop long enough for the sustained clock
                 t0 = time.perf_counter()
                 n = 0
                 for _i, _s in m.recommend_iter(feeds(reps), k=500, want_scores=False, dtype=mode):

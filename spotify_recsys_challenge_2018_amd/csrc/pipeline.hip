@@ -364,6 +364,35 @@ const char* dae_pipeline_last_error(const dae_pipeline* p)
     return copy.c_str();
 }
 
+// Lane and copy streams are taken from a process-wide pool and RETURNED to it, never destroyed: the runtime binds a stream to a
+// hardware queue when it is created, and after a pipeline's streams were destroyed the next pipeline's fresh ones came out sharing
+// queues -- its lanes' launches queued behind each other (bench.py's host-loop rows run fp32, then exact_bf16, on one model: the
+// second pipeline measured 5.8 M playlists/s against 7.3 M as the process's first; scripts/probe/row_diag.py)
+static std::mutex g_stream_pool_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+static hipStream_t pool_take_stream(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); ++i)
+            if (g_stream_pool[i].first == device) {
+                hipStream_t s = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return s;
+            }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+static void pool_give_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_stream_pool.emplace_back(device, s);
+}
+
 int dae_pipeline_destroy(dae_pipeline* p)
 {
     if (!p) return DAE_OK;
@@ -403,11 +432,11 @@ int dae_pipeline_destroy(dae_pipeline* p)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
         if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        pool_give_stream(p->device, L.stream);
         void* dev[] = {L.d_rp, L.d_col, L.d_status, L.d_srp, L.d_scol, L.d_idx, L.d_cval, L.d_score, L.d_guard};
         for (void* q : dev) if (q) (void)hipFree(q);
     }
-    if (p->copy_stream) { (void)hipStreamSynchronize(p->copy_stream); (void)hipStreamDestroy(p->copy_stream); }
+    pool_give_stream(p->device, p->copy_stream);
     for (Slot& S : p->slots) {
         if (S.ev_fetch) (void)hipEventDestroy(S.ev_fetch);
         if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
@@ -451,13 +480,13 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
     auto bail = [&](int rc, const char* msg) { const std::string m(msg); dae_pipeline_destroy(p); g_pipe_err = m; return rc; };
     DeviceGuard dev_guard(device);
     { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) return bail(DAE_ERR_HIP, "hipSetDevice failed"); }
-    if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(DAE_ERR_HIP, "stream creation failed");
+    if (!(p->copy_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
     const size_t rows = (size_t)group_rows, nz = (size_t)max_nnz, kk = (size_t)k;
     for (int i = 0; i < lanes; ++i) {
         Lane& L = p->lanes[i];
         int rc = dae_create(device, &L.ctx);
         if (rc) return bail(rc, dae_last_error(nullptr));
-        bool ok = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess &&
+        bool ok = (L.stream = pool_take_stream(device)) != nullptr &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_rp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_col), nz * sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_cval), nz * sizeof(float)) == hipSuccess &&

@@ -906,7 +906,10 @@ class DAE_tied:
             # one pipeline at a time per model: each holds (2 lanes + 2) staging slots of pinned + device memory and a dozen
             # result blocks -- a caller that alternates dtypes pays a re-creation, not half a gigabyte of pinned memory
             for key_, (_g, old) in list(cache.items()):
-                old.close()
+                if self.__dict__.get("keep_pipelines"):      # (diagnosis: scripts/probe/row_diag.py)
+                    self.__dict__.setdefault("_old_pipes", []).append(old)
+                else:
+                    old.close()
                 cache.pop(key_, None)
             self._flush_rows_adam()
             torch.cuda.current_stream(self.device_index).synchronize()      # the weights are final before another thread reads them
