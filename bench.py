@@ -317,12 +317,13 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
     row = {"unit": "playlists/s", "what": _drivers_loop_row.__doc__.split("\n\n")[0].replace("\n    ", " "),
            "feeds_per_launch": {}}
     first = {}
-    # ORDER: the north-star mode first.  A process's FIRST pipeline is what a real run has (main.py --challenge creates one);
-    # every pipeline created later in the same process measured 15 - 25 % lower whatever its mode (scripts/probe/row_diag.py,
-    # profiles/r05_notes.md section 8: exact_bf16 7.2 M playlists/s as the first, 5.5 - 5.9 M after an fp32 or bf16 one; the
-    # kernels' durations under rocprofv3 are the same, fewer hardware queues make it worse) -- so the later rows of this
-    # loop are LOWER bounds.  fp32 is bound by its matrix time either way.
-    for name, reps, warm in (("exact_bf16", 500, 200), ("bf16", 600, 250), ("f32", 150, 60)):
+    # One pipeline at a time: the model destroys a mode's pipeline when the next mode asks for its own -- which it can only do
+    # once nothing views the old one's pinned result blocks (`_idx = _s = None` below).  A pipeline that lingers keeps its four
+    # streams, the next one creates four more, and beyond ~8 streams per process the device's queue scheduler time-slices the
+    # hardware queues: the SAME loop measured 5.5 - 5.9 M playlists/s instead of 7.1 - 7.3 M (scripts/probe/row_diag.py,
+    # profiles/r05_notes.md section 8; kernel durations and HIP call times identical, hipStreamCreate count 8 against 4).  The
+    # library hands a destroyed pipeline's streams to the next one (csrc/pipeline.hip: a process-wide pool).
+    for name, reps, warm in (("f32", 150, 60), ("exact_bf16", 500, 200), ("bf16", 600, 250)):
         # warm-up: ~0.4 s of the same loop (the row follows seconds of host-only work: the device is back at its sustained
         # state before the timed pass, as for the headline's prime phase; with 30 ms of warm-up the fp32 loop measured
         # 0.9 - 1.07 M playlists/s here against 1.31 M in scripts/bench_loop.py); the timed pass runs ~1 s
@@ -338,9 +339,9 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
         el = time.perf_counter() - t0
         row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B}
         row["feeds_per_launch"][name] = m._coalesce_count(m._dtype_of(name))
+        _idx = _s = idx_ = None                      # (the last views of this mode's result blocks: see above)
     row["exact_bf16"]["identical_to_fp32_lists"] = bool(np.array_equal(first["f32"], first["exact_bf16"]))
     row["engine"] = "native (dae_pipeline_*: a library-owned thread issues the launches; models/DAEs.py recommend_iter)"
-    row["pipeline_order"] = "exact_bf16,bf16,f32"          # (a process's later pipelines measure 15 - 25 % lower: see above)
     row["note"] = ("NOT the headline: host feeds in, host lists out (indices only; seeds = the playlist's own tracks, cut "
                    "out of the input on the device).  scripts/bench_loop.py is the longer version (both engines, lane counts)")
     _release_model(torch, m)
@@ -389,11 +390,12 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
                 yield b_
     row = {"unit": "playlists/s", "what": _titled_row.__doc__.split("\n\n")[0].replace("\n    ", " "), "batch": B}
     lists = {}
-    for name, reps, warm in (("exact_bf16", 250, 60), ("f32", 60, 15)):      # (the north-star mode as the row's first pipeline: see _drivers_loop_row)
+    for name, reps, warm in (("f32", 60, 15), ("exact_bf16", 250, 60)):
         got = [(i_.copy(), s_.copy()) for i_, s_ in m.recommend_iter(feeds(2), k=k, want_scores=True, dtype=name)][:len(batches)]
         lists[name] = got
         for _ in m.recommend_iter(feeds(warm), k=k, want_scores=False, dtype=name):      # (the timed loop's own pipeline: the model keeps
             pass                                                                          #  one per (dtype, k, scores wanted))
+        _ = None                                     # (a loop variable is a view of a result block: _drivers_loop_row)
         torch.cuda.synchronize()
         _settle_interpreter()
         t0 = time.perf_counter()
@@ -402,6 +404,7 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
             n += B
         el = time.perf_counter() - t0
         row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B}
+        _idx = _s = None                             # (no view of this mode's result blocks is left: _drivers_loop_row)
     same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
                for a, b in zip(lists["f32"], lists["exact_bf16"]))
     row["exact_bf16"]["identical_to_fp32_lists_and_scores"] = bool(same)

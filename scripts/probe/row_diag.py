@@ -42,6 +42,9 @@ for name in modes:
     for _idx, _s in m.recommend_iter(feeds(reps), k=k, want_scores=False, dtype=name):
         n += B
     el = time.perf_counter() - t0
+    if os.environ.get("RELEASE_VIEWS"):       # nothing views the pipeline's pinned blocks any more: the next mode's pipeline reuses its streams
+        _idx = _s = idx_ = None
+        import gc; gc.collect()
     extra = ""
     for pp in m.__dict__.get("_pipes", {}).values():
         extra = "  %s %s total_ms=%.1f" % (pp[1].times(), pp[1].stats(), el * 1e3)
