@@ -38,6 +38,10 @@ d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, col, val, W_
 NS = max(nstr)
 ctxs = [_lib.Context(0) for _ in range(NS)]
 streams = [torch.cuda.Stream() for _ in range(NS)]
+idle_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("EXTRA_STREAMS", "0")))]      # A/B: idle streams (hardware queues) in the process
+for s_ in idle_streams:
+    with torch.cuda.stream(s_):
+        torch.zeros(1, device="cuda")
 share = os.environ.get("SHARE", "1") != "0"          # one packed image for all contexts (dae_share_decoder)
 for n_, (c, st) in enumerate(zip(ctxs, streams)):
     with torch.cuda.stream(st):
