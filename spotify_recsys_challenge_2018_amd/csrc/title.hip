@@ -296,10 +296,15 @@ __global__ __launch_bounds__(256) void title_features_table_kernel(const TitleP 
         for (int pos = 0; pos < TT_PMAX; ++pos) acc[pos] = b;
         for (int d = 0; d < fs; ++d) {                // d ascending; the 32 positions' reads are independent of each other
             const float* Td = Tf + (size_t)d * nc1 * p.F;
-            // (only the size's own P positions are fetched: the launch is bound by the table bytes it pulls through L1)
+            // (positions beyond the size's own P read the ZERO row -- one cached line -- instead of being skipped: a predicated
+            // load is a branch, and hipcc then waits for every load before the next one goes out: 460 memory round trips in a
+            // row, 50.7 us for 750 titles against 33.9 us.  Measured on top and dropped: 512 threads (one pass over the 400
+            // filters) 34.7 us; two offsets d per round and 24 positions 43.3 us)
+            float tv[TT_PMAX];
 #pragma unroll
-            for (int pos = 0; pos < TT_PMAX; ++pos)
-                if (pos < P) acc[pos] += Td[(size_t)ts[pos + d] * p.F];
+            for (int pos = 0; pos < TT_PMAX; ++pos) tv[pos] = Td[(size_t)(pos < P ? ts[pos + d] : p.n_char) * p.F];
+#pragma unroll
+            for (int pos = 0; pos < TT_PMAX; ++pos) acc[pos] += tv[pos];
         }
         float best = 0.0f;                            // ReLU, then the first maximum over the positions
         bool first = true;
