@@ -244,8 +244,11 @@ def _pmc_json(fname, source_file):
         tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
     except Exception:
         return {}
-    want = (tj.get("kernel_source_sha256_16") or {}).get(source_file)
-    return tj if (want is not None and want == _src_sha(source_file)) else {}
+    sha = tj.get("kernel_source_sha256_16") or {}
+    want, want_h = sha.get(source_file), sha.get("dae_internal.h")
+    # (the shared header too: a summary taken before it changed describes other structs / launch geometry -- VERDICT r4 12d)
+    ok = want is not None and want == _src_sha(source_file) and (want_h is None or want_h == _src_sha("dae_internal.h"))
+    return tj if ok else {}
 
 
 def _pmc_traffic(key, kernel):
