@@ -434,3 +434,30 @@ def test_forged_bound_is_detected_in_a_launch_of_many_rows():
         assert n > 0 and 0 <= col < nt
     finally:
         c.close()
+
+
+def test_many_rows_with_rows_outside_the_unit_interval():
+    """dae_decode_topk at >= 768 rows: flagged rows (hidden entries outside [0, 1], NaN) return nothing, the shared recomputation
+    leaves them alone, every other row is the oracle's."""
+    import torch
+    c = _lib.Context(0)
+    try:
+        V, nt, H, B, k = 12000, 10000, 128, 801, 100
+        p = _problem(V, nt, H, B, bias="zipf")
+        h = oracle.encode(p["rp"], p["col"], p["val"], p["W_enc"], p["b_enc"])
+        bad = [0, 31, 32, 400, 800]
+        h[0, 5] = 1.5; h[31, 0] = -0.25; h[32, 127] = np.nan; h[400, 64] = 2.0; h[800, 3] = -1e-3
+        c.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
+        score = torch.empty((B, k), dtype=torch.float32, device="cuda")
+        idx = torch.empty((B, k), dtype=torch.int32, device="cuda")
+        c.decode_topk(_dev(h), nt, _dev(p["srp"]), _dev(p["sc"]), k, score, idx, dtype=EX)
+        ig, sg = idx.cpu().numpy(), score.cpu().numpy()
+        assert (ig[bad] == -1).all() and np.isneginf(sg[bad]).all()
+        good = [r for r in range(B) if r not in bad]
+        hg = h.copy(); hg[bad] = 0.5
+        z_ref = oracle.decode(hg, p["W_dec"], p["b_dec"], 0, nt)
+        sc_r, idx_r = oracle.topk(z_ref, k, p["srp"], p["sc"])
+        _check(ig[good], sg[good], idx_r[good], sc_r[good])
+        assert c.exact_guard_read() == (0, -1)
+    finally:
+        c.close()
