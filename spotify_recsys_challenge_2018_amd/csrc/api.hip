@@ -502,7 +502,10 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
         // tile_band_kernel); the list is this context's, rebuilt when the order or the geometry changes
         static const bool no_band = dae_exp_env("DAE_NO_BAND") != nullptr;                    // A/B (experiments build)
         const int n_ws_s = g.nb_rg * g.waves;
-        if (dtype == DAE_DTYPE_BF16 && n_samp > n_ws_s && !no_band) {
+        // (not when the launch takes per-WAVE groups -- see wave_groups below: there the plain order IS band-dealt)
+        const bool wg_early = dtype == DAE_DTYPE_BF16 && ctx->mixT == nullptr && dae_sample_wave_groups(g, pk->Hp, n_samp) &&
+                              ((int64_t)((n_samp + n_ws_s - 1) / n_ws_s) * g.nb_rg * 32 >= 4 * (int64_t)k);
+        if (dtype == DAE_DTYPE_BF16 && n_samp > n_ws_s && !no_band && !wg_early) {
             const void* band_was = ctx->tile_band.p;
             rc = dae_reserve(ctx, ctx->tile_band, (size_t)ntiles * sizeof(int));
             if (rc) return rc;
@@ -522,10 +525,16 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
     // ... unless that leaves too few maxima for the rank tau needs (k + seeds): small samples -- vocabulary shards,
     // large batches -- keep one value per wave slot and position, i.e. every sample element
-    const int gmax_per_wave = ld_g < 4 * (int64_t)k ? 1 : 0;
+    int gmax_per_wave = ld_g < 4 * (int64_t)k ? 1 : 0;
     if (gmax_per_wave) ld_g *= g.waves;
     const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
     if (mixed && exact) return dae_fail(ctx, DAE_ERR_ARG, "DAE_DTYPE_BF16_EXACT is not available with dae_set_score_mix");
+    static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
+    // launches of many rows (>= 1 024 at the full vocabulary): the groups are the tiles ONE wave of the filter kernel's shape
+    // decodes (decode_bf16_h256_wavemax_kernel: no exchange through LDS, two waves per SIMD) -- 8 nb_rg x 32 maxima per row
+    const bool wave_groups = fused && !gmax_per_wave && dtype == DAE_DTYPE_BF16 && !mixed && (!no_whole || exact) &&
+                             dae_sample_wave_groups(g, pk->Hp, n_samp);
+    if (wave_groups) { gmax_per_wave = 3; ld_g = (int64_t)8 * g.nb_rg * 32; }
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
         if (rc) return rc;
@@ -536,11 +545,10 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     // A through LDS, read back by the threshold kernel, its survivors compacted there) costs more.  Phase A then leaves
     // the group maxima only, the threshold kernel emits no survivors, and every candidate comes from the filter launch.
     // (fp32 keeps the buffer: the same tiles are 13.6 us of its matrix time.)
-    static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
     // exact mode (DAE_DTYPE_BF16_EXACT): always so, on BOUNDS -- phase A decodes with the bias b - eps (its maxima are
     // lower bounds of fp32 logits, so tau is a valid threshold for the fp32 ranking), the filter launch with b + eps
     // (nothing whose fp32 logit reaches tau is dropped), and the refine step recomputes every survivor in fp32
-    const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && ((!gmax_per_wave && !mixed && !no_whole) || exact);
+    const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && ((gmax_per_wave != 1 && !mixed && !no_whole) || exact);
     if (whole_b) g_plan.n_other = ntiles;
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
     rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, whole_b ? nullptr : sample, ld_s, 1, dtype, gmax, ld_g,

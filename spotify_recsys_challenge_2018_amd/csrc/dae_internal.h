@@ -268,6 +268,7 @@ int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, i
 // band[0 .. n_samp): the sample of `order` dealt to the phase-A launch's slots so that the tiles ONE workgroup decodes in a round
 // (item = round * nb_rg * waves + wave * nb_rg + bir) come from `waves` different popularity bands; band[n_samp ..) = order
 int dae_launch_tile_band(dae_ctx* ctx, const int* order, int ntiles, int n_samp, int nb_rg, int waves, int* band);
+bool dae_sample_wave_groups(const dae_rowgeom& g, int Hp, int n_samp);
 
 struct dae_tileset {        // which wave tiles a decode launch walks
     int n_items;            // number of tiles in the set
@@ -282,6 +283,8 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
                                 int apply_sigmoid, int mask_from_col, float* out, int64_t ld,
                                 int fill_pad, int dtype = DAE_DTYPE_F32, float* gmax = nullptr,
                                 int64_t ld_gmax = 0, int gmax_per_wave = 0, int bias_sel = 0);
+// gmax_per_wave: 0 = one maximum per (workgroup, round, position) over the workgroup's waves; 1 = every wave slot's value (small
+// samples); 3 = per-WAVE groups over all of a wave's tiles, 8 wave slots per workgroup (dae_sample_wave_groups: ld_gmax = 8 nb_rg 32)
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,

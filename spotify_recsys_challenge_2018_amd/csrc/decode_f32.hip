@@ -1093,6 +1093,128 @@ __global__ __launch_bounds__(256, 1) void decode_f32_h256_filter_kernel(const De
 // from LDS one step ahead, no global memory) reaches 2.3-2.4 PFLOP/s, so neither LDS nor the MFMA issue
 // limits it; what the real kernel adds is the W ring, tile indices two groups ahead, the bias MFMA and the
 // epilogue (a max-reduction and one compare per row block unless some lane really passes).
+// ---- phase A for launches of many rows: per-WAVE group maxima, no exchange ---------------------------------------------------
+// The generic phase-A kernel (decode_f32_kernel<4, EPI_GMAX, 16, 4, DT_BF16>) takes the maximum over the tiles the FOUR waves of a
+// workgroup decode in a round: row block by row block through LDS, two barriers each, one wave per SIMD (468 registers) -- at
+// 2 048 rows the sample (1 / 9 of the tiles) costs 40 us where the filter launch decodes everything in 113.  When a launch's
+// sample gives every one of the filter kernel's wave slots (8 per workgroup) at least two tiles, the group can be the tiles ONE
+// wave decodes: wave w of workgroup bir takes items w nb_rg + bir + r n_ws, r = 0, 1, ... -- in the plain bias order, so its tiles
+// sit n_ws places apart (round r = popularity band r) -- and keeps the running maximum per (row, position in the tile) in
+// registers: no LDS traffic beyond the hidden fragments, no barrier after the prologue, two waves per SIMD.  The structure of
+// decode_bf16_h256_filter_kernel<1, 4, 8, 8> (same hidden tile, W ring, bias through the matrix pipe: the same logits bit for
+// bit) with a static tile assignment and fmax as the epilogue.  Groups are disjoint sets of columns as before: the (k + seeds)-th
+// largest of the 8 nb_rg x 32 maxima of a row is a valid threshold.  gmax[row][(wave nb_rg + bir) 32 + position].
+__global__ __launch_bounds__(512, 1) void decode_bf16_h256_wavemax_kernel(const DecP p)
+{
+    constexpr int NS = 16, RB = 4, QR = 8, NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int j = lane & 31;
+    const int gs = DAE_NUM_XCD * p.n_rg;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int rg = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    constexpr int n_h4 = RB * 64 * NS;
+    constexpr int NTH = NW * 64;
+    constexpr int PER = n_h4 / NTH;                              // 8 uint4 of the hidden tile per thread
+    const int n_items = p.ts.n_items;
+    const int n_ws = p.nb_rg * NW;
+    const int it0 = wave * p.nb_rg + bir;
+    const uint4* Wq = reinterpret_cast<const uint4*>(p.Wp);
+    const uint4* ldsq = reinterpret_cast<const uint4*>(lds4);
+    const uint4 ones = bf16_ones_fragment(hi);
+    const bool has = it0 < n_items;
+    const int tv0 = tile_of_item(p.ts, has ? it0 : 0);
+    const int tv1 = tile_of_item(p.ts, has ? (it0 + n_ws < n_items ? it0 + n_ws : it0) : 0);
+    {
+        const float4* hsrc = p.hp + (size_t)rg * n_h4;
+        float4 hv[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) hv[e] = hsrc[e * NTH + tid];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) lds4[e * NTH + tid] = hv[e];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int t = __builtin_amdgcn_readfirstlane(tv0), u = __builtin_amdgcn_readfirstlane(tv1);
+    uint4 wq[QR];
+    uint4 cb[2][RB];
+    uint4 bfr = p.bias16[(size_t)t * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < QR; ++k) wq[k] = Wq[(size_t)t * (NS * 64) + k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) cb[0][rb] = ldsq[rb * 64 + lane];
+
+    f32x16 mx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx[rb][e] = -__builtin_inff();
+
+    for (int it = it0; it < n_items; it += n_ws) {
+        const int it_nn = it + 2 * n_ws;
+        const int wv = tile_of_item(p.ts, it_nn < n_items ? it_nn : it);   // consumed at the end of this tile
+        const uint4* cur = Wq + (size_t)t * (NS * 64);
+        const uint4* nxt = Wq + (size_t)u * (NS * 64);
+        f32x16 acc[RB];
+        {
+            f32x16 zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zero[e] = 0.0f;
+            const uint4 bc = bfr;
+            bfr = p.bias16[(size_t)u * 64 + lane];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(bc), as_bf16x8(ones), zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int sn = (s + 1) % NS;
+            const uint4 a = wq[s % QR];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(cb[s & 1][rb]), acc[rb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                cb[(s + 1) & 1][rb] = ldsq[(sn * RB + rb) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wq[s % QR] = (s + QR < NS) ? cur[(s + QR) * 64 + lane] : nxt[(s + QR - NS) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // register reg of the tile is column 32 t + (reg & 3) + 8 (reg >> 2) + 4 hi; columns that are not ranked never enter a maximum
+        const bool whole = t * 32 + 31 < p.ncols && p.col_lo + t * 32 + 31 < p.mask_from_col;          // wave-uniform
+        if (whole) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) mx[rb][reg] = fmaxf(mx[rb][reg], acc[rb][reg]);
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int lc = t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
+                const bool ok = lc < p.ncols && p.col_lo + lc < p.mask_from_col;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) mx[rb][reg] = ok ? fmaxf(mx[rb][reg], acc[rb][reg]) : mx[rb][reg];
+            }
+        }
+        t = u; u = __builtin_amdgcn_readfirstlane(wv);
+    }
+    // a wave without a tile leaves -inf: absent for the threshold kernel
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rg * 128 + rb * 32 + j;
+        if (row >= p.B) continue;
+        float* gp = p.gmax + (size_t)row * p.ld_gmax + (size_t)(wave * p.nb_rg + bir) * 32 + 4 * hi;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(gp + 8 * qd) = make_float4(mx[rb][4 * qd], mx[rb][4 * qd + 1], mx[rb][4 * qd + 2], mx[rb][4 * qd + 3]);
+    }
+}
+
 template <int NT, int RB, int QR, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void decode_bf16_h256_filter_kernel(const DecP p)
 {
@@ -2128,6 +2250,14 @@ int dae_launch_tile_order(dae_ctx* ctx, dae_packed& pk, int nrank, int n_samp, i
     return DAE_OK;
 }
 
+// phase A with per-WAVE group maxima (decode_bf16_h256_wavemax_kernel): bf16 image of hidden 256, 128-row groups, and a sample
+// that gives each of the 8 wave slots per workgroup at least two tiles
+bool dae_sample_wave_groups(const dae_rowgeom& g, int Hp, int n_samp)
+{
+    static const bool off = dae_exp_env("DAE_NO_WAVEMAX") != nullptr;                    // A/B (experiments build)
+    return !off && Hp == 256 && g.R_TILE == 128 && g.waves == 4 && n_samp >= 2 * g.nb_rg * 8;
+}
+
 int dae_launch_tile_band(dae_ctx* ctx, const int* order, int ntiles, int n_samp, int nb_rg, int waves, int* band)
 {
     if (ntiles <= 0) return DAE_OK;
@@ -2180,6 +2310,19 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (out && fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
+    if (gmax && gmax_per_wave == 3) {
+        // per-wave group maxima (the caller sized gmax for 8 wave slots per workgroup: dae_sample_wave_groups)
+        if (dtype != DAE_DTYPE_BF16 || out || p.G != 16 || g.R_TILE != 128 || p.mixT)
+            return dae_fail(ctx, DAE_ERR_ARG, "per-wave group maxima: bf16, hidden 256, 128-row groups, maxima only");
+        const size_t lds = (size_t)4 * 64 * 16 * sizeof(float4);
+        static const char wm_key = 0;
+        if (dae_first_use(ctx, &wm_key))
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_bf16_h256_wavemax_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(decode_bf16_h256_wavemax_kernel, dim3(g.grid), dim3(512), lds, ctx->stream, p);
+        DAE_CHECK_LAUNCH(ctx, "decode_bf16_h256_wavemax_kernel");
+        return DAE_OK;
+    }
     if (gmax) {
         if (g.waves != 4) return dae_fail(ctx, DAE_ERR_ARG, "group maxima need 4-wave workgroups");
         static const bool no_half = dae_exp_env("DAE_GMAX_FULL") != nullptr;             // A/B against one workgroup per CU
