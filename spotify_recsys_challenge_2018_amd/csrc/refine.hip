@@ -63,7 +63,12 @@ struct RefineP {
 #define RSTAMP(i)
 #endif
 
-template <int RF_THREADS, int RF_DEPTH>
+// HT > 0: hidden = 16 HT known at compile time.  A trip of the recomputation's block loop then has no branch around a load, and
+// hipcc counts the waits inside it: with the run-time bounds EVERY wait of the loop was vmcnt(0) -- a block waited for the ring's
+// refill it had just requested, a memory round trip per pair of blocks whatever the ring's depth (ISA of round 5; the same finding
+// as in exact_rescore_shared_kernel).  The trip loop itself stays rolled: fully unrolled, hipcc hoists the chain's loads and spills
+// hundreds of registers (128 are all a 1 024-thread workgroup has).
+template <int RF_THREADS, int RF_DEPTH, int HT = 0>
 __device__ __forceinline__ void refine_body(const RefineP& p)
 {
     constexpr int RF_WAVES = RF_THREADS / 64;
@@ -287,8 +292,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
 
     // ---- 2. recompute the survivors -------------------------------------------------------------------------------
     float* tbuf = reinterpret_cast<float*>(rf_dyn) + wave * (64 * RF_ROWSTRIDE);      // (shares the staging area: see the barriers)
-    const int H16 = p.x.H >> 4;                                  // blocks of 16 k (H % 16 remainder handled below)
-    const int Hrem4 = (p.x.H & 15) >> 2;                         // float4 left over after the whole blocks
+    const int H16 = HT > 0 ? HT : (p.x.H >> 4);                  // blocks of 16 k (H % 16 remainder handled below)
+    const int Hrem4 = HT > 0 ? 0 : ((p.x.H & 15) >> 2);          // float4 left over after the whole blocks
 
     // one group of <= 64 candidates, a lane each: its column `colv` (any valid column for lanes without one: `in` false)
     // -> the fp32 logit.  The rows are fetched quad-wise (see the header), the lanes' columns travel by shuffle.
@@ -310,7 +315,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
         // every product takes its factor by v_readlane (an SGPR operand of the v_fma) -- as four broadcast ds_read_b128 per
         // 16 k they were a third of the LDS instructions of this loop, which is LDS-bound (stage stamps, DAE_DBG_R)
         constexpr int RF_U = RF_DEPTH < 4 ? 4 : RF_DEPTH;         // blocks per trip: whole 64-k chunks, so a block's lanes are constants
-        for (int j0 = 0; j0 < H16; j0 += RF_U) {
+        auto trip = [&](const int j0) {
             float hq[RF_U / 4];
 #pragma unroll
             for (int c = 0; c < RF_U / 4; ++c) hq[c] = hrow[(16 * j0 + 64 * c + lane) & 1023];      // (zero beyond H)
@@ -319,7 +324,7 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                 const int j = j0 + dd;
                 constexpr int dmask = RF_DEPTH - 1;
                 const int d = dd & dmask;                         // ring slot (RF_DEPTH is a power of two)
-                if (j < H16) {                                    // wave-uniform
+                if (HT > 0 || j < H16) {                          // wave-uniform (HT: whole trips, 16 HT % RF_U == 0)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         *reinterpret_cast<float4*>(tbuf + (4 * Q + i) * RF_ROWSTRIDE + 4 * q) = v[d][i];
@@ -331,13 +336,23 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                     if (dd & 1) {
                         const int dp = (dd - 1) & dmask;
                         const int jn0 = j - 1 + RF_DEPTH, jn1 = j + RF_DEPTH;
-                        if (jn0 < H16) {
+                        if (HT > 0) {
+                            // no branch around a load: the last trip's refills re-read the row's last blocks (never used).  With the
+                            // branches every wait of the trip was vmcnt(0) -- a block waited for the refill it had just requested
+                            const int c0 = jn0 < HT ? jn0 : HT - 1, c1 = jn1 < HT ? jn1 : HT - 1;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[dp][i] = rp[i][4 * jn0];
-                        }
-                        if (jn1 < H16) {
+                            for (int i = 0; i < 4; ++i) v[dp][i] = rp[i][4 * c0];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn1];
+                            for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * c1];
+                        } else {
+                            if (jn0 < H16) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[dp][i] = rp[i][4 * jn0];
+                            }
+                            if (jn1 < H16) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[d][i] = rp[i][4 * jn1];
+                            }
                         }
                     }                                             // (RF_DEPTH is even: every block beyond the prologue's has a partner)
                     float4 w[4];
@@ -355,7 +370,8 @@ __device__ __forceinline__ void refine_body(const RefineP& p)
                     }
                 }
             }
-        }
+        };
+        for (int j0 = 0; j0 < H16; j0 += RF_U) trip(j0);
         if (Hrem4 && in) {                                       // hidden sizes that are not a multiple of 16: the tail, lane-owned
             const float4* wr = reinterpret_cast<const float4*>(p.x.W32 + (size_t)(colv - p.x.col_lo) * p.x.H);
             for (int t = 0; t < Hrem4; ++t) {
@@ -834,15 +850,18 @@ __global__ __launch_bounds__(256, 1) void exact_rescore_shared_kernel(const Shar
     SSTAMP(7)
 }
 
-__global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8>(p); }
+template <int HT>
+__global__ __launch_bounds__(512) void exact_refine_kernel(const RefineP p) { refine_body<512, 8, HT>(p); }
 // one row per CU (launches of <= 512 rows): 16 waves, so that the ~530 - 700 recomputed survivors of a row are ONE group of 64 per
 // wave -- with 8 waves the ninth group made wave 0 run two groups one after the other, and a group is a chain of memory round
 // trips (~9 us): the launch's length was that wave's
-__global__ __launch_bounds__(1024) void exact_refine_wide_kernel(const RefineP p) { refine_body<1024, 4>(p); }
+template <int HT>
+__global__ __launch_bounds__(1024) void exact_refine_wide_kernel(const RefineP p) { refine_body<1024, 4, HT>(p); }
 // the shape that shares a CU with another batch's filter workgroup: one wave per SIMD within the 112 registers those leave
+template <int HT>
 __global__ __launch_bounds__(256) void exact_refine_slim_kernel(const RefineP p)
 {
-    refine_body<256, 2>(p);
+    refine_body<256, 2, HT>(p);
 }
 
 }  // namespace
@@ -966,19 +985,23 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
     if (dae_first_use(ctx, &key)) {
         const int mx = (int)RF_DYN_MAX;
         static_assert(RF_DYN_MAX >= (size_t)RF_STAGE * sizeof(float), "staging area");
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_slim_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_refine_wide_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        const void* ks[] = {reinterpret_cast<const void*>(&exact_refine_kernel<0>), reinterpret_cast<const void*>(&exact_refine_kernel<16>),
+                            reinterpret_cast<const void*>(&exact_refine_slim_kernel<0>),
+                            reinterpret_cast<const void*>(&exact_refine_wide_kernel<0>), reinterpret_cast<const void*>(&exact_refine_wide_kernel<16>)};
+        for (const void* kf : ks) DAE_HIP_CHECK(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     }
-    if (shape == 0)
-        hipLaunchKernelGGL(exact_refine_slim_kernel, dim3(B), dim3(256), dyn, ctx->stream, p);
-    else if (shape == 2)
-        hipLaunchKernelGGL(exact_refine_wide_kernel, dim3(B), dim3(1024), dyn, ctx->stream, p);
-    else
-        hipLaunchKernelGGL(exact_refine_kernel, dim3(B), dim3(512), dyn, ctx->stream, p);
+    static const bool no_ht = dae_exp_env("DAE_RF_NO_HT") != nullptr;                         // A/B (experiments build)
+    const bool h256 = x.H == 256 && !no_ht;                                                    // the compile-time block loop
+    if (shape == 0) {
+        // (the slim shape keeps the run-time loop: 91 registers against 137 -- it exists to fit next to another batch's filter waves)
+        hipLaunchKernelGGL(exact_refine_slim_kernel<0>, dim3(B), dim3(256), dyn, ctx->stream, p);
+    } else if (shape == 2) {
+        if (h256) hipLaunchKernelGGL(exact_refine_wide_kernel<16>, dim3(B), dim3(1024), dyn, ctx->stream, p);
+        else hipLaunchKernelGGL(exact_refine_wide_kernel<0>, dim3(B), dim3(1024), dyn, ctx->stream, p);
+    } else {
+        if (h256) hipLaunchKernelGGL(exact_refine_kernel<16>, dim3(B), dim3(512), dyn, ctx->stream, p);
+        else hipLaunchKernelGGL(exact_refine_kernel<0>, dim3(B), dim3(512), dyn, ctx->stream, p);
+    }
     DAE_CHECK_LAUNCH(ctx, "exact_refine_kernel");
     return DAE_OK;
 }
