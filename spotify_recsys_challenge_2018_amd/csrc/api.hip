@@ -534,7 +534,14 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     // decodes (decode_bf16_h256_wavemax_kernel: no exchange through LDS, two waves per SIMD) -- 8 nb_rg x 32 maxima per row
     const bool wave_groups = fused && !gmax_per_wave && dtype == DAE_DTYPE_BF16 && !mixed && (!no_whole || exact) &&
                              dae_sample_wave_groups(g, pk->Hp, n_samp);
-    if (wave_groups) { gmax_per_wave = 3; ld_g = (int64_t)8 * g.nb_rg * 32; }
+    if (wave_groups) {
+        // (fewer than four tiles per wave slot: waves w and w + 4 share a group -- value 4 -- so that a row has 4 nb_rg x 32 maxima:
+        // 4 096 at 1 024 rows, the threshold kernel's 16-key shape)
+        static const bool no_pair = dae_exp_env("DAE_WAVEMAX_NOPAIR") != nullptr;            // A/B (experiments build)
+        const bool pair = n_samp < 4 * g.nb_rg * 8 && (int64_t)4 * g.nb_rg * 32 >= 4 * (int64_t)k && !no_pair;
+        gmax_per_wave = pair ? 4 : 3;
+        ld_g = (int64_t)(pair ? 4 : 8) * g.nb_rg * 32;
+    }
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
         if (rc) return rc;

@@ -284,7 +284,8 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
                                 int fill_pad, int dtype = DAE_DTYPE_F32, float* gmax = nullptr,
                                 int64_t ld_gmax = 0, int gmax_per_wave = 0, int bias_sel = 0);
 // gmax_per_wave: 0 = one maximum per (workgroup, round, position) over the workgroup's waves; 1 = every wave slot's value (small
-// samples); 3 = per-WAVE groups over all of a wave's tiles, 8 wave slots per workgroup (dae_sample_wave_groups: ld_gmax = 8 nb_rg 32)
+// samples); 3 = per-WAVE groups over all of a wave's tiles, 8 wave slots per workgroup (dae_sample_wave_groups: ld_gmax = 8 nb_rg 32);
+// 4 = the same with waves w and w + 4 sharing a group (ld_gmax = 4 nb_rg 32)
 // filter epilogue: append (logit, global col) with logit >= tau[row] and col < n_valid_col
 int dae_launch_decode_filter_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_tileset& ts,
                                  const float* tau, int n_valid_col, uint2* cand, int* cand_cnt,

@@ -1204,6 +1204,37 @@ __global__ __launch_bounds__(512, 1) void decode_bf16_h256_wavemax_kernel(const 
         t = u; u = __builtin_amdgcn_readfirstlane(wv);
     }
     // a wave without a tile leaves -inf: absent for the threshold kernel
+    if (p.gmax_per_wave == 4) {
+        // few tiles per wave (1 024 rows: 2.3): waves w and w + 4 share a group -- ONE exchange at the end of the launch, through the
+        // hidden tile's LDS (dead by now): 4 nb_rg x 32 maxima per row instead of 8 nb_rg x 32, so that the threshold kernel reads
+        // 4 096, not 8 192 (its 16-key shape).  Groups of ~4.6 tiles from as many bands, as a wave's own tiles are at 2 048 rows.
+        // (Pairing NEIGHBOURING positions instead doubles the candidates: in the hottest tiles every column is a winner.)
+        __syncthreads();                                          // every wave is past its last hidden fragment
+        float* xl = reinterpret_cast<float*>(lds4);
+        if (wave >= 4) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd)
+                    *reinterpret_cast<float4*>(xl + ((((wave - 4) * RB + rb) * 4 + qd) * 64 + lane) * 4) =
+                        make_float4(mx[rb][4 * qd], mx[rb][4 * qd + 1], mx[rb][4 * qd + 2], mx[rb][4 * qd + 3]);
+        }
+        __syncthreads();
+        if (wave >= 4) return;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int row = rg * 128 + rb * 32 + j;
+            float* gp = p.gmax + (size_t)row * p.ld_gmax + (size_t)(wave * p.nb_rg + bir) * 32 + 4 * hi;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float4 o = *reinterpret_cast<const float4*>(xl + (((wave * RB + rb) * 4 + qd) * 64 + lane) * 4);
+                if (row < p.B)
+                    *reinterpret_cast<float4*>(gp + 8 * qd) = make_float4(fmaxf(mx[rb][4 * qd], o.x), fmaxf(mx[rb][4 * qd + 1], o.y),
+                                                                          fmaxf(mx[rb][4 * qd + 2], o.z), fmaxf(mx[rb][4 * qd + 3], o.w));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int row = rg * 128 + rb * 32 + j;
@@ -2310,7 +2341,7 @@ int dae_launch_decode_dense_f32(dae_ctx* ctx, const dae_rowgeom& g, int B, const
     // fill_pad: the (internal) buffer covers whole tiles; columns past the image get -inf
     p.fill_pad = (out && fill_pad && ld >= (int64_t)ts.n_items * 32) ? 1 : 0;
     p.vec_ok = ((ld % 4) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1 : 0;
-    if (gmax && gmax_per_wave == 3) {
+    if (gmax && (gmax_per_wave == 3 || gmax_per_wave == 4)) {
         // per-wave group maxima (the caller sized gmax for 8 wave slots per workgroup: dae_sample_wave_groups)
         if (dtype != DAE_DTYPE_BF16 || out || p.G != 16 || g.R_TILE != 128 || p.mixT)
             return dae_fail(ctx, DAE_ERR_ARG, "per-wave group maxima: bf16, hidden 256, 128-row groups, maxima only");
