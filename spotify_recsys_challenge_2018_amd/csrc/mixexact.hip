@@ -81,6 +81,30 @@ __device__ __forceinline__ bool mix_can_reach(float zt, float zd, float wt, floa
     const float rhs = (tau * et) * ed;
     return fmaf(lhs, 0x1p-15f, lhs) >= rhs;
 }
+// Per-lane LOGIT thresholds that every column passing mix_can_reach must meet, given the lane's maxima mT >= z_t, mD >= z_d over its
+// columns: w_t s(z_t) + w_p s(z_d) >= tau with s(z_d) <= s(mD) needs s(z_t) >= (tau - w_p s(mD)) / w_t =: a, i.e. z_t >= logit(a) -- and the
+// same with the roles swapped.  One compare per element instead of two v_exp_f32 and five multiply-adds: on a title scorer whose
+// score is a flat background (an untrained one: bench.py's) the pair of maxima passes in nearly every lane, and the per-element tests
+// were a third of the launch.  NECESSARY conditions only (the exact test still decides): every bound is taken on the safe side --
+// tau 2^-12 lower (mix_can_reach's own slack is 2^-15 plus a few 1e-7 of hardware exp / rcp error), the maxima's sigmoids 2^-18 higher,
+// the quotient 2^-18 lower, the logit 2^-16 (relative and absolute) lower; a >= 0.999 (a column that needs a saturated sigmoid) keeps
+// logit(0.999), a <= 0 (the other scorer's maximum alone reaches tau) keeps -inf.  A scorer with weight 0 puts no condition on its logit.
+__device__ __forceinline__ float mix_logit_floor(float a)
+{
+    if (!(a > 1e-30f)) return -__builtin_inff();
+    a = fminf(a, 0.999f);
+    const float l = (__builtin_amdgcn_logf(a) - __builtin_amdgcn_logf(1.0f - a)) * 0.69314718f;        // ln(a / (1 - a))
+    return l - (fabsf(l) * 0x1p-16f + 0x1p-16f);
+}
+__device__ __forceinline__ void mix_thresholds(float mT, float mD, float wt, float wp, float tau, float& th_t, float& th_d)
+{
+    const float sT = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(mT * -1.44269504088896341f, 60.0f))) * (1.0f + 0x1p-18f);
+    const float sD = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fminf(mD * -1.44269504088896341f, 60.0f))) * (1.0f + 0x1p-18f);
+    const float tl = tau * (1.0f - 0x1p-12f);
+    const float nt = tl - wp * sD, nd = tl - wt * sT;            // what the title / the DAE term has to supply at least
+    th_t = wt > 0.0f ? mix_logit_floor(nt > 0.0f ? nt * __builtin_amdgcn_rcpf(wt) * (1.0f - 0x1p-18f) : -1.0f) : -__builtin_inff();
+    th_d = wp > 0.0f ? mix_logit_floor(nd > 0.0f ? nd * __builtin_amdgcn_rcpf(wp) * (1.0f - 0x1p-18f) : -1.0f) : -__builtin_inff();
+}
 __device__ __forceinline__ float mix_fast_dn(float zt, float zd, float wt, float wp)
 {
     const float y = sig_fast(zt) * wt + sig_fast(zd) * wp;
@@ -267,11 +291,22 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
                 if (p.exp_mode == 2) { if (mix_can_reach(mT, mD, wt, wp, tv) && tv == 123.456f) p.cand_cnt[0] = 1; continue; }
 #endif
                 if (mix_can_reach(mT, mD, wt, wp, tv)) {
+                    // one compare pair per element first (mix_thresholds); the exact test only for the registers in which SOME lane
+                    // of the wave still has a column in play (wave-uniform: __ballot)
+                    float th_t, th_d;
+                    mix_thresholds(mT, mD, wt, wp, tv, th_t, th_d);
+                    unsigned pm = 0;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (accT[rb][reg] >= th_t && accD[rb][reg] >= th_d) pm |= 1u << reg;
                     unsigned m = 0;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int lc = t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
-                        if (mix_can_reach(accT[rb][reg], accD[rb][reg], wt, wp, tv) && lc < p.n_valid_col) m |= 1u << reg;
+                        if (__ballot((pm >> reg) & 1u)) {
+                            const int lc = t * 32 + 4 * hi + (reg & 3) + 8 * (reg >> 2);
+                            if (((pm >> reg) & 1u) && mix_can_reach(accT[rb][reg], accD[rb][reg], wt, wp, tv) && lc < p.n_valid_col)
+                                m |= 1u << reg;
+                        }
                     }
                     if (m) {
                         int at = atomicAdd(&lcnt[rb * 32 + j], __popc(m));
