@@ -494,7 +494,10 @@ __global__ __launch_bounds__(256) void mix_prep_pack_kernel(const float* __restr
 }
 
 // ---- refine: bounds of every candidate, the ones that can still be among the k best recomputed in fp32 -------------------
-constexpr int MR_THREADS = 1024, MR_WAVES = 16, MR_DEPTH = 4;
+constexpr int MR_THREADS = 1024, MR_WAVES = 16;
+// ring of 2 blocks per chain: hipcc waits for every load in flight at each block anyway (run-time bounds around the refills), so a deeper
+// ring bought nothing but registers -- at depth 4 the kernel spilled 12 of them into its chains (137 -> 131 us per 750 rows)
+constexpr int MR_DEPTH = 2;
 constexpr int MR_ROWSTRIDE = 20;       // dwords per candidate in a wave's transposition buffer (refine.hip)
 constexpr int MR_MAX_SEG = 1024;
 constexpr int MR_STAGE = 8192;         // candidates of a row whose two keys fit LDS (next to the 16 waves' 80 KiB of buffers)
