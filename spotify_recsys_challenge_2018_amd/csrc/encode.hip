@@ -278,20 +278,33 @@ __global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
         constexpr int CK = 32;
         float xa[CK], xb[CK];
         const int nch = (min(nnz, 256) + CK - 1) / CK;            // chunks held in registers (wave-uniform)
-        if (nch > 0) { ENC_ISSUE(xa, cl[0], 0, min(CK, nnz), CK) }
+        // WHOLE chunks, issued unconditionally (round 5): the registers beyond the row's end hold column 0 / weight 0, so a full chunk
+        // reads W row 0 (one cached line) for them and adds +0 -- as the partial groups of 16 always did.  With the per-group guards
+        // and the "is there a next chunk" branch around the issue, hipcc could not count the loads in flight and every chain waited
+        // with vmcnt(0): for the chunk it needed AND the one it had just requested -- a memory round trip per chunk instead of a
+        // double buffer (ISA, profiles/r05_notes.md 15).  Now chunk c + 1 always goes out before chunk c's chain (the last of the
+        // eight excepted, at compile time), and the wait in between is a count.
+#define ENC_ISSUE_ALL(X, CL, OFF)                                                              \
+        _Pragma("unroll") for (int u = 0; u < CK; ++u)                                         \
+            X[u] = ld1(rs, voff, __builtin_amdgcn_readlane(CL, (OFF) + u) * hbytes);
+#define ENC_CHAIN_ALL(X, WL, OFF)                                                              \
+        _Pragma("unroll") for (int u = 0; u < CK; ++u)                                         \
+            acc = fmaf(rl_f(WL, (OFF) + u), X[u], acc);
+        if (nch > 0) { ENC_ISSUE_ALL(xa, cl[0], 0) }
 #pragma unroll
         for (int c2 = 0; c2 < 256 / CK; ++c2) {
             if (c2 < nch) {
-                const int n_cur = min(CK, nnz - CK * c2), n_nxt = min(CK, nnz - CK * (c2 + 1));
                 if (c2 & 1) {
-                    if (c2 + 1 < nch) { ENC_ISSUE(xa, cl[((c2 + 1) * CK) >> 6], ((c2 + 1) * CK) & 63, n_nxt, CK) }
-                    ENC_CHAIN(xb, wl[(c2 * CK) >> 6], (c2 * CK) & 63, n_cur, CK)
+                    if (c2 + 1 < 256 / CK) { ENC_ISSUE_ALL(xa, cl[(((c2 + 1) * CK) >> 6) & 3], ((c2 + 1) * CK) & 63) }
+                    ENC_CHAIN_ALL(xb, wl[(c2 * CK) >> 6], (c2 * CK) & 63)
                 } else {
-                    if (c2 + 1 < nch) { ENC_ISSUE(xb, cl[((c2 + 1) * CK) >> 6], ((c2 + 1) * CK) & 63, n_nxt, CK) }
-                    ENC_CHAIN(xa, wl[(c2 * CK) >> 6], (c2 * CK) & 63, n_cur, CK)
+                    if (c2 + 1 < 256 / CK) { ENC_ISSUE_ALL(xb, cl[(((c2 + 1) * CK) >> 6) & 3], ((c2 + 1) * CK) & 63) }
+                    ENC_CHAIN_ALL(xa, wl[(c2 * CK) >> 6], (c2 * CK) & 63)
                 }
             }
         }
+#undef ENC_ISSUE_ALL
+#undef ENC_CHAIN_ALL
         for (int base = beg + 256; base < end; base += 64) {     // rare long tail, chunk by chunk
             const int n = min(64, end - base);
             int c_l = 0; float w_l = 0.0f;
