@@ -199,3 +199,32 @@ def test_bf16_fused_equals_unfused_across_shapes(ctx, V, nt, B, k):
     assert torch.equal(i16, i_u) and torch.equal(s16, s_u)
     z_ref = oracle.decode(h.cpu().numpy(), W_dec, b_dec, bf16=True)
     assert np.max(np.abs(z.cpu().numpy() - z_ref)) <= 3e-5
+
+
+@pytest.mark.parametrize("B", [1024, 2048])
+def test_bf16_fused_equals_unfused_at_the_loops_launch_sizes(B):
+    """Full vocabulary, the launches the drivers' loop issues (1 024 / 2 048 rows): phase A takes per-WAVE group maxima there
+    (decode_bf16_h256_wavemax_kernel; waves paired at 1 024 rows).  A threshold that was too high would lose winners: the fused
+    lists must equal the dense bf16 logits ranked by the same rule, indices and scores."""
+    import torch
+    c = _lib.Context(0)
+    try:
+        V, nt, H, k = 170000, 140000, 256, 500
+        W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=0, bias="zipf", n_tracks=nt)
+        pos, ones, seeds = make_playlists(B, nt, V - nt, seed=21)
+        rp, col, val = coo_to_csr(pos, ones, B, V)
+        srp, sc = seeds_to_csr(seeds, B, nt)
+        d = [_dev(a) for a in (rp, col, val, W_enc, b_enc, W_dec, b_dec, srp, sc)]
+        c.prepack_decoder(d[5], d[6], dtype=BF)
+        s16 = torch.empty((B, k), device="cuda"); i16 = torch.empty((B, k), dtype=torch.int32, device="cuda")
+        c.score_topk(d[0], d[1], d[2], d[3], d[4], nt, d[7], d[8], k, s16, i16, dtype=BF)
+        assert c.last_plan()["fused"] == 1
+        h = torch.empty((B, H), device="cuda")
+        c.encode(d[0], d[1], d[2], d[3], d[4], h)
+        z = torch.empty((B, V), device="cuda")
+        c.decode_dense(h, z, apply_sigmoid=False, dtype=BF)
+        s_u = torch.empty_like(s16); i_u = torch.empty_like(i16)
+        c.topk_dense(z, nt, 0, d[7], d[8], k, s_u, i_u)
+        assert torch.equal(i16, i_u) and torch.equal(s16, s_u)
+    finally:
+        c.close()
