@@ -245,7 +245,8 @@ def test_exact_needs_its_own_prepack_and_rejects_the_title_mix(ctx):
 
 # (1 024 / 2 048 rows: the launches the drivers' loop issues -- per-wave group maxima in phase A (waves paired at 1 024), the shared
 #  recomputation before the per-row ordering; b_dec = 0 at 1 024: rows that take the narrowing next to it)
-@pytest.mark.parametrize("bias,B", [("zipf", 256), ("zeros", 256), ("zipf", 1024), ("zipf", 2048), ("zeros", 1024)])
+#  640 rows: a sample of several rounds below the per-wave kernel's size -- the generic phase A on the re-dealt (band) list)
+@pytest.mark.parametrize("bias,B", [("zipf", 256), ("zeros", 256), ("zipf", 640), ("zipf", 1024), ("zipf", 2048), ("zeros", 1024)])
 def test_exact_full_size_equals_the_fp32_path(bias, B):
     """BASELINE.json configs[1] at full size (V = 170 000, H = 256): the exact mode's lists are the fp32 MFMA path's
     lists, bit for bit in indices and scores; rows 0..31 are also checked against the CPU oracle."""
