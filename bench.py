@@ -169,7 +169,8 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if isinstance(cb, dict):
         cc = {k_: cb[k_] for k_ in ("value", "unit", "cores", "kind") if k_ in cb}
-        cc["sample"] = str(cb.get("sample", ""))[:110]
+        # (whole clauses only: the driver-visible record of what the oracle ran and for how long -- VERDICT r5 Weak #11)
+        cc["sample"] = str(cb.get("sample", "")).split(";")[0][:160]
         for k_ in ("host_cpus", "gpu_matches_oracle_bitwise", "tensorflow"):
             if k_ in cb:
                 cc[k_] = cb[k_]

@@ -197,6 +197,25 @@ int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3]);
  * results).  < 1 VOIDS the guarantee and exists so that the guard can be exercised: results may then differ from the
  * fp32 path, and dae_exact_guard_read reports it (tests/test_gpu_exact.py).  0 < scale <= 1024. */
 int dae_set_exact_margin(dae_ctx* ctx, float scale);
+/* The same hook for the columns [col_from, col_to) alone (global ids; applied by the NEXT exact prepack, the other columns
+ * keep dae_set_exact_margin's factor): lets a test void the bound of a column that every row DROPS, which only the audit
+ * below can see (tests/test_gpu_exact.py::test_audit_sees_a_violation_on_a_dropped_column).  col_from == col_to: none. */
+int dae_set_exact_margin_range(dae_ctx* ctx, int col_from, int col_to, float scale);
+
+/* DAE_DTYPE_BF16_EXACT, the AUDIT of what the guard cannot see (csrc/audit.hip).  The guard tests the survivors the refine
+ * launch recomputes; a column the bf16 filter launch DROPPED (upper bound u < the row's threshold) is never recomputed, so a
+ * bound that fails there -- the only failure that can change a top-k list of main_challenge.py:28-36 -- would go unseen.
+ * Every every_n-th exact scoring launch of the context (dae_decode_topk / dae_score_topk / dae_score_topk_finish; default 32,
+ * 0 = never) therefore takes n_tiles (default 16, <= 64) pseudo-random 32-column tiles of the ranked columns -- different ones
+ * each time; nearly all of their elements are dropped ones -- and for EVERY row of the launch recomputes both the filter
+ * launch's upper bound u (the same bf16 MFMA sequence on the same operands: the same bits) and the canonical fp32 logit, and
+ * counts every element outside [u - 2 eps_c, u] in the GUARD WORDS above: callers react exactly as to a survivor's violation.
+ *   dae_exact_audit_read: out3 = {audits run, (row, column) elements checked, violations among them} since the context was
+ *                         created; synchronises the ctx stream.
+ * Proven: the bound, given the accumulation model of the bf16 MFMA.  Checked always: survivors.  Checked on a sample: dropped
+ * columns (all rows x n_tiles x 32 columns per audit).  Assumed: nothing else. */
+int dae_set_exact_audit(dae_ctx* ctx, int every_n, int n_tiles);
+int dae_exact_audit_read(dae_ctx* ctx, uint64_t out3[3]);
 
 /* ---- decode (DAEs.py:73-77 tied / :141-145 untied) ---------------------------------------- */
 

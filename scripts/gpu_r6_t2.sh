@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+export GPU_MAX_HW_QUEUES=32
+o=gpurun_out; mkdir -p $o
+export DAE_LIB_AB=$GRAFT_REPO_ROOT/scripts/probe/libdae_hip_exp.so
+for rep in 1 2; do
+DAE_PIPE_DIRECT=1 python scripts/bench_loop.py 256 native exact_bf16,bf16 3 2>&1 | grep "playlists/s" | sed "s/^/direct /"
+python scripts/bench_loop.py 256 native exact_bf16,bf16 3 2>&1 | grep "playlists/s" | sed "s/^/copyk  /"
+done | tee $o/r06_t2.log
+unset DAE_LIB_AB
+python -m pytest tests/test_gpu_stream_loop.py tests/test_gpu_title.py tests/test_gpu_title_exact.py -x -q 2>&1 | tail -4 | tee -a $o/r06_t2.log

@@ -16,7 +16,7 @@ EXPORTS = [
     "dae_version", "dae_create", "dae_destroy", "dae_set_stream", "dae_last_error",
     "dae_scratch_bytes", "dae_profile_enable", "dae_profile_read", "dae_profile_kernel", "dae_clock_probe", "dae_last_plan",
     "dae_coo_to_csr", "dae_seeds_from_csr", "dae_encode", "dae_prepack_decoder", "dae_prepack_decoder_rows", "dae_share_decoder", "dae_exact_bounds",
-    "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_guard_snapshot", "dae_exact_stats_read", "dae_set_exact_margin", "dae_decode_dense", "dae_decode_topk",
+    "dae_exact_guard_read", "dae_exact_guard_words", "dae_exact_guard_snapshot", "dae_exact_stats_read", "dae_set_exact_margin", "dae_set_exact_margin_range", "dae_set_exact_audit", "dae_exact_audit_read", "dae_decode_dense", "dae_decode_topk",
     "dae_score_topk", "dae_score_topk_begin", "dae_score_topk_finish", "dae_topk_dense", "dae_topk_merge", "dae_set_train_dtype", "dae_train_forward_backward",
     "dae_train_shard_encode", "dae_train_shard_decode", "dae_train_shard_finish", "dae_title_features", "dae_title_prepack_features",
     "dae_mix_scores", "dae_decode_mix_term", "dae_set_score_mix", "dae_mix_topk_exact", "dae_title_score_exact", "dae_title_score", "dae_row_sums", "dae_mix_weights", "dae_title_loss_backward", "dae_title_conv_backward", "dae_adam_step",
@@ -76,6 +76,9 @@ def load():
     lib.dae_exact_guard_snapshot.argtypes = [vp, vp]
     lib.dae_set_exact_margin.argtypes = [vp, c_f]
     lib.dae_exact_stats_read.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.dae_set_exact_margin_range.argtypes = [vp, c_int, c_int, c_f]
+    lib.dae_set_exact_audit.argtypes = [vp, c_int, c_int]
+    lib.dae_exact_audit_read.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.dae_decode_dense.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, c_i64]
     lib.dae_decode_topk.argtypes = [vp, vp, c_int, c_int, c_int, c_int, vp, vp, c_int, c_int, vp, vp]
     lib.dae_score_topk.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp, vp,
@@ -271,6 +274,20 @@ class Context:
         guard's test hook)."""
         self.check(self.lib.dae_set_exact_margin(self.h, float(scale)))
         self._exact_margin = float(scale)        # (models/DAEs.py hands it on to the pipelines it builds from this model)
+
+    def set_exact_margin_range(self, col_from, col_to, scale):
+        """The same for the columns [col_from, col_to) alone (the audit's test hook: a column every row drops)."""
+        self.check(self.lib.dae_set_exact_margin_range(self.h, int(col_from), int(col_to), float(scale)))
+
+    def set_exact_audit(self, every_n, n_tiles=16):
+        """Every every_n-th exact scoring launch audits n_tiles random tiles of DROPPED columns (0: never; include/dae_hip.h)."""
+        self.check(self.lib.dae_set_exact_audit(self.h, int(every_n), int(n_tiles)))
+
+    def exact_audit_read(self):
+        """{audits, checked, violations} of the dropped-column audit since the context was created (synchronises)."""
+        a = (ctypes.c_uint64 * 3)()
+        self.check(self.lib.dae_exact_audit_read(self.h, a))
+        return {"audits": int(a[0]), "checked": int(a[1]), "violations": int(a[2])}
 
     def exact_guard_read(self):
         """(violations, column) of the exact mode's bound guard since the last non-zero read; synchronises the stream."""
@@ -503,6 +520,13 @@ class Pipeline:
             raise DaeError("dae_pipeline_create failed (%d): %s" % (rc, self.lib.dae_pipeline_last_error(None).decode()))
         self.h = h
         self.pending = 0                     # feeds submitted and not yet yielded
+        # the foreign calls' out-parameters, made once (a feed is ~25 us of this thread: five ctypes objects and their byref()
+        # per poll were 3 us of it)
+        self._t, self._n, self._b = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int()
+        self._ip, self._sp = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_float)()
+        self._poll_args = (ctypes.byref(self._t), ctypes.byref(self._ip), ctypes.byref(self._sp) if self.want_scores else None,
+                           ctypes.byref(self._n), ctypes.byref(self._b))
+        self._t_ref = ctypes.byref(self._t)
         # a pipeline owns a library thread and streams: it must be gone before the runtime is (a destructor running HIP calls
         # during interpreter teardown is undefined -- ADVICE r4)
         global _live_pipelines
@@ -525,12 +549,13 @@ class Pipeline:
         import numpy as np
         if self._closing:
             raise DaeError("dae_pipeline: closed")
-        pos = np.ascontiguousarray(positions, np.int64).reshape(-1, 2)
-        val = np.ascontiguousarray(values, np.float32).reshape(-1)
-        nnz = pos.shape[0]
+        pos = positions if (type(positions) is np.ndarray and positions.dtype == np.int64 and positions.flags.c_contiguous) \
+            else np.ascontiguousarray(positions, np.int64)
+        val = values if (type(values) is np.ndarray and values.dtype == np.float32 and values.flags.c_contiguous) \
+            else np.ascontiguousarray(values, np.float32)
+        nnz = pos.size >> 1
         if val.size != nnz and val.size != 1:
             raise ValueError("positions (%d) and values (%d) differ in length" % (nnz, val.size))
-        t = ctypes.c_uint64()
         if titles is not None:
             tt = np.ascontiguousarray(titles, np.int32).reshape(-1)
             uu = np.ascontiguousarray(titles_use, np.float32).reshape(-1)
@@ -539,10 +564,13 @@ class Pipeline:
             rc = self._check(self.lib.dae_pipeline_submit_titled(
                 self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
                 1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), tt.ctypes.data_as(ctypes.c_void_p),
-                uu.ctypes.data_as(ctypes.c_void_p), ctypes.byref(t)))
+                uu.ctypes.data_as(ctypes.c_void_p), self._t_ref))
         else:
-            rc = self._check(self.lib.dae_pipeline_submit(self.h, pos.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
-                                                          1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), ctypes.byref(t)))
+            rc = self.lib.dae_pipeline_submit(self.h, ctypes.c_void_p(pos.__array_interface__["data"][0]),
+                                              ctypes.c_void_p(val.__array_interface__["data"][0]),
+                                              1 if (val.size == 1 and nnz != 1) else 0, nnz, int(n_rows), self._t_ref)
+            if rc < 0:
+                self._check(rc)
         if rc == DAE_PIPE_BUSY:
             return False
         self.pending += 1
@@ -558,10 +586,10 @@ class Pipeline:
         import numpy as np
         if self.pending == 0:
             return None
-        t, n, b = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int()
-        ip_, sp_ = ctypes.POINTER(ctypes.c_int32)(), ctypes.POINTER(ctypes.c_float)()
-        rc = self._check(self.lib.dae_pipeline_poll(self.h, 1 if wait else 0, ctypes.byref(t), ctypes.byref(ip_),
-                                                    ctypes.byref(sp_) if self.want_scores else None, ctypes.byref(n), ctypes.byref(b)))
+        n, b, ip_, sp_ = self._n, self._b, self._ip, self._sp
+        rc = self.lib.dae_pipeline_poll(self.h, 1 if wait else 0, *self._poll_args)
+        if rc < 0:
+            self._check(rc)
         if rc == DAE_PIPE_BUSY:
             raise DaeError("dae_pipeline: every result block is held (drop or copy the arrays of earlier feeds)")
         if n.value == 0:

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdae_hip.so")
-SOURCES = ["api.hip", "encode.hip", "decode_f32.hip", "topk.hip", "refine.hip", "mixexact.hip", "train.hip", "csr.hip", "title.hip", "pipeline.hip"]
+SOURCES = ["api.hip", "encode.hip", "decode_f32.hip", "topk.hip", "refine.hip", "audit.hip", "mixexact.hip", "train.hip", "csr.hip", "title.hip", "pipeline.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-vectorize: hipcc's LOOP vectorizer miscompiles per-lane strided loops of these kernels (a loop `for (i = lane; i < n;
 # i += 64) { kl[b + i] = f(x[i]); ku[b + i] = g(x[i]); min / max of f }` leaves the key of entry i + 64 m in slot i of the

@@ -486,6 +486,40 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     const int n_other = ntiles - n_samp;
     g_plan = Plan{g.R_TILE, g.n_rg, g.nb_rg, fused ? S : 1, n_samp, n_other, fused ? 1 : 0, ntiles};
 
+    // ---- the sample launch's OWN geometry (round 6) ------------------------------------------------------------------------------
+    // Phase A decodes 1 / 11 of the tiles the filter launch decodes, yet on the filter launch's grid (a workgroup per CU) it held
+    // every CU for 8 - 15 us: one or two tiles per wave behind a 64 KB hidden-tile fill, with registers / LDS that let nothing of
+    // another batch in.  With several batches in flight the step is the SUM of such chip-wide launches (filter + sample + refine:
+    // profiles/r06_notes.md).  So the sample takes fewer workgroups per row group -- ~4 tiles per wave slot of the per-wave-maxima
+    // kernel (decode_bf16_h256_wavemax_kernel), 8 nbA x 32 maxima per row -- and leaves the other CUs to the other batches' launches.
+    // Same sample tiles, same logits; the groups (the tiles one wave decodes, n_ws places apart in the bias order) change, i.e.
+    // only how tight tau is.  Only where that kernel applies (bf16 image of hidden 256, 128-row groups, no title mix).
+    const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
+    static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
+    // does a launch of geometry gg take per-WAVE groups?  (the one predicate behind `wave_groups` below)
+    auto takes_wave_groups = [&](const dae_rowgeom& gg) {
+        const int n_ws = gg.nb_rg * gg.waves;
+        const bool enough = (int64_t)((n_samp + n_ws - 1) / n_ws) * gg.nb_rg * 32 >= 4 * (int64_t)k;      // (else: one value per wave slot)
+        return fused && enough && dtype == DAE_DTYPE_BF16 && !mixed && (!no_whole || exact) && dae_sample_wave_groups(gg, pk->Hp, n_samp);
+    };
+    dae_rowgeom gA = g;
+    {
+        // measured (profiles/r06_notes.md 2, four batches in flight / alone, M playlists/s, exact mode): 256 rows 6.28 -> 6.62 / 3.92 ->
+        // 3.59 at 16 workgroups per row group; 1 024 rows 9.10 -> 9.86 / 7.10 -> 6.53 at 8; 2 048 rows 10.85 -> 11.50 / 8.0 -> 8.0 at 8
+        // -- a gain only when other batches' launches can use the CUs: taken under dae_set_overlap_hint, ~4 tiles per wave slot for
+        // launches of few row groups, ~8 from 8 row groups on
+        const int per_slot = g.n_rg >= 8 ? 8 : 4;
+        int nbA = ctx->overlap_hint ? ((n_samp + 8 * per_slot - 1) / (8 * per_slot) + DAE_NUM_XCD - 1) / DAE_NUM_XCD * DAE_NUM_XCD : g.nb_rg;
+        static const int nba_env = dae_exp_env("DAE_SAMPLE_NB") ? atoi(dae_exp_env("DAE_SAMPLE_NB")) : 0;            // A/B (experiments)
+        if (nba_env > 0) nbA = nba_env / DAE_NUM_XCD * DAE_NUM_XCD;
+        if (nbA < DAE_NUM_XCD) nbA = DAE_NUM_XCD;
+        if (nbA < g.nb_rg) {
+            dae_rowgeom t = g;
+            t.nb_rg = nbA; t.grid = g.n_rg * nbA;
+            if (takes_wave_groups(t) && (int64_t)8 * nbA * 32 >= 4 * (int64_t)k) gA = t;
+        }
+    }
+
     // phase A (or the whole problem when it is small): dense logits of the sampled tiles
     const int64_t ld_s = (int64_t)n_samp * 32;
     rc = dae_reserve(ctx, ctx->sample, (size_t)B * ld_s * sizeof(float));
@@ -501,19 +535,19 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
         // sample re-dealt so that a workgroup's tiles of a round come from different popularity bands (decode_f32.hip
         // tile_band_kernel); the list is this context's, rebuilt when the order or the geometry changes
         static const bool no_band = dae_exp_env("DAE_NO_BAND") != nullptr;                    // A/B (experiments build)
-        const int n_ws_s = g.nb_rg * g.waves;
+        const int n_ws_s = gA.nb_rg * gA.waves;
         // (not when the launch takes per-WAVE groups -- see wave_groups below: there the plain order IS band-dealt)
-        const bool wg_early = dtype == DAE_DTYPE_BF16 && ctx->mixT == nullptr && dae_sample_wave_groups(g, pk->Hp, n_samp) &&
-                              ((int64_t)((n_samp + n_ws_s - 1) / n_ws_s) * g.nb_rg * 32 >= 4 * (int64_t)k);
+        const bool wg_early = dtype == DAE_DTYPE_BF16 && ctx->mixT == nullptr && dae_sample_wave_groups(gA, pk->Hp, n_samp) &&
+                              ((int64_t)((n_samp + n_ws_s - 1) / n_ws_s) * gA.nb_rg * 32 >= 4 * (int64_t)k);
         if (dtype == DAE_DTYPE_BF16 && n_samp > n_ws_s && !no_band && !wg_early) {
             const void* band_was = ctx->tile_band.p;
             rc = dae_reserve(ctx, ctx->tile_band, (size_t)ntiles * sizeof(int));
             if (rc) return rc;
             if (ctx->tile_band.p != band_was) ctx->band_gen = -1;
-            if (ctx->band_gen != pkm.order_gen || ctx->band_nsamp != n_samp || ctx->band_nbrg != g.nb_rg || ctx->band_waves != g.waves) {
-                rc = dae_launch_tile_band(ctx, order, ntiles, n_samp, g.nb_rg, g.waves, static_cast<int*>(ctx->tile_band.p));
+            if (ctx->band_gen != pkm.order_gen || ctx->band_nsamp != n_samp || ctx->band_nbrg != gA.nb_rg || ctx->band_waves != gA.waves) {
+                rc = dae_launch_tile_band(ctx, order, ntiles, n_samp, gA.nb_rg, gA.waves, static_cast<int*>(ctx->tile_band.p));
                 if (rc) return rc;
-                ctx->band_gen = pkm.order_gen; ctx->band_nsamp = n_samp; ctx->band_nbrg = g.nb_rg; ctx->band_waves = g.waves;
+                ctx->band_gen = pkm.order_gen; ctx->band_nsamp = n_samp; ctx->band_nbrg = gA.nb_rg; ctx->band_waves = gA.waves;
             }
             order = static_cast<const int*>(ctx->tile_band.p);
         }
@@ -521,26 +555,23 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     dae_tileset tsA{n_samp, fused ? S : 1, fused ? 3 : 0, order};
     float* gmax = nullptr;
     // one maximum per (workgroup of the row group, round of sample tiles, position in the tile)
-    const int n_ws_a = g.nb_rg * g.waves;
-    int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * g.nb_rg * 32;
+    const int n_ws_a = gA.nb_rg * gA.waves;
+    int64_t ld_g = (int64_t)((n_samp + n_ws_a - 1) / n_ws_a) * gA.nb_rg * 32;
     // ... unless that leaves too few maxima for the rank tau needs (k + seeds): small samples -- vocabulary shards,
     // large batches -- keep one value per wave slot and position, i.e. every sample element
     int gmax_per_wave = ld_g < 4 * (int64_t)k ? 1 : 0;
-    if (gmax_per_wave) ld_g *= g.waves;
-    const bool mixed = ctx->mixT != nullptr;               // dae_set_score_mix: the launches rank the MIXED score
+    if (gmax_per_wave) ld_g *= gA.waves;
     if (mixed && exact) return dae_fail(ctx, DAE_ERR_ARG, "DAE_DTYPE_BF16_EXACT is not available with dae_set_score_mix");
-    static const bool no_whole = dae_exp_env("DAE_BF16_KEEP_SAMPLE") != nullptr;       // A/B
-    // launches of many rows (>= 1 024 at the full vocabulary): the groups are the tiles ONE wave of the filter kernel's shape
-    // decodes (decode_bf16_h256_wavemax_kernel: no exchange through LDS, two waves per SIMD) -- 8 nb_rg x 32 maxima per row
-    const bool wave_groups = fused && !gmax_per_wave && dtype == DAE_DTYPE_BF16 && !mixed && (!no_whole || exact) &&
-                             dae_sample_wave_groups(g, pk->Hp, n_samp);
+    // the groups are the tiles ONE wave of the filter kernel's shape decodes (decode_bf16_h256_wavemax_kernel: no exchange
+    // through LDS, two waves per SIMD) -- 8 nb_rg x 32 maxima per row
+    const bool wave_groups = takes_wave_groups(gA);        // (== !gmax_per_wave && ...: the same `enough`)
     if (wave_groups) {
         // (fewer than four tiles per wave slot: waves w and w + 4 share a group -- value 4 -- so that a row has 4 nb_rg x 32 maxima:
         // 4 096 at 1 024 rows, the threshold kernel's 16-key shape)
         static const bool no_pair = dae_exp_env("DAE_WAVEMAX_NOPAIR") != nullptr;            // A/B (experiments build)
-        const bool pair = n_samp < 4 * g.nb_rg * 8 && (int64_t)4 * g.nb_rg * 32 >= 4 * (int64_t)k && !no_pair;
+        const bool pair = n_samp < 4 * gA.nb_rg * 8 && (int64_t)4 * gA.nb_rg * 32 >= 4 * (int64_t)k && !no_pair;
         gmax_per_wave = pair ? 4 : 3;
-        ld_g = (int64_t)(pair ? 4 : 8) * g.nb_rg * 32;
+        ld_g = (int64_t)(pair ? 4 : 8) * gA.nb_rg * 32;
     }
     if (fused || mixed) {                                  // (the mix lives in the GMAX / FILTER epilogues)
         rc = dae_reserve(ctx, ctx->gmax, (size_t)B * ld_g * sizeof(float));
@@ -558,7 +589,8 @@ static int topk_phase_a(dae_ctx* ctx, const dae_packed* pk, const dae_rowgeom& g
     const bool whole_b = fused && dtype == DAE_DTYPE_BF16 && ((gmax_per_wave != 1 && !mixed && !no_whole) || exact);
     if (whole_b) g_plan.n_other = ntiles;
     if (!fused) { rc = prof_begin(ctx); if (rc) return rc; }
-    rc = dae_launch_decode_dense_f32(ctx, g, B, tsA, 0, n_valid_col, whole_b ? nullptr : sample, ld_s, 1, dtype, gmax, ld_g,
+    // (gA != g only with per-wave groups: the generic kernels run on the filter launch's geometry)
+    rc = dae_launch_decode_dense_f32(ctx, wave_groups ? gA : g, B, tsA, 0, n_valid_col, whole_b ? nullptr : sample, ld_s, 1, dtype, gmax, ld_g,
                                      gmax_per_wave, exact ? 1 : 0);
     if (rc) return rc;
     if (!fused) { rc = prof_end(ctx); if (rc) return rc; }
@@ -672,6 +704,10 @@ static int topk_phase_b(dae_ctx* ctx, const float* tau_src, const int32_t* seed_
         const bool fuse = !no_fuse && dae_exact_refine_can_fuse(ta);
         rc = dae_launch_exact_refine(ctx, g1, xs, B, k, seed_row_ptr, rf, rf_cnt, DAE_REFINED_CAP, static_cast<int*>(ctx->refstat.p),
                                      fuse ? &ta : nullptr);
+        // every audit_every-th launch: a sample of the columns the filter launch DROPPED against its own promise (audit.hip) --
+        // behind the refine launch, so that the lists are not held up; its verdict lands in the guard words the callers fetch
+        if (!rc && ctx->audit_every > 0 && ctx->audit_tiles > 0 && (++ctx->audit_seq % (uint64_t)ctx->audit_every) == 0)
+            rc = dae_launch_exact_audit(ctx, g, B, xs, tk.nrank, ctx->audit_tiles);
         if (rc || fuse) return rc;
         dae_pair_group gr{rf, rf_cnt, 0, DAE_REFINED_CAP, 0, 1, 0};
         return dae_launch_topk_pairs(ctx, gr, g1, ta);

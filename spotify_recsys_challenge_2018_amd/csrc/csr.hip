@@ -16,7 +16,10 @@ namespace {
 
 constexpr int CSR_ROW_CAP = 4096;      // entries of one row held in LDS (16 B each)
 
-__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ pos, int64_t nnz,
+// PT: the feed's index type -- int64_t (the reference's feed: models/DAEs.py:23 x_positions is tf.int64) or int32_t (what
+// dae_pipeline stages: its copy of a feed narrows the pairs, half the pinned bytes and half the upload)
+template <typename PT>
+__global__ __launch_bounds__(256) void csr_count_kernel(const PT* __restrict__ pos, int64_t nnz,
                                                         int n_rows, int n_cols, int* __restrict__ cnt,
                                                         int* __restrict__ status)
 {
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int* __restrict__ 
     if (tid == 0) out[n] = carry;
 }
 
-__global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restrict__ pos,
+template <typename PT>
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const PT* __restrict__ pos,
                                                           const float* __restrict__ val, int val_bcast,
                                                           int64_t nnz, int n_rows, int n_cols,
                                                           const int* __restrict__ bptr, int* __restrict__ cursor,
@@ -82,15 +86,17 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
                                                       const int* __restrict__ t_feed,
                                                       const float* __restrict__ t_val,
                                                       int* __restrict__ k_col, float* __restrict__ k_val,
-                                                      int* __restrict__ kcnt)
+                                                      int* __restrict__ kcnt, int n_tracks, int* __restrict__ scnt)
 {
+    // scnt (nullable): kept entries of the row with column < n_tracks -- the row's seed list when the seeds are the playlist's own
+    // tracks (seeds_from_csr_kernel below); columns ascend, so they are the row's FIRST scnt[row] kept entries
     __shared__ int s_col[CSR_ROW_CAP];
     __shared__ int s_feed[CSR_ROW_CAP];
     __shared__ unsigned char s_keep[CSR_ROW_CAP];
-    __shared__ int s_n;
+    __shared__ int s_n, s_ns;
     const int row = blockIdx.x, tid = threadIdx.x;
     const int b = bptr[row], n = bptr[row + 1] - b;
-    if (tid == 0) s_n = 0;
+    if (tid == 0) { s_n = 0; s_ns = 0; }
     if (n <= CSR_ROW_CAP) {
         // ---- the row fits the LDS buffers (always, for playlist batches) ----
         float my_val[CSR_ROW_CAP / 256];
@@ -123,10 +129,11 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
             int slot = 0;
             for (int j = 0; j < n; ++j) slot += (s_keep[j] != 0) & (s_col[j] < c);
             atomicAdd(&s_n, 1);
+            if (c < n_tracks) atomicAdd(&s_ns, 1);
             k_col[b + slot] = c; k_val[b + slot] = my_val[u];
         }
         __syncthreads();
-        if (tid == 0) kcnt[row] = s_n;
+        if (tid == 0) { kcnt[row] = s_n; if (scnt) scnt[row] = s_ns; }
         return;
     }
     // ---- a row longer than the LDS buffers: the same steps over global memory ----
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
         int slot = 0;
         for (int j = 0; j < n; ++j) slot += (k_col[b + j] != 0 && colp[j] < c) ? 1 : 0;
         atomicAdd(&s_n, 1);
+        if (c < n_tracks) atomicAdd(&s_ns, 1);
         k_val[b + slot] = __int_as_float(i);
     }
     __syncthreads();
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
         k_col[b + s] = t_col[b + i];
         k_val[b + s] = t_val[b + i];
     }
-    if (tid == 0) kcnt[row] = s_n;
+    if (tid == 0) { kcnt[row] = s_n; if (scnt) scnt[row] = s_ns; }
 }
 
 __global__ __launch_bounds__(256) void csr_compact_kernel(const int* __restrict__ bptr,
@@ -184,7 +192,8 @@ __global__ __launch_bounds__(256) void csr_compact_kernel(const int* __restrict_
 // own.  4 launches per feed (count, scatter, per-row order + dedup, compact) instead of 6.
 constexpr int CSR_SMALL_ROWS = 4096;     // 2 x 16 KiB of LDS counters in the scatter kernel
 
-__global__ __launch_bounds__(1024) void csr_count_lds_kernel(const int64_t* __restrict__ pos, int64_t nnz,
+template <typename PT>
+__global__ __launch_bounds__(1024) void csr_count_lds_kernel(const PT* __restrict__ pos, int64_t nnz,
                                                              int n_rows, int n_cols, int* __restrict__ cnt,
                                                              int* __restrict__ status)
 {
@@ -227,7 +236,8 @@ __device__ int block_exclusive_scan_1024(int* a, int n, int* wsum /*[16]*/)
     return carry;
 }
 
-__global__ __launch_bounds__(1024) void csr_scatter_lds_kernel(const int64_t* __restrict__ pos,
+template <typename PT>
+__global__ __launch_bounds__(1024) void csr_scatter_lds_kernel(const PT* __restrict__ pos,
                                                                const float* __restrict__ val, int val_bcast,
                                                                int64_t nnz, int n_rows, int n_cols,
                                                                const int* __restrict__ cnt, int* __restrict__ cursor,
@@ -277,24 +287,39 @@ __global__ __launch_bounds__(256) void csr_compact_sum_kernel(const int* __restr
                                                               int32_t* __restrict__ row_ptr,
                                                               int32_t* __restrict__ col, float* __restrict__ val,
                                                               const int* __restrict__ sflag,
-                                                              int32_t* __restrict__ status)
+                                                              int32_t* __restrict__ status,
+                                                              const int* __restrict__ scnt,
+                                                              int32_t* __restrict__ seed_row_ptr,
+                                                              int32_t* __restrict__ seed_col)
 {
-    __shared__ int ws[4];
+    // scnt / seed_row_ptr / seed_col (all or none): the seed lists of the batch from the same launch (round 6: the two launches of
+    // dae_launch_seeds_from_csr folded in -- the drivers' loop builds both for every launch) -- a row's seeds are its first scnt[row]
+    // kept entries, their offset the sum of the counts before it
+    __shared__ int ws[4], wq[4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    int s = 0;
-    for (int r = tid; r < row; r += 256) s += kcnt[r];
+    int s = 0, q = 0;
+    for (int r = tid; r < row; r += 256) { s += kcnt[r]; if (scnt) q += scnt[r]; }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if (lane == 0) ws[tid >> 6] = s;
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d); q += __shfl_xor(q, d); }
+    if (lane == 0) { ws[tid >> 6] = s; wq[tid >> 6] = q; }
     __syncthreads();
     const int o = ws[0] + ws[1] + ws[2] + ws[3];
-    const int b = bptr[row], m = kcnt[row];
+    const int so = wq[0] + wq[1] + wq[2] + wq[3];
+    const int b = bptr[row], m = kcnt[row], sm = scnt ? scnt[row] : 0;
     if (tid == 0) {
         row_ptr[row] = o;
         if (row == n_rows - 1) row_ptr[n_rows] = o + m;
+        if (scnt) {
+            seed_row_ptr[row] = so;
+            if (row == n_rows - 1) seed_row_ptr[n_rows] = so + sm;
+        }
         if (row == 0) *status = *sflag;              // the caller's flag, written once
     }
-    for (int s2 = tid; s2 < m; s2 += 256) { col[o + s2] = k_col[b + s2]; val[o + s2] = k_val[b + s2]; }
+    for (int s2 = tid; s2 < m; s2 += 256) {
+        const int c = k_col[b + s2];
+        col[o + s2] = c; val[o + s2] = k_val[b + s2];
+        if (s2 < sm) seed_col[so + s2] = c;
+    }
 }
 
 // The seed lists of a scoring call when the seeds ARE the playlist's own tracks (main_challenge.py:76-88: `seed` is
@@ -384,24 +409,28 @@ int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_
     return DAE_OK;
 }
 
-int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
-                          int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
-                          int32_t* status)
+namespace {
+template <typename PT>
+int launch_coo_to_csr(dae_ctx* ctx, const PT* positions, const float* values, int values_broadcast,
+                      int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                      int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col)
 {
     hipStream_t st = ctx->stream;
     int rc;
-    // scratch: cnt | cursor | bptr | kcnt  (n_rows + 1 each), then t_col | t_feed | t_val | k_col | k_val
+    const bool seeds = seed_row_ptr != nullptr;
+    // scratch: cnt | cursor | bptr | kcnt | scnt  (n_rows + 1 each), then t_col | t_feed | t_val | k_col | k_val
     // (n_rows + 1 rounded up to a multiple of 4: the fill of cnt | cursor | flag below is then a whole number of 16-byte
     // words and ONE fill kernel -- 6 024 bytes for 750 rows went out as two, 5 us each on the launch's critical path)
     const size_t nr = ((size_t)n_rows + 1 + 3) & ~(size_t)3;
-    const size_t ints = 4 * nr + 4 + 5 * (size_t)(nnz > 0 ? nnz : 1);
+    const size_t ints = 5 * nr + 4 + 5 * (size_t)(nnz > 0 ? nnz : 1);
     if ((rc = dae_reserve(ctx, ctx->csr_tmp, ints * sizeof(int)))) return rc;
     int* cnt = static_cast<int*>(ctx->csr_tmp.p);
     int* cursor = cnt + nr;
     int* sflag = cursor + nr;                      // range flag of this build, cleared with cnt | cursor in ONE fill
     int* bptr = sflag + 4;
     int* kcnt = bptr + nr;
-    int* t_col = kcnt + nr;
+    int* scnt = kcnt + nr;
+    int* t_col = scnt + nr;
     int* t_feed = t_col + nnz;
     float* t_val = reinterpret_cast<float*>(t_feed + nnz);
     int* k_col = reinterpret_cast<int*>(t_val + nnz);
@@ -413,18 +442,18 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
         const int blocks = (int)((nnz + 1023) / 1024) > 0 ? (int)((nnz + 1023) / 1024) : 1;
         const size_t lds = (size_t)n_rows * sizeof(int);
         if (nnz > 0) {
-            hipLaunchKernelGGL(csr_count_lds_kernel, dim3(blocks), dim3(1024), lds, st, positions, nnz, n_rows, n_cols,
+            hipLaunchKernelGGL(csr_count_lds_kernel<PT>, dim3(blocks), dim3(1024), lds, st, positions, nnz, n_rows, n_cols,
                                cnt, sflag);
             DAE_CHECK_LAUNCH(ctx, "csr_count_lds_kernel");
         }
-        hipLaunchKernelGGL(csr_scatter_lds_kernel, dim3(blocks), dim3(1024), 2 * lds, st, positions, values,
+        hipLaunchKernelGGL(csr_scatter_lds_kernel<PT>, dim3(blocks), dim3(1024), 2 * lds, st, positions, values,
                            values_broadcast, nnz, n_rows, n_cols, cnt, cursor, bptr, t_col, t_feed, t_val);
         DAE_CHECK_LAUNCH(ctx, "csr_scatter_lds_kernel");
         hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
-                           kcnt);
+                           kcnt, n_tracks, seeds ? scnt : nullptr);
         DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
         hipLaunchKernelGGL(csr_compact_sum_kernel, dim3(n_rows), dim3(256), 0, st, bptr, kcnt, n_rows, k_col, k_val,
-                           row_ptr, col, val, sflag, status);
+                           row_ptr, col, val, sflag, status, seeds ? scnt : nullptr, seed_row_ptr, seed_col);
         DAE_CHECK_LAUNCH(ctx, "csr_compact_sum_kernel");
         return DAE_OK;
     }
@@ -433,7 +462,7 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     if (nnz > 0) {
         int blocks = (int)((nnz + 255) / 256);
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(csr_count_kernel, dim3(blocks), dim3(256), 0, st, positions, nnz, n_rows, n_cols, cnt,
+        hipLaunchKernelGGL(csr_count_kernel<PT>, dim3(blocks), dim3(256), 0, st, positions, nnz, n_rows, n_cols, cnt,
                            status);
         DAE_CHECK_LAUNCH(ctx, "csr_count_kernel");
     }
@@ -442,16 +471,37 @@ int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* v
     if (nnz > 0) {
         int blocks = (int)((nnz + 255) / 256);
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(csr_scatter_kernel, dim3(blocks), dim3(256), 0, st, positions, values, values_broadcast,
+        hipLaunchKernelGGL(csr_scatter_kernel<PT>, dim3(blocks), dim3(256), 0, st, positions, values, values_broadcast,
                            nnz, n_rows, n_cols, bptr, cursor, t_col, t_feed, t_val);
         DAE_CHECK_LAUNCH(ctx, "csr_scatter_kernel");
     }
     hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
-                       kcnt);
+                       kcnt, n_tracks, static_cast<int*>(nullptr));
     DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, kcnt, n_rows, row_ptr);
     DAE_CHECK_LAUNCH(ctx, "csr_scan_kernel");
     hipLaunchKernelGGL(csr_compact_kernel, dim3(n_rows), dim3(256), 0, st, bptr, row_ptr, k_col, k_val, col, val);
     DAE_CHECK_LAUNCH(ctx, "csr_compact_kernel");
+    // (more than CSR_SMALL_ROWS rows: the seed lists by their own two launches)
+    if (seeds) return dae_launch_seeds_from_csr(ctx, row_ptr, col, n_rows, n_tracks, seed_row_ptr, seed_col);
     return DAE_OK;
+}
+}  // namespace
+
+int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                          int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                          int32_t* status)
+{
+    return launch_coo_to_csr<int64_t>(ctx, positions, values, values_broadcast, nnz, n_rows, n_cols, row_ptr, col, val, status,
+                                      0, nullptr, nullptr);
+}
+
+// the drivers' loop (pipeline.hip): 32-bit (row, col) pairs as dae_pipeline stages them, and the seed lists (the playlist's own
+// tracks: columns < n_tracks) from the same four launches
+int dae_launch_coo32_to_csr_seeds(dae_ctx* ctx, const int32_t* positions, const float* values, int values_broadcast,
+                                  int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                                  int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col)
+{
+    return launch_coo_to_csr<int32_t>(ctx, positions, values, values_broadcast, nnz, n_rows, n_cols, row_ptr, col, val, status,
+                                      n_tracks, seed_row_ptr, seed_col);
 }

@@ -16,6 +16,7 @@
 // ---------------------------------------------------------------------------------------------
 // geometry constants of the decode path (see DESIGN.md "HBM layout")
 // ---------------------------------------------------------------------------------------------
+constexpr int DAE_TITLE_MAX_SIZES = 8;   // filter sizes a title scorer may have (title.hip's kernels, the table, dae_pipeline_create_titled)
 constexpr int DAE_VT = 32;        // vocabulary columns per wave tile (MFMA M = 32)
 constexpr int DAE_KG = 8;         // k values per packed group (4 MFMA 32x32x2 steps)
 constexpr int DAE_HPAD = 32;      // hidden size is zero-padded to a multiple of this
@@ -125,12 +126,17 @@ struct dae_ctx {
     dae_buf refstat; int refstat_rows = 0;   // DAE_DTYPE_BF16_EXACT: [rows][2] {candidates, recomputed} of the last refine launch
     dae_buf guard;             // DAE_DTYPE_BF16_EXACT: {violations of the bound seen by the refine launches, a violating column}
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
+    int margin_lo = 0, margin_hi = 0; float margin_scale = 1.0f;   // dae_set_exact_margin_range: columns [lo, hi) take this factor instead
+    // the audit of dropped columns (audit.hip): every audit_every-th exact scoring launch checks audit_tiles random tiles
+    int audit_every = 32, audit_tiles = 16;
+    uint64_t audit_seq = 0, audits_run = 0;
+    dae_buf audit; void* audit_stat_ptr = nullptr;   // {elements checked, violations} | tile ids | upper bounds [Bpad][tiles * 32]
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
     dae_buf title_scratch;     // dae_title_score_exact: CSR, seed lists, hidden rows, features, mixing weights of the launch
     // dae_title_prepack_features (title.hip): the convolutions of a FROZEN title scorer as a table over (filter size, offset,
     // character) -- which variables it was built from
     dae_buf title_tab; const float* ttab_emb = nullptr; const float* ttab_w = nullptr; int ttab_nchar = 0, ttab_E = 0, ttab_F = 0,
-        ttab_nsizes = 0; int ttab_fs[8] = {0};
+        ttab_nsizes = 0; int ttab_fs[DAE_TITLE_MAX_SIZES] = {0};
     // the bias-ordered tile list with its sample RE-DEALT for a launch geometry (dae_launch_tile_band): which order it was cut from
     dae_buf tile_band; long long band_gen = -1; int band_nsamp = 0, band_nbrg = 0, band_waves = 0;
 
@@ -345,6 +351,9 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
 int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                           int32_t* status);
+int dae_launch_coo32_to_csr_seeds(dae_ctx* ctx, const int32_t* positions, const float* values, int values_broadcast,
+                                  int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                                  int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col);
 
 int dae_launch_seeds_from_csr(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, int B, int n_tracks,
                               int32_t* seed_row_ptr, int32_t* seed_col);
@@ -432,6 +441,8 @@ struct dae_exact_src {
 // fused (nullable; dae_exact_refine_can_fuse): the launch ENDS the scoring call -- seeds removed, the k best of every row in
 // order to fused->out_score / out_idx, exactly what dae_launch_topk_pairs over the refined lists returns -- and the lists it
 // leaves behind are not meant to be read
+// audit.hip: one audit of the exact scoring launch in progress (n_tiles random ranked tiles x all B rows -> the guard words)
+int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_exact_src& x, int nrank, int n_tiles);
 bool dae_exact_refine_can_fuse(const dae_topk_args& a);
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
                             const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0,

@@ -1781,7 +1781,8 @@ __device__ __forceinline__ uint4 bias_fragment(float bv)
 __global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                                            int H, int Hp, int col_lo, int col_hi, int ntiles,
                                                            float* __restrict__ eps, uint4* __restrict__ bias16_lo,
-                                                           uint4* __restrict__ bias16_hi, float margin)
+                                                           uint4* __restrict__ bias16_hi, float margin,
+                                                           int m_lo, int m_hi, float m_scale)
 {
     float* eps_max = eps + (size_t)ntiles * 32;          // zeroed by the launcher; positive floats order like their bits
     const int tid = threadIdx.x;
@@ -1809,7 +1810,8 @@ __global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restri
                 double e = d + 0x1p-9 * n + A16 * (n + d + 1.01 * ab) + A32 * (n + ab);
                 e = e * (1.0 + 4.0 * A16) + 0x1p-23 * (ab + e) + 1e-30;      // eps feeds back through the shifted bias; split error
                 e *= 1.0 + 1e-6;
-                e *= (double)margin;              // dae_set_exact_margin: 1 by default; < 1 voids the bound (the guard's test hook)
+                // dae_set_exact_margin: 1 by default; < 1 voids the bound (the guard's test hook; _range: for some columns only)
+                e *= (double)((v >= m_lo && v < m_hi) ? m_scale : margin);
                 e_f = (float)e;
                 if ((double)e_f < e) e_f = __uint_as_float(__float_as_uint(e_f) + 1u);      // e > 0: next float up
                 const double lo = bv - (double)e_f, hi = bv + (double)e_f;
@@ -2196,7 +2198,7 @@ int dae_launch_prepack_bf16(dae_ctx* ctx, const float* W, const float* b, int V,
         const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
         hipLaunchKernelGGL(exact_bounds_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, Hp, col_lo, col_hi,
                            ntiles, static_cast<float*>(pk.eps.p), static_cast<uint4*>(pk.bias16_lo.p),
-                           static_cast<uint4*>(pk.bias16_hi.p), ctx->exact_margin);
+                           static_cast<uint4*>(pk.bias16_hi.p), ctx->exact_margin, ctx->margin_lo, ctx->margin_hi, ctx->margin_scale);
         DAE_CHECK_LAUNCH(ctx, "exact_bounds_kernel");
         DAE_HIP_CHECK(ctx, hipMemcpyAsync(pk.W32.p, W + (size_t)col_lo * H, wbytes, hipMemcpyDeviceToDevice, ctx->stream));
         // the same image read as the title side of the exact title mix: row-scaled bounds (mixexact.hip)

@@ -976,11 +976,21 @@ int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_ex
         else hipLaunchKernelGGL(exact_rescore_shared_kernel<0>, dim3((unsigned)(ngrp * nblk)), dim3(256), 0, ctx->stream, sp);
         DAE_CHECK_LAUNCH(ctx, "exact_rescore_shared_kernel");
     }
-    size_t dyn = (size_t)p.stage_cap * sizeof(float);
-    const size_t tb = (size_t)(shape == 0 ? 4 : shape == 1 ? 8 : 16) * 64 * RF_ROWSTRIDE * sizeof(float);
-    if (dyn < tb) dyn = tb;
+    // dynamic LDS of a shape: the staging area or the waves' transposition buffers, whichever is larger, + the fused selection's
+    // seed bitmap behind them.  dae_exact_refine_can_fuse admits what the 512-thread shape holds; the wide shape's buffers are
+    // 16 KB larger, so a vocabulary of 393 217 .. 524 288 ranked columns takes the 512-thread shape instead
+    auto dyn_of = [&](int sh) {
+        size_t d = (size_t)p.stage_cap * sizeof(float);
+        const size_t tb = (size_t)(sh == 0 ? 4 : sh == 1 ? 8 : 16) * 64 * RF_ROWSTRIDE * sizeof(float);
+        return d < tb ? tb : d;
+    };
+    if (p.fuse && shape == 2 && dyn_of(2) + fuse_bitmap_bytes(p.bitmap_n) > RF_DYN_MAX) shape = 1;
+    slim = shape == 0;
+    size_t dyn = dyn_of(shape);
     p.bm_off = (int)dyn;
     if (p.fuse) dyn += fuse_bitmap_bytes(p.bitmap_n);
+    if (dyn > RF_DYN_MAX)
+        return dae_fail(ctx, DAE_ERR_ARG, "exact refine: %zu bytes of LDS for %d ranked columns (shape %d)", dyn, p.bitmap_n, shape);
     static const char key = 0;
     if (dae_first_use(ctx, &key)) {
         const int mx = (int)RF_DYN_MAX;

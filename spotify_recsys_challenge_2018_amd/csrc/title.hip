@@ -12,7 +12,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int T_MAX_SIZES = 8;
+constexpr int T_MAX_SIZES = DAE_TITLE_MAX_SIZES;
 constexpr int T_MAX_LEN = 64;
 constexpr int T_MAX_EMB = 128;
 

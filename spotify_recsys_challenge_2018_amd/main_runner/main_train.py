@@ -112,17 +112,13 @@ def _init_distributed(conf):
 
 def run(conf, only_testmode):
     rank, world = _init_distributed(conf)
-    if -1 in conf.firstN:                                           # main_train.py:129-133
-        reader = data_reader(data_dir=conf.data_dir, filename='train', batch_size=conf.batch)
-    else:
-        reader = data_reader_firstN(data_dir=conf.data_dir, filename='train',
-                                    batch_size=conf.batch, from_to=conf.firstN)
-    conf.class_divpnt = reader.class_divpnt
-    conf.n_tracks = reader.num_tracks
-    conf.n_input = reader.num_items
-    conf.n_output = reader.num_items
-    conf.charsize = reader.num_char
-    conf.strmaxlen = reader.max_title_len
+    # the training reader (main_train.py:129-133): whole playlists, or -- with a [DAE] firstN_range -- their first-N prefixes
+    reader_args = dict(data_dir=conf.data_dir, filename='train', batch_size=conf.batch)
+    reader = data_reader(**reader_args) if -1 in conf.firstN else data_reader_firstN(from_to=conf.firstN, **reader_args)
+    # what the models read off `conf` (main_train.py:134-148): the vocabulary and title shapes come from the data file
+    for attr, value in (("class_divpnt", reader.class_divpnt), ("n_tracks", reader.num_tracks), ("n_input", reader.num_items),
+                        ("n_output", reader.num_items), ("charsize", reader.num_char), ("strmaxlen", reader.max_title_len)):
+        setattr(conf, attr, value)
     kp_range = conf.input_kp
 
     readers_test = {}

@@ -37,6 +37,14 @@ def _title_dtype(dtype, model=None):
     tm = getattr(model, "title_model", None)
     if (tm is not None and model.n_hidden == 256 and tm.ld == 448 and not getattr(model, "title_exact_off", False)):
         return dtype
+    if tm is not None and not getattr(model, "title_exact_off", False) and not model.__dict__.get("_title_fp32_said"):
+        # [DAE] hidden, [TITLE] filter_num / filter_size are free keys of the schema (main.py:46, :73-75): say ONCE that this
+        # model's titled launches cost the fp32 kernels' time (about 6 x), instead of silently
+        model.__dict__["_title_fp32_said"] = True
+        import sys
+        print("[dae] decode_dtype = exact_bf16: the exact title mix is built for hidden = 256 and 448-wide title feature rows; "
+              "this model has hidden = %d, %d-wide rows -- its titled launches run on the fp32 kernels (same lists, slower)"
+              % (model.n_hidden, tm.ld), file=sys.stderr)
     return _lib.DAE_DTYPE_F32
 
 
@@ -906,6 +914,8 @@ class DAE_tied:
             # one pipeline at a time per model: each holds (2 lanes + 2) staging slots of pinned + device memory and a dozen
             # result blocks -- a caller that alternates dtypes pays a re-creation, not half a gigabyte of pinned memory
             for key_, (_g, old) in list(cache.items()):
+                if getattr(old, "_users", 0) > 0:            # a recommend_iter generator of another (dtype, k, scores) key is still
+                    continue                                 # running on it (two loops interleaved): it closes with that loop
                 if self.__dict__.get("keep_pipelines"):      # (diagnosis: scripts/probe/row_diag.py)
                     self.__dict__.setdefault("_old_pipes", []).append(old)
                 else:
@@ -940,6 +950,7 @@ class DAE_tied:
             return r[0][:n], (r[1][:n] if want_scores else None)
         clean = False
         fallbacks0 = pipe.stats()["guard_fallbacks"] if dtype == _lib.DAE_DTYPE_BF16_EXACT else 0
+        pipe._users = getattr(pipe, "_users", 0) + 1             # (_native_pipe never closes a pipeline a loop is running on)
         try:
             for f in feeds:
                 x_positions, x_ones, seeds, n_rows = f[:4]
@@ -987,6 +998,7 @@ class DAE_tied:
                 raise ValueError(str(e))
             raise
         finally:
+            pipe._users -= 1
             if dtype == _lib.DAE_DTYPE_BF16_EXACT and pipe.h is not None:
                 n_fb = pipe.stats()["guard_fallbacks"] - fallbacks0
                 if n_fb > 0:         # (the lists that went out are the fp32 kernels': the pipeline re-scored those launches itself)
@@ -994,8 +1006,13 @@ class DAE_tied:
                     self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + n_fb
                     warnings.warn("exact_bf16: the bound guard fired in %d launch(es) of the streamed loop: they were re-scored with "
                                   "the fp32 kernels" % n_fb)
+            cache = self.__dict__.get("_pipes", {})
             if not clean:        # an error, or a consumer that stopped early: feeds may be queued -- this pipeline is not reused
-                self.__dict__.get("_pipes", {}).pop(key, None)
+                if cache.get(key, (None, None))[1] is pipe:
+                    cache.pop(key, None)
+                pipe.close()
+            elif pipe._users == 0 and len(cache) > 1 and cache.get(key, (None, None))[1] is pipe:
+                cache.pop(key, None)                             # another key's pipeline was created while this loop ran: one stays
                 pipe.close()
 
     def _coalesce_count(self, dtype=None):

@@ -33,7 +33,9 @@ def _dev(a):
 
 @pytest.mark.parametrize("dtype,world,B", [(_lib.DAE_DTYPE_F32, 4, 1024), (_lib.DAE_DTYPE_BF16, 4, 1024),
                                            (_lib.DAE_DTYPE_F32, 8, 512), (_lib.DAE_DTYPE_F32, 8, 2048),     # 2048 rows: the wave-per-row threshold kernel
-                                           (_lib.DAE_DTYPE_BF16_EXACT, 4, 1024), (_lib.DAE_DTYPE_BF16_EXACT, 8, 512)])
+                                           (_lib.DAE_DTYPE_BF16_EXACT, 4, 1024), (_lib.DAE_DTYPE_BF16_EXACT, 8, 512),
+                                           # BASELINE.json configs[2] literally: batch 1024, the vocabulary in 8 column shards
+                                           (_lib.DAE_DTYPE_F32, 8, 1024), (_lib.DAE_DTYPE_BF16, 8, 1024), (_lib.DAE_DTYPE_BF16_EXACT, 8, 1024)])
 def test_shard_contexts_full_size_equal_unsharded(dtype, world, B):
     import torch
     V, nt, H, k = 170000, 140000, 256, 500
