@@ -429,8 +429,50 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
     return row
 
 
+def _cu_partition_rate(torch, ctxs, streams, step_fn, reset_fn, n_steps, B):
+    """VERDICT r5 item 1(d), the spatial-partition experiment as a driver-visible number: the same step loop with the contexts'
+    streams confined to CU sets (hipExtStreamCreateWithCUMask) -- streams 0, 2 on one half of EVERY XCD's CUs, streams 1, 3 on the
+    other half (a mask that empties an XCD is ignored by the runtime: whole XCDs per stream are not expressible;
+    scripts/probe/cumask_probe.hip).  Measured in scripts/time_cumask.py: +7 % at 1 024 rows per launch, -5 % at 256, a quarter of
+    every XCD per stream -12 %.  Reported next to the row's value, never as it."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        raws = []
+        for j in range(len(ctxs)):
+            m = (ctypes.c_uint32 * 8)()
+            for i in range(256):                     # mask bit i = CU i // 8 of XCD i % 8
+                if (i // 8) % 2 == j % 2:
+                    m[i // 32] |= 1 << (i % 32)
+            st = ctypes.c_void_p()
+            if hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, m) != 0:
+                return {"error": "hipExtStreamCreateWithCUMask failed"}
+            raws.append(st)
+        torch.cuda.synchronize()
+        for c, st in zip(ctxs, raws):
+            c.check(c.lib.dae_set_stream(c.h, st))
+        for _ in range(16):
+            step_fn()
+        torch.cuda.synchronize()
+        reset_fn()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step_fn()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"value": round(B * n_steps / el, 1), "ms_per_step": round(el / n_steps * 1e3, 4),
+                "partition": "streams 0,2 on CUs 0-15 of every XCD, streams 1,3 on CUs 16-31"}
+    except Exception as e:                           # noqa: BLE001
+        return {"error": repr(e)[:200]}
+    finally:
+        torch.cuda.synchronize()
+        for c, s_ in zip(ctxs, streams):
+            with torch.cuda.stream(s_):
+                c.bind_stream()
+
+
 def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k, n_steps, n_warm, ref32, oracle_ref,
-              peaks, traffic_key):
+              peaks, traffic_key, cu_partition=False):
     """Extra row of the default run: the same step (rotating the same resident batches) with another decode arithmetic.
     dt = DAE_DTYPE_BF16 (BASELINE.json configs[4]: bf16 MFMA decode, fp32 accumulate; encode, threshold, top-k fp32) or
     DAE_DTYPE_BF16_EXACT (north_star: that GEMM as a filter on rigorous bounds, survivors recomputed in fp32)."""
@@ -460,14 +502,24 @@ def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k
     for _ in range(max(n_warm, 4)):
         step()
     torch.cuda.synchronize()
-    for c in ctxs:
-        c.profile_enable(True)
+    # the row's rate: the plain step loop -- no event pairs in it (round 6: an event pair around the dominant launch is two more
+    # barrier packets per step in every stream; the rate was ~3 % lower with them) ...
     cnt[0] = 0
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    part = None
+    if cu_partition:
+        part = _cu_partition_rate(torch, ctxs, streams, step, lambda: cnt.__setitem__(0, 0), n_steps, B)
+    # ... and the dominant launch's duration with the SAME batches in flight: a second pass of the same steps with the pairs on
+    for c in ctxs:
+        c.profile_enable(True)
+    cnt[0] = 0
+    for _ in range(n_steps):
+        step()
+    torch.cuda.synchronize()
     kms, kn = 0.0, 0
     for c in ctxs:
         a, b = c.profile_read()
@@ -514,9 +566,15 @@ def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k
                                      "note": "same launch with no other batch in flight"},
                         "note": "%.1f us of matrix time at the bf16 peak, %.1f us to stream the launch's bytes at the "
                                 "HBM peak: the binding roof is the larger" % (t_mfma * 1e6, t_hbm * 1e6)}}
+    if part is not None:
+        row["cu_partition_half"] = part
     if exact:
         s32, i32 = ref32
         row["identical_to_fp32_path"] = bool(torch.equal(i16, i32) and torch.equal(s16.view(torch.int32), s32.view(torch.int32)))
+        # the audit of DROPPED columns (csrc/audit.hip: every 64th launch of a context, all rows x 16 random ranked tiles against the
+        # filter launch's own promise) -- inside the timed loop, like the survivors' guard
+        au = [c.exact_audit_read() for c in ctxs]
+        row["dropped_column_audit"] = {k_: int(sum(a[k_] for a in au)) for k_ in ("audits", "checked", "violations")}
         if oracle_ref is not None:
             s_ref, i_ref = oracle_ref
             ns = i_ref.shape[0]
@@ -1505,7 +1563,8 @@ def main():
                                       feeds_k[0][4], k, s_k, i_k, dtype=DT)
                     torch.cuda.synchronize()
                     r_k = _mode_row(torch, _lib, met, ctxs_b, streams_b, feeds_k, (d_We, d_be), n_tracks, _lib.DAE_DTYPE_BF16_EXACT,
-                                    1024, H, k, max(args.steps // 2, 10), args.warmup, (s_k, i_k), None, peaks, None)
+                                    1024, H, k, max(args.steps // 2, 10), args.warmup, (s_k, i_k), None, peaks, None,
+                                    cu_partition=True)
                     r_k["global_batch"] = 1024
                     r_k["note"] = "NOT the headline: exact_bf16 at 1024 playlists per launch; identical_to_fp32_path checked on batch 0"
                     out["exact_b1024"] = r_k

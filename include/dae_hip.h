@@ -205,7 +205,7 @@ int dae_set_exact_margin_range(dae_ctx* ctx, int col_from, int col_to, float sca
 /* DAE_DTYPE_BF16_EXACT, the AUDIT of what the guard cannot see (csrc/audit.hip).  The guard tests the survivors the refine
  * launch recomputes; a column the bf16 filter launch DROPPED (upper bound u < the row's threshold) is never recomputed, so a
  * bound that fails there -- the only failure that can change a top-k list of main_challenge.py:28-36 -- would go unseen.
- * Every every_n-th exact scoring launch of the context (dae_decode_topk / dae_score_topk / dae_score_topk_finish; default 32,
+ * Every every_n-th exact scoring launch of the context (dae_decode_topk / dae_score_topk / dae_score_topk_finish; default 64,
  * 0 = never) therefore takes n_tiles (default 16, <= 64) pseudo-random 32-column tiles of the ranked columns -- different ones
  * each time; nearly all of their elements are dropped ones -- and for EVERY row of the launch recomputes both the filter
  * launch's upper bound u (the same bf16 MFMA sequence on the same operands: the same bits) and the canonical fp32 logit, and

@@ -150,7 +150,7 @@ int dae_destroy(dae_ctx* ctx)
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
-                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band, &ctx->title_tab};
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band, &ctx->title_tab, &ctx->audit, &ctx->audit_stat};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);

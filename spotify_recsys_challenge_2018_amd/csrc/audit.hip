@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int AU_ROWS = 32;        // playlists per workgroup (8 per wave)
-constexpr int AU_KC = 256;         // k values staged per pass
+constexpr int AU_KC = 128;         // k values staged per pass (49 KB of LDS per workgroup with the hidden rows: three fit a CU)
 constexpr int AU_LD = 65;          // dwords per staged k (64 columns + 1: conflict-free both ways)
 
 // n tiles of [0, n_rank_tiles), different ones every launch (a 32-bit mixer on (seed, i))
@@ -50,7 +50,8 @@ struct AuditP {
 // live across the passes, so every chain runs k = 0 .. H-1 in order from +0: the canonical chain, bit for bit.
 __global__ __launch_bounds__(256) void exact_audit_kernel(const AuditP p)
 {
-    extern __shared__ float wt[];                   // [AU_KC][AU_LD]
+    extern __shared__ float wt[];                   // [AU_KC][AU_LD] decoder rows, transposed | [AU_ROWS][AU_KC] hidden rows
+    float* hs = wt + AU_KC * AU_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int item = blockIdx.x * 2 + (lane >> 5);
     const int tile = item < p.n_tiles ? p.tiles[item] : -1;
@@ -72,13 +73,20 @@ __global__ __launch_bounds__(256) void exact_audit_kernel(const AuditP p)
             const float* wr = p.W32 + (size_t)(ok_c ? cl_c : 0) * p.H + k0;
             for (int k = lane; k < kn; k += 64) wt[k * AU_LD + c] = ok_c ? wr[k] : 0.0f;
         }
+        // ... and the block's hidden rows (a broadcast LDS read per k instead of a dependent trip to memory)
+        for (int r = wave; r < AU_ROWS; r += 4) {
+            const int row = row0 + r;
+            const float* hr = p.h + (size_t)(row < p.B ? row : 0) * p.ld_h + k0;
+            for (int k = lane; k < kn; k += 64) hs[r * AU_KC + k] = hr[k];
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < AU_ROWS / 4; ++i) {
-            const int row = row0 + wave + 4 * i;                               // wave-uniform
-            if (row >= p.B) break;
-            const float* hr = p.h + (size_t)row * p.ld_h + k0;
+            const int r = wave + 4 * i;                                        // wave-uniform
+            if (row0 + r >= p.B) break;
+            const float* hr = hs + r * AU_KC;
             float a = acc[i];
+#pragma unroll 8
             for (int k = 0; k < kn; ++k) a = fmaf(hr[k], wt[k * AU_LD + lane], a);
             acc[i] = a;
         }
@@ -117,16 +125,17 @@ int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_
     if (B <= 0 || nrank <= 0 || n_tiles <= 0 || !x.guard) return DAE_OK;
     if (n_tiles > 64) n_tiles = 64;
     const int n_rank_tiles = (nrank + 31) / 32;
-    int rc = dae_reserve(ctx, ctx->audit, (size_t)64 * sizeof(int) + 2 * sizeof(unsigned long long) +
-                                              (size_t)g.Bpad * n_tiles * 32 * sizeof(float));
+    // {elements checked, violations} | 64 tile ids: a block of its own, allocated once (the totals outlive every launch shape);
+    // the upper bounds [Bpad][n_tiles * 32] grow with the launch
+    const bool fresh = ctx->audit_stat.p == nullptr;
+    int rc = dae_reserve(ctx, ctx->audit_stat, 2 * sizeof(unsigned long long) + (size_t)64 * sizeof(int));
     if (rc) return rc;
-    unsigned long long* stat = static_cast<unsigned long long*>(ctx->audit.p);
+    rc = dae_reserve(ctx, ctx->audit, (size_t)g.Bpad * n_tiles * 32 * sizeof(float));
+    if (rc) return rc;
+    unsigned long long* stat = static_cast<unsigned long long*>(ctx->audit_stat.p);
     int* tiles = reinterpret_cast<int*>(stat + 2);
-    float* u = reinterpret_cast<float*>(tiles + 64);
-    if (ctx->audit_stat_ptr != ctx->audit.p) {                                 // (a fresh buffer: the totals start at zero)
-        DAE_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        ctx->audit_stat_ptr = ctx->audit.p;
-    }
+    float* u = static_cast<float*>(ctx->audit.p);
+    if (fresh) DAE_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(audit_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned)ctx->audit_seq, n_rank_tiles, n_tiles, tiles);
     DAE_CHECK_LAUNCH(ctx, "audit_pick_kernel");
     // the filter launch's upper bounds of those tiles: dense bf16 decode on the b + eps image (bias_sel 2), nothing masked
@@ -138,7 +147,7 @@ int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_
     p.h = x.h; p.ld_h = x.ld_h; p.H = x.H; p.W32 = x.W32; p.bias = x.bias; p.eps = x.eps; p.col_lo = x.col_lo;
     p.ncols = pk.col_hi - pk.col_lo; p.u = u; p.ld_u = ld_u; p.tiles = tiles; p.n_tiles = n_tiles; p.B = B;
     p.col_bound = pk.col_lo + nrank; p.row_bad = x.row_bad; p.guard = x.guard; p.stat = stat;
-    const size_t lds = (size_t)AU_KC * AU_LD * sizeof(float);
+    const size_t lds = ((size_t)AU_KC * AU_LD + (size_t)AU_ROWS * AU_KC) * sizeof(float);
     static const char key = 0;
     if (dae_first_use(ctx, &key))
         DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_audit_kernel),
@@ -165,9 +174,9 @@ int dae_exact_audit_read(dae_ctx* ctx, uint64_t out3[3])
     if (!ctx) return DAE_ERR_ARG;
     if (!out3) return dae_fail(ctx, DAE_ERR_ARG, "null pointer");
     out3[0] = ctx->audits_run; out3[1] = out3[2] = 0;
-    if (!ctx->audit.p || ctx->audit_stat_ptr != ctx->audit.p) return DAE_OK;
+    if (!ctx->audit_stat.p) return DAE_OK;
     unsigned long long h[2] = {0, 0};
-    DAE_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->audit.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    DAE_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->audit_stat.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     DAE_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     out3[1] = h[0]; out3[2] = h[1];
     return DAE_OK;

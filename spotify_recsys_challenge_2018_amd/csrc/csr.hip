@@ -81,7 +81,12 @@ __global__ __launch_bounds__(256) void csr_scatter_kernel(const PT* __restrict__
 // a smaller column.  Kept entries go to k_col / k_val at the row's bucket offset, their number to kcnt.
 // The two cases are separate kernels: picking `s_col` or `t_col + b` through one pointer makes every access a FLAT
 // load (25 us per launch for rows of ~100 entries; 256 workgroups), while the LDS-only body is plain ds_reads.
-__global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bptr,
+// <CAP, NT>: entries of a row held in LDS / threads per row.  <4096, 256> takes any batch; <512, 64> -- one wave and 4.6 KB per
+// row -- is the drivers' loop's: a playlist holds at most 250 tracks + 250 artists (utils/spotify_reader.py drops longer ones),
+// and with 36 KB of LDS per row the launch got ONE row per CU at a time next to the other lanes' decode workgroups: 70 us for
+// 2 048 rows in the loop's timeline against 9 alone (profiles/r06_notes.md).  Longer rows take the global-memory path below.
+template <int CAP, int NT>
+__global__ __launch_bounds__(NT) void csr_row_kernel(const int* __restrict__ bptr,
                                                       const int* __restrict__ t_col,
                                                       const int* __restrict__ t_feed,
                                                       const float* __restrict__ t_val,
@@ -90,24 +95,24 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
 {
     // scnt (nullable): kept entries of the row with column < n_tracks -- the row's seed list when the seeds are the playlist's own
     // tracks (seeds_from_csr_kernel below); columns ascend, so they are the row's FIRST scnt[row] kept entries
-    __shared__ int s_col[CSR_ROW_CAP];
-    __shared__ int s_feed[CSR_ROW_CAP];
-    __shared__ unsigned char s_keep[CSR_ROW_CAP];
+    __shared__ int s_col[CAP];
+    __shared__ int s_feed[CAP];
+    __shared__ unsigned char s_keep[CAP];
     __shared__ int s_n, s_ns;
     const int row = blockIdx.x, tid = threadIdx.x;
     const int b = bptr[row], n = bptr[row + 1] - b;
     if (tid == 0) { s_n = 0; s_ns = 0; }
-    if (n <= CSR_ROW_CAP) {
+    if (n <= CAP) {
         // ---- the row fits the LDS buffers (always, for playlist batches) ----
-        float my_val[CSR_ROW_CAP / 256];
+        float my_val[CAP / NT];
 #pragma unroll
-        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
-            const int i = tid + u * 256;
+        for (int u = 0; u < CAP / NT; ++u) {
+            const int i = tid + u * NT;
             if (i < n) { s_col[i] = t_col[b + i]; s_feed[i] = t_feed[b + i]; my_val[u] = t_val[b + i]; }
         }
         __syncthreads();
         // pass 1: keep flags
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += NT) {
             const int c = s_col[i], f = s_feed[i];
             int later = 0;
             for (int j = 0; j < n; ++j) later |= (s_col[j] == c) & (s_feed[j] > f);
@@ -115,15 +120,15 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
             if (!later) s_keep[i] = 2;             // provisional: survives the duplicate rule
         }
 #pragma unroll
-        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
-            const int i = tid + u * 256;
+        for (int u = 0; u < CAP / NT; ++u) {
+            const int i = tid + u * NT;
             if (i < n) s_keep[i] = (s_keep[i] == 2 && my_val[u] != 0.0f) ? 1 : 0;
         }
         __syncthreads();
         // pass 2: slot among the kept entries, output written directly
 #pragma unroll
-        for (int u = 0; u < CSR_ROW_CAP / 256; ++u) {
-            const int i = tid + u * 256;
+        for (int u = 0; u < CAP / NT; ++u) {
+            const int i = tid + u * NT;
             if (i >= n || !s_keep[i]) continue;
             const int c = s_col[i];
             int slot = 0;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
     const int* colp = t_col + b;
     const int* feedp = t_feed + b;
     // pass 1: keep flags, kept in the low bit of k_col's slot until every reader is done
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int c = colp[i], f = feedp[i];
         bool later = false;
         for (int j = 0; j < n; ++j) later = later || (colp[j] == c && feedp[j] > f);
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
     }
     __syncthreads();
     // pass 2: slot among the kept entries; the SOURCE INDEX of slot s is parked in k_val[s]
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         if (k_col[b + i] == 0) continue;
         const int c = colp[i];
         int slot = 0;
@@ -160,12 +165,12 @@ __global__ __launch_bounds__(256) void csr_row_kernel(const int* __restrict__ bp
     }
     __syncthreads();
     const int m = s_n;
-    for (int s = tid; s < m; s += 256) {
+    for (int s = tid; s < m; s += NT) {
         const int i = __float_as_int(k_val[b + s]);
         k_col[b + s] = -1 - i;                   // flags are dead now; mark as "source index"
     }
     __syncthreads();
-    for (int s = tid; s < m; s += 256) {
+    for (int s = tid; s < m; s += NT) {
         const int i = -1 - k_col[b + s];
         k_col[b + s] = t_col[b + i];
         k_val[b + s] = t_val[b + i];
@@ -449,8 +454,12 @@ int launch_coo_to_csr(dae_ctx* ctx, const PT* positions, const float* values, in
         hipLaunchKernelGGL(csr_scatter_lds_kernel<PT>, dim3(blocks), dim3(1024), 2 * lds, st, positions, values,
                            values_broadcast, nnz, n_rows, n_cols, cnt, cursor, bptr, t_col, t_feed, t_val);
         DAE_CHECK_LAUNCH(ctx, "csr_scatter_lds_kernel");
-        hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
-                           kcnt, n_tracks, seeds ? scnt : nullptr);
+        if (seeds)                 // (the drivers' loop: playlist rows)
+            hipLaunchKernelGGL((csr_row_kernel<512, 64>), dim3(n_rows), dim3(64), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
+                               kcnt, n_tracks, scnt);
+        else
+            hipLaunchKernelGGL((csr_row_kernel<CSR_ROW_CAP, 256>), dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
+                               kcnt, n_tracks, static_cast<int*>(nullptr));
         DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
         hipLaunchKernelGGL(csr_compact_sum_kernel, dim3(n_rows), dim3(256), 0, st, bptr, kcnt, n_rows, k_col, k_val,
                            row_ptr, col, val, sflag, status, seeds ? scnt : nullptr, seed_row_ptr, seed_col);
@@ -475,7 +484,7 @@ int launch_coo_to_csr(dae_ctx* ctx, const PT* positions, const float* values, in
                            nnz, n_rows, n_cols, bptr, cursor, t_col, t_feed, t_val);
         DAE_CHECK_LAUNCH(ctx, "csr_scatter_kernel");
     }
-    hipLaunchKernelGGL(csr_row_kernel, dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
+    hipLaunchKernelGGL((csr_row_kernel<CSR_ROW_CAP, 256>), dim3(n_rows), dim3(256), 0, st, bptr, t_col, t_feed, t_val, k_col, k_val,
                        kcnt, n_tracks, static_cast<int*>(nullptr));
     DAE_CHECK_LAUNCH(ctx, "csr_row_kernel");
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, kcnt, n_rows, row_ptr);

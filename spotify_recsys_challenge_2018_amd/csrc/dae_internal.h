@@ -128,9 +128,10 @@ struct dae_ctx {
     float exact_margin = 1.0f; // dae_set_exact_margin: factor on every eps_c at the next exact prepack
     int margin_lo = 0, margin_hi = 0; float margin_scale = 1.0f;   // dae_set_exact_margin_range: columns [lo, hi) take this factor instead
     // the audit of dropped columns (audit.hip): every audit_every-th exact scoring launch checks audit_tiles random tiles
-    int audit_every = 32, audit_tiles = 16;
+    int audit_every = 64, audit_tiles = 16;
     uint64_t audit_seq = 0, audits_run = 0;
-    dae_buf audit; void* audit_stat_ptr = nullptr;   // {elements checked, violations} | tile ids | upper bounds [Bpad][tiles * 32]
+    dae_buf audit_stat;        // {elements checked, violations} | the sampled tile ids (allocated once)
+    dae_buf audit;             // upper bounds of the sampled tiles [Bpad][tiles * 32]
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
     dae_buf title_scratch;     // dae_title_score_exact: CSR, seed lists, hidden rows, features, mixing weights of the launch
     // dae_title_prepack_features (title.hip): the convolutions of a FROZEN title scorer as a table over (filter size, offset,

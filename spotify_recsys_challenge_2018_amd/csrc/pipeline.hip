@@ -29,8 +29,8 @@ struct OutBlock {                 // pinned result block of one launch: idx [row
 struct Lane {                     // a context + stream + the device buffers its launches reuse in stream order
     dae_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
-    int32_t *d_rp = nullptr, *d_col = nullptr, *d_status = nullptr, *d_srp = nullptr, *d_scol = nullptr, *d_idx = nullptr;
-    float *d_cval = nullptr, *d_score = nullptr;
+    int32_t* d_status = nullptr;  // (titled launches: the CSR build inside dae_title_score reports here)
+    float* d_score = nullptr;     // scores nobody fetches
     bool has_f32 = false;         // (guard fallback) an fp32 image of its own
     // titled pipelines (dae_pipeline_create_titled): the title scorer's context on the same stream, its guard words as the
     // launch left them, the count the previous polled launch of this lane saw (the words are cumulative)
@@ -51,9 +51,13 @@ struct Slot {                     // one launch from staging to its last polled 
     float* h_val = nullptr;       // (pinned staging of the feed)
     int32_t* h_flags = nullptr;   // pinned: {csr status, guard violations, guard column}
     int64_t* d_pos = nullptr; float* d_val = nullptr;      // the feed on the device (uploaded on the copy stream, ahead of the lane)
+    // the launch's CSR and seed lists (plain launches), built on the PREP stream while the lane still scores its previous launch
+    int32_t *d_rp = nullptr, *d_col = nullptr, *d_srp = nullptr, *d_scol = nullptr, *d_status = nullptr; float* d_cval = nullptr;
+    hipEvent_t ev_prep = nullptr;
     int32_t* d_idx = nullptr; float* d_score = nullptr;    // the launch's lists on the device (moved out on the OUT stream, round 6)
     int32_t* d_flags = nullptr;                            // {csr status, guard violations, guard column} as the launch left them
     hipEvent_t ev_scored = nullptr;                        // the scoring call's last kernel (the out stream waits for it)
+    bool sync_fetch = true;                                // ev_fetch was recorded by issue() (modes 0, 1): the wait ends on it
     int32_t* h_titles = nullptr; float* h_use = nullptr;   // titled pipelines: [group_rows][L] characters, [group_rows] titles_use
     int32_t* d_titles = nullptr; float* d_use = nullptr;
     int titled = 0;               // this launch ranks the title-mixed score (its feeds came through dae_pipeline_submit_titled)
@@ -78,7 +82,12 @@ struct dae_pipeline {
     std::vector<Lane> lanes;
     std::vector<Slot> slots;
     std::vector<OutBlock> blocks;
-    hipStream_t out_stream = nullptr;     // the lists' way out: lists_to_host_kernel + the flag words, behind the lane's event
+    // the feed -> CSR + seed lists of launch n + 1 on a stream (and library context) of their own: five small launches that are
+    // independent of the lane's previous launch -- in the lane's stream they were 170 us of a 600 us chain (queued behind the
+    // other lanes' decode workgroups, each takes 5 - 10 x its time alone: profiles/r06_notes.md)
+    hipStream_t prep_stream = nullptr;
+    dae_ctx* prep_ctx = nullptr;
+    hipStream_t out_stream = nullptr;     // the lists' way out (out_mode 2): the out thread's copies
     hipStream_t copy_stream = nullptr;    // uploads: hipMemcpyAsync on a stream that still has kernels queued blocks its caller
                                           // until they have run (measured: 0.43 ms per launch next to the fp32 decode) -- on a
                                           // stream of their own the uploads run ahead and the lane waits for their event
@@ -88,6 +97,17 @@ struct dae_pipeline {
     std::deque<int> queue;        // slots waiting for the worker, in submission order
     std::thread worker;
     bool stop = false;
+    // how a launch's lists reach the host (round 6, measured in profiles/r06_notes.md 5: M playlists/s through the loop, exact /
+    // bf16): 0 = the scoring call's last kernel stores them straight into the pinned block (round 5: 7.9 - 8.1 / 8.8), 2 = the copy
+    // ENGINE, driven by a thread of its own that makes no HIP call until the launch's "scored" word has arrived (8.3 / 9.05: the
+    // last scoring kernel no longer sits on its CUs while the link takes 4 MB).  (A 32-workgroup copy kernel on a stream of its
+    // own lost: 6.7 / 7.5.  Without any copy-out the loop runs at 9.9 / 11.4: the link is what the loop pays for.)
+    int out_mode = 2;
+    std::thread out_worker;
+    std::deque<int> out_queue;
+    std::mutex out_mu;
+    std::condition_variable cv_out;
+    bool out_stop = false;
     std::mutex err_mu;            // err / err_code: written by the library thread and by the caller, read by dae_pipeline_last_error
     std::string err;
     int err_code = 0;
@@ -164,37 +184,26 @@ hipError_t wait_launch(const Slot& S)
         if (spins < 200) std::this_thread::yield();
         else std::this_thread::sleep_for(std::chrono::microseconds(20));
         if ((spins & 1023) == 1023) {                        // (a failed launch never writes its word: ask the runtime now and then)
-            const hipError_t q = hipEventQuery(S.ev_fetch);
-            if (q != hipErrorNotReady) return q;
+            // ev_scored: recorded by issue() behind the scoring call on the lane's stream (ev_fetch is recorded later in the copy-
+            // engine mode: until then it still holds its previous, completed record).  Complete but no word yet = the lists are
+            // on their way out: keep waiting
+            const hipError_t q = hipEventQuery(S.ev_scored);
+            if (q != hipErrorNotReady && q != hipSuccess) return q;
         }
     }
-    return hipEventSynchronize(S.ev_fetch);
-}
-
-// A launch's lists, device -> its pinned result block, by a FEW workgroups ON ANOTHER STREAM (round 6).  Round 5 had the last
-// scoring kernel store straight into host memory: no copy call -- but that kernel (a workgroup per row, on every CU) then sat on
-// its CUs for as long as the link took its 4 MB (2 048 rows x 500 ids: ~80 us for a 38 us kernel), CUs the other lanes' launches
-// wanted, and the lane itself could not start its next launch.  Now the scoring call ends on the device; the OUT stream waits
-// for its event and moves the lists with 32 workgroups (the link is the bound either way) while the lane goes on.  (The same
-// kernel IN the lane's stream lost: exact_bf16 8.1 -> 7.2 M playlists/s -- the lane waits for the link; profiles/r06_notes.md.)
-__global__ __launch_bounds__(256) void lists_to_host_kernel(uint4* __restrict__ dst_idx, const uint4* __restrict__ src_idx,
-                                                            uint4* __restrict__ dst_score, const uint4* __restrict__ src_score,
-                                                            size_t n16)
-{
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-        dst_idx[i] = src_idx[i];
-        if (dst_score) dst_score[i] = src_score[i];
-    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return S.sync_fetch ? hipEventSynchronize(S.ev_fetch) : hipSuccess;
 }
 
 // {csr status, guard violations, guard column} as the launch's own stream leaves them -> the slot's device words (the lane's
 // NEXT launch moves the cumulative guard words; the out stream reads this snapshot, not the live words)
-__global__ void flags_snapshot_kernel(int32_t* dst, const int32_t* status, const int32_t* guard)
+__global__ void flags_snapshot_kernel(int32_t* dst, const int32_t* status, const int32_t* guard, int32_t* scored_host, int32_t seq)
 {
     if (threadIdx.x == 0) {
         dst[0] = status[0];
         dst[1] = guard ? guard[0] : 0;
         dst[2] = guard ? guard[1] : -1;
+        if (scored_host) { __threadfence_system(); *scored_host = seq; }         // (copy-engine mode: the out thread watches this word)
     }
 }
 
@@ -264,7 +273,7 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
         PIPE_HIP(p, hipMemcpyAsync(S.d_use, S.h_use, (size_t)S.rows * sizeof(float), hipMemcpyHostToDevice, p->copy_stream));
     }
     PIPE_HIP(p, hipEventRecord(S.ev_h2d, p->copy_stream));
-    PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_h2d, 0));
+    if (S.titled) PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_h2d, 0));      // (plain launches: the prep stream waits for it, below)
     if (p->dtype == DAE_DTYPE_F32 && p->lanes.size() > 1) {
         // the fp32 filter launch takes every CU, two of them in flight only queue behind each other: this launch's waits for
         // the one issued before it (on another lane) and announces its own end.  One event per launch SLOT: re-recording a
@@ -289,7 +298,7 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
     // library thread sat in those calls for the length of every launch and a second launch was never in flight
     // (0.77 of a titled launch's 0.9 ms of issue time; profiles/r05_notes.md).
     OutBlock& ob = p->blocks[S.block];
-    static const bool direct = dae_exp_env("DAE_PIPE_DIRECT") != nullptr;               // A/B (experiments build): round 5's direct stores
+    const bool direct = p->out_mode == 0;
     int32_t* const out_idx = direct ? ob.idx : S.d_idx;
     float* const out_score = !p->want_scores ? L.d_score : direct ? ob.score : S.d_score;     // (scores nobody fetches stay on the lane)
     lap(0);
@@ -304,10 +313,15 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
         lap(1);
     } else {
         // the feed -> CSR and the seed lists (the playlist's own tracks) in ONE group of four launches (round 6: six + a wider feed)
-        rc = dae_launch_coo32_to_csr_seeds(L.ctx, reinterpret_cast<const int32_t*>(S.d_pos), S.d_val, 0, S.nnz, S.rows, p->V, L.d_rp,
-                                           L.d_col, L.d_cval, L.d_status, p->n_tracks, L.d_srp, L.d_scol);
-        if (!rc) rc = dae_score_topk(L.ctx, L.d_rp, L.d_col, L.d_cval, p->W_enc, p->b_enc, p->V, p->H, S.rows, dtype, p->n_tracks,
-                                     L.d_srp, L.d_scol, p->k, DAE_OUT_SCORE, out_score, out_idx);
+        // ... on the prep stream, behind the upload; the lane's stream only waits for the finished CSR
+        PIPE_HIP(p, hipStreamWaitEvent(p->prep_stream, S.ev_h2d, 0));
+        rc = dae_launch_coo32_to_csr_seeds(p->prep_ctx, reinterpret_cast<const int32_t*>(S.d_pos), S.d_val, 0, S.nnz, S.rows, p->V, S.d_rp,
+                                           S.d_col, S.d_cval, S.d_status, p->n_tracks, S.d_srp, S.d_scol);
+        if (rc) return pfatal(p, rc, dae_last_error(p->prep_ctx));
+        PIPE_HIP(p, hipEventRecord(S.ev_prep, p->prep_stream));
+        PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_prep, 0));
+        rc = dae_score_topk(L.ctx, S.d_rp, S.d_col, S.d_cval, p->W_enc, p->b_enc, p->V, p->H, S.rows, dtype, p->n_tracks,
+                            S.d_srp, S.d_scol, p->k, DAE_OUT_SCORE, out_score, out_idx);
         if (rc) return pfatal(p, rc, dae_last_error(L.ctx));
     }
     // The downloads go to the lane's FETCH stream, behind an event of the launch: a hipMemcpyAsync on a stream that still has
@@ -326,26 +340,74 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
     // after its first issue, whose word is still in h_flags[3]; the counter wraps after 2^30 launches)
     S.seq = (int32_t)(((++p->seq_counter << 1) | 1u) & 0x7FFFFFFFu);
     S.polls = 0;
-    hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, L.stream, S.d_flags, L.d_status, gw);
+    hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, L.stream, S.d_flags, S.titled ? L.d_status : S.d_status, gw,
+                       p->out_mode == 2 ? S.h_flags + 4 : nullptr, S.seq);
     PIPE_HIP(p, hipGetLastError());
 #ifdef DAE_EXPERIMENTS
     if (dbg_pipe) (void)hipEventRecord(S.dbg_t1, L.stream);
 #endif
-    // ... and out, on the out stream: the lane is free for its next launch while the link carries these lists
     PIPE_HIP(p, hipEventRecord(S.ev_scored, L.stream));
-    PIPE_HIP(p, hipStreamWaitEvent(p->out_stream, S.ev_scored, 0));
-    if (!direct) {
-        const size_t n16 = ((size_t)S.rows * p->k * sizeof(int32_t) + 15) / 16;           // (buffers are whole multiples of 16 bytes)
-        hipLaunchKernelGGL(lists_to_host_kernel, dim3(32), dim3(256), 0, p->out_stream, reinterpret_cast<uint4*>(ob.idx),
-                           reinterpret_cast<const uint4*>(S.d_idx), p->want_scores ? reinterpret_cast<uint4*>(ob.score) : nullptr,
-                           reinterpret_cast<const uint4*>(S.d_score), n16);
-        PIPE_HIP(p, hipGetLastError());
+    if (p->out_mode == 2) {
+        // the copy engine, from the out thread: nothing more to enqueue here
+        S.sync_fetch = false;
+        {
+            std::lock_guard<std::mutex> g(p->out_mu);
+            p->out_queue.push_back((int)(&S - p->slots.data()));
+        }
+        p->cv_out.notify_one();
+        lap(2);
+        return DAE_OK;
     }
-    hipLaunchKernelGGL(flags_to_host_kernel, dim3(1), dim3(64), 0, p->out_stream, S.h_flags, S.d_flags, S.seq);
+    S.sync_fetch = true;
+    hipStream_t fs = L.stream;
+    hipLaunchKernelGGL(flags_to_host_kernel, dim3(1), dim3(64), 0, fs, S.h_flags, S.d_flags, S.seq);
     PIPE_HIP(p, hipGetLastError());
-    PIPE_HIP(p, hipEventRecord(S.ev_fetch, p->out_stream));
+    PIPE_HIP(p, hipEventRecord(S.ev_fetch, fs));
     lap(2);
     return DAE_OK;
+}
+
+// out_mode 2: the lists of every issued launch, in issue order, through the copy engine.  The thread makes no HIP call until the
+// launch's "scored" word (written by flags_snapshot_kernel, the scoring call's last kernel) has arrived -- a thread parked inside
+// hipEventSynchronize slowed the issuing thread's enqueueing down (profiles/r05_notes.md) -- then three asynchronous copies on the
+// out stream (nothing is queued there: they do not block), one synchronize, and the sequence word the caller's wait watches.
+void out_worker_main(dae_pipeline* p)
+{
+    (void)hipSetDevice(p->device);
+    for (;;) {
+        int si;
+        {
+            std::unique_lock<std::mutex> lk(p->out_mu);
+            p->cv_out.wait(lk, [&] { return p->out_stop || !p->out_queue.empty(); });
+            if (p->out_queue.empty()) return;                // (stop, and nothing left to move)
+            si = p->out_queue.front();
+            p->out_queue.pop_front();
+        }
+        Slot& S = p->slots[si];
+        const int32_t seq = S.seq;
+        const volatile int32_t* scored = S.h_flags + 4;
+        hipError_t e = hipSuccess;
+        for (int spins = 0; *scored != seq; ++spins) {
+            if (spins < 200) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            if ((spins & 1023) == 1023) {                    // (a faulted launch never writes its word)
+                const hipError_t q = hipEventQuery(S.ev_scored);
+                if (q != hipErrorNotReady && q != hipSuccess) { e = q; break; }
+            }
+        }
+        const OutBlock& ob = p->blocks[S.block];
+        const size_t nb = (size_t)S.rows * p->k;
+        if (e == hipSuccess) e = hipMemcpyAsync(ob.idx, S.d_idx, nb * sizeof(int32_t), hipMemcpyDeviceToHost, p->out_stream);
+        if (e == hipSuccess && p->want_scores) e = hipMemcpyAsync(ob.score, S.d_score, nb * sizeof(float), hipMemcpyDeviceToHost, p->out_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(S.h_flags, S.d_flags, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, p->out_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->out_stream);
+        if (e != hipSuccess) {
+            (void)pfatal(p, DAE_ERR_HIP, hipGetErrorString(e));
+            // (the caller's wait ends on the word all the same: it finds err_code set)
+        }
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        *(volatile int32_t*)(S.h_flags + 3) = seq;
+    }
 }
 
 void worker_main(dae_pipeline* p)
@@ -453,6 +515,12 @@ int dae_pipeline_destroy(dae_pipeline* p)
     }
     p->cv_worker.notify_all();
     if (p->worker.joinable()) p->worker.join();
+    {
+        std::lock_guard<std::mutex> g(p->out_mu);
+        p->out_stop = true;
+    }
+    p->cv_out.notify_all();
+    if (p->out_worker.joinable()) p->out_worker.join();
     DeviceGuard dev_guard(p->device);
 #ifdef DAE_EXPERIMENTS
     if (dae_exp_env("DAE_DBG_PIPE"))
@@ -484,14 +552,18 @@ int dae_pipeline_destroy(dae_pipeline* p)
         if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
         if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
         pool_give_stream(p->device, L.stream);
-        void* dev[] = {L.d_rp, L.d_col, L.d_status, L.d_srp, L.d_scol, L.d_idx, L.d_cval, L.d_score, L.d_guard};
+        void* dev[] = {L.d_status, L.d_score, L.d_guard};
         for (void* q : dev) if (q) (void)hipFree(q);
     }
     pool_give_stream(p->device, p->copy_stream);
     if (p->out_stream) { (void)hipStreamSynchronize(p->out_stream); pool_give_stream(p->device, p->out_stream); }
+    if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
+    if (p->prep_ctx) (void)dae_destroy(p->prep_ctx);
+    pool_give_stream(p->device, p->prep_stream);
     for (Slot& S : p->slots) {
         if (S.ev_scored) (void)hipEventDestroy(S.ev_scored);
-        void* outs[] = {S.d_idx, S.d_score, S.d_flags};
+        if (S.ev_prep) (void)hipEventDestroy(S.ev_prep);
+        void* outs[] = {S.d_idx, S.d_score, S.d_flags, S.d_rp, S.d_col, S.d_srp, S.d_scol, S.d_status, S.d_cval};
         for (void* q : outs) if (q) (void)hipFree(q);
         if (S.ev_fetch) (void)hipEventDestroy(S.ev_fetch);
         if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
@@ -537,18 +609,19 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
     { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) return bail(DAE_ERR_HIP, "hipSetDevice failed"); }
     if (!(p->copy_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
     if (!(p->out_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
+    if (!(p->prep_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
+    {
+        int rc_p = dae_create(device, &p->prep_ctx);
+        if (!rc_p) rc_p = dae_set_stream(p->prep_ctx, p->prep_stream);
+        if (rc_p) return bail(rc_p, dae_last_error(p->prep_ctx));
+    }
     const size_t rows = (size_t)group_rows, nz = (size_t)max_nnz, kk = (size_t)k;
     for (int i = 0; i < lanes; ++i) {
         Lane& L = p->lanes[i];
         int rc = dae_create(device, &L.ctx);
         if (rc) return bail(rc, dae_last_error(nullptr));
         bool ok = (L.stream = pool_take_stream(device)) != nullptr &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_rp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_col), nz * sizeof(int32_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_cval), nz * sizeof(float)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_srp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_scol), nz * sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_score), (rows * kk * sizeof(float) + 15) / 16 * 16) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");
         rc = dae_set_stream(L.ctx, L.stream);
@@ -585,28 +658,36 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
                   hipMalloc(reinterpret_cast<void**>(&S.d_idx), (rows * kk * sizeof(int32_t) + 15) / 16 * 16) == hipSuccess &&
                   (!want_scores || hipMalloc(reinterpret_cast<void**>(&S.d_score), (rows * kk * sizeof(float) + 15) / 16 * 16) == hipSuccess) &&
                   hipMalloc(reinterpret_cast<void**>(&S.d_flags), 4 * sizeof(int32_t)) == hipSuccess &&
+                  hipEventCreateWithFlags(&S.ev_prep, hipEventDisableTiming) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_rp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_col), nz * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_cval), nz * sizeof(float)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_status), sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_srp), (rows + 1) * sizeof(int32_t)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&S.d_scol), nz * sizeof(int32_t)) == hipSuccess &&
                   hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&S.ev_gate, hipEventDisableTiming) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&S.d_pos), nz * 2 * sizeof(int64_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&S.d_val), nz * sizeof(float)) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_pos), nz * 2 * sizeof(int64_t)) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_val), nz * sizeof(float)) == hipSuccess &&
-                  hipHostMalloc(reinterpret_cast<void**>(&S.h_flags), 4 * sizeof(int32_t)) == hipSuccess;
+                  hipHostMalloc(reinterpret_cast<void**>(&S.h_flags), 8 * sizeof(int32_t)) == hipSuccess;
         if (ok && tw)
             ok = hipMalloc(reinterpret_cast<void**>(&S.d_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
                  hipMalloc(reinterpret_cast<void**>(&S.d_use), rows * sizeof(float)) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&S.h_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&S.h_use), rows * sizeof(float)) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: pinned allocation failed");
-        S.h_flags[0] = S.h_flags[1] = 0; S.h_flags[2] = -1; S.h_flags[3] = 0;
+        S.h_flags[0] = S.h_flags[1] = 0; S.h_flags[2] = -1; S.h_flags[3] = 0; S.h_flags[4] = 0;
     }
     for (OutBlock& b : p->blocks) {
-        // (+ 16: lists_to_host_kernel moves whole 16-byte words)
         bool ok = hipHostMalloc(reinterpret_cast<void**>(&b.idx), rows * kk * sizeof(int32_t) + 16) == hipSuccess &&
                   (!want_scores || hipHostMalloc(reinterpret_cast<void**>(&b.score), rows * kk * sizeof(float) + 16) == hipSuccess);
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: pinned allocation failed");
     }
     for (Lane& L : p->lanes) if (hipStreamSynchronize(L.stream) != hipSuccess) return bail(DAE_ERR_HIP, "setup failed");
+    if (const char* om = dae_exp_env("DAE_PIPE_OUT")) p->out_mode = atoi(om) == 0 ? 0 : 2;       // A/B (experiments build)
+    if (p->out_mode == 2) p->out_worker = std::thread(out_worker_main, p);
     p->worker = std::thread(worker_main, p);
     *out = p;
     return DAE_OK;
@@ -766,12 +847,13 @@ int dae_pipeline_poll(dae_pipeline* p, int wait, uint64_t* ticket, const int32_t
         if (!wait) {
             if (*(const volatile int32_t*)(S.h_flags + 3) != S.seq) {                   // (no HIP call while the launch runs ...
                 if ((++S.polls & 255) == 0) {                    // ... but a launch that faulted never writes its word: ask now and then)
-                    const hipError_t q = hipEventQuery(S.ev_fetch);
+                    const hipError_t q = hipEventQuery(S.ev_scored);
                     if (q != hipErrorNotReady && q != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(q)); }
                 }
                 return DAE_OK;
             }
-            const hipError_t q = hipEventSynchronize(S.ev_fetch);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            const hipError_t q = S.sync_fetch ? hipEventSynchronize(S.ev_fetch) : hipSuccess;
             if (q != hipSuccess) { lk.lock(); return pfatal(p, DAE_ERR_HIP, hipGetErrorString(q)); }
         } else {
             const auto t_w = std::chrono::steady_clock::now();

@@ -943,10 +943,18 @@ class DAE_tied:
         pipe = self._native_pipe(dtype, k, want_scores)
         key = (int(dtype), int(k), bool(want_scores), self.n_batch)
 
-        rows_out = []                # rows each pending feed asked for (a feed is fed as the graph's n_batch rows, DAEs.py:34)
+        from collections import deque
+        rows_out = deque()           # rows each pending feed asked for (a feed is fed as the graph's n_batch rows, DAEs.py:34)
+        nb_full = self.n_batch
+        # results arrive a LAUNCH at a time: asking the pipeline after every feed whether something is ready is a foreign call
+        # per feed for an answer that changes once per launch (the caller's thread is what bounds the bf16 loops: round 6)
+        per_launch = max(1, pipe.group_rows // max(1, self.n_batch))
+        n_fed = 0
 
         def out(r):
-            n = rows_out.pop(0)
+            n = rows_out.popleft()
+            if n == nb_full:
+                return r[0], (r[1] if want_scores else None)
             return r[0][:n], (r[1][:n] if want_scores else None)
         clean = False
         fallbacks0 = pipe.stats()["guard_fallbacks"] if dtype == _lib.DAE_DTYPE_BF16_EXACT else 0
@@ -984,11 +992,13 @@ class DAE_tied:
                 while not pipe.submit(x_positions, x_ones, self.n_batch, titles, use):      # every lane full: hand the oldest lists out first
                     yield out(pipe.poll(True))
                 rows_out.append(n)
-                while True:                                      # ... and whatever else is ready, without waiting
-                    r = pipe.poll(False)
-                    if r is None:
-                        break
-                    yield out(r)
+                n_fed += 1
+                if n_fed % per_launch == 0 or titles is not None:
+                    while True:                                  # ... and whatever else is ready, without waiting
+                        r = pipe.poll(False)
+                        if r is None:
+                            break
+                        yield out(r)
             pipe.flush()
             while pipe.pending:
                 yield out(pipe.poll(True))

@@ -537,6 +537,7 @@ def test_audit_sees_a_violation_on_a_dropped_column():
         V, nt, H, B, k = 5000, 4096, 128, 48, 100
         p = _problem(V, nt, H, B, bias="zipf", scale=20.0)
         lo, hi = nt - 64, nt
+        p["b_dec"][lo:hi] = -60.0                      # far below every row's threshold: the filter launch drops them everywhere
         c.set_exact_margin_range(lo, hi, 1e-4)
         c.set_exact_audit(0, 0)
         c.prepack_decoder(_dev(p["W_dec"]), _dev(p["b_dec"]), dtype=EX)
@@ -583,6 +584,7 @@ def test_recommend_re_scores_when_only_a_dropped_column_violates(tmp_path):
     V = nt + na
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=9, bias="zipf", n_tracks=nt)
     W_dec = (W_dec * 20).astype(np.float32)
+    b_dec = b_dec.copy(); b_dec[nt - 256:nt] = -60.0  # 256 tracks no row's filter launch keeps
     path = str(tmp_path / "init.pkl")
     with open(path, "wb") as f:
         pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
@@ -596,7 +598,7 @@ def test_recommend_re_scores_when_only_a_dropped_column_violates(tmp_path):
     m.ctx.set_exact_audit(1, 64)                      # all 64 ranked tiles of this vocabulary are sampled w.h.p. within a few launches
     ok = m.recommend(pos, ones, SEEDS_FROM_INPUT, k=k, dtype="exact_bf16")
     assert np.array_equal(ok[0], want[0]) and m.__dict__.get("_guard_fallbacks", 0) == 0
-    m.ctx.set_exact_margin_range(nt - 256, nt, 1e-4)  # the 256 least popular tracks: in nobody's top 100
+    m.ctx.set_exact_margin_range(nt - 256, nt, 1e-4)  # only THEIR bound is void: no survivor can notice
     m._mark_dirty()
     assert not (want[0] >= nt - 256).any()
     with pytest.warns(UserWarning, match="bound guard"):

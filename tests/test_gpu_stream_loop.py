@@ -246,3 +246,72 @@ def test_clock_probe_reads_a_plausible_engine_clock():
     ghz = cyc / ticks * khz / 1e6
     assert 0.1 < ghz < 3.0, ghz
     ctx.close()
+
+
+def test_native_pipeline_feed_semantics_duplicates_long_rows_and_bad_indices(tmp_path):
+    """Round 6: dae_pipeline stages a feed as 32-bit pairs in ONE pass (row check included) and builds CSR + seed lists with the
+    light per-row kernel (one wave, 512 entries in LDS).  The feed's semantics must be what dae_coo_to_csr gives `recommend`:
+    the LAST duplicate wins (DAEs.py:33-35), zeros drop out, a row longer than the kernel's LDS takes its global-memory path,
+    a column outside the vocabulary raises ValueError, a row index outside the feed is refused at submit and the pipeline lives on."""
+    nt, na, H, k, B = 6000, 1000, 64, 100, 8
+    V = nt + na
+    W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=4, bias="zipf", n_tracks=nt)
+    path = str(tmp_path / "init.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
+
+    class C:
+        save = str(tmp_path / "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
+        n_tracks = nt; initval = path
+    m = DAE(C()); m.fit()
+    rng = np.random.default_rng(5)
+    feeds = []
+    for f in range(5):
+        rows, cols, vals = [], [], []
+        for r in range(B):
+            n = 700 if (r == 3 and f == 1) else int(rng.integers(1, 60))        # one row past the 512-entry LDS buffer
+            c = rng.integers(0, V, size=n)
+            c[n // 2:] = rng.choice(c[:max(n // 2, 1)], size=n - n // 2)        # duplicates, in feed order ...
+            v = rng.choice(np.array([1.0, 0.5, 0.15, 0.0], np.float32), size=n)  # ... with different weights, some of them zero
+            rows += [r] * n; cols += c.tolist(); vals += v.tolist()
+        order = rng.permutation(len(rows)) if f == 2 else np.arange(len(rows))    # one feed that is not row-ordered at all
+        pos = np.stack([np.asarray(rows, np.int64)[order], np.asarray(cols, np.int64)[order]], 1)
+        feeds.append((pos, np.asarray(vals, np.float32)[order]))
+    want = [m.recommend(p, v, SEEDS_FROM_INPUT, k=k, dtype="f32") for p, v in feeds]
+    got = list(m.recommend_iter([(p, v, SEEDS_FROM_INPUT, B) for p, v in feeds], k=k, dtype="f32"))
+    for (gi, gs), (wi, ws) in zip(got, want):
+        assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+    # a column outside [0, V): the device flags it, the loop raises like the host CSR builder
+    bad = feeds[0][0].copy(); bad[5, 1] = V + 3
+    with pytest.raises(ValueError):
+        list(m.recommend_iter([(bad, feeds[0][1], SEEDS_FROM_INPUT, B)], k=k, dtype="f32"))
+    big = feeds[0][0].copy(); big[7, 1] = 2 ** 40          # does not fit 32 bits: the same error, not a wrapped column
+    with pytest.raises(ValueError):
+        list(m.recommend_iter([(big, feeds[0][1], SEEDS_FROM_INPUT, B)], k=k, dtype="f32"))
+    # a row index outside the feed is refused by submit; the same pipeline object then scores the next feeds
+    pipe = _lib.Pipeline(m.weights["encoder_h"], m.biases["encoder_b"], m.weights["decoder_h"], m.biases["decoder_b"], nt,
+                         k=k, group_rows=4 * B, lanes=2)
+    try:
+        assert pipe.submit(feeds[0][0], feeds[0][1], B)
+        wrong = feeds[1][0].copy(); wrong[0, 0] = B
+        with pytest.raises(_lib.DaeError, match="row index"):
+            pipe.submit(wrong, feeds[1][1], B)
+        neg = feeds[1][0].copy(); neg[3, 0] = -1
+        with pytest.raises(_lib.DaeError, match="row index"):
+            pipe.submit(neg, feeds[1][1], B)
+        assert pipe.submit(feeds[1][0], feeds[1][1], B)
+        pipe.flush()
+        out = [pipe.poll(True, copy=True) for _ in range(2)]
+        for (gi, gs), (wi, ws) in zip(out, want[:2]):
+            assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
+        # a refused FIRST feed of a launch leaves no half-open launch behind
+        with pytest.raises(_lib.DaeError, match="row index"):
+            pipe.submit(wrong, feeds[1][1], B)
+        pipe.flush()
+        assert pipe.poll(False) is None
+        assert pipe.submit(feeds[3][0], feeds[3][1], B)
+        pipe.flush()
+        gi, gs = pipe.poll(True, copy=True)
+        assert np.array_equal(gi, want[3][0])
+    finally:
+        pipe.close()
