@@ -4,6 +4,8 @@ import json, sys, time
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spotify_recsys_challenge_2018_amd import _lib
+if os.environ.get("DAE_LIB_AB"):       # A/B against another build of the library
+    _lib.LIB_PATH = os.environ["DAE_LIB_AB"]
 from spotify_recsys_challenge_2018_amd.models.DAEs import coo_to_csr
 from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, make_weights
 tied = "--tied" in sys.argv

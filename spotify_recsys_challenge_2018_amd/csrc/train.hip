@@ -670,14 +670,12 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_out = p.n_half * p.n_rblk;
     const int total = n_out * p.n_chunk;
-    // Workgroups 2c and 2c + 1 (in the ORDER BELOW) walk the same chunk of W_dec when a chunk has eight output tiles (hidden 256,
-    // batch 256: 2 halves x 4 row blocks).  The hardware deals blockIdx round robin over the 8 XCDs, whose L2s are private: with
-    // the plain order the pair sat on two XCDs and every W row left HBM twice -- 474 MB per launch by the counters for 261 MB
-    // algorithmic (profiles/traffic_train.json; FETCH_SIZE x 2 holds for every access width: scripts/probe/fetch_calib.hip).
-    // So blocks b and b + 8 (same XCD, dispatched together) take the pair.
-    int bl = blockIdx.x;
-    if ((gridDim.x & 15) == 0) bl = (bl & ~15) + ((bl & 7) << 1) + ((bl >> 3) & 1);
-    for (int w = bl * 4 + wave; w < total; w += gridDim.x * 4) {
+    // (Round 6, settled with scripts/probe/fetch_calib.hip: this launch really pulls 430 - 474 MB through the fabric for 261 MB
+    // algorithmic -- every W row leaves HBM twice.  A chunk's eight output tiles are two workgroups; dealing the pair to ONE XCD
+    // (blocks b, b + 8) changed nothing (FETCH_SIZE 215 113 KB before and after): an XCD streams 16 chunks of 1.36 MB at once
+    // through 4 MB of L2, the partner's lines are gone before it arrives.  Reading W once needs the eight tiles in one workgroup
+    // with the W block shared through LDS -- not built.)
+    for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
         const int ot = w % n_out, ch = w / n_out;      // neighbours share the W chunk (L2)
         const int half = ot % p.n_half, rblk = ot / p.n_half;
         const int hc0 = half * HW, r0 = rblk * 64;
