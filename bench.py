@@ -354,7 +354,7 @@ def _drivers_loop_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_track
     row["exact_bf16"]["identical_to_fp32_lists"] = bool(np.array_equal(first["f32"], first["exact_bf16"]))
     row["engine"] = "native (dae_pipeline_*: a library-owned thread issues the launches; models/DAEs.py recommend_iter)"
     row["note"] = ("NOT the headline: host feeds in, host lists out (indices only; seeds = the playlist's own tracks, cut "
-                   "out of the input on the device).  scripts/bench_loop.py is the longer version (both engines, lane counts)")
+                   "out of the input on the device).  scripts/bench_loop.py is the longer version (lane counts, batch sizes)")
     _release_model(torch, m)
     return row
 
@@ -408,14 +408,18 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
             pass                                                                          #  one per (dtype, k, scores wanted))
         _ = None                                     # (a loop variable is a view of a result block: _drivers_loop_row)
         torch.cuda.synchronize()
-        _settle_interpreter()
-        t0 = time.perf_counter()
-        n = 0
-        for _idx, _s in m.recommend_iter(feeds(reps), k=k, want_scores=False, dtype=name):
-            n += B
-        el = time.perf_counter() - t0
-        row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B}
-        _idx = _s = None                             # (no view of this mode's result blocks is left: _drivers_loop_row)
+        runs = []                                    # (three timed passes, the median reported: _drivers_loop_row)
+        for _rep in range(3):
+            _settle_interpreter()
+            t0 = time.perf_counter()
+            n = 0
+            for _idx, _s in m.recommend_iter(feeds(reps), k=k, want_scores=False, dtype=name):
+                n += B
+            runs.append((time.perf_counter() - t0, n))
+            _idx = _s = None                         # (no view of this mode's result blocks is left: _drivers_loop_row)
+        el, n = sorted(runs)[1]
+        row[name] = {"value": round(n / el, 1), "ms_per_feed": round(el / (n / B) * 1e3, 4), "feeds": n // B,
+                     "runs": [round(n_ / el_ / 1e6, 2) for el_, n_ in runs]}
     same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
                for a, b in zip(lists["f32"], lists["exact_bf16"]))
     row["exact_bf16"]["identical_to_fp32_lists_and_scores"] = bool(same)
@@ -423,11 +427,11 @@ def _titled_row(torch, make_playlists, W_enc, b_enc, W_dec, b_dec, n_tracks, n_a
     fb = sum(p_.stats()["guard_fallbacks"] for _g, p_ in m.__dict__.get("_pipes", {}).values())
     row["exact_bf16"]["fp32_fallbacks"] = int(fb) + int(getattr(m, "_guard_fallbacks", 0))
     row["exact_bf16"]["bound_guard_violations"] = int(fb)
-    # one launch through the interpreter loop on the MODEL's contexts, for the refine launch's statistics (and as a second engine)
-    m.iter_engine = "python"
-    py = [(i_.copy(), s_.copy()) for i_, s_ in m.recommend_iter(feeds(2), k=k, want_scores=True, dtype="exact_bf16")][:len(batches)]
-    row["exact_bf16"]["python_engine_identical"] = bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
-                                                            for a, b in zip(lists["f32"], py)))
+    # one batch through the per-batch call on the MODEL's contexts: the second way to the same lists, and the refine launch's statistics
+    b0 = batches[0]
+    pb = m.recommend(b0[0], b0[1], b0[2], k=k, n_rows=b0[3], dtype="exact_bf16", titles=b0[4], titles_use=b0[5])
+    row["exact_bf16"]["per_batch_call_identical"] = bool(np.array_equal(pb[0], lists["f32"][0][0]) and
+                                                         np.array_equal(pb[1].view(np.uint32), lists["f32"][0][1].view(np.uint32)))
     row["exact_bf16"]["refine"] = m.title_model.ctx.exact_stats_read()
     row["engine"] = "native (dae_pipeline_create_titled / _submit_titled: the titled launches on the library's own thread, 3 lanes)"
     row["note"] = ("NOT the headline: the title scorer is randomly initialised (no trained title variables ship); host feeds in, "

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""The drivers' loop (DAE.recommend_iter: host feeds in, host index lists out) per engine, decode mode and lane count.
-usage: bench_loop.py [batch] [engines native,python] [modes f32,exact_bf16,bf16] [lanes 2,3,4]"""
+"""The drivers' loop (DAE.recommend_iter on the library's dae_pipeline: host feeds in, host index lists out) per decode mode and
+lane count.  usage: bench_loop.py [batch] native [modes f32,exact_bf16,bf16] [lanes 2,3,4]   (the second argument is kept for the
+command lines of rounds 4 - 5: "native" is the only engine since round 6)"""
 import os
 import pickle
 import sys
@@ -21,7 +22,7 @@ def main():
     import torch
     nt, na, H = 140000, 30000, 256
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    engines = sys.argv[2].split(",") if len(sys.argv) > 2 else ["native", "python"]
+    engines = ["native"]
     modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "exact_bf16", "bf16"]
     lanes = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
     V = nt + na
@@ -43,7 +44,6 @@ def main():
             for p_, o_ in batches:
                 yield p_, o_, SEEDS_FROM_INPUT, B
     for eng in engines:
-        m.iter_engine = eng
         for mode in modes:
             for nl in lanes:
                 m.n_lanes = nl or None

@@ -50,7 +50,7 @@ def main():
     it_dtype = "bf16" if "--bf16" in sys.argv else ("exact_bf16" if "--exact" in sys.argv else None)   # decode mode of the streamed loop
     if "--alone" in sys.argv:                 # one feed per launch, one context: the loop before coalescing / two lanes
         m.coalesce = 1
-        m.two_lanes = False
+        m.n_lanes = 1
     for label, seeds_of, scores in (("seed lists from the host, idx + score", lambda s_: s_, True),
                                     ("seeds = input tracks (device), idx only", lambda s_: SEEDS_FROM_INPUT, False)):
         def feeds(reps):

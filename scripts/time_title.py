@@ -43,14 +43,8 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "f32"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     m, feed = build()
-    if os.environ.get('TITLE_NO_COMPOSITE'):
-        m.title_no_composite = True
     if os.environ.get('TITLE_COALESCE'):
         m.coalesce = int(os.environ['TITLE_COALESCE'])
-    if os.environ.get('TITLE_DEPTH'):
-        m.title_depth = int(os.environ['TITLE_DEPTH'])
-    if os.environ.get('TITLE_ENGINE'):          # native (default: dae_pipeline_create_titled) | python
-        m.iter_engine = os.environ['TITLE_ENGINE']
     if os.environ.get('TITLE_LANES'):
         m.n_lanes = int(os.environ['TITLE_LANES'])
     for _ in m.recommend_iter([feed] * 10, k=500, dtype=mode, want_scores=False):

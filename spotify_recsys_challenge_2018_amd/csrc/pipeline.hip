@@ -620,7 +620,18 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
         Lane& L = p->lanes[i];
         int rc = dae_create(device, &L.ctx);
         if (rc) return bail(rc, dae_last_error(nullptr));
-        bool ok = (L.stream = pool_take_stream(device)) != nullptr &&
+#ifdef DAE_EXPERIMENTS
+        // DAE_PIPE_CUMASK=1 (experiments build): lane i's stream confined to one half of every XCD's CUs (i odd / even), the
+        // partition that won at 1 024 rows per launch in scripts/time_cumask.py -- measured on the loop in profiles/r06_notes.md 4
+        if (dae_exp_env("DAE_PIPE_CUMASK")) {
+            uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < 256; ++b) if ((b / 8) % 2 == i % 2) m[b / 32] |= 1u << (b % 32);
+            if (hipExtStreamCreateWithCUMask(&L.stream, 8, m) != hipSuccess) L.stream = nullptr;
+        }
+        if (!L.stream)
+#endif
+        L.stream = pool_take_stream(device);
+        bool ok = L.stream != nullptr &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_score), (rows * kk * sizeof(float) + 15) / 16 * 16) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");

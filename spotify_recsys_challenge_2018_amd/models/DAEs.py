@@ -240,8 +240,7 @@ class DAE_tied:
         and blocks the host until it has happened; on the compute stream that means "until everything queued before
         it has run", so the training loop could never get ahead of the GPU (0.25 ms per feed measured).  On its own
         stream the copy waits for earlier copies only; the compute stream waits for its event.  (The scoring loop
-        stages through pinned buffers instead -- `_stage_pinned`; round 1 measured torch's pinned memory as uncached for
-        CPU writes, 3 ms to fill 400 KB, round 3 measures 14 us per MB on the same image: scripts/attic/host_copy_probe.py.)"""
+        stages its feeds inside the library: csrc/pipeline.hip.)"""
         import torch
         src = torch.from_numpy(np.ascontiguousarray(a))
         dev = torch.device("cuda", self.device_index)
@@ -266,49 +265,15 @@ class DAE_tied:
             raise ValueError("positions (%d) and values (%d) differ in length" % (pos.shape[0], vals.size))
         return pos, vals
 
-    def _stage_pinned(self, slot, positions, values):
-        """The raw feed -> device COO through the pinned host buffers of `slot` (recommend_iter's staging ring), copied
-        asynchronously on the copy stream.  The host does not wait: a copy from pageable memory would block it until
-        the copy engine (a blit kernel that queues behind the decode launches) got to it.  -> `staged` for
-        `_upload_csr` (which makes the launch's stream wait for the copies' event)."""
-        import torch
-        pos, vals = self._feed_arrays(positions, values)
-        dev = torch.device("cuda", self.device_index)
-        n, nv = max(pos.shape[0], 1), max(vals.size, 1)
-        pp = _pinned(slot, "pos", 2 * n, torch.int64)
-        pv = _pinned(slot, "val", nv, torch.float32)
-        if pos.shape[0] and not np.may_share_memory(pp.numpy(), pos):
-            np.copyto(pp.numpy()[:2 * n].reshape(n, 2), pos)
-        if vals.size and not np.may_share_memory(pv.numpy(), vals):
-            np.copyto(pv.numpy()[:nv], vals)
-        cs = self.__dict__.get("_copy_stream")
-        if cs is None:
-            cs = self._copy_stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(cs):                         # not the launch's stream: the other lane's decode would wait
-            d_pos = torch.empty((n, 2), dtype=torch.int64, device=dev)
-            d_val = torch.empty(nv, dtype=torch.float32, device=dev)
-            d_pos.copy_(pp[:2 * n].view(n, 2), non_blocking=True)
-            d_val.copy_(pv[:nv], non_blocking=True)
-            ev = slot["busy"] = cs.record_event()
-        return d_pos[:pos.shape[0]], d_val, ev
-
-    def _upload_csr(self, positions, values, side_stream=False, ctx=None, n_rows=None, staged=None):
+    def _upload_csr(self, positions, values, side_stream=False, ctx=None, n_rows=None):
         """The feed (COO in feed order, duplicates allowed) -> device CSR.  Default: upload the raw feed
         and build the CSR on the GPU (dae_coo_to_csr, csrc/csr.hip); `device_csr = False` keeps the numpy
-        restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly).  `staged`: the feed is
-        on the device already (`_stage_pinned`)."""
+        restatement `coo_to_csr` (same result entry for entry; it also range-checks eagerly)."""
         import torch
         if self.device_csr:
-            if staged is not None:
-                d_pos, d_val, ev_up = staged
-                if ev_up is not None:                       # copied on another stream
-                    cur = torch.cuda.current_stream(self.device_index)
-                    cur.wait_event(ev_up)
-                    d_pos.record_stream(cur); d_val.record_stream(cur)
-            else:
-                pos, vals = self._feed_arrays(positions, values)
-                d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
-                d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
+            pos, vals = self._feed_arrays(positions, values)
+            d_pos = self._to_dev(pos if pos.shape[0] else np.zeros((1, 2), np.int64), torch.int64, side_stream)[:pos.shape[0]]
+            d_val = self._to_dev(vals if vals.size else np.zeros(1, np.float32), torch.float32, side_stream)
             rp, c, v, status = (ctx or self.ctx).coo_to_csr(d_pos, d_val, n_rows or self.n_batch, self.n_input)
             # checked lazily (no sync on the scoring path).  A flag is written on the stream that is current NOW -- the
             # main stream or the second scoring lane's -- so it travels with an event recorded behind its writer: whoever
@@ -496,7 +461,7 @@ class DAE_tied:
             return int(dtype)
         raise ValueError("decode dtype %r: one of %s" % (dtype, sorted(_DECODE_DTYPES)))
 
-    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None, slot=None):
+    def _seed_csr_dev(self, seeds, csr, side_stream=False, ctx=None, n_rows=None):
         """Seed lists -> device CSR.  `seeds` is a list of per-row track-id lists (main_challenge.py:31-35), or
         SEEDS_FROM_INPUT: the seeds are the playlist's own tracks -- what both reference drivers pass -- and are cut
         out of the input CSR on the device (dae_seeds_from_csr): no per-row list handling, no uploads."""
@@ -508,45 +473,23 @@ class DAE_tied:
         srp, sc = seeds_to_csr(seeds, n_rows or self.n_batch, self.n_tracks)
         if sc.size == 0:
             sc = np.zeros(1, np.int32)
-        if slot is not None:           # recommend_iter's asynchronous loop: through the slot's pinned buffers, like the feed
-            dev = torch.device("cuda", self.device_index)
-            ps, pc = _pinned(slot, "srp", srp.size, torch.int32), _pinned(slot, "sc", sc.size, torch.int32)
-            np.copyto(ps.numpy()[:srp.size], srp)
-            np.copyto(pc.numpy()[:sc.size], sc)
-            cur = torch.cuda.current_stream(self.device_index)
-            with torch.cuda.stream(self._copy_stream):
-                d_srp = torch.empty(srp.size, dtype=torch.int32, device=dev)
-                d_sc = torch.empty(sc.size, dtype=torch.int32, device=dev)
-                d_srp.copy_(ps[:srp.size], non_blocking=True)
-                d_sc.copy_(pc[:sc.size], non_blocking=True)
-                ev = slot["busy"] = self._copy_stream.record_event()
-            cur.wait_event(ev)
-            d_srp.record_stream(cur); d_sc.record_stream(cur)
-            return d_srp, d_sc
         return self._to_dev(srp, torch.int32, side_stream), self._to_dev(sc, torch.int32, side_stream)
 
     def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
-                n_rows=None, staged=None, seed_slot=None):
+                n_rows=None):
         """Enqueue one batch of the fused scoring path on the current stream; nothing is fetched.
         -> (score, idx, done event).  `ctx`: the library context to run on (default: the model's); `n_rows`: rows of
-        this launch when it is not the model's batch (several feeds coalesced by recommend_iter); `staged`: the feed
-        as `_stage_pinned` left it on the device."""
+        this launch when it is not the model's batch."""
         import torch
         ctx = ctx or self.ctx
         nb = n_rows or self.n_batch
         dev = self.weights["encoder_h"].device
-        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb, staged=staged)
-        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb, slot=seed_slot)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, ctx=ctx, n_rows=nb)
+        d_srp, d_sc = self._seed_csr_dev(seeds, csr, side_stream, ctx=ctx, n_rows=nb)
         score = torch.empty((nb, k), dtype=torch.float32, device=dev)
         idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
         ctx.score_topk(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"],
                        self.n_tracks, d_srp, d_sc, k, score, idx, dtype=dtype)
-        if dtype == _lib.DAE_DTYPE_BF16_EXACT and side_stream:
-            # the streamed loop: the context's guard words as THIS launch left them travel with its lists (recommend_iter
-            # compares them with the previous launch's on the same context and re-scores the launch in fp32 when they moved)
-            gw = torch.empty(2, dtype=torch.int32, device=dev)
-            ctx.exact_guard_snapshot(gw)
-            idx._exact_guard = (gw, ctx, (x_positions, x_ones, seeds, n_rows))
         ev = torch.cuda.current_stream(self.device_index).record_event()
         return score, idx, ev
 
@@ -606,293 +549,33 @@ class DAE_tied:
 
     def recommend_iter(self, feeds, k=500, dtype=None, want_scores=True):
         """`recommend` over a stream of batches with the host and the device overlapped (the loop of
-        main_challenge.py:72-93 / main_train.py:62-96): `feeds` yields (x_positions, x_ones, seeds, n_rows); the
-        (DAE_title: + titles, titles_use) and the
-        generator yields (idx [n_rows,k], score [n_rows,k] or None) in order, one pair per feed.  Consecutive feeds are
-        scored in ONE launch of up to 1024 rows (2048 in the bf16 modes; `_coalesce_count`: the reference's batches of 150 / 250 rows pad to 256
-        alone), the plain DAE alternates two library contexts (`_scoring_lanes`), launch n + 1 is uploaded (pinned staging
-        buffers, asynchronous copies) and enqueued BEFORE the results of launch n are handed out, and the fetch (an
-        asynchronous copy into pinned buffers) runs on its own stream behind launch n's event; the reader builds the
-        next feeds while the device scores.  Rows are
-        scored independently: every feed gets the bits `recommend` returns for it alone (tests/test_gpu_stream_loop.py)."""
-        import torch
+        main_challenge.py:72-93 / main_train.py:62-96): `feeds` yields (x_positions, x_ones, seeds, n_rows) (DAE_title:
+        + titles, titles_use); the generator yields (idx [n_rows,k], score [n_rows,k] or None) in order, one pair per feed.
+        The loop itself is the library's (`dae_pipeline_*`, csrc/pipeline.hip): consecutive feeds are scored in
+        ONE launch of up to 1024 rows (2048 in the bf16 modes; `_coalesce_count`: the reference's batches of 150 / 250 rows
+        pad to 256 alone), three library contexts take the launches in turn, the CSR of launch n + 1 is built while launch n
+        scores, the lists leave through the copy engine.  Rows are scored independently: every feed gets the bits
+        `recommend` returns for it alone (tests/test_gpu_stream_loop.py)."""
         if self._score_shard is not None:
             for x_positions, x_ones, seeds, n_rows in feeds:         # the exchange is a collective: no run-ahead
                 idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype)
                 yield idx, (score if want_scores else None)
             return
         dtype = self._dtype_of(dtype)
-        # THE NATIVE LOOP (default for the plain DAE): the library's own streaming pipeline (include/dae_hip.h
-        # dae_pipeline_*) -- this generator only copies feeds in and hands views of pinned result blocks out; a
-        # library-owned thread issues the launches.  `model.iter_engine = "python"` keeps the interpreter loop below
-        # (what a title model, explicit seed lists or host-built CSRs take anyway).
-        if (self.__dict__.get("iter_copies") or "async") not in ("async", "blocking"):
-            raise ValueError("iter_copies: 'async' or 'blocking'")
+        # THE LOOP LIVES IN THE LIBRARY (include/dae_hip.h dae_pipeline_*): this generator copies feeds in and hands views of
+        # pinned result blocks out; a library-owned thread issues the launches.  (Rounds 2 - 5 kept an interpreter loop beside it
+        # -- staging rings, lane contexts, fetch streams, 270 lines of closures; round 6 retired it: the pipeline takes plain and
+        # titled feeds, and what it does not take goes through `recommend` feed by feed, in order.)
         titled_native = (getattr(self, "title_model", None) is not None and getattr(self.title_model, "ctx", None) is not None
                          and type(self)._submit is DAE_title._submit)
-        if (self.__dict__.get("iter_engine", "native") == "native" and self.device_csr and
-                (type(self)._submit is DAE._submit or titled_native)):
-            # (a title model: the library's titled pipeline, dae_pipeline_create_titled -- round 5)
+        if self.device_csr and (type(self)._submit is DAE._submit or titled_native):
             yield from self._recommend_iter_native(feeds, k, _title_dtype(dtype, self) if titled_native else dtype, want_scores)
             return
-        self._ensure_packed(dtype)
-        if getattr(self, "title_model", None) is not None:
-            self.title_model._ensure_packed(_title_dtype(dtype, self))
-            if _title_dtype(dtype, self) != dtype:
-                self._ensure_packed(_title_dtype(dtype, self))     # shapes without the exact title mix: fp32 kernels
-        self.ctx.bind_stream()
-        fs = self.__dict__.get("_fetch_stream")
-        if fs is None:
-            fs = self._fetch_stream = torch.cuda.Stream(device=self.weights["encoder_h"].device)
-
-        lanes = self._scoring_lanes(dtype)              # [(context, stream)]: one, or two that take the batches in turn
-        group = self._coalesce_count(dtype if type(self)._submit is DAE._submit else None)
-        pending = []
-
-        def launches():
-            """Feeds -> launches.  The plain DAE scores `group` consecutive feeds in ONE launch (rows of feed i become
-            rows i * n_batch ... of the launch): the reference's batch of 150 pads to 256 rows on its own (41 % of the
-            decode wasted) and leaves the per-launch costs to 150 playlists; 5 feeds make 750 rows of a 768-row launch.
-            Rows are scored independently, so every row gets the bits it gets alone."""
-            if group == 1:
-                for feed in feeds:
-                    yield (lambda slot, f=feed: (f, [self.n_batch if f[3] is None else f[3]], None))
-                return
-            buf = []
-
-            def flush(buf, slot):
-                # rows of feed i become rows i * n_batch ... of the launch; the launch's COO is written straight into
-                # the staging slot's pinned buffers (`slot`; None: DAE_title's own upload path takes host arrays)
-                nb = self.n_batch
-                raw = [np.asarray(f[0], np.int64).reshape(-1, 2) for f in buf]
-                n_pos = sum(r.shape[0] for r in raw)
-                if slot is None:
-                    P, O = np.empty((n_pos, 2), np.int64), np.empty(n_pos, np.float32)
-                else:
-                    P = _pinned(slot, "pos", 2 * max(n_pos, 1), torch.int64).numpy()[:2 * n_pos].reshape(n_pos, 2)
-                    O = _pinned(slot, "val", max(n_pos, 1), torch.float32).numpy()[:n_pos]
-                off = 0
-                for i, (f, r) in enumerate(zip(buf, raw)):
-                    m = r.shape[0]
-                    P[off:off + m] = r
-                    if i:
-                        P[off:off + m, 0] += i * nb       # (an [m, 2] + [2] broadcast costs 4 x this: inner loops of 2)
-                    v = np.asarray(f[1], np.float32).reshape(-1)
-                    if v.size != 1 and v.size != m:
-                        raise ValueError("positions (%d) and values (%d) differ in length" % (m, v.size))
-                    O[off:off + m] = v
-                    off += m
-                pos = [P[o_:o_ + r.shape[0]] for o_, r in zip(np.cumsum([0] + [r.shape[0] for r in raw[:-1]]), raw)]
-                if all(isinstance(f[2], str) for f in buf):
-                    seeds = buf[0][2]
-                else:
-                    seeds = []
-                    for f, pp in zip(buf, pos):
-                        if isinstance(f[2], str):          # the playlist's own tracks, as lists
-                            own = [[] for _ in range(nb)]
-                            for r_, c_ in np.asarray(f[0], np.int64).reshape(-1, 2):
-                                if c_ < self.n_tracks:
-                                    own[int(r_)].append(int(c_))
-                            seeds += own
-                        else:
-                            seeds += list(f[2]) + [[] for _ in range(nb - len(f[2]))]
-                rows = [nb if f[3] is None else f[3] for f in buf]
-                feed = (P, O, seeds, None)
-                if any(len(f) > 4 for f in buf):           # DAE_title feeds: titles / titles_use, one entry per row
-                    L_ = self.title_model.input_len
-                    pad = [-1] * L_
-                    titles = np.full((len(buf) * nb, L_), -1, np.int32)        # (one array per launch: 750 Python lists cost the
-                    use = np.zeros(len(buf) * nb, np.float32)                   #  upload a conversion of their own)
-                    for i, f in enumerate(buf):
-                        t = [] if len(f) <= 4 or f[4] is None else f[4]
-                        nt = min(len(t), nb)
-                        if nt:
-                            if not isinstance(t, np.ndarray):
-                                t = [pad if x is None else x for x in t[:nt]]
-                            titles[i * nb:i * nb + nt] = np.asarray(t, np.int64).reshape(-1, L_)[:nt]
-                        if len(f) > 5 and f[5] is not None:
-                            u = np.asarray(f[5], np.float32).reshape(-1)[:nt]        # (no title, no use)
-                            use[i * nb:i * nb + len(u)] = u
-                    feed = feed + (titles, use)
-                return feed, rows, len(buf) * nb
-            def titled(f):
-                return len(f) > 5 and f[5] is not None and bool(np.any(np.asarray(f[5])))
-            for feed in feeds:
-                # a launch ranks EITHER the plain logits or the title-mixed score (DAE_title._submit decides per launch):
-                # a feed without titles in use must not share a launch with a titled one, or its rows would be ranked on
-                # sigmoid(z) * 1.0f -- same order up to fp32 saturation ties, not the bits `recommend` returns for it alone
-                if buf and titled(feed) != titled(buf[0]):
-                    yield (lambda slot, b=buf: flush(b, slot))
-                    buf = []
-                buf.append(feed)
-                if len(buf) == group:
-                    yield (lambda slot, b=buf: flush(b, slot))
-                    buf = []
-            if buf:
-                yield (lambda slot, b=buf: flush(b, slot))
-
-        def split(res, rows):
-            i_h, s_h = res
-            nb = self.n_batch
-            for i, n in enumerate(rows):
-                yield i_h[i * nb:i * nb + n], (None if s_h is None else s_h[i * nb:i * nb + n])
-        # Nothing on the host side of a launch blocks: the feed goes up through pinned buffers, copied asynchronously on
-        # the launch's own stream, the lists come down into pinned buffers on the fetch stream, and the host waits for
-        # a fetch event only when it hands that launch's rows out -- one launch per lane later.  (Copies from / to
-        # pageable memory block their caller until a blit kernel got a turn between the decode launches: ~0.2 ms each
-        # next to a 0.2 ms launch.  profiles/r03_notes.md, "the drivers' loop".)
-        stage_ring = self.__dict__.get("_iter_ring")
-        if stage_ring is None or len(stage_ring) != len(lanes) + 2:
-            stage_ring = self._iter_ring = [{} for _ in range(len(lanes) + 2)]
-        # Measured at batch 256 (scripts/bench_shim.py): bf16 1.6 -> 4.3 M playlists/s, exact_bf16 1.65 -> 3.4 M.  The
-        # fp32 loop, limited by the device, runs at 1.22 M either way on average: with blocking copies it alternates
-        # between 1.33 M and ~0.95 M from one second to the next (the host's waits fall in or out of step with the two
-        # lanes' decode launches), asynchronous it is steady.  `model.iter_copies = "blocking"` brings the old loop back.
-        mode = self.__dict__.get("iter_copies") or "async"
-        if mode not in ("async", "blocking"):
-            raise ValueError("iter_copies: 'async' or 'blocking'")
-        # (a title model uploads titles / mix weights through its own calls: all of its copies stay blocking -- mixing
-        # the two kinds is worse than either)
-        blocking = mode == "blocking" or type(self)._submit is not DAE._submit or not self.device_csr
-        plain = not blocking
-        pool = self.__dict__.get("_iter_pool")
-        if pool is None:
-            pool = self._iter_pool = _PinnedPool()
-        fetch_ring = self.__dict__.get("_iter_fetch_ring")
-        if fetch_ring is None or len(fetch_ring) != len(lanes) + 2:
-            fetch_ring = self._iter_fetch_ring = [{} for _ in range(len(lanes) + 2)]
-
-        def results(t):
-            # copied out of the ring's pinned buffers (30 us for 2 MB): a pinned allocation per launch instead costs a
-            # hipHostMalloc whenever torch's host cache has no free block of the size -- 0.66 M playlists/s at batch 150
-            if blocking:                                    # (score, idx, done event): a blocking copy on the fetch stream
-                score_, idx_, ev_, n_fetch, rws, nt_ = t
-                fs.wait_event(ev_)
-                redo = self._plain_guard_fired(getattr(idx_, "_exact_guard", None), k)
-                if redo is not None:
-                    score_, idx_ = redo
-                    fs.wait_stream(torch.cuda.current_stream(self.device_index))
-                if getattr(idx_, "_mix_guard", None) is not None:          # exact title mix: see DAE_title._mix_guard_fired
-                    with torch.cuda.stream(fs):                             # (on the compute stream the copy would wait for the NEXT launch too)
-                        idx_._mix_guard[0].record_stream(fs)
-                        words = idx_._mix_guard[0].cpu()
-                    redo = self._mix_guard_fired(idx_, k, words, score_)
-                    if redo is not None:
-                        score_, idx_ = redo
-                        fs.wait_stream(torch.cuda.current_stream(self.device_index))
-                with torch.cuda.stream(fs):
-                    idx_.record_stream(fs)
-                    i_h = idx_[:n_fetch].cpu().numpy()
-                    s_h = None
-                    if want_scores:
-                        score_.record_stream(fs)
-                        s_h = score_[:n_fetch].cpu().numpy()
-            else:
-                pin_i, pin_s, ev2, n_fetch, rws, nt_ = t[:6]
-                ev2.synchronize()
-                redo = self._plain_guard_fired(t[6] if len(t) > 6 else None, k)
-                if redo is not None:                        # the bound guard fired under this launch: the fp32 kernels' lists instead
-                    i_h = redo[1][:n_fetch].cpu().numpy()
-                    s_h = redo[0][:n_fetch].cpu().numpy() if want_scores else None
-                    del pin_i, pin_s, t
-                    if nt_ is None:
-                        yield i_h, s_h
-                    else:
-                        yield from split((i_h, s_h), rws)
-                    return
-                if isinstance(pin_i, _Lease):               # the lists ARE the pinned block (see _PinnedPool)
-                    i_h = pin_i.array(n_fetch, k)
-                    s_h = pin_s.array(n_fetch, k) if pin_s is not None else None
-                else:                                       # too many blocks out: copied out of the ring
-                    i_h = pin_i[:n_fetch * k].numpy().reshape(n_fetch, k).copy()
-                    s_h = pin_s[:n_fetch * k].numpy().reshape(n_fetch, k).copy() if pin_s is not None else None
-                del pin_i, pin_s, t
-            if nt_ is None:
-                yield i_h, s_h
-            else:
-                yield from split((i_h, s_h), rws)
-        try:
-            for n_launch, make in enumerate(launches()):
-                sslot = stage_ring[n_launch % len(stage_ring)] if plain else None
-                if plain and sslot.get("busy") is not None:
-                    sslot["busy"].synchronize()             # its previous upload has left the buffers (long ago)
-                feed, rows, n_total = make(sslot)
-                x_positions, x_ones, seeds = feed[:3]
-                ctx, stream = lanes[n_launch % len(lanes)]
-                kw = {} if n_total is None else {"n_rows": n_total}
-                if stream is None:                          # the model's own context (also DAE_title's _submit)
-                    if plain:
-                        kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
-                        kw["seed_slot"] = sslot
-                    score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, *feed[4:], **kw)
-                else:
-                    with torch.cuda.stream(stream):
-                        if plain:
-                            kw["staged"] = self._stage_pinned(sslot, x_positions, x_ones)
-                            kw["seed_slot"] = sslot
-                        score, idx, ev = self._submit(x_positions, x_ones, seeds, k, dtype, True, ctx=ctx, **kw)
-                n_fetch = rows[0] if n_total is None else n_total
-                if blocking:
-                    pending.append((score, idx, ev, n_fetch, rows, n_total))
-                    # a title model has one lane; TWO of its launches stay queued behind the fetch (same stream: their scratch
-                    # is reused in stream order), so the host's ~0.6 ms per launch runs under the device's ~0.55 ms
-                    if len(pending) > (self.__dict__.get("title_depth", 2) if type(self)._submit is not DAE._submit else len(lanes)):
-                        yield from results(pending.pop(0))
-                    continue
-                # destination of the fetch: a leased pinned block the caller's arrays will be views of, or -- with too
-                # many blocks out -- this launch's slot of the ring, copied out on the host afterwards
-                n_el = -(-n_fetch // 256) * 256 * k                 # few distinct block sizes
-                pin_i = pool.take(n_el, torch.int32)
-                pin_s = pool.take(n_el, torch.float32) if want_scores and pin_i is not None else None
-                if pin_i is None or (want_scores and pin_s is None):
-                    fslot = fetch_ring[n_launch % len(fetch_ring)]  # free again: at most len(lanes) + 1 launches are pending
-                    pin_i = _pinned(fslot, "idx", n_fetch * k, torch.int32)
-                    pin_s = _pinned(fslot, "score", n_fetch * k, torch.float32) if want_scores else None
-                t_i = pin_i.t if isinstance(pin_i, _Lease) else pin_i
-                t_s = None if pin_s is None else (pin_s.t if isinstance(pin_s, _Lease) else pin_s)
-                fs.wait_event(ev)
-                with torch.cuda.stream(fs):
-                    idx.record_stream(fs)
-                    t_i[:n_fetch * k].view(n_fetch, k).copy_(idx[:n_fetch], non_blocking=True)
-                    if want_scores:
-                        score.record_stream(fs)
-                        t_s[:n_fetch * k].view(n_fetch, k).copy_(score[:n_fetch], non_blocking=True)
-                    ev2 = fs.record_event()
-                del t_i, t_s
-                pending.append((pin_i, pin_s, ev2, n_fetch, rows, n_total, getattr(idx, "_exact_guard", None)))
-                if len(pending) > len(lanes):              # one launch per lane stays in flight behind the fetch
-                    yield from results(pending.pop(0))
-            while pending:
-                yield from results(pending.pop(0))
-        finally:
-            for t in pending:                               # a consumer that stopped early: the rings are idle again
-                t[2].synchronize()                          # (the launch's event, or its fetch's)
-            if len(lanes) > 1:
-                for _c, s_ in lanes[1:]:
-                    torch.cuda.current_stream(self.device_index).wait_stream(s_)
-                for c, _s in lanes:                          # other entry points run ungated
-                    c.check(c.lib.dae_set_decode_gate(c.h, None, None))
-        self._check_feed()
-
-    def _plain_guard_fired(self, tag, k):
-        """The interpreter loop under exact_bf16: `tag` = (snapshot of the context's guard words taken behind the launch, the
-        context, the launch's feed).  -> (score, idx) of the same feed through the fp32 kernels when the words moved under the
-        launch (a recomputed survivor left the interval the bf16 filter promised: include/dae_hip.h dae_exact_guard_read), or
-        None when the launch stands.  (the native pipeline and `recommend` had this, the Python loop did not.)"""
-        if tag is None:
-            return None
-        gw, ctx, (x_positions, x_ones, seeds, n_rows) = tag
-        n_bad, col = (int(v) for v in gw.cpu())
-        if not ctx.guard_moved(n_bad):
-            return None
-        import warnings
-        warnings.warn("exact_bf16: the bound guard fired (%d survivors so far, e.g. column %d): this launch is re-scored with the "
-                      "fp32 kernels" % (n_bad, col))
-        self._guard_fallbacks = self.__dict__.get("_guard_fallbacks", 0) + 1
-        self._ensure_packed(_lib.DAE_DTYPE_F32)
-        self.ctx.bind_stream()
-        score, idx, _ev = DAE_tied._submit(self, x_positions, x_ones, seeds, k, _lib.DAE_DTYPE_F32, False, n_rows=n_rows)
-        return score, idx
+        for f in feeds:                  # (device_csr = False: host-built CSRs -- the per-batch call)
+            x_positions, x_ones, seeds, n_rows = f[:4]
+            kw = {} if len(f) <= 4 else {"titles": f[4], "titles_use": f[5] if len(f) > 5 else None}
+            idx, score = self.recommend(x_positions, x_ones, seeds, k=k, n_rows=n_rows, dtype=dtype, **kw)
+            yield idx, (score if want_scores else None)
 
     def _native_pipe(self, dtype, k, want_scores):
         """The model's dae_pipeline for (dtype, k, scores wanted): created on first use, again after the weights changed."""
@@ -1046,62 +729,6 @@ class DAE_tied:
                 best, best_eff = m, max(eff, best_eff)
         return best
 
-    def _scoring_lanes(self, dtype):
-        """Contexts the streamed scoring loop hands its launches to in turn.  The plain DAE runs SEVERAL: every extra
-        lane has its own HIP stream and library context and scores from the first context's packed decoder image
-        (dae_share_decoder); with the fp32 decode the dominant launches take turns around the ring of lanes
-        (dae_set_decode_gate) and everything else of a launch -- CSR build, seed lists, encode, threshold, selection --
-        runs next to the other lanes' decodes.  Two by default: three or four measured no better in any mode (fp32 1.03 -
-        1.17 M against 1.22 M playlists/s through the loop, exact_bf16 3.2 against 3.5 M; profiles/r03_notes.md);
-        `model.n_lanes` overrides, `model.two_lanes = False`: one.  A title model keeps one (its mix runs on two
-        contexts already)."""
-        import ctypes
-        import torch
-        if type(self)._submit is not DAE._submit or not self.__dict__.get("two_lanes", True):
-            return [(self.ctx, None)]
-        n_lanes = int(self.__dict__.get("n_lanes") or 2)
-        if n_lanes <= 1:
-            return [(self.ctx, None)]
-        extra = self.__dict__.setdefault("_lanes", [])
-        cur = torch.cuda.current_stream(self.device_index)
-        if "_lane_ev0" not in self.__dict__:
-            self._lane_ev0 = torch.cuda.Event()
-            self._lane_ev0.record(cur)                      # materialise the hipEvent_t handle
-        while len(extra) < n_lanes - 1:
-            ctx_n = _lib.Context(self.device_index)
-            s_n = torch.cuda.Stream(device=self.weights["encoder_h"].device)
-            with torch.cuda.stream(s_n):
-                ctx_n.bind_stream()
-            ev = torch.cuda.Event()
-            ev.record(s_n)
-            extra.append({"ctx": ctx_n, "stream": s_n, "ev": ev, "packed": {}})
-        lanes = extra[:n_lanes - 1]
-        # the extra lanes score from the FIRST context's packed image (one copy stays in the Infinity Cache, several evict
-        # each other), borrowed again whenever that context has re-tiled the slot (`_pack_gen`)
-        self._ensure_packed(dtype)
-        slot = "f32" if dtype == _lib.DAE_DTYPE_F32 else "bf16"
-        gen = (self.__dict__.get("_pack_gen") or {}).get(slot, 0)
-        for st in lanes:
-            if st["packed"].get(dtype) != gen:
-                cur.synchronize()                           # the owner's prepack is done ...
-                st["stream"].synchronize()                  # ... and nothing of the old image is in flight
-                st["ctx"].share_decoder(self.ctx, dtype)
-                for d_ in ([_lib.DAE_DTYPE_F32] if slot == "f32" else [_lib.DAE_DTYPE_BF16, _lib.DAE_DTYPE_BF16_EXACT]):
-                    st["packed"].pop(d_, None)
-                st["packed"][dtype] = gen
-                if dtype == _lib.DAE_DTYPE_BF16_EXACT:      # the exact image serves plain bf16 launches as well
-                    st["packed"][_lib.DAE_DTYPE_BF16] = gen
-        for c in [self.ctx] + [st["ctx"] for st in lanes]:
-            c.set_overlap_hint(int(self.__dict__.get("lane_hint", n_lanes)))
-        gate = dtype == _lib.DAE_DTYPE_F32                  # bf16 launches are short and share CUs: ungated
-        evs = [self._lane_ev0] + [st["ev"] for st in lanes]
-        ctxs = [self.ctx] + [st["ctx"] for st in lanes]
-        P = lambda e: ctypes.c_void_p(e.cuda_event) if gate else None      # noqa: E731
-        for i, c in enumerate(ctxs):                        # lane i's decode waits for lane i - 1's, around the ring
-            c.check(c.lib.dae_set_decode_gate(c.h, P(evs[i - 1]), P(evs[i])))
-        return [(self.ctx, None)] + [(st["ctx"], st["stream"]) for st in lanes]
-
-    # -- training -----------------------------------------------------------------------------------
     def train_step(self, x_positions, x_ones, y_positions, y_ones, keep_prob, input_keep_prob, fetch_cost=True):
         """sess.run([model.optimizer, model.cost], ...) (main_train.py:204-213) -> cost (float).
         `fetch_cost=False` returns the cost as a 0-dim DEVICE tensor and does not wait for the step: the host
@@ -1201,58 +828,6 @@ class DAE_tied:
             pickle.dump(self.get_params(), f)
 
 
-def _pinned(slot, name, n, dtype):
-    """A pinned host buffer of >= n elements kept in `slot` (a dict of recommend_iter's staging / fetch rings)."""
-    import torch
-    t = slot.get(name)
-    if t is None or t.numel() < n or t.dtype != dtype:
-        t = slot[name] = torch.empty(max(int(n), 2 * (t.numel() if t is not None and t.dtype == dtype else 0)),
-                                     dtype=dtype, pin_memory=True)
-    return t
-
-
-class _PinnedPool:
-    """Pinned host blocks for the lists recommend_iter hands out.  A launch's lists are copied into one block by the
-    device; the arrays the caller receives are views of that block (no second copy on the host: 0.2 ms per 4 MB that a
-    single core spends reading memory the DMA has just written), and the block returns to the pool when the last of
-    them is garbage.  At most `max_out` blocks are out at a time -- a caller that keeps every result (list(...)) gets
-    ordinary copies from then on, so the pinned memory held stays bounded."""
-
-    def __init__(self, max_out=12):
-        self.free = {}                # (dtype, n elements) -> [tensor]
-        self.out = 0
-        self.max_out = max_out
-
-    def take(self, n, dtype):
-        """-> a lease on a block of n elements, or None when too many are out."""
-        import torch
-        if self.out >= self.max_out:
-            return None
-        lst = self.free.get((dtype, n))
-        t = lst.pop() if lst else torch.empty(n, dtype=dtype, pin_memory=True)
-        self.out += 1
-        return _Lease(self, t, n, dtype)
-
-
-class _Lease:
-    """Owns one block of a _PinnedPool; numpy arrays made from it (`array()`) keep it alive through their base chain."""
-
-    def __init__(self, pool, t, n, dtype):
-        self.pool, self.t, self.key = pool, t, (dtype, n)
-        self.__array_interface__ = {"shape": (n,), "typestr": {4: "<i4" if not t.dtype.is_floating_point else "<f4"}[t.element_size()],
-                                    "data": (t.data_ptr(), False), "version": 3}
-
-    def array(self, rows, k):
-        return np.asarray(self)[:rows * k].reshape(rows, k)
-
-    def __del__(self):
-        try:
-            self.pool.free.setdefault(self.key, []).append(self.t)
-            self.pool.out -= 1
-        except Exception:             # noqa: BLE001 -- interpreter shutdown
-            pass
-
-
 class DAE(DAE_tied):
     """Untied DAE, optionally initialised from a pretrain pickle (reference DAEs.py:114-150)."""
 
@@ -1342,7 +917,7 @@ class DAE_title(DAE):
             u[:len(tu)] = tu[:nb]
             u = self._to_dev(u, torch.float32, side_stream)
         else:
-            u = u_dev                                         # staged with the feed (`_stage_titled`)
+            u = u_dev                                         # (already on the device)
         w_t = torch.empty(nb, dtype=torch.float32, device=dev)
         w_p = torch.empty(nb, dtype=torch.float32, device=dev)
         # one launch (dae_mix_weights: the row sums of dae_row_sums and the four elementwise operations behind them)
@@ -1416,52 +991,6 @@ class DAE_title(DAE):
         self._check_feed()
         return cost
 
-    def _stage_titled(self, x_positions, x_ones, titles, titles_use, nb):
-        """The streamed loop's upload of a titled launch: feed positions / values, titles and titles_use through ONE pinned
-        block and ONE asynchronous copy on the copy stream (four blocking copies from pageable memory were 0.25 ms of
-        the host's ~1 ms per launch, with the GPU's share at 0.55 ms).  -> (d_pos, d_val, d_titles [nb, L] int32, d_use [nb])."""
-        import torch
-        pos, vals = self._feed_arrays(x_positions, x_ones)
-        L = self.title_model.input_len
-        t = np.full((nb, L), -1, np.int32)
-        src = np.asarray(titles, np.int64).reshape(-1, L) if len(titles) else np.zeros((0, L), np.int64)
-        t[:min(len(src), nb)] = src[:nb]
-        u = np.zeros(nb, np.float32)
-        tu = np.asarray(titles_use, np.float32).reshape(-1)
-        u[:min(len(tu), nb)] = tu[:nb]
-        n, nv = max(pos.shape[0], 1), max(vals.size, 1)
-        parts = [(pos if pos.shape[0] else np.zeros((1, 2), np.int64), n * 16), (vals if vals.size else np.zeros(1, np.float32), nv * 4),
-                 (t, nb * L * 4), (u, nb * 4)]
-        offs, total = [], 0
-        for _a, nbytes in parts:
-            offs.append(total)
-            total += (nbytes + 15) // 16 * 16
-        ring = self.__dict__.setdefault("_title_ring", [{} for _ in range(4)])
-        slot = ring[self.__dict__.get("_title_ring_at", 0) % len(ring)]
-        self._title_ring_at = self.__dict__.get("_title_ring_at", 0) + 1
-        if slot.get("busy") is not None:
-            slot["busy"].synchronize()                           # its previous upload left the block long ago
-        pin = _pinned(slot, "blk", total, torch.uint8)
-        host = pin.numpy()
-        for (a, nbytes), o in zip(parts, offs):
-            host[o:o + nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-        dev = torch.device("cuda", self.device_index)
-        cs = self.__dict__.get("_copy_stream")
-        if cs is None:
-            cs = self._copy_stream = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream(self.device_index)
-        with torch.cuda.stream(cs):
-            d = torch.empty(total, dtype=torch.uint8, device=dev)
-            d.copy_(pin[:total], non_blocking=True)
-            slot["busy"] = ev = cs.record_event()
-        cur.wait_event(ev)
-        d.record_stream(cur)
-        d_pos = d[offs[0]:offs[0] + n * 16].view(torch.int64).view(n, 2)[:pos.shape[0]]
-        d_val = d[offs[1]:offs[1] + nv * 4].view(torch.float32)
-        d_t = d[offs[2]:offs[2] + nb * L * 4].view(torch.int32).view(nb, L)
-        d_u = d[offs[3]:offs[3] + nb * 4].view(torch.float32)
-        return d_pos, d_val, d_t, d_u
-
     def _submit(self, x_positions, x_ones, seeds, k, dtype, side_stream, titles=None, titles_use=None, ctx=None,
                 n_rows=None):
         """One batch enqueued, nothing fetched (`n_rows`: rows of a launch that coalesces several feeds).  Without titles in use the mix reduces to the plain DAE (w_playlist is
@@ -1488,29 +1017,7 @@ class DAE_title(DAE):
         # title features -- on streams of their own, joined before dae_mix_topk_exact: 1.12 - 1.17 M playlists/s against
         # 1.22 M without.  The loop is bound by the host's ~0.6 ms per launch, and the fork adds events and stream switches.)
         feat = None
-        if side_stream and self.device_csr:                   # the streamed loop: one pinned block, one asynchronous copy
-            d_pos, d_val, d_titles, d_use = self._stage_titled(x_positions, x_ones, titles, titles_use, nb)
-            if (dtype == _lib.DAE_DTYPE_BF16_EXACT and isinstance(seeds, str) and seeds == SEEDS_FROM_INPUT
-                    and not self.__dict__.get("title_no_composite")):
-                # the drivers' case (seeds = the playlist's own tracks): the whole launch in ONE library call
-                # (dae_title_score_exact) -- made call by call from here it cost ~0.2 ms of Python per launch
-                score = torch.empty((nb, k), dtype=torch.float32, device=dev)
-                idx = torch.empty((nb, k), dtype=torch.int32, device=dev)
-                gw = torch.empty(2, dtype=torch.int32, device=dev)
-                status = torch.empty(1, dtype=torch.int32, device=dev)
-                tm.ctx.title_score_exact(self.ctx, d_pos, d_val, nb, self.n_input, self.weights["encoder_h"],
-                                         self.biases["encoder_b"], d_titles, tm, d_use, self.n_tracks, k, score, idx, gw, status)
-                cur = torch.cuda.current_stream(self.device_index)
-                ev = cur.record_event()
-                pending = (self._csr_status or []) + [(status, ev)]
-                if len(pending) > 64:
-                    pending = [(self._fold_status(pending), cur.record_event())]
-                self._csr_status = pending
-                idx._mix_guard = (gw, (x_positions, x_ones, seeds, titles, titles_use, n_rows))
-                return score, idx, ev
-            csr = self._upload_csr(None, None, n_rows=nb, staged=(d_pos, d_val, None))
-        else:
-            csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
+        csr = self._upload_csr(x_positions, x_ones, side_stream=side_stream, n_rows=nb)
         h = torch.empty((nb, self.n_hidden), dtype=torch.float32, device=dev)
         self.ctx.encode(csr[0], csr[1], csr[2], self.weights["encoder_h"], self.biases["encoder_b"], h)
         w_t, w_p = self._mix_weights(csr, titles_use, side_stream=side_stream, n_rows=nb, u_dev=d_use)

@@ -1,6 +1,7 @@
 """GPU (-m gpu): the drivers' streamed loop (`DAE.recommend_iter`: main_challenge.py:72-93 / main_train.py:62-96 with the
-host and the device overlapped, two or three library contexts taking the launches in turn) returns, batch for batch, what
-`recommend` returns for the same feed -- fp32 bit for bit, bf16 likewise (same kernels, same order of operations)."""
+host and the device overlapped -- the library's dae_pipeline_*, three contexts taking the launches in turn) returns, batch
+for batch, what `recommend` returns for the same feed -- fp32 bit for bit, bf16 likewise (same kernels, same order of
+operations).  (Round 6 retired the interpreter loop these tests used to run beside it.)"""
 import pickle
 
 import numpy as np
@@ -13,11 +14,10 @@ from spotify_recsys_challenge_2018_amd.utils.synthetic import make_playlists, ma
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("engine", ["native", "python"])
 @pytest.mark.parametrize("dtype,B", [("f32", 256), ("bf16", 256), ("f32", 150), ("f32", 250), ("exact_bf16", 256), ("exact_bf16", 150)])
-def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B, engine):
+def test_recommend_iter_equals_recommend(tmp_path, dtype, B):
     """7 feeds (short ones among them) through the streamed loop: coalesced 4 or 5 to a launch (256 / 250 -> 4, the
-    reference's challenge batch of 150 -> 5), launches alternating between two contexts."""
+    reference's challenge batch of 150 -> 5; 8 in the bf16 modes), launches dealt to the pipeline's lanes in turn."""
     nt, na, H, k = 20000, 4000, 256, 500
     V = nt + na
     W_enc, b_enc, W_dec, b_dec = make_weights(V, H, seed=2, bias="zipf", n_tracks=nt)
@@ -29,7 +29,6 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B, engine):
         save = str(tmp_path / "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
         n_tracks = nt; initval = path
     m = DAE(C()); m.fit()
-    m.iter_engine = engine              # "native": the library's dae_pipeline; "python": the interpreter loop of round 3
     batches = [make_playlists(B, nt, na, seed=10 + s) for s in range(7)]           # odd count: the lanes end unevenly
     rows = [B, B, 100, B, 1, B, 37]                                                # short last batches of a file
     assert m._coalesce_count() == {256: 4, 250: 4, 150: 5}[B]
@@ -40,81 +39,44 @@ def test_recommend_iter_two_lanes_equals_recommend(tmp_path, dtype, B, engine):
             assert np.array_equal(fi, wi) and np.array_equal(fs.view(np.uint32), ws.view(np.uint32))
     feeds = [(p, o, SEEDS_FROM_INPUT, n) for (p, o, _s), n in zip(batches, rows)]
     got = list(m.recommend_iter(feeds, k=k, dtype=dtype))
-    assert len(got) == len(want) and len(m._scoring_lanes(m._dtype_of(dtype))) == 2
+    assert len(got) == len(want)
     for (gi, gs), (wi, ws) in zip(got, want):
         assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
-    # the second context follows a weight change (its packed image is rebuilt), and a single-lane model agrees
+    # the pipeline follows a weight change (its packed image is rebuilt), and other lane counts agree
     m.weights["decoder_h"].mul_(-1.0); m._mark_dirty()
     want2 = m.recommend(*batches[0], k=k, dtype=dtype)
     got2 = list(m.recommend_iter(feeds[:3], k=k, dtype=dtype))
     assert np.array_equal(got2[0][0], want2[0]) and not np.array_equal(got2[0][0], want[0][0])
-    m.two_lanes = False
-    got1 = list(m.recommend_iter(feeds[:3], k=k, dtype=dtype))
-    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got1, got2))
-    # explicit seed lists (and a mix of both kinds) through the coalesced launches
-    m.two_lanes = True
+    for nl in (1, 2):
+        m.n_lanes = nl
+        m.__dict__.pop("_pipes", None)
+        got1 = list(m.recommend_iter(feeds[:3], k=k, dtype=dtype))
+        assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got1, got2))
+    m.n_lanes = None
+    # explicit seed lists (feeds the pipeline does not take go through `recommend`, in order) mixed with the drivers' kind
     mixed = [(p, o, (s if i % 2 else SEEDS_FROM_INPUT), n) for i, ((p, o, s), n) in enumerate(zip(batches, rows))]
     got3 = list(m.recommend_iter(mixed, k=k, dtype=dtype))
     want3 = [m.recommend(p, o, s, k=k, n_rows=n, dtype=dtype) for (p, o, s), n in zip(batches, rows)]
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(got3, want3))
-    # both copy policies of the loop (pinned asynchronous copies by default, the blocking ones on request), three lanes,
-    # with and without the scores, twice over the staging ring; a consumer that stops early leaves the loop reusable
-    for mode in ("async", "blocking"):
-        m.iter_copies = mode
-        m.n_lanes = 3 if mode == "async" else None
-        for ws_ in (True, False):
-            got4 = list(m.recommend_iter(mixed * 2, k=k, dtype=dtype, want_scores=ws_))
-            assert len(got4) == 2 * len(want3)
-            for a, b in zip(got4, want3 * 2):
-                assert np.array_equal(a[0], b[0]) and (a[1] is None if not ws_ else np.array_equal(a[1], b[1]))
-        it = m.recommend_iter(mixed * 2, k=k, dtype=dtype)
-        first = next(it); it.close()
-        assert np.array_equal(first[0], want3[0][0])
-    m.n_lanes = None
-    m.iter_copies = "nonsense"
-    with pytest.raises(ValueError):
-        list(m.recommend_iter(mixed, k=k, dtype=dtype))
-    m.iter_copies = None
+    # with and without the scores, twice over the launch slots; a consumer that stops early leaves the model usable
+    for ws_ in (True, False):
+        got4 = list(m.recommend_iter(mixed * 2, k=k, dtype=dtype, want_scores=ws_))
+        assert len(got4) == 2 * len(want3)
+        for a, b in zip(got4, want3 * 2):
+            assert np.array_equal(a[0], b[0]) and (a[1] is None if not ws_ else np.array_equal(a[1], b[1]))
+    it = m.recommend_iter(mixed * 2, k=k, dtype=dtype)
+    first = next(it); it.close()
+    assert np.array_equal(first[0], want3[0][0])
+    got5 = list(m.recommend_iter(feeds[:2], k=k, dtype=dtype))
+    assert np.array_equal(got5[1][0], want2[0]) is False and len(got5) == 2
     bad = [(np.array([[0, 1], [1, 2]], np.int64), np.ones(3, np.float32), SEEDS_FROM_INPUT, 2)]
     with pytest.raises(ValueError):
         list(m.recommend_iter(bad * 4, k=k, dtype=dtype))
-
-
-def test_recommend_iter_hands_out_leased_pinned_blocks(tmp_path):
-    """The lists of the asynchronous loop are views of pinned blocks leased from a pool: kept results stay intact while
-    the loop goes on, blocks return when the last view is garbage, and with the pool exhausted the loop copies instead."""
-    import gc
-    nt, na, H, k, B = 6000, 1000, 64, 100, 64
-    W_enc, b_enc, W_dec, b_dec = make_weights(nt + na, H, seed=4, bias="zipf", n_tracks=nt)
-    path = str(tmp_path / "init.pkl")
-    with open(path, "wb") as f:
-        pickle.dump([W_enc, W_dec, b_enc, b_dec], f)
-
-    class C:
-        save = str(tmp_path / "unused"); batch = B; n_input = nt + na; hidden = H; lr = 0.005; reg_lambda = 0.0
-        n_tracks = nt; initval = path
-    m = DAE(C()); m.fit()
-    m.iter_engine = "python"            # (the pool belongs to the interpreter loop; the native loop lends result blocks: below)
-    batches = [make_playlists(B, nt, na, seed=30 + s) for s in range(6)]
-    want = [m.recommend(p, o, s, k=k) for p, o, s in batches]
-    feeds = [(p, o, SEEDS_FROM_INPUT, B) for p, o, _s in batches] * 4
-    kept = list(m.recommend_iter(feeds, k=k))
-    pool = m._iter_pool
-    assert 0 < pool.out <= pool.max_out
-    for (gi, gs), (wi, ws) in zip(kept, want * 4):
-        assert np.array_equal(gi, wi) and np.array_equal(gs.view(np.uint32), ws.view(np.uint32))
-    pool.max_out = pool.out                      # exhausted: the next loop copies out of its ring
-    kept2 = list(m.recommend_iter(feeds, k=k))
-    assert pool.out == pool.max_out
-    for (gi, gs), (wi, ws) in zip(kept2, want * 4):
-        assert np.array_equal(gi, wi) and np.array_equal(gs, ws)
-    for (gi, gs), (wi, ws) in zip(kept, want * 4):   # the first loop's blocks were not touched by the second
-        assert np.array_equal(gi, wi) and np.array_equal(gs, ws)
-    del kept, kept2, gi, gs
-    gc.collect()
-    assert pool.out == 0 and sum(len(v) for v in pool.free.values()) > 0
-    again = list(m.recommend_iter(feeds[:6], k=k))                # served from the free lists
-    assert all(np.array_equal(a[0], b[0]) for a, b in zip(again, want))
+    # a model that builds its CSRs on the host (device_csr = False) is served feed by feed: the same lists
+    m.device_csr = False
+    got6 = list(m.recommend_iter(feeds[:2], k=k, dtype=dtype))
+    m.device_csr = True
+    assert all(np.array_equal(a[0], b[0]) for a, b in zip(got6, got5))
 
 
 def test_native_pipeline_orders_lends_and_recovers(tmp_path):
@@ -184,12 +146,10 @@ def test_native_pipeline_orders_lends_and_recovers(tmp_path):
         pipe.close()
 
 
-@pytest.mark.parametrize("engine", ["python", "native"])
-def test_streamed_loop_re_scores_when_the_guard_fires(tmp_path, engine):
-    """the interpreter loop (iter_engine = "python", two lane contexts) never looked at the exact mode's guard
-    words.  Now every launch carries a snapshot of its context's words (dae_exact_guard_snapshot); a forged bound
-    (dae_set_exact_margin < 1 on the model's context, handed on to the lanes / the pipeline) makes the loop warn and return the
-    fp32 kernels' lists -- and an honest bound stays silent, with the counters of earlier hits NOT charged to later launches."""
+def test_streamed_loop_re_scores_when_the_guard_fires(tmp_path):
+    """A forged bound (dae_set_exact_margin < 1 on the model's context, handed on to the pipeline's own images) makes the
+    streamed loop warn and return the fp32 kernels' lists (dae_pipeline_poll re-scores the launch) -- and an honest bound stays
+    silent, with the counters of earlier hits NOT charged to later launches."""
     import warnings
     nt, na, H, k, B = 20000, 3000, 128, 300, 64
     V = nt + na
@@ -203,7 +163,6 @@ def test_streamed_loop_re_scores_when_the_guard_fires(tmp_path, engine):
         save = str(tmp_path / "unused"); batch = B; n_input = V; hidden = H; lr = 0.005; reg_lambda = 0.0
         n_tracks = nt; initval = path
     m = DAE(C()); m.fit()
-    m.iter_engine = engine
     batches = [make_playlists(B, nt, na, seed=70 + i)[:2] for i in range(6)]
     feeds = [(p, o, SEEDS_FROM_INPUT, B) for p, o in batches]
     want = [m.recommend(p, o, SEEDS_FROM_INPUT, k=k, dtype="f32") for p, o in batches]
@@ -218,15 +177,11 @@ def test_streamed_loop_re_scores_when_the_guard_fires(tmp_path, engine):
     assert m.__dict__.get("_guard_fallbacks", 0) == 0
     m.ctx.set_exact_margin(1e-3)
     m._mark_dirty()
-    for st in m.__dict__.get("_lanes", []):               # the extra lanes borrow the first context's image: nothing of their own to forge
-        st["packed"].clear()
     with pytest.warns(UserWarning, match="bound guard"):
         same(list(m.recommend_iter(feeds, k=k, dtype="exact_bf16")))
     assert m._guard_fallbacks >= 1
     m.ctx.set_exact_margin(1.0)
     m._mark_dirty()
-    for st in m.__dict__.get("_lanes", []):
-        st["packed"].clear()
     n0 = m._guard_fallbacks
     with warnings.catch_warnings():
         warnings.simplefilter("error")

@@ -233,8 +233,7 @@ def test_mix_weights_in_one_launch_equal_the_elementwise_composition(tmp_path, i
     assert float(w_p[4]) == 0.0 and float(w_t[4]) == float(use[4] / (use[4] + np.float32(1e-10))) if use[4] else True
 
 
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_titled_recommend_iter_coalesced_equals_recommend(tmp_path, engine):
+def test_titled_recommend_iter_coalesced_equals_recommend(tmp_path):
     """The streamed loop coalesces title feeds too (5 feeds of 24 rows -> one 120-row launch of both scorers): every
     feed gets what `recommend` returns for it alone -- rows with and without a title, short feeds, a feed whose rows use
     no title at all."""
@@ -249,7 +248,6 @@ def test_titled_recommend_iter_coalesced_equals_recommend(tmp_path, engine):
     mt.fit(tn.make_params(41, 50, FS, 100, conf.n_output, seed=4))
     model = DAE_title(conf, mt)
     model.fit()
-    model.iter_engine = engine          # "native": dae_pipeline_create_titled / _submit_titled (fp32 here); "python": the interpreter loop
     B = conf.batch
     assert model._coalesce_count() == 5
     feeds, want = [], []

@@ -99,14 +99,12 @@ def test_exact_title_mix_returns_the_fp32_lists(tmp_path, bias, w_scale, feat_sc
     assert not getattr(m, "_guard_fallbacks", 0)
 
 
-@pytest.mark.parametrize("engine", ["native", "python"])
-def test_exact_title_mix_streamed_and_coalesced(tmp_path, engine):
+def test_exact_title_mix_streamed_and_coalesced(tmp_path):
     """The drivers' loop: 5 feeds of 150 rows in one 750-row launch (8 row groups of 96), a vocabulary of 1 400 tiles;
-    rows with and without titles, short feeds, a feed without any title (the plain exact path).  Both engines: the
-    library's titled pipeline (dae_pipeline_create_titled / _submit_titled, round 5) and the interpreter loop."""
+    rows with and without titles, short feeds, a feed without any title (the plain exact path), through the library's titled
+    pipeline (dae_pipeline_create_titled / _submit_titled)."""
     conf = _conf(n_tracks=40000, n_input=45000, batch=150)
     m = _model(tmp_path, conf)
-    m.iter_engine = engine
     m.decode_dtype = _lib.DAE_DTYPE_BF16_EXACT
     B = conf.batch
     feeds, want = [], []
@@ -130,12 +128,9 @@ def test_exact_title_mix_streamed_and_coalesced(tmp_path, engine):
     assert len(got) == 7
     for g, w in zip(got, want):
         _same(g, w)
-    if engine == "python":
-        assert m.title_model.ctx.exact_stats_read()["rows"] > 0
-    else:                                                         # (the pipeline's own contexts ran the launches)
-        (_gen, pipe), = m._pipes.values()
-        st = pipe.stats()
-        assert st["feeds"] == 7 and 0 < st["launches"] < 7 and st["guard_fallbacks"] == 0, st
+    (_gen, pipe), = m._pipes.values()                             # (the pipeline's own contexts ran the launches)
+    st = pipe.stats()
+    assert st["feeds"] == 7 and 0 < st["launches"] < 7 and st["guard_fallbacks"] == 0, st
     assert not getattr(m, "_guard_fallbacks", 0)
 
 
@@ -220,9 +215,8 @@ def test_exact_title_mix_guard_and_fallback(tmp_path):
     feeds = [(pos, ones, SEEDS_FROM_INPUT, conf.batch, [list(t) for t in titles], use)] * 7
     own = [sorted(set(int(c) for r, c in np.asarray(pos) if r == row and c < conf.n_tracks)) for row in range(conf.batch)]
     want_own = m.recommend(pos, ones, own, k=100, titles=titles, titles_use=use, dtype="f32")
-    for engine in ("native", "python"):                 # (native: the pipeline re-scores the launch itself and counts it)
-        m.iter_engine = engine
-        m.ctx.set_exact_margin(1e-3)
+    for _rep in range(2):                               # (the pipeline re-scores the launch itself and counts it; twice: the counters
+        m.ctx.set_exact_margin(1e-3)                    # of the first pass are not charged to the second)
         m._mark_dirty()
         n0 = m._guard_fallbacks
         with pytest.warns(UserWarning, match="bound guard"):
