@@ -51,6 +51,13 @@ def main():
                 for _ in m.recommend_iter(feeds(40 if mode == "f32" else 120), k=500, want_scores=False, dtype=mode):
                     pass                                          # (~0.3 s: the device at its sustained state, as bench.py's prime phase)
                 torch.cuda.synchronize()
+                if os.environ.get("FREEZE"):          # as bench.py's host-loop rows: one full collection, survivors frozen
+                    import gc
+                    gc.collect(); gc.freeze()
+                hold = None
+                if os.environ.get("HOLD"):            # ... and one view of a result block kept alive across the timed loop
+                    for hold in m.recommend_iter(feeds(1), k=500, want_scores=False, dtype=mode):
+                        pass
                 reps = (100 if mode == "f32" else 300) * int(os.environ.get("REPS_X", "1"))      # REPS_X=4: a loop long enough for the sustained clock
                 t0 = time.perf_counter()
                 n = 0

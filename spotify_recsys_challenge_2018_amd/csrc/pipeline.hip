@@ -481,15 +481,21 @@ const char* dae_pipeline_last_error(const dae_pipeline* p)
 // hardware queue when it is created, and after a pipeline's streams were destroyed the next pipeline's fresh ones came out sharing
 // queues -- its lanes' launches queued behind each other (bench.py's host-loop rows run fp32, then exact_bf16, on one model: the
 // second pipeline measured 5.8 M playlists/s against 7.3 M as the process's first; scripts/probe/row_diag.py)
+// Round 6: the pool is keyed by ROLE as well.  It was first-in first-out over all of a pipeline's streams, so every other pipeline
+// of a process got its LANES on streams that had been the copy / out / prep streams before (and the other way round): such a
+// pipeline ran 25 - 30 % slower -- 6.1 against 8.4 M playlists/s, instance after instance in the pattern fast, fast, slow, slow
+// (scripts/gpu_r6_t14.sh; bench.py's host-loop rows and scripts/bench_loop.py disagreed by exactly that).  A stream now returns to
+// the role it was created for: 0 = a lane (kernels of the scoring call), 1 = copies (upload / out), 2 = the CSR build.
 static std::mutex g_stream_pool_mu;
-static std::vector<std::pair<int, hipStream_t>> g_stream_pool;
-static hipStream_t pool_take_stream(int device)
+struct PooledStream { int device, role; hipStream_t s; };
+static std::vector<PooledStream> g_stream_pool;
+static hipStream_t pool_take_stream(int device, int role)
 {
     {
         std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-        for (size_t i = 0; i < g_stream_pool.size(); ++i)
-            if (g_stream_pool[i].first == device) {
-                hipStream_t s = g_stream_pool[i].second;
+        for (size_t i = g_stream_pool.size(); i-- > 0;)                        // (last in, first out: a lane gets a lane's stream back)
+            if (g_stream_pool[i].device == device && g_stream_pool[i].role == role) {
+                hipStream_t s = g_stream_pool[i].s;
                 g_stream_pool.erase(g_stream_pool.begin() + (long)i);
                 return s;
             }
@@ -498,12 +504,12 @@ static hipStream_t pool_take_stream(int device)
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return s;
 }
-static void pool_give_stream(int device, hipStream_t s)
+static void pool_give_stream(int device, hipStream_t s, int role)
 {
     if (!s) return;
     (void)hipStreamSynchronize(s);
     std::lock_guard<std::mutex> lk(g_stream_pool_mu);
-    g_stream_pool.emplace_back(device, s);
+    g_stream_pool.push_back(PooledStream{device, role, s});
 }
 
 int dae_pipeline_destroy(dae_pipeline* p)
@@ -551,15 +557,15 @@ int dae_pipeline_destroy(dae_pipeline* p)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
         if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
-        pool_give_stream(p->device, L.stream);
+        pool_give_stream(p->device, L.stream, 0);
         void* dev[] = {L.d_status, L.d_score, L.d_guard};
         for (void* q : dev) if (q) (void)hipFree(q);
     }
-    pool_give_stream(p->device, p->copy_stream);
-    if (p->out_stream) { (void)hipStreamSynchronize(p->out_stream); pool_give_stream(p->device, p->out_stream); }
+    pool_give_stream(p->device, p->copy_stream, 1);
+    if (p->out_stream) { (void)hipStreamSynchronize(p->out_stream); pool_give_stream(p->device, p->out_stream, 1); }
     if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
     if (p->prep_ctx) (void)dae_destroy(p->prep_ctx);
-    pool_give_stream(p->device, p->prep_stream);
+    pool_give_stream(p->device, p->prep_stream, 2);
     for (Slot& S : p->slots) {
         if (S.ev_scored) (void)hipEventDestroy(S.ev_scored);
         if (S.ev_prep) (void)hipEventDestroy(S.ev_prep);
@@ -607,9 +613,9 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
     auto bail = [&](int rc, const char* msg) { const std::string m(msg); dae_pipeline_destroy(p); g_pipe_err = m; return rc; };
     DeviceGuard dev_guard(device);
     { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) return bail(DAE_ERR_HIP, "hipSetDevice failed"); }
-    if (!(p->copy_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
-    if (!(p->out_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
-    if (!(p->prep_stream = pool_take_stream(device))) return bail(DAE_ERR_HIP, "stream creation failed");
+    if (!(p->copy_stream = pool_take_stream(device, 1))) return bail(DAE_ERR_HIP, "stream creation failed");
+    if (!(p->out_stream = pool_take_stream(device, 1))) return bail(DAE_ERR_HIP, "stream creation failed");
+    if (!(p->prep_stream = pool_take_stream(device, 2))) return bail(DAE_ERR_HIP, "stream creation failed");
     {
         int rc_p = dae_create(device, &p->prep_ctx);
         if (!rc_p) rc_p = dae_set_stream(p->prep_ctx, p->prep_stream);
@@ -620,17 +626,7 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
         Lane& L = p->lanes[i];
         int rc = dae_create(device, &L.ctx);
         if (rc) return bail(rc, dae_last_error(nullptr));
-#ifdef DAE_EXPERIMENTS
-        // DAE_PIPE_CUMASK=1 (experiments build): lane i's stream confined to one half of every XCD's CUs (i odd / even), the
-        // partition that won at 1 024 rows per launch in scripts/time_cumask.py -- measured on the loop in profiles/r06_notes.md 4
-        if (dae_exp_env("DAE_PIPE_CUMASK")) {
-            uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < 256; ++b) if ((b / 8) % 2 == i % 2) m[b / 32] |= 1u << (b % 32);
-            if (hipExtStreamCreateWithCUMask(&L.stream, 8, m) != hipSuccess) L.stream = nullptr;
-        }
-        if (!L.stream)
-#endif
-        L.stream = pool_take_stream(device);
+        L.stream = pool_take_stream(device, 0);
         bool ok = L.stream != nullptr &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_score), (rows * kk * sizeof(float) + 15) / 16 * 16) == hipSuccess;
