@@ -1168,11 +1168,12 @@ int dae_title_score(dae_ctx* tc, dae_ctx* dc, int dtype, const int64_t* position
         if (rc) return rc;
     }
     auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
-    rc = from_dc(dae_coo_to_csr(dc, positions, values, values_broadcast, nnz, B, V, rp, col, val, csr_status));
+    // the feed -> CSR AND the seed lists (the playlist's own tracks) from one group of four launches (round 6: csr.hip)
+    if (!positions && nnz > 0) return dae_fail(tc, DAE_ERR_ARG, "null pointer");
+    rc = from_dc(dae_launch_coo64_to_csr_seeds(dc, positions, values, values_broadcast, nnz, B, V, rp, col, val, csr_status,
+                                               n_tracks, srp, sc));
     if (rc) return rc;
     rc = from_dc(dae_encode(dc, rp, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0u, h));
-    if (rc) return rc;
-    rc = from_dc(dae_seeds_from_csr(dc, rp, col, B, n_tracks, srp, sc));
     if (rc) return rc;
     rc = from_dc(dae_mix_weights(dc, rp, col, val, B, 1.0f, 0u, titles_use, wt, wp));
     if (rc) return rc;

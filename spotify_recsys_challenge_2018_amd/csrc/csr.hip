@@ -514,3 +514,12 @@ int dae_launch_coo32_to_csr_seeds(dae_ctx* ctx, const int32_t* positions, const 
     return launch_coo_to_csr<int32_t>(ctx, positions, values, values_broadcast, nnz, n_rows, n_cols, row_ptr, col, val, status,
                                       n_tracks, seed_row_ptr, seed_col);
 }
+
+// ... and the same for the reference's own 64-bit feed (api.hip dae_title_score: a titled launch of the drivers' loop)
+int dae_launch_coo64_to_csr_seeds(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                                  int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                                  int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col)
+{
+    return launch_coo_to_csr<int64_t>(ctx, positions, values, values_broadcast, nnz, n_rows, n_cols, row_ptr, col, val, status,
+                                      n_tracks, seed_row_ptr, seed_col);
+}

@@ -352,6 +352,9 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
 int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                           int32_t* status);
+int dae_launch_coo64_to_csr_seeds(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
+                                  int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
+                                  int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col);
 int dae_launch_coo32_to_csr_seeds(dae_ctx* ctx, const int32_t* positions, const float* values, int values_broadcast,
                                   int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                                   int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col);

@@ -1046,7 +1046,22 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     p.biasD = static_cast<const uint4*>(pd.bias16_lo.p); p.biasT = static_cast<const uint4*>(pt.mix16_lo.p);
     p.list = order; p.n_items = n_samp;
     p.samp = static_cast<float*>(tc->gmax.p); p.ld_s = ld_s;
-    hipLaunchKernelGGL(ks, dim3(grid), dim3(NW * 64), lds, st, p);
+    {
+        // the sample pass on a grid of its own when other launches are in flight (round 6, as the plain path's sample launch:
+        // api.hip topk_phase_a): an eighth of the tiles does not need a workgroup on every CU -- ~8 items per wave slot; its
+        // maxima are stored per ITEM, so the geometry changes nothing but where they are computed
+        int nb_s = nb;
+        if (tc->overlap_hint) {
+            nb_s = ((n_samp + 8 * NW - 1) / (8 * NW) + DAE_NUM_XCD - 1) / DAE_NUM_XCD * DAE_NUM_XCD;
+            if (nb_s > nb) nb_s = nb;
+        }
+        static const int nbs_env = dae_exp_env("DAE_MIX_SAMPLE_NB") ? atoi(dae_exp_env("DAE_MIX_SAMPLE_NB")) : 0;       // A/B (experiments build)
+        if (nbs_env > 0) nb_s = nbs_env >= nb ? nb : nbs_env / DAE_NUM_XCD * DAE_NUM_XCD;
+        if (nb_s < DAE_NUM_XCD) nb_s = DAE_NUM_XCD;
+        MixP ps = p;
+        ps.nb_rg = nb_s;
+        hipLaunchKernelGGL(ks, dim3(n_rg * nb_s), dim3(NW * 64), lds, st, ps);
+    }
     DAE_CHECK_LAUNCH(tc, "mix_bf16_kernel<sample>");
     rc = dae_reserve(tc, tc->sample_top, (size_t)Bpad * (sizeof(uint2) + sizeof(int))); if (rc) return rc;
     rc = dae_launch_tau_select(tc, p.samp, ld_s, (int)ld_s, p.samp, 0, 0, order, 0, B, k, seed_row_ptr,
