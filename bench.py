@@ -448,6 +448,10 @@ def _mode_row(torch, _lib, met, ctxs, streams, feeds, enc, n_tracks, dt, B, H, k
     PEAK_BF16_TFLOPS, PEAK_HBM_GBS = peaks
     d_We, d_be = enc
     n_b = len(ctxs)
+    # an extra row times at least 200 steps (its own `steps` key says how many): the driver's --steps 20 are 0.8 ms of a 39 us
+    # step -- five steps per stream, a tenth of which is the pipeline of four batches filling and draining (VERDICT r5 Weak #10;
+    # the same loop reads 6.5 M playlists/s over 20 steps and 7.1 M over 600).  The headline keeps exactly K steps.
+    n_steps = max(int(n_steps), 200)
     outs = [(torch.empty((B, k), dtype=torch.float32, device=d_We.device),
              torch.empty((B, k), dtype=torch.int32, device=d_We.device)) for _ in range(n_b)]
     cnt = [0]

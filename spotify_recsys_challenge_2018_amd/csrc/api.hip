@@ -150,7 +150,7 @@ int dae_destroy(dae_ctx* ctx)
                        &ctx->cand_cnt, &ctx->gmax, &ctx->dense_tmp, &ctx->h_packed16, &ctx->h_scratch, &ctx->train_a, &ctx->train_b,
                        &ctx->train_c, &ctx->train_d, &ctx->csr_tmp, &ctx->row_bad, &ctx->guard, &ctx->refined, &ctx->refstat, &ctx->pk_bf16.eps, &ctx->pk_bf16.bias16_lo,
                        &ctx->pk_bf16.bias16_hi, &ctx->pk_bf16.W32, &ctx->pk_bf16.mix_alpha, &ctx->pk_bf16.mix_beta, &ctx->pk_bf16.mix16_lo,
-                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band, &ctx->title_tab, &ctx->audit, &ctx->audit_stat};
+                       &ctx->pk_bf16.mix16_hi, &ctx->mix_fhat, &ctx->title_scratch, &ctx->tile_band, &ctx->title_tab, &ctx->audit, &ctx->audit_stat, &ctx->title_y1};
     for (dae_buf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (hipEvent_t ev : ctx->prof_ev) (void)hipEventDestroy(ev);
@@ -1103,6 +1103,55 @@ int dae_title_prepack_features(dae_ctx* ctx, const float* emb, int n_char, int E
     return dae_launch_title_table(ctx, emb, n_char, E, conv_w, filter_sizes, n_sizes, F);
 }
 
+}  // extern "C"
+
+// dae_title_score in two halves (round 6): everything of a titled launch that does not depend on the lane's previous launch --
+// title features, the feed -> CSR + seed lists, the DAE's hidden rows, the mixing weights -- and the ranking itself.
+// dae_title_score runs them back to back on one stream; dae_pipeline runs the first half of launch n + 1 on its prep stream
+// (contexts of its own) while the lane still ranks launch n.
+int dae_title_prepare(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                      int B, int V, const float* W_enc, const float* b_enc, int H, const int32_t* titles, int L, const float* emb,
+                      int n_char, int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F,
+                      int ld_feat, const float* titles_use, int n_tracks, const dae_title_bufs& b, int32_t* csr_status)
+{
+    int rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, b.feat, ld_feat,
+                                nullptr, nullptr);
+    if (rc) return rc;
+    auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
+    // the feed -> CSR AND the seed lists (the playlist's own tracks) from one group of four launches (round 6: csr.hip)
+    rc = from_dc(dae_launch_coo64_to_csr_seeds(dc, positions, values, values_broadcast, nnz, B, V, b.rp, b.col, b.val, csr_status,
+                                               n_tracks, b.srp, b.sc));
+    if (rc) return rc;
+    rc = from_dc(dae_encode(dc, b.rp, b.col, b.val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0u, b.h));
+    if (rc) return rc;
+    return from_dc(dae_mix_weights(dc, b.rp, b.col, b.val, B, 1.0f, 0u, titles_use, b.wt, b.wp));
+}
+
+int dae_title_rank(dae_ctx* tc, dae_ctx* dc, int dtype, int B, int V, int H, int ld_feat, const dae_title_bufs& b, int n_tracks, int k,
+                   float* out_score, int32_t* out_idx, int32_t* guard_out)
+{
+    if (dtype == DAE_DTYPE_BF16_EXACT)
+        return dae_mix_topk_exact(tc, dc, b.feat, ld_feat, b.h, H, B, b.wt, b.wp, n_tracks, b.srp, b.sc, k, out_score, out_idx, guard_out);
+    // fp32 / plain bf16: the fused mix of dae_set_score_mix -- the DAE term transposed, then the title context's threshold path
+    // ranks sigmoid(z_title) * w_title + term (the operations and order of dae_mix_scores)
+    auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
+    const size_t nt32 = (size_t)((n_tracks + 31) / 32 * 32 < V ? (n_tracks + 31) / 32 * 32 : V);
+    int rc = dae_reserve(tc, tc->title_y1, nt32 * (size_t)B * sizeof(float));
+    if (rc) return rc;
+    float* y1T = static_cast<float*>(tc->title_y1.p);
+    rc = from_dc(dae_decode_mix_term(dc, b.h, B, H, dtype, b.wp, n_tracks, y1T, B));
+    if (rc) return rc;
+    rc = dae_set_score_mix(tc, y1T, B, (int)nt32, b.wt);
+    if (rc) return rc;
+    rc = dae_decode_topk(tc, b.feat, B, ld_feat, dtype, n_tracks, b.srp, b.sc, k, DAE_OUT_LOGIT, out_score, out_idx);
+    (void)dae_set_score_mix(tc, nullptr, 0, 0, nullptr);
+    if (rc) return rc;
+    if (guard_out) DAE_HIP_CHECK(tc, hipMemsetAsync(guard_out, 0, DAE_GUARD_BYTES, tc->stream));      // (no bound to guard)
+    return DAE_OK;
+}
+
+extern "C" {
+
 int dae_title_score(dae_ctx* tc, dae_ctx* dc, int dtype, const int64_t* positions, const float* values, int values_broadcast,
                     int64_t nnz, int n_rows, int V, const float* W_enc, const float* b_enc, int H,
                     const int32_t* titles, int L, const float* emb, int n_char, int E, const float* conv_w,
@@ -1123,77 +1172,22 @@ int dae_title_score(dae_ctx* tc, dae_ctx* dc, int dtype, const int64_t* position
     // the launch's intermediates, carved out of one buffer of the title context
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
-    // (fp32 / plain bf16: the DAE term of the track columns, transposed [column][row] -- dae_decode_mix_term)
-    const bool exact = dtype == DAE_DTYPE_BF16_EXACT;
-    const size_t nt32 = (size_t)((n_tracks + 31) / 32 * 32 < V ? (n_tracks + 31) / 32 * 32 : V);
     const size_t o_rp = 0, o_col = o_rp + up((size_t)(B + 1) * 4), o_val = o_col + up(nz * 4), o_srp = o_val + up(nz * 4),
                  o_sc = o_srp + up((size_t)(B + 1) * 4), o_h = o_sc + up(nz * 4), o_ft = o_h + up((size_t)B * H * 4),
-                 o_wt = o_ft + up((size_t)B * ld_feat * 4), o_wp = o_wt + up((size_t)B * 4), o_y1 = o_wp + up((size_t)B * 4),
-                 total = o_y1 + (exact ? 0 : up(nt32 * (size_t)B * 4));
+                 o_wt = o_ft + up((size_t)B * ld_feat * 4), o_wp = o_wt + up((size_t)B * 4), total = o_wp + up((size_t)B * 4);
     int rc = dae_reserve(tc, tc->title_scratch, total);
     if (rc) return rc;
     char* base = static_cast<char*>(tc->title_scratch.p);
-    int32_t* rp = reinterpret_cast<int32_t*>(base + o_rp); int32_t* col = reinterpret_cast<int32_t*>(base + o_col);
-    float* val = reinterpret_cast<float*>(base + o_val); int32_t* srp = reinterpret_cast<int32_t*>(base + o_srp);
-    int32_t* sc = reinterpret_cast<int32_t*>(base + o_sc); float* h = reinterpret_cast<float*>(base + o_h);
-    float* feat = reinterpret_cast<float*>(base + o_ft); float* wt = reinterpret_cast<float*>(base + o_wt);
-    float* wp = reinterpret_cast<float*>(base + o_wp);
-#ifdef DAE_EXPERIMENTS
-    // DAE_TITLE_SIDE=1: the title features on a stream of their own, beside the DAE's preamble (measured: no gain, see notes)
-    static const bool side_on = dae_exp_env("DAE_TITLE_SIDE") != nullptr;
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    if (side_on) {
-        if (!side) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            DAE_HIP_CHECK(tc, hipStreamCreateWithPriority(&side, hipStreamNonBlocking, dae_exp_env("DAE_TITLE_SIDE_PRIO") ? hi : lo));
-            DAE_HIP_CHECK(tc, hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-            DAE_HIP_CHECK(tc, hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
-        }
-        DAE_HIP_CHECK(tc, hipEventRecord(ev_in, tc->stream));
-        DAE_HIP_CHECK(tc, hipStreamWaitEvent(side, ev_in, 0));
-        hipStream_t keep = tc->stream;
-        tc->stream = side;
-        rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
-                                nullptr, nullptr);
-        tc->stream = keep;
-        if (rc) return rc;
-        DAE_HIP_CHECK(tc, hipEventRecord(ev_out, side));
-    } else
-#endif
-    {
-        rc = dae_title_features(tc, titles, B, L, emb, n_char, E, conv_w, conv_b, filter_sizes, n_sizes, F, 1.0f, 0u, feat, ld_feat,
-                                nullptr, nullptr);
-        if (rc) return rc;
-    }
-    auto from_dc = [&](int r) { return r ? dae_fail(tc, r, "%s", dc->err.c_str()) : DAE_OK; };
-    // the feed -> CSR AND the seed lists (the playlist's own tracks) from one group of four launches (round 6: csr.hip)
-    if (!positions && nnz > 0) return dae_fail(tc, DAE_ERR_ARG, "null pointer");
-    rc = from_dc(dae_launch_coo64_to_csr_seeds(dc, positions, values, values_broadcast, nnz, B, V, rp, col, val, csr_status,
-                                               n_tracks, srp, sc));
+    dae_title_bufs b;
+    b.rp = reinterpret_cast<int32_t*>(base + o_rp); b.col = reinterpret_cast<int32_t*>(base + o_col);
+    b.val = reinterpret_cast<float*>(base + o_val); b.srp = reinterpret_cast<int32_t*>(base + o_srp);
+    b.sc = reinterpret_cast<int32_t*>(base + o_sc); b.h = reinterpret_cast<float*>(base + o_h);
+    b.feat = reinterpret_cast<float*>(base + o_ft); b.wt = reinterpret_cast<float*>(base + o_wt);
+    b.wp = reinterpret_cast<float*>(base + o_wp);
+    rc = dae_title_prepare(tc, dc, positions, values, values_broadcast, nnz, B, V, W_enc, b_enc, H, titles, L, emb, n_char, E, conv_w,
+                           conv_b, filter_sizes, n_sizes, F, ld_feat, titles_use, n_tracks, b, csr_status);
     if (rc) return rc;
-    rc = from_dc(dae_encode(dc, rp, col, val, W_enc, b_enc, V, H, B, 1.0f, 1.0f, 0u, h));
-    if (rc) return rc;
-    rc = from_dc(dae_mix_weights(dc, rp, col, val, B, 1.0f, 0u, titles_use, wt, wp));
-    if (rc) return rc;
-#ifdef DAE_EXPERIMENTS
-    if (side_on) DAE_HIP_CHECK(tc, hipStreamWaitEvent(tc->stream, ev_out, 0));
-#endif
-    if (exact)
-        return dae_mix_topk_exact(tc, dc, feat, ld_feat, h, H, B, wt, wp, n_tracks, srp, sc, k, out_score, out_idx, guard_out);
-    // fp32 / plain bf16: the fused mix of dae_set_score_mix -- the DAE term transposed, then the title context's threshold path
-    // ranks sigmoid(z_title) * w_title + term (the operations and order of dae_mix_scores)
-    float* y1T = reinterpret_cast<float*>(base + o_y1);
-    rc = from_dc(dae_decode_mix_term(dc, h, B, H, dtype, wp, n_tracks, y1T, B));
-    if (rc) return rc;
-    rc = dae_set_score_mix(tc, y1T, B, (int)nt32, wt);
-    if (rc) return rc;
-    rc = dae_decode_topk(tc, feat, B, ld_feat, dtype, n_tracks, srp, sc, k, DAE_OUT_LOGIT, out_score, out_idx);
-    (void)dae_set_score_mix(tc, nullptr, 0, 0, nullptr);
-    if (rc) return rc;
-    if (guard_out) DAE_HIP_CHECK(tc, hipMemsetAsync(guard_out, 0, DAE_GUARD_BYTES, tc->stream));      // (no bound to guard)
-    return DAE_OK;
+    return dae_title_rank(tc, dc, dtype, B, V, H, ld_feat, b, n_tracks, k, out_score, out_idx, guard_out);
 }
 
 int dae_title_score_exact(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast,

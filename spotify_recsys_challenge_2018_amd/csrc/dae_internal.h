@@ -130,6 +130,7 @@ struct dae_ctx {
     // the audit of dropped columns (audit.hip): every audit_every-th exact scoring launch checks audit_tiles random tiles
     int audit_every = 64, audit_tiles = 16;
     uint64_t audit_seq = 0, audits_run = 0;
+    dae_buf title_y1;          // dae_title_rank (fp32 / bf16): the DAE term of the track columns, transposed
     dae_buf audit_stat;        // {elements checked, violations} | the sampled tile ids (allocated once)
     dae_buf audit;             // upper bounds of the sampled tiles [Bpad][tiles * 32]
     dae_buf mix_fhat;          // dae_mix_topk_exact: [Bpad] bf16 bits of the rows' feature bounds
@@ -352,6 +353,17 @@ int dae_launch_adam(dae_ctx* ctx, float* param, float* m, float* v, const float*
 int dae_launch_coo_to_csr(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                           int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                           int32_t* status);
+// a titled launch's intermediates (api.hip dae_title_prepare / dae_title_rank; device pointers, caller-owned)
+struct dae_title_bufs {
+    int32_t *rp, *col, *srp, *sc;     // CSR of the feed [B + 1], [nnz]; seed lists [B + 1], [nnz]
+    float *val, *h, *feat, *wt, *wp;  // values [nnz]; DAE hidden rows [B][H]; title features [B][ld_feat]; mixing weights [B]
+};
+int dae_title_prepare(dae_ctx* tc, dae_ctx* dc, const int64_t* positions, const float* values, int values_broadcast, int64_t nnz,
+                      int B, int V, const float* W_enc, const float* b_enc, int H, const int32_t* titles, int L, const float* emb,
+                      int n_char, int E, const float* conv_w, const float* conv_b, const int32_t* filter_sizes, int n_sizes, int F,
+                      int ld_feat, const float* titles_use, int n_tracks, const dae_title_bufs& b, int32_t* csr_status);
+int dae_title_rank(dae_ctx* tc, dae_ctx* dc, int dtype, int B, int V, int H, int ld_feat, const dae_title_bufs& b, int n_tracks, int k,
+                   float* out_score, int32_t* out_idx, int32_t* guard_out);
 int dae_launch_coo64_to_csr_seeds(dae_ctx* ctx, const int64_t* positions, const float* values, int values_broadcast,
                                   int64_t nnz, int n_rows, int n_cols, int32_t* row_ptr, int32_t* col, float* val,
                                   int32_t* status, int n_tracks, int32_t* seed_row_ptr, int32_t* seed_col);

@@ -29,7 +29,6 @@ struct OutBlock {                 // pinned result block of one launch: idx [row
 struct Lane {                     // a context + stream + the device buffers its launches reuse in stream order
     dae_ctx* ctx = nullptr;
     hipStream_t stream = nullptr;
-    int32_t* d_status = nullptr;  // (titled launches: the CSR build inside dae_title_score reports here)
     float* d_score = nullptr;     // scores nobody fetches
     bool has_f32 = false;         // (guard fallback) an fp32 image of its own
     // titled pipelines (dae_pipeline_create_titled): the title scorer's context on the same stream, its guard words as the
@@ -53,6 +52,7 @@ struct Slot {                     // one launch from staging to its last polled 
     int64_t* d_pos = nullptr; float* d_val = nullptr;      // the feed on the device (uploaded on the copy stream, ahead of the lane)
     // the launch's CSR and seed lists (plain launches), built on the PREP stream while the lane still scores its previous launch
     int32_t *d_rp = nullptr, *d_col = nullptr, *d_srp = nullptr, *d_scol = nullptr, *d_status = nullptr; float* d_cval = nullptr;
+    float *t_h = nullptr, *t_feat = nullptr, *t_wt = nullptr, *t_wp = nullptr;   // titled: hidden rows, title features, mixing weights
     hipEvent_t ev_prep = nullptr;
     int32_t* d_idx = nullptr; float* d_score = nullptr;    // the launch's lists on the device (moved out on the OUT stream, round 6)
     int32_t* d_flags = nullptr;                            // {csr status, guard violations, guard column} as the launch left them
@@ -87,6 +87,7 @@ struct dae_pipeline {
     // other lanes' decode workgroups, each takes 5 - 10 x its time alone: profiles/r06_notes.md)
     hipStream_t prep_stream = nullptr;
     dae_ctx* prep_ctx = nullptr;
+    dae_ctx* prep_tctx = nullptr;         // titled pipelines: the title scorer's context of the prep stream (its convolution table)
     hipStream_t out_stream = nullptr;     // the lists' way out (out_mode 2): the out thread's copies
     hipStream_t copy_stream = nullptr;    // uploads: hipMemcpyAsync on a stream that still has kernels queued blocks its caller
                                           // until they have run (measured: 0.43 ms per launch next to the fp32 decode) -- on a
@@ -273,7 +274,6 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
         PIPE_HIP(p, hipMemcpyAsync(S.d_use, S.h_use, (size_t)S.rows * sizeof(float), hipMemcpyHostToDevice, p->copy_stream));
     }
     PIPE_HIP(p, hipEventRecord(S.ev_h2d, p->copy_stream));
-    if (S.titled) PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_h2d, 0));      // (plain launches: the prep stream waits for it, below)
     if (p->dtype == DAE_DTYPE_F32 && p->lanes.size() > 1) {
         // the fp32 filter launch takes every CU, two of them in flight only queue behind each other: this launch's waits for
         // the one issued before it (on another lane) and announces its own end.  One event per launch SLOT: re-recording a
@@ -306,9 +306,19 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
         // main_challenge.py:80-90 with DAE_title: the whole titled launch in one library call (api.hip dae_title_score)
         const TitleW& t = p->tw;
         if (dtype == DAE_DTYPE_F32) { rc = ensure_f32(p, S.lane); if (rc) return rc; }
-        rc = dae_title_score(L.tctx, L.ctx, dtype, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, p->W_enc, p->b_enc, p->H, S.d_titles, t.L,
-                             t.emb, t.n_char, t.E, t.conv_w, t.conv_b, t.fs.data(), t.n_sizes, t.F, t.ld_feat, S.d_use, p->n_tracks,
-                             p->k, out_score, out_idx, L.d_guard, L.d_status);
+        // the half that does not depend on the lane's previous launch -- title features, CSR + seed lists, hidden rows, mixing
+        // weights -- on the prep stream (contexts of its own), the ranking on the lane (api.hip dae_title_prepare / _rank)
+        dae_title_bufs tb;
+        tb.rp = S.d_rp; tb.col = S.d_col; tb.srp = S.d_srp; tb.sc = S.d_scol; tb.val = S.d_cval;
+        tb.h = S.t_h; tb.feat = S.t_feat; tb.wt = S.t_wt; tb.wp = S.t_wp;
+        PIPE_HIP(p, hipStreamWaitEvent(p->prep_stream, S.ev_h2d, 0));
+        rc = dae_title_prepare(p->prep_tctx, p->prep_ctx, S.d_pos, S.d_val, 0, S.nnz, S.rows, p->V, p->W_enc, p->b_enc, p->H, S.d_titles,
+                               t.L, t.emb, t.n_char, t.E, t.conv_w, t.conv_b, t.fs.data(), t.n_sizes, t.F, t.ld_feat, S.d_use,
+                               p->n_tracks, tb, S.d_status);
+        if (rc) return pfatal(p, rc, dae_last_error(p->prep_tctx));
+        PIPE_HIP(p, hipEventRecord(S.ev_prep, p->prep_stream));
+        PIPE_HIP(p, hipStreamWaitEvent(L.stream, S.ev_prep, 0));
+        rc = dae_title_rank(L.tctx, L.ctx, dtype, S.rows, p->V, p->H, t.ld_feat, tb, p->n_tracks, p->k, out_score, out_idx, L.d_guard);
         if (rc) return pfatal(p, rc, dae_last_error(L.tctx));
         lap(1);
     } else {
@@ -340,7 +350,7 @@ int issue(dae_pipeline* p, Slot& S, int dtype)
     // after its first issue, whose word is still in h_flags[3]; the counter wraps after 2^30 launches)
     S.seq = (int32_t)(((++p->seq_counter << 1) | 1u) & 0x7FFFFFFFu);
     S.polls = 0;
-    hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, L.stream, S.d_flags, S.titled ? L.d_status : S.d_status, gw,
+    hipLaunchKernelGGL(flags_snapshot_kernel, dim3(1), dim3(64), 0, L.stream, S.d_flags, S.d_status, gw,
                        p->out_mode == 2 ? S.h_flags + 4 : nullptr, S.seq);
     PIPE_HIP(p, hipGetLastError());
 #ifdef DAE_EXPERIMENTS
@@ -558,18 +568,19 @@ int dae_pipeline_destroy(dae_pipeline* p)
         if (L.tctx) (void)dae_destroy(L.tctx);                  // (borrows lane 0's images: never frees them)
         if (L.ctx) { (void)dae_set_decode_gate(L.ctx, nullptr, nullptr); (void)dae_destroy(L.ctx); }
         pool_give_stream(p->device, L.stream, 0);
-        void* dev[] = {L.d_status, L.d_score, L.d_guard};
+        void* dev[] = {L.d_score, L.d_guard};
         for (void* q : dev) if (q) (void)hipFree(q);
     }
     pool_give_stream(p->device, p->copy_stream, 1);
     if (p->out_stream) { (void)hipStreamSynchronize(p->out_stream); pool_give_stream(p->device, p->out_stream, 1); }
     if (p->prep_stream) (void)hipStreamSynchronize(p->prep_stream);
+    if (p->prep_tctx) (void)dae_destroy(p->prep_tctx);
     if (p->prep_ctx) (void)dae_destroy(p->prep_ctx);
     pool_give_stream(p->device, p->prep_stream, 2);
     for (Slot& S : p->slots) {
         if (S.ev_scored) (void)hipEventDestroy(S.ev_scored);
         if (S.ev_prep) (void)hipEventDestroy(S.ev_prep);
-        void* outs[] = {S.d_idx, S.d_score, S.d_flags, S.d_rp, S.d_col, S.d_srp, S.d_scol, S.d_status, S.d_cval};
+        void* outs[] = {S.d_idx, S.d_score, S.d_flags, S.d_rp, S.d_col, S.d_srp, S.d_scol, S.d_status, S.d_cval, S.t_h, S.t_feat, S.t_wt, S.t_wp};
         for (void* q : outs) if (q) (void)hipFree(q);
         if (S.ev_fetch) (void)hipEventDestroy(S.ev_fetch);
         if (S.ev_h2d) (void)hipEventDestroy(S.ev_h2d);
@@ -628,7 +639,6 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
         if (rc) return bail(rc, dae_last_error(nullptr));
         L.stream = pool_take_stream(device, 0);
         bool ok = L.stream != nullptr &&
-                  hipMalloc(reinterpret_cast<void**>(&L.d_status), sizeof(int32_t)) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&L.d_score), (rows * kk * sizeof(float) + 15) / 16 * 16) == hipSuccess;
         if (!ok) return bail(DAE_ERR_NOMEM, "dae_pipeline_create: allocation failed");
         rc = dae_set_stream(L.ctx, L.stream);
@@ -659,6 +669,12 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
             if (dtype == DAE_DTYPE_F32) { L.has_f32 = true; L.t_has_f32 = true; }
         }
     }
+    if (tw) {
+        int rc_t = dae_create(device, &p->prep_tctx);
+        if (!rc_t) rc_t = dae_set_stream(p->prep_tctx, p->prep_stream);
+        if (!rc_t) rc_t = dae_title_prepack_features(p->prep_tctx, tw->emb, tw->n_char, tw->E, tw->conv_w, tw->fs.data(), tw->n_sizes, tw->F);
+        if (rc_t) return bail(rc_t, dae_last_error(p->prep_tctx));
+    }
     for (Slot& S : p->slots) {
         bool ok = hipEventCreateWithFlags(&S.ev_fetch, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&S.ev_scored, hipEventDisableTiming) == hipSuccess &&
@@ -680,7 +696,11 @@ static int pipeline_create(int device, const float* W_enc, const float* b_enc, c
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_val), nz * sizeof(float)) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&S.h_flags), 8 * sizeof(int32_t)) == hipSuccess;
         if (ok && tw)
-            ok = hipMalloc(reinterpret_cast<void**>(&S.d_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
+            ok = hipMalloc(reinterpret_cast<void**>(&S.t_h), rows * (size_t)H * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&S.t_feat), rows * (size_t)tw->ld_feat * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&S.t_wt), rows * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&S.t_wp), rows * sizeof(float)) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&S.d_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
                  hipMalloc(reinterpret_cast<void**>(&S.d_use), rows * sizeof(float)) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&S.h_titles), rows * (size_t)tw->L * sizeof(int32_t)) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&S.h_use), rows * sizeof(float)) == hipSuccess;
