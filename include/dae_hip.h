@@ -199,7 +199,9 @@ int dae_exact_stats_read(dae_ctx* ctx, uint64_t out3[3]);
 int dae_set_exact_margin(dae_ctx* ctx, float scale);
 /* The same hook for the columns [col_from, col_to) alone (global ids; applied by the NEXT exact prepack, the other columns
  * keep dae_set_exact_margin's factor): lets a test void the bound of a column that every row DROPS, which only the audit
- * below can see (tests/test_gpu_exact.py::test_audit_sees_a_violation_on_a_dropped_column).  col_from == col_to: none. */
+ * below can see (tests/test_gpu_exact.py::test_audit_sees_a_violation_on_a_dropped_column).  col_from == col_to: none.
+ * scale < 0 (>= -1024) FORGES the filter outright: the UPPER bound of those columns is put |scale| logits too low, so rows
+ * drop columns that belong in their lists -- the failure the audits exist for (tests/test_gpu_title_exact.py). */
 int dae_set_exact_margin_range(dae_ctx* ctx, int col_from, int col_to, float scale);
 
 /* DAE_DTYPE_BF16_EXACT, the AUDIT of what the guard cannot see (csrc/audit.hip).  The guard tests the survivors the refine
@@ -213,7 +215,11 @@ int dae_set_exact_margin_range(dae_ctx* ctx, int col_from, int col_to, float sca
  *   dae_exact_audit_read: out3 = {audits run, (row, column) elements checked, violations among them} since the context was
  *                         created; synchronises the ctx stream.
  * Proven: the bound, given the accumulation model of the bf16 MFMA.  Checked always: survivors.  Checked on a sample: dropped
- * columns (all rows x n_tiles x 32 columns per audit).  Assumed: nothing else. */
+ * columns (all rows x n_tiles x 32 columns per audit).  Assumed: nothing else.
+ * Under the exact title mix (dae_mix_topk_exact / dae_title_score; set on the TITLE context, same defaults) the audit tests the
+ * OUTCOME instead: the sampled tiles' mixed scores, recomputed with the canonical chains of both images and the fp32 path's mix
+ * (DAEs.py:153-181), against the lists the launch just wrote -- an element above its row's k-th listed score that is neither
+ * listed nor one of the row's seeds counts as a violation in the title context's guard words (csrc/mixexact.hip mix_audit). */
 int dae_set_exact_audit(dae_ctx* ctx, int every_n, int n_tiles);
 int dae_exact_audit_read(dae_ctx* ctx, uint64_t out3[3]);
 

@@ -18,6 +18,7 @@
 #include "dae_internal.h"
 
 #include <limits.h>
+#include <string.h>
 
 namespace {
 
@@ -43,6 +44,8 @@ struct AuditP {
     int B, col_bound;                                // rows; global end of the ranked columns
     const int* row_bad;                              // nullable: rows outside the bound's precondition
     int* guard; unsigned long long* stat;            // guard words {violations, a column}; {elements checked, violations}
+    float* zout;                                     // non-null: no test here -- z32 goes out ([B][n_tiles * 32], like u) for the
+                                                     // caller's own (the exact title mix: mixexact.hip mix_audit_kernel)
 };
 
 // workgroup (pair of sampled tiles = 64 columns, block of AU_ROWS playlists); lane = column, a wave walks 8 playlists.
@@ -96,6 +99,11 @@ __global__ __launch_bounds__(256) void exact_audit_kernel(const AuditP p)
     for (int i = 0; i < AU_ROWS / 4; ++i) {
         const int row = row0 + wave + 4 * i;
         if (row >= p.B) break;
+        if (p.zout) {
+            if (item < p.n_tiles)
+                p.zout[(size_t)row * p.ld_u + (size_t)item * 32 + (lane & 31)] = col_ok ? acc[i] + p.bias[cl] : -__builtin_inff();
+            continue;
+        }
         if (p.row_bad && p.row_bad[row]) continue;                             // (no bound is claimed for such a row)
         bool bad = false;
         if (col_ok) {
@@ -118,6 +126,46 @@ __global__ __launch_bounds__(256) void exact_audit_kernel(const AuditP p)
 
 }  // namespace
 
+static int launch_audit_kernel(dae_ctx* ctx, const AuditP& p)
+{
+    const size_t lds = ((size_t)AU_KC * AU_LD + (size_t)AU_ROWS * AU_KC) * sizeof(float);
+    static const char key = 0;
+    if (dae_first_use(ctx, &key))
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_audit_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(exact_audit_kernel, dim3((p.n_tiles + 1) / 2, (p.B + AU_ROWS - 1) / AU_ROWS), dim3(256), lds, ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "exact_audit_kernel");
+    return DAE_OK;
+}
+
+// the context's audit block {elements checked, violations} | 64 tile ids (a block of its own, allocated once: the totals
+// outlive every launch shape) and this audit's tiles: n of [0, n_rank_tiles), other ones every time
+int dae_audit_pick_tiles(dae_ctx* ctx, int n_rank_tiles, int n_tiles, unsigned long long** stat_out, int** tiles_out)
+{
+    const bool fresh = ctx->audit_stat.p == nullptr;
+    int rc = dae_reserve(ctx, ctx->audit_stat, 2 * sizeof(unsigned long long) + (size_t)64 * sizeof(int));
+    if (rc) return rc;
+    unsigned long long* stat = static_cast<unsigned long long*>(ctx->audit_stat.p);
+    int* tiles = reinterpret_cast<int*>(stat + 2);
+    if (fresh) DAE_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(audit_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned)ctx->audit_seq, n_rank_tiles, n_tiles, tiles);
+    DAE_CHECK_LAUNCH(ctx, "audit_pick_kernel");
+    *stat_out = stat; *tiles_out = tiles;
+    return DAE_OK;
+}
+
+// z32 = the canonical chain of rows [0, B) of h against the decoder rows of the sampled tiles, + bias, into zout[B][n_tiles * 32]
+// (-inf where a sampled tile runs past the image or past col_bound)
+int dae_launch_audit_chains(dae_ctx* ctx, const float* h, int64_t ld_h, int H, const float* W32, const float* bias, int ncols,
+                            int col_bound, int B, const int* tiles, int n_tiles, float* zout)
+{
+    AuditP p;
+    memset(&p, 0, sizeof(p));
+    p.h = h; p.ld_h = ld_h; p.H = H; p.W32 = W32; p.bias = bias; p.ncols = ncols; p.col_bound = col_bound;
+    p.tiles = tiles; p.n_tiles = n_tiles; p.B = B; p.ld_u = (int64_t)n_tiles * 32; p.zout = zout;
+    return launch_audit_kernel(ctx, p);
+}
+
 // one audit of the scoring launch in progress on ctx (its packed bf16 hidden tile and fp32 rows are still in place)
 int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_exact_src& x, int nrank, int n_tiles)
 {
@@ -125,35 +173,25 @@ int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_
     if (B <= 0 || nrank <= 0 || n_tiles <= 0 || !x.guard) return DAE_OK;
     if (n_tiles > 64) n_tiles = 64;
     const int n_rank_tiles = (nrank + 31) / 32;
-    // {elements checked, violations} | 64 tile ids: a block of its own, allocated once (the totals outlive every launch shape);
     // the upper bounds [Bpad][n_tiles * 32] grow with the launch
-    const bool fresh = ctx->audit_stat.p == nullptr;
-    int rc = dae_reserve(ctx, ctx->audit_stat, 2 * sizeof(unsigned long long) + (size_t)64 * sizeof(int));
+    unsigned long long* stat; int* tiles;
+    int rc = dae_audit_pick_tiles(ctx, n_rank_tiles, n_tiles, &stat, &tiles);
     if (rc) return rc;
     rc = dae_reserve(ctx, ctx->audit, (size_t)g.Bpad * n_tiles * 32 * sizeof(float));
     if (rc) return rc;
-    unsigned long long* stat = static_cast<unsigned long long*>(ctx->audit_stat.p);
-    int* tiles = reinterpret_cast<int*>(stat + 2);
     float* u = static_cast<float*>(ctx->audit.p);
-    if (fresh) DAE_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(audit_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, (unsigned)ctx->audit_seq, n_rank_tiles, n_tiles, tiles);
-    DAE_CHECK_LAUNCH(ctx, "audit_pick_kernel");
     // the filter launch's upper bounds of those tiles: dense bf16 decode on the b + eps image (bias_sel 2), nothing masked
     const int64_t ld_u = (int64_t)n_tiles * 32;
     dae_tileset ts{n_tiles, 1, 3, tiles};
     rc = dae_launch_decode_dense_f32(ctx, g, B, ts, 0, INT_MAX, u, ld_u, 1, DAE_DTYPE_BF16, nullptr, 0, 0, 2);
     if (rc) return rc;
     AuditP p;
+    memset(&p, 0, sizeof(p));
     p.h = x.h; p.ld_h = x.ld_h; p.H = x.H; p.W32 = x.W32; p.bias = x.bias; p.eps = x.eps; p.col_lo = x.col_lo;
     p.ncols = pk.col_hi - pk.col_lo; p.u = u; p.ld_u = ld_u; p.tiles = tiles; p.n_tiles = n_tiles; p.B = B;
     p.col_bound = pk.col_lo + nrank; p.row_bad = x.row_bad; p.guard = x.guard; p.stat = stat;
-    const size_t lds = ((size_t)AU_KC * AU_LD + (size_t)AU_ROWS * AU_KC) * sizeof(float);
-    static const char key = 0;
-    if (dae_first_use(ctx, &key))
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&exact_audit_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(exact_audit_kernel, dim3((n_tiles + 1) / 2, (B + AU_ROWS - 1) / AU_ROWS), dim3(256), lds, ctx->stream, p);
-    DAE_CHECK_LAUNCH(ctx, "exact_audit_kernel");
+    rc = launch_audit_kernel(ctx, p);
+    if (rc) return rc;
     ++ctx->audits_run;
     return DAE_OK;
 }
@@ -185,8 +223,10 @@ int dae_exact_audit_read(dae_ctx* ctx, uint64_t out3[3])
 int dae_set_exact_margin_range(dae_ctx* ctx, int col_from, int col_to, float scale)
 {
     if (!ctx) return DAE_ERR_ARG;
-    if (!(scale > 0.0f) || !(scale <= 1024.0f) || col_to < col_from)
-        return dae_fail(ctx, DAE_ERR_ARG, "dae_set_exact_margin_range: scale in (0, 1024], col_from <= col_to");
+    // scale > 0: the factor on those columns' bounds; scale < 0: their UPPER bound is put |scale| logits too low outright -- a
+    // forged filter that drops columns it must keep (the only way to make a dropped column CHANGE a list: the audits' tests)
+    if (!(scale >= -1024.0f) || !(scale <= 1024.0f) || scale == 0.0f || col_to < col_from)
+        return dae_fail(ctx, DAE_ERR_ARG, "dae_set_exact_margin_range: scale in [-1024, 1024] \\ {0}, col_from <= col_to");
     ctx->margin_lo = col_from; ctx->margin_hi = col_to; ctx->margin_scale = scale;
     return DAE_OK;
 }

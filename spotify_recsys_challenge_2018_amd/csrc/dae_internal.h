@@ -459,6 +459,11 @@ struct dae_exact_src {
 // leaves behind are not meant to be read
 // audit.hip: one audit of the exact scoring launch in progress (n_tiles random ranked tiles x all B rows -> the guard words)
 int dae_launch_exact_audit(dae_ctx* ctx, const dae_rowgeom& g, int B, const dae_exact_src& x, int nrank, int n_tiles);
+// (pieces the exact title mix's audit shares: mixexact.hip mix_audit) this audit's tile ids + the context's totals; the canonical
+// logits of those tiles for rows [0, B) into zout[B][n_tiles * 32]
+int dae_audit_pick_tiles(dae_ctx* ctx, int n_rank_tiles, int n_tiles, unsigned long long** stat_out, int** tiles_out);
+int dae_launch_audit_chains(dae_ctx* ctx, const float* h, int64_t ld_h, int H, const float* W32, const float* bias, int ncols,
+                            int col_bound, int B, const int* tiles, int n_tiles, float* zout);
 bool dae_exact_refine_can_fuse(const dae_topk_args& a);
 int dae_launch_exact_refine(dae_ctx* ctx, const dae_pair_group& g1, const dae_exact_src& x, int B, int k,
                             const int32_t* seed_row_ptr, uint2* out = nullptr, int* out_cnt = nullptr, int out_cap = 0,

@@ -1812,10 +1812,12 @@ __global__ __launch_bounds__(256) void exact_bounds_kernel(const float* __restri
                 e = e * (1.0 + 4.0 * A16) + 0x1p-23 * (ab + e) + 1e-30;      // eps feeds back through the shifted bias; split error
                 e *= 1.0 + 1e-6;
                 // dae_set_exact_margin: 1 by default; < 1 voids the bound (the guard's test hook; _range: for some columns only)
-                e *= (double)((v >= m_lo && v < m_hi) ? m_scale : margin);
+                const bool in_range = v >= m_lo && v < m_hi;
+                e *= (double)(in_range && m_scale > 0.0f ? m_scale : margin);
                 e_f = (float)e;
                 if ((double)e_f < e) e_f = __uint_as_float(__float_as_uint(e_f) + 1u);      // e > 0: next float up
-                const double lo = bv - (double)e_f, hi = bv + (double)e_f;
+                double lo = bv - (double)e_f, hi = bv + (double)e_f;
+                if (in_range && m_scale < 0.0f) hi = bv + (double)m_scale;     // (a FORGED filter: the upper bound |scale| logits low)
                 lo_f = (float)lo; if ((double)lo_f > lo) lo_f = nextafterf(lo_f, -__builtin_inff());
                 hi_f = (float)hi; if ((double)hi_f < hi) hi_f = nextafterf(hi_f, __builtin_inff());
             }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void mix_title_bounds_kernel(const float* __re
                                                                int H, int Hp, int col_lo, int col_hi, int ntiles,
                                                                float* __restrict__ alpha_hat, float* __restrict__ beta,
                                                                uint4* __restrict__ frag_lo, uint4* __restrict__ frag_hi,
-                                                               float margin)
+                                                               float margin, int m_lo, int m_hi, float m_scale)
 {
     const int tid = threadIdx.x;
     const int c = tid >> 3, part = tid & 7;
@@ -396,14 +396,18 @@ __global__ __launch_bounds__(256) void mix_title_bounds_kernel(const float* __re
                 double be = (1.01 * A16 + A32 + 0x1p-23) * ab;
                 al = al * (1.0 + 4.0 * A16 * up * up) * (1.0 + 1e-6) + 1e-30;      // the shift feeds back through the accumulation
                 be = be * (1.0 + 4.0 * A16) * (1.0 + 1e-6) + 0x1p-23 * be + 1e-30;
-                al *= (double)margin; be *= (double)margin;   // dae_set_exact_margin (< 1 voids the bound: the guard's test hook)
+                // dae_set_exact_margin (< 1 voids the bound: the guard's test hook); _range: some columns only
+                const bool in_range = v >= m_lo && v < m_hi;
+                const double mg = (double)(in_range && m_scale > 0.0f ? m_scale : margin);
+                al *= mg; be *= mg;
                 a_f = (float)al;
                 if ((double)a_f < al) a_f = __uint_as_float(__float_as_uint(a_f) + 1u);
                 a16 = (__float_as_uint(a_f) + 0xFFFFu) >> 16;                     // bf16, rounded up (a_f > 0)
                 a_f = __uint_as_float(a16 << 16);
                 be_f = (float)be;
                 if ((double)be_f < be) be_f = __uint_as_float(__float_as_uint(be_f) + 1u);
-                const double lo = bv - (double)be_f, hi = bv + (double)be_f;
+                double lo = bv - (double)be_f, hi = bv + (double)be_f;
+                if (in_range && m_scale < 0.0f) hi = bv + (double)m_scale;     // (a FORGED filter: the upper bound |scale| logits low)
                 lo_f = (float)lo; if ((double)lo_f > lo) lo_f = nextafterf(lo_f, -__builtin_inff());
                 hi_f = (float)hi; if ((double)hi_f < hi) hi_f = nextafterf(hi_f, __builtin_inff());
             }
@@ -934,7 +938,92 @@ __global__ __launch_bounds__(MR_THREADS, 1) void mix_refine_kernel(const MixRefP
 }
 #undef MSTAMP
 
+// ---- the audit of dropped columns (round 6; the plain exact mode's is audit.hip) ---------------------------------------------
+// The refine launch's guard sees survivors only; a column the filter launch dropped is never recomputed.  Every N-th launch
+// (dae_set_exact_audit on the TITLE context) a random set of ranked tiles is recomputed in fp32 for every row -- z_t and z_d
+// with the canonical chains (audit.hip's kernel, both images), mixed as the lists' scores are -- and tested against the
+// lists THIS launch wrote: an element whose score lies above the row's k-th listed score must be in the list or among the
+// row's seeds.  Anything else is a column the filter dropped although it belongs in the list: counted in the title context's
+// guard words (DAE_title.recommend / dae_pipeline_poll re-score such a launch with the fp32 kernels, as for a survivor).
+// This tests the OUTCOME (main_challenge.py:26-36 on DAEs.py:180's y), whatever the bound's shape; ties with the k-th score
+// are not judged.
+struct MixAuditP {
+    const float* zt; const float* zd; int64_t ld_z;  // [B][n_tiles * 32] canonical logits of the sampled tiles
+    const int* tiles; int n_tiles; int B, k, n_valid_col;
+    const float* w_t; const float* w_p; const int* row_bad;
+    const float* out_score; const int32_t* out_idx;  // the launch's lists [B][k]
+    const int32_t* seed_row_ptr; const int32_t* seed_col;
+    int* guard; unsigned long long* stat;
+};
+
+__global__ __launch_bounds__(256) void mix_audit_kernel(const MixAuditP p)
+{
+    const int per_row = p.n_tiles * 32;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(e / per_row), j = (int)(e % per_row);
+    bool counted = false, bad = false;
+    if (row < p.B && !p.row_bad[row]) {
+        const float wt = p.w_t[row], wp = p.w_p[row];
+        const int col = p.tiles[j >> 5] * 32 + (j & 31);
+        const float zt = p.zt[(size_t)row * p.ld_z + j], zd = p.zd[(size_t)row * p.ld_z + j];
+        if (col < p.n_valid_col && zt > -__builtin_inff() && zd > -__builtin_inff() && !(wt == 0.0f && wp == 0.0f)) {
+            counted = true;
+            const float s = mixf(zt, zd, wt, wp);
+            const size_t last = (size_t)row * p.k + (p.k - 1);
+            const float thr = p.out_idx[last] < 0 ? -__builtin_inff() : p.out_score[last];      // (a short list: every column belongs)
+            if (s > thr) {
+                bool found = false;
+                for (int i = 0; i < p.k && !found; ++i) found = p.out_idx[(size_t)row * p.k + i] == col;
+                if (!found && p.seed_row_ptr)
+                    for (int i = p.seed_row_ptr[row]; i < p.seed_row_ptr[row + 1] && !found; ++i) found = p.seed_col[i] == col;
+                bad = !found;
+                if (bad) { atomicAdd(p.guard, 1); p.guard[1] = col; }
+            }
+        }
+    }
+    const unsigned nc = (unsigned)__popcll(__ballot(counted)), nb = (unsigned)__popcll(__ballot(bad));
+    if ((threadIdx.x & 63) == 0 && nc) {
+        atomicAdd(p.stat, (unsigned long long)nc);
+        if (nb) atomicAdd(p.stat + 1, (unsigned long long)nb);
+    }
+}
+
 }  // namespace
+
+static int mix_audit(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t ld_feat, const float* h, int64_t ld_h, int B,
+                     const float* w_title, const float* w_playlist, int n_valid_col, const int32_t* seed_row_ptr,
+                     const int32_t* seed_col, int k, const float* out_score, const int32_t* out_idx)
+{
+    if (tc->audit_every <= 0 || tc->audit_tiles <= 0 || !out_score || !out_idx) return DAE_OK;
+    if ((++tc->audit_seq % (uint64_t)tc->audit_every) != 0) return DAE_OK;
+    const dae_packed& pt = tc->pk_bf16;
+    const dae_packed& pd = dc->pk_bf16;
+    const int n_tiles = tc->audit_tiles > 64 ? 64 : tc->audit_tiles;
+    unsigned long long* stat; int* tiles;
+    int rc = dae_audit_pick_tiles(tc, (n_valid_col + 31) / 32, n_tiles, &stat, &tiles);
+    if (rc) return rc;
+    const size_t per = (size_t)B * n_tiles * 32;
+    rc = dae_reserve(tc, tc->audit, 2 * per * sizeof(float));
+    if (rc) return rc;
+    float* zt = static_cast<float*>(tc->audit.p);
+    float* zd = zt + per;
+    rc = dae_launch_audit_chains(tc, feat, ld_feat, pt.H, static_cast<const float*>(pt.W32.p), static_cast<const float*>(pt.bias.p),
+                                 pt.col_hi - pt.col_lo, n_valid_col, B, tiles, n_tiles, zt);
+    if (rc) return rc;
+    rc = dae_launch_audit_chains(tc, h, ld_h, pd.H, static_cast<const float*>(pd.W32.p), static_cast<const float*>(pd.bias.p),
+                                 pd.col_hi - pd.col_lo, n_valid_col, B, tiles, n_tiles, zd);
+    if (rc) return rc;
+    MixAuditP a;
+    a.zt = zt; a.zd = zd; a.ld_z = (int64_t)n_tiles * 32; a.tiles = tiles; a.n_tiles = n_tiles; a.B = B; a.k = k;
+    a.n_valid_col = n_valid_col; a.w_t = w_title; a.w_p = w_playlist; a.row_bad = static_cast<const int*>(tc->row_bad.p);
+    a.out_score = out_score; a.out_idx = out_idx; a.seed_row_ptr = seed_row_ptr; a.seed_col = seed_col;
+    a.guard = static_cast<int*>(tc->guard.p); a.stat = stat;
+    const int64_t total = (int64_t)per;
+    hipLaunchKernelGGL(mix_audit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tc->stream, a);
+    DAE_CHECK_LAUNCH(tc, "mix_audit_kernel");
+    ++tc->audits_run;
+    return DAE_OK;
+}
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 int dae_launch_mix_title_bounds(dae_ctx* ctx, const float* W, const float* b, int H, int Hp, int col_lo, int col_hi,
@@ -951,7 +1040,8 @@ int dae_launch_mix_title_bounds(dae_ctx* ctx, const float* W, const float* b, in
     const int blocks = ntiles < 8 * DAE_NUM_CU ? ntiles : 8 * DAE_NUM_CU;
     hipLaunchKernelGGL(mix_title_bounds_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, b, H, Hp, col_lo, col_hi, ntiles,
                        static_cast<float*>(pk.mix_alpha.p), static_cast<float*>(pk.mix_beta.p),
-                       static_cast<uint4*>(pk.mix16_lo.p), static_cast<uint4*>(pk.mix16_hi.p), ctx->exact_margin);
+                       static_cast<uint4*>(pk.mix16_lo.p), static_cast<uint4*>(pk.mix16_hi.p), ctx->exact_margin,
+                       ctx->margin_lo, ctx->margin_hi, ctx->margin_scale);
     DAE_CHECK_LAUNCH(ctx, "mix_title_bounds_kernel");
     return DAE_OK;
 }
@@ -1131,8 +1221,8 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     }
 #endif
 
-    if (fuse) return DAE_OK;
-    dae_topk_args ta;
+    if (!fuse) {
+        dae_topk_args ta;
     memset(&ta, 0, sizeof(ta));
     ta.B = B; ta.k = k;
     ta.bitmap_base = 0; ta.bitmap_n = n_valid_col;
@@ -1141,5 +1231,8 @@ int dae_mix_topk_exact_impl(dae_ctx* tc, dae_ctx* dc, const float* feat, int64_t
     ta.out_score = out_score; ta.out_idx = out_idx;
     dae_pair_group gr{rf, rf_cnt, 0, MX_REF_CAP, 0, 1, 0};
     dae_pair_group g_none{nullptr, nullptr, 0, 0, 0, 0, 0};
-    return dae_launch_topk_pairs(tc, gr, g_none, ta);
+    rc = dae_launch_topk_pairs(tc, gr, g_none, ta);
+    if (rc) return rc;
+    }
+    return mix_audit(tc, dc, feat, ld_feat, h, ld_h, B, w_title, w_playlist, n_valid_col, seed_row_ptr, seed_col, k, out_score, out_idx);
 }

@@ -37,7 +37,7 @@ def _titles(B, seed=0):
     return t
 
 
-def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.0, out_scale=1.0, flat_title=False):
+def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.0, out_scale=1.0, flat_title=False, boost=None):
     W_enc, b_enc, W_dec, b_dec = make_weights(conf.n_input, conf.hidden, seed=1, bias=bias, n_tracks=conf.n_tracks)
     W_dec = (W_dec * np.float32(w_scale)).astype(np.float32)
     p = tmp_path / ("w_dae_%s_%g" % (bias, w_scale))
@@ -54,6 +54,9 @@ def _model(tmp_path, conf, bias="zipf", w_scale=1.0, title_seed=4, feat_scale=1.
     if flat_title:                                     # a title scorer that says 0.5 for every track
         host["Output_W"] = np.zeros_like(host["Output_W"])
         host["Output_b"] = np.zeros_like(host["Output_b"])
+    if boost is not None:                              # (lo, hi, v): the title scorer likes these tracks for every title
+        host["Output_b"] = host["Output_b"].copy()
+        host["Output_b"][boost[0]:boost[1]] += np.float32(boost[2])
     mt.fit(host)
     m = DAE_title(conf, mt)
     m.fit()
@@ -237,6 +240,85 @@ def test_exact_title_mix_guard_and_fallback(tmp_path):
         warnings.simplefilter("error")
         got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
     _same(got, want)
+
+
+# ---- round 6: the audit of DROPPED columns under the title mix (csrc/mixexact.hip mix_audit) -----------------------------------
+def test_title_mix_audit_is_silent_on_honest_images_and_counts_its_work(tmp_path):
+    """Every launch audited (dae_set_exact_audit(1, 16) on the title context): 16 random ranked tiles x all rows recomputed in
+    fp32 and held against the lists the launch wrote -- nothing above a row's k-th score is missing from its list, the lists
+    are the fp32 ones, and the counters say what was checked."""
+    conf = _conf()
+    m = _model(tmp_path, conf)
+    tc = m.title_model.ctx
+    tc.set_exact_audit(1, 16)
+    before = tc.exact_audit_read()
+    for trial, k in enumerate((100, 500, 37)):
+        pos, ones, seeds = _feed(conf, 5 + trial, empty_rows=(2, 11))
+        titles = _titles(conf.batch, seed=6 + trial)
+        use = (np.arange(conf.batch) % 3 != trial).astype(np.float32)
+        use[2] = 1.0
+        want = m.recommend(pos, ones, seeds, k=k, titles=titles, titles_use=use, dtype="f32")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            got = m.recommend(pos, ones, seeds, k=k, titles=titles, titles_use=use, dtype="exact_bf16")
+        _same(got, want)
+    after = tc.exact_audit_read()
+    assert after["audits"] - before["audits"] == 3
+    # rows with neither a title nor a playlist are not judged (every score is +0); the others: 16 tiles x 32 columns each,
+    # less what a sampled last tile holds past the 2 000 tracks
+    per_audit = (after["checked"] - before["checked"]) / 3
+    assert 0.8 * 16 * 32 * conf.batch <= per_audit <= 16 * 32 * conf.batch
+    assert after["violations"] == 0 and tc.exact_guard_read()[0] == 0
+    tc.set_exact_audit(0, 0)                          # off: nothing counted
+    m.recommend(pos, ones, seeds, k=37, titles=titles, titles_use=use, dtype="exact_bf16")
+    assert tc.exact_audit_read() == after
+
+
+def test_title_mix_audit_sees_a_dropped_column_that_belongs_in_the_list(tmp_path):
+    """A FORGED filter (dae_set_exact_margin_range with a negative scale: the title side's upper bound of 64 tracks put 30
+    logits low) on title-only playlists: every row drops tracks the title scorer ranks first.  No survivor is involved, so
+    the refine launch's guard is silent and the lists are WRONG without a word -- with the audit, a launch that samples one
+    of the two forged tiles is re-scored with the fp32 kernels and says so."""
+    conf = _conf()
+    m = _model(tmp_path, conf, boost=(0, 64, 12.0))
+    tc = m.title_model.ctx
+    B = conf.batch
+    pos = np.zeros((0, 2), np.int64)
+    ones = np.zeros(0, np.float32)
+    seeds = [[] for _ in range(B)]
+    titles = _titles(B, seed=6)
+    use = np.ones(B, np.float32)
+    want = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="f32")
+    assert (want[0][:, :64] < 64).all()                # the boosted tracks lead every list
+    tc.set_exact_audit(0, 0)
+    tc.set_exact_margin_range(0, 64, -30.0)
+    m.title_model._packed_dirty = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                 # nobody notices ...
+        wrong = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
+    assert not (wrong[0] < 64).any() and tc.exact_guard_read()[0] == 0          # ... that the lists lost their head
+    tc.set_exact_audit(1, 64)                          # 64 draws among the 63 ranked tiles per launch, other ones each time
+    fired = 0
+    for _ in range(40):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16")
+        if any("bound guard" in str(x.message) for x in w):
+            _same(got, want)                           # the audited launch was re-scored with the fp32 kernels
+            fired += 1
+            break
+        assert np.array_equal(got[0], wrong[0])
+    assert fired, "no audit of 40 sampled a forged tile"
+    a = tc.exact_audit_read()
+    assert a["violations"] > 0 and m._guard_fallbacks >= 1
+    # the honest image again: audited every launch, silent
+    tc.set_exact_margin_range(0, 0, 1.0)
+    m.title_model._packed_dirty = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(3):
+            _same(m.recommend(pos, ones, seeds, k=100, titles=titles, titles_use=use, dtype="exact_bf16"), want)
+    assert tc.exact_audit_read()["violations"] == a["violations"]
 
 
 def test_exact_title_mix_other_shapes_run_fp32(tmp_path, capfd):
