@@ -19,7 +19,7 @@ gemm = 2.0 * B * V * H
 def work(kernel, bf16, fused):
     """-> (flop, bytes) of one launch, or None for kernels that are not rated."""
     dz = (2.0 if bf16 else 4.0) * B * V
-    if "decode_loss_rowmajor" in kernel:
+    if "decode_loss_" in kernel:
         return gemm, mat + dz
     if "grad_wdec" in kernel:
         return gemm, dz + (6 * mat if fused else mat)

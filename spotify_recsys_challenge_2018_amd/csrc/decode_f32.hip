@@ -722,9 +722,13 @@ __global__ __launch_bounds__(256, 1) void decode_loss_rowmajor_kernel(const Loss
         // a tile that lies wholly inside the matrix and the batch (all but the last tile / row group) takes the
         // epilogue without per-element bounds tests: 64 exec-mask branches per tile otherwise (233 -> 218 us)
         if (t * 32 + 32 <= p.V && rg * R_TILE + R_TILE <= p.B) {
+            // (round 6: a wave-uniform column base + one 32-bit lane offset per row block -- a lane-dependent base made every
+            // store a 64-bit multiply; the launcher checks that the offsets fit)
+            const unsigned lane_off0 = (unsigned)(4 * hi) * (unsigned)p.ldT + (unsigned)(rg * R_TILE + j);
+            float* const d32 = p.dzT + (size_t)t * 32 * p.ldT;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                float* drow = p.dzT + (size_t)tcol0 * p.ldT + rg * R_TILE + rb * 32 + j;
+                const unsigned lane_off = lane_off0 + (unsigned)(rb * 32);
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void decode_loss_rowmajor_kernel(const Loss
                         const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
                         const float a0 = 1.0f - pr + 1e-10f;
                         loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
-                        drow[(size_t)(8 * qd + e) * p.ldT] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                        (d32 + (size_t)(8 * qd + e) * p.ldT)[lane_off] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
                     }
                 }
             }
@@ -770,91 +774,176 @@ __global__ __launch_bounds__(256, 1) void decode_loss_rowmajor_kernel(const Loss
     if (tid == 0) p.loss_part[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * p.inv_nb;
 }
 
-// The same with bf16 operands (dae_set_train_dtype): a lane reads W[32 t + i][16 s + 8 hi .. + 7] as two 16-byte loads
-// and rounds them to the 8 bf16 k-slots of its MFMA operand in registers; the hidden fragments are rounded once while
-// LDS is filled (64 KB).  Twice the bytes of the bf16 image are read (fp32 rows), but the image no longer has to be
-// built every step (58 us); the bias is added in fp32 in the epilogue.  Two waves per SIMD: the launch is bound by its
-// epilogue.  dz16: dL/dz stored as bf16.
-__global__ __launch_bounds__(512, 1) void decode_loss_rowmajor_bf16_kernel(const LossRmP p, int dz16)
+// ---- K5, bf16 operands, hidden 256, batches of at most 256 playlists: the W tile through LDS (round 6) ---------------
+// Until round 6 this launch had the fp32 kernel's shape (decode_loss_rowmajor_kernel above: a wave = a tile of 32 decoder rows x
+// 128 playlists, every lane reading ITS decoder row in 32-byte pieces): 64 lanes, 32 rows -- 64 different cache lines per load
+// instruction, one tag lookup each.  Measured (rocprofv3 counters + the launch with one part removed at a time,
+// profiles/r06_notes.md 8): 90 us with, 48 us without the W loads; halving the epilogue's instruction count changed nothing.
+// Here a workgroup of 8 waves takes a tile x ALL playlists (58.8 us):
+//   * the 8 waves fetch the tile's 32 rows as 32 plain 1 KB row reads (4 per wave), round them to bf16 and put them in LDS
+//     ([row][k], 528-byte rows: conflict-free both ways), two tiles in rotation, one barrier per tile;
+//   * a wave is one block of 32 playlists: its hidden fragments (16 k-steps x 16 B) live in REGISTERS for the whole launch,
+//     the A fragments (decoder rows) come from LDS, 16 MFMAs per tile, then the epilogue of its 32 x 32 logits;
+//   * every W byte is read once per launch by one workgroup (the 128-row kernel read it per row group, through L2).
+// The k order of every dot product is what the 128-row kernel's was (16 steps of 16, fp32 accumulate in the matrix pipe): the
+// same loss, bit for bit.
+template <bool DZ16>
+__global__ __launch_bounds__(512, 1) void decode_loss_shared_bf16_kernel(const LossRmP p)
 {
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];       // uint4 [NS = 16][RB = 4][64]
-    uint4* ldsq = reinterpret_cast<uint4*>(lds4);
-    constexpr int RB = 4, NS = 16, R_TILE = 128, NW = 8;
+    constexpr int NW = 8, LDW = 132;                                   // dwords per staged decoder row (128 + 4 of padding)
+    __shared__ __attribute__((aligned(16))) unsigned wt[2][32 * LDW];
+    __shared__ float wsum[NW];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gs = DAE_NUM_XCD * p.n_rg;
-    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
-    const int rg = rem / DAE_NUM_XCD;
-    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
-    const int H4 = p.H >> 2;
-    const float4* h4 = reinterpret_cast<const float4*>(p.h);
-    for (int f = tid; f < NS * RB * 64; f += NW * 64) {
-        const int fl = f & 63, frb = (f >> 6) & 3, fs = f >> 8;
-        const int row = rg * R_TILE + frb * 32 + (fl & 31);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (row < p.B) {
-            const float4* src = h4 + (size_t)row * H4 + 4 * fs + 2 * (fl >> 5);
-            a = src[0]; b = src[1];
+    const int row = wave * 32 + j;                                     // this lane's playlist
+    const int H4 = p.H >> 2;                                           // (64)
+    const float4* W4 = reinterpret_cast<const float4*>(p.W);
+    const int n_tiles = (p.V + 31) >> 5;
+    const int nb = gridDim.x;
+
+    // hidden fragments of the lane's playlist: step s = k 16 s + 8 hi .. + 7 (zeros past the batch)
+    uint4 hb[16];
+    {
+        const float4* hr = reinterpret_cast<const float4*>(p.h) + (size_t)(row < p.B ? row : 0) * H4 + 2 * hi;
+        float4 ha[16], hc[16];                                         // (all 32 loads in flight at once)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) { ha[s_] = hr[4 * s_]; hc[s_] = hr[4 * s_ + 1]; }
+        const unsigned keep = row < p.B ? 0xFFFFFFFFu : 0u;            // bf16(0) = 0
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const float4 a = ha[s_], b = hc[s_];
+            hb[s_] = make_uint4((bf16_rne(a.x) | (bf16_rne(a.y) << 16)) & keep, (bf16_rne(a.z) | (bf16_rne(a.w) << 16)) & keep,
+                                (bf16_rne(b.x) | (bf16_rne(b.y) << 16)) & keep, (bf16_rne(b.z) | (bf16_rne(b.w) << 16)) & keep);
         }
-        ldsq[f] = make_uint4(bf16_rne(a.x) | (bf16_rne(a.y) << 16), bf16_rne(a.z) | (bf16_rne(a.w) << 16),
-                             bf16_rne(b.x) | (bf16_rne(b.y) << 16), bf16_rne(b.z) | (bf16_rne(b.w) << 16));
     }
-    __syncthreads();
+    // the wave's four rows of a tile: lane l holds floats 4 l .. 4 l + 3 of each (rows past V: the last row, masked later)
+    auto load_rows = [&](int t, float4 (&wr)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = t * 32 + 4 * wave + r;
+            wr[r] = W4[(size_t)(v < p.V ? v : p.V - 1) * H4 + lane];
+        }
+    };
+    auto stage_rows = [&](int buf, const float4 (&wr)[4]) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4_t f = {wr[r].x, wr[r].y, wr[r].z, wr[r].w};
+            const uint2 pk = __builtin_bit_cast(uint2, __builtin_convertvector(f, bf16x4_t));        // 2 x v_cvt_pk_bf16_f32 (RNE)
+            *reinterpret_cast<uint2*>(&wt[buf][(4 * wave + r) * LDW + 2 * lane]) = pk;
+        }
+    };
+
+    // the bias of the lane's 16 columns of a tile (columns past V: b[V - 1], never used)
+    auto load_bias = [&](int t, float4 (&b)[4]) {
+        if (t * 32 + 32 <= p.V) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) b[qd] = *reinterpret_cast<const float4*>(p.bias + t * 32 + 4 * hi + 8 * qd);
+        } else {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int c = t * 32 + 4 * hi + 8 * qd, last = p.V - 1;
+                b[qd] = make_float4(p.bias[c < last ? c : last], p.bias[c + 1 < last ? c + 1 : last],
+                                    p.bias[c + 2 < last ? c + 2 : last], p.bias[c + 3 < last ? c + 3 : last]);
+            }
+        }
+    };
 
     float loss_acc = 0.0f;
-    const int n_tiles = (p.V + 31) >> 5;
-    const int n_ws = p.nb_rg * NW;
-    const float4* W4 = reinterpret_cast<const float4*>(p.W);
-    auto wrow = [&](int t) {
-        const int v = t * 32 + j;
-        return W4 + (size_t)(v < p.V ? v : p.V - 1) * H4 + 2 * hi;
-    };
-    constexpr int QR = 4;                                                // k-steps of W in flight (round 6: 8 changes nothing -- 92.4 us
-                                                                         // against 91.6 --, 16 spills: 250 us; the launch is not waiting for W)
-    float4 wa[QR], wb[QR];
-    const int item0 = wave * p.nb_rg + bir;
-    if (item0 < n_tiles) {
-        const float4* w0 = wrow(item0);
+    float4 wr[4], bq[4], bq_n[4];
+    int t = blockIdx.x;
 #pragma unroll
-        for (int u = 0; u < QR; ++u) { wa[u] = w0[4 * u]; wb[u] = w0[4 * u + 1]; }
+    for (int qd = 0; qd < 4; ++qd) bq[qd] = bq_n[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < n_tiles) {
+        load_rows(t, wr);
+        load_bias(t, bq);
+        stage_rows(0, wr);
+        if (t + nb < n_tiles) load_rows(t + nb, wr);
     }
-    for (int t = item0; t < n_tiles; t += n_ws) {
-        const float4* wp = wrow(t);
-        const float4* wn = wrow(t + n_ws < n_tiles ? t + n_ws : t);
-        float4 bq[4];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int c = t * 32 + 4 * hi + 8 * qd;
-            bq[qd] = make_float4(c < p.V ? p.bias[c] : 0.f, c + 1 < p.V ? p.bias[c + 1] : 0.f,
-                                 c + 2 < p.V ? p.bias[c + 2] : 0.f, c + 3 < p.V ? p.bias[c + 3] : 0.f);
+    __syncthreads();
+    const float k1 = 0.55f * p.inv_nb;
+    const bool rows_in = wave * 32 + 32 <= p.B;                        // wave-uniform
+    int buf = 0;
+    for (; t < n_tiles; t += nb, buf ^= 1) {
+        // everything requested one iteration ago has arrived: W rows of tile t + nb (registers), this tile's bias
+        if (t + nb < n_tiles) {
+            stage_rows(buf ^ 1, wr);                                   // (that buffer's readers passed the barrier)
+            load_bias(t + nb, bq_n);
         }
-        f32x16 acc[RB];
+        if (t + 2 * nb < n_tiles) load_rows(t + 2 * nb, wr);           // consumed one iteration from now
+        f32x16 acc;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        const unsigned* wl = &wt[buf][j * LDW + 4 * hi];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.0f;
-#pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
-            const float4 a0 = wa[s_ % QR], a1 = wb[s_ % QR];
-            const float4* nx = (s_ + QR < NS) ? wp + 4 * (s_ + QR) : wn + 4 * (s_ + QR - NS);
-            wa[s_ % QR] = nx[0]; wb[s_ % QR] = nx[1];
-            uint4 bf[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) bf[rb] = ldsq[(s_ * RB + rb) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-            typedef float f32x8_t __attribute__((ext_vector_type(8)));
-            const f32x8_t a8 = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const bf16x8 af = __builtin_convertvector(a8, bf16x8);             // 4 x v_cvt_pk_bf16_f32 (RNE)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, as_bf16x8(bf[rb]), acc[rb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const uint4 af = *reinterpret_cast<const uint4*>(wl + 8 * s_);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(af), as_bf16x8(hb[s_]), acc, 0, 0, 0);
         }
-        const int tcol0 = t * 32 + 4 * hi;
+        // epilogue: lane (j, hi) holds, for playlist `row`, the columns t 32 + 4 hi + 8 qd + e
+        if (t * 32 + 32 <= p.V && rows_in) {
+            const unsigned lane_off = (unsigned)(4 * hi) * (unsigned)p.ldT + (unsigned)row;
+            unsigned short* const d16 = reinterpret_cast<unsigned short*>(p.dzT) + (size_t)t * 32 * p.ldT;
+            float* const d32 = p.dzT + (size_t)t * 32 * p.ldT;
+            if (DZ16) {
+                // dL/dz = 0.55 y (1 - y) / (1 - y + 1e-10) (DAEs.py:98-99's negatives); the quotient is 1 to 2^-13 -- far below a
+                // bf16's half unit -- unless 1 - y < 1e-6 (a logit above 13.8): those elements are redone below
+                float q_min = 1.0f;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int row = rg * R_TILE + rb * 32 + j;
-            if (row >= p.B) continue;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        float dzv[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float zz = acc[4 * qd + e + u] + zb[e + u];
+                            const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                            const float q = 1.0f - pr;
+                            loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(q + 1e-10f);
+                            q_min = fminf(q_min, q);
+                            dzv[u] = k1 * pr;
+                        }
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                        const f32x2_t d2 = {dzv[0], dzv[1]};
+                        const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(d2, bf16x2_t));
+                        (d16 + (size_t)(8 * qd + e) * p.ldT)[lane_off] = (unsigned short)(pk & 0xFFFFu);
+                        (d16 + (size_t)(8 * qd + e + 1) * p.ldT)[lane_off] = (unsigned short)(pk >> 16);
+                    }
+                }
+                if (__builtin_expect(__ballot(q_min < 1e-6f) != 0ull, 0)) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float zz = acc[4 * qd + e] + zb[e];
+                            const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                            const float q = 1.0f - pr;
+                            if (q < 1e-6f)
+                                (d16 + (size_t)(8 * qd + e) * p.ldT)[lane_off] =
+                                    (unsigned short)bf16_rne(k1 * __builtin_amdgcn_rcpf(q + 1e-10f) * pr * q);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float zz = acc[4 * qd + e] + zb[e];
+                        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                        const float a0 = 1.0f - pr + 1e-10f;
+                        loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
+                        (d32 + (size_t)(8 * qd + e) * p.ldT)[lane_off] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                    }
+                }
+            }
+        } else if (row < p.B) {
+            const int tcol0 = t * 32 + 4 * hi;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int lc = tcol0 + 8 * qd;
@@ -862,12 +951,12 @@ __global__ __launch_bounds__(512, 1) void decode_loss_rowmajor_bf16_kernel(const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (lc + e < p.V) {
-                        const float zz = acc[rb][4 * qd + e] + zb[e];
+                        const float zz = acc[4 * qd + e] + zb[e];
                         const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
                         const float a0 = 1.0f - pr + 1e-10f;
                         loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
                         const float dzv = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
-                        if (dz16)
+                        if (DZ16)
                             reinterpret_cast<unsigned short*>(p.dzT)[(size_t)(lc + e) * p.ldT + row] = (unsigned short)bf16_rne(dzv);
                         else
                             p.dzT[(size_t)(lc + e) * p.ldT + row] = dzv;
@@ -875,10 +964,12 @@ __global__ __launch_bounds__(512, 1) void decode_loss_rowmajor_bf16_kernel(const
                 }
             }
         }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = bq_n[qd];
+        __syncthreads();
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
-    __shared__ float wsum[NW];
     if (lane == 0) wsum[wave] = loss_acc;
     __syncthreads();
     if (tid == 0) {
@@ -2401,13 +2492,17 @@ int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, i
                                     float* loss_part, int dtype, int dz16)
 {
     if (H != 256 || g.R_TILE != 128 || g.waves != 4) return DAE_ERR_STATE;
+    if ((uint64_t)ldT * 4 + (uint64_t)g.Bpad >= (1ull << 30)) return DAE_ERR_STATE;          // (32-bit lane offsets in the epilogues)
     LossRmP p;
     p.W = W; p.bias = bias; p.h = h; p.V = V; p.H = H; p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg;
     p.inv_nb = inv_n_batch; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part;
     if (dtype == DAE_DTYPE_BF16) {
-        const size_t lds16 = (size_t)16 * 4 * 64 * sizeof(uint4);
-        hipLaunchKernelGGL(decode_loss_rowmajor_bf16_kernel, dim3(g.grid), dim3(512), lds16, ctx->stream, p, dz16);
-        DAE_CHECK_LAUNCH(ctx, "decode_loss_rowmajor_bf16_kernel");
+        // the W tile through LDS, a workgroup per tile x all playlists (training batches are <= 256: train.hip): g.grid
+        // workgroups, one loss partial each, as the caller sized them
+        if (B > 256) return DAE_ERR_STATE;
+        if (dz16) hipLaunchKernelGGL(decode_loss_shared_bf16_kernel<true>, dim3(g.grid), dim3(512), 0, ctx->stream, p);
+        else hipLaunchKernelGGL(decode_loss_shared_bf16_kernel<false>, dim3(g.grid), dim3(512), 0, ctx->stream, p);
+        DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_bf16_kernel");
         return DAE_OK;
     }
     const size_t lds = (size_t)32 * 4 * 64 * sizeof(float4);

@@ -657,6 +657,7 @@ struct DhP {
     const float* W; int H, V;
     float* part;                       // [n_chunk][Bpad64][H]
     int n_chunk, chunk, Bpad64, n_half, n_rblk;
+    int fast32;                        // W and dz^T both end below 4 GB: whole chunks take 32-bit byte offsets from the matrix base
 };
 
 // BF16 (dae_set_train_dtype, NA = 4 only): the 8 k-steps of a block (16 vocabulary rows) become ONE
@@ -676,8 +677,10 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
     // through 4 MB of L2, the partner's lines are gone before it arrives.  Reading W once needs the eight tiles in one workgroup
     // with the W block shared through LDS -- not built.)
     for (int w = blockIdx.x * 4 + wave; w < total; w += gridDim.x * 4) {
-        const int ot = w % n_out, ch = w / n_out;      // neighbours share the W chunk (L2)
-        const int half = ot % p.n_half, rblk = ot / p.n_half;
+        const int ot = w % n_out, ch = w / n_out;      // neighbours share the W chunk
+        // the four waves of a workgroup take the playlist blocks of ONE hidden half (n_rblk = 4: the shipped batch of 256), so
+        // every W byte is read by one workgroup only -- its waves ask for the same lines within a few hundred cycles
+        const int half = ot / p.n_rblk, rblk = ot % p.n_rblk;
         const int hc0 = half * HW, r0 = rblk * 64;
         const int v_beg = ch * p.chunk;
         int v_end = v_beg + p.chunk;
@@ -689,6 +692,10 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+        // (byte offsets, 32 bits: the launcher takes the fast form only when both matrices lie below 4 GB)
+        const unsigned w_row = (unsigned)p.H * 4u, d_row = (unsigned)p.ldT * (DZ16 ? 2u : 4u);
+        const unsigned lane_w = (unsigned)(hc0 + NA * j) * 4u + (unsigned)hi * w_row;
+        const unsigned lane_d = (unsigned)(r0 + 2 * j) * (DZ16 ? 2u : 4u) + (unsigned)hi * d_row;
         const float* Wl = p.W + hc0 + NA * j;
         const float* Dl = p.dzT + r0 + 2 * j;
         const unsigned short* Dl16 = reinterpret_cast<const unsigned short*>(p.dzT) + r0 + 2 * j;
@@ -701,7 +708,11 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             const int v = (V0) + 2 * s + hi;                                                   \
             const bool in = FASTV || v < v_end;                                                \
             const int vc = in ? v : v_beg;                                                     \
-            const float* wr = Wl + (size_t)vc * p.H;                                           \
+            /* FASTV: a wave-uniform row base (scalar registers) + one 32-bit lane offset -- the per-lane form costs a */ \
+            /* 64-bit multiply (four quarter-rate instructions) per load, ~700 cycles per block next to 256 of MFMA   */ \
+            const float* wr = FASTV ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.W) +     \
+                                          ((unsigned)((V0) + 2 * s) * w_row + lane_w))                         \
+                                    : Wl + (size_t)vc * p.H;                                   \
             if (NA == 4) {                                                                     \
                 const float4 t4 = *reinterpret_cast<const float4*>(wr);                        \
                 AV[s][0] = t4.x; AV[s][1 % NA] = t4.y; AV[s][2 % NA] = t4.z; AV[s][3 % NA] = t4.w; \
@@ -711,8 +722,11 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
             } else {                                                                           \
                 AV[s][0] = wr[0];                                                              \
             }                                                                                  \
-            if (DZ16) D[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(Dl16 + (size_t)vc * p.ldT)); \
-            else D[s] = *reinterpret_cast<const float2*>(Dl + (size_t)vc * p.ldT);             \
+            const char* dfast = reinterpret_cast<const char*>(p.dzT) + ((unsigned)((V0) + 2 * s) * d_row + lane_d); \
+            if (DZ16) D[s].x = __uint_as_float(*reinterpret_cast<const unsigned*>(             \
+                FASTV ? dfast : reinterpret_cast<const char*>(Dl16 + (size_t)vc * p.ldT)));    \
+            else D[s] = *reinterpret_cast<const float2*>(                                      \
+                FASTV ? dfast : reinterpret_cast<const char*>(Dl + (size_t)vc * p.ldT));       \
         }
 // the "past the chunk -> 0" select sits HERE, not next to the load: a select on a loaded value in the load
 // stage makes the compiler wait for that load before the sched_barrier, i.e. before the MFMAs it should hide under
@@ -775,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void grad_hidden_kernel(const DhP p)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (((v_end - v_beg) & 31) == 0 && v_end + 16 <= p.V) body(IntC<1>{});
+        if (((v_end - v_beg) & 31) == 0 && v_end + 16 <= p.V && p.fast32) body(IntC<1>{});
         else body(IntC<0>{});
 #undef DH_LOAD
 #undef DH_MMA
@@ -1401,6 +1415,7 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
         p.dzT = t.dzT; p.ldT = t.Bpad64; p.W = Wd; p.H = H; p.V = Vl; p.part = t.part;
         p.n_chunk = t.n_chunk; p.chunk = t.chunk; p.Bpad64 = t.Bpad64; p.n_half = H / (32 * NA);
         p.n_rblk = t.Bpad64 / 64;
+        p.fast32 = ((uint64_t)(Vl + 32) * (uint64_t)H * 4 < (1ull << 32) && (uint64_t)(Vl + 32) * (uint64_t)t.Bpad64 * 4 < (1ull << 32)) ? 1 : 0;
         const int total = p.n_half * p.n_rblk * t.n_chunk;
         int blocks = (total + 3) / 4;
         if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;
@@ -1536,6 +1551,7 @@ int dae_launch_grad_h(dae_ctx* ctx, const float* dzT, int64_t ldT, const float* 
     p.dzT = dzT; p.ldT = ldT; p.W = W; p.H = H; p.V = V; p.part = part;
     p.n_chunk = n_chunk; p.chunk = chunk; p.Bpad64 = Bpad64; p.n_half = H / (32 * NA);
     p.n_rblk = Bpad64 / 64;
+    p.fast32 = ((uint64_t)(V + 32) * (uint64_t)H * 4 < (1ull << 32) && (uint64_t)(V + 32) * (uint64_t)ldT * 4 < (1ull << 32)) ? 1 : 0;
     const int total = p.n_half * p.n_rblk * n_chunk;
     int blocks = (total + 3) / 4;
     if (blocks > DAE_NUM_CU) blocks = DAE_NUM_CU;

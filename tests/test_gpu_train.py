@@ -239,7 +239,11 @@ def _step(ctx, csr, d, V, H, B, tied, ikp, kp, seed, lam):
 
 
 @pytest.mark.parametrize("V,nt,H,B,tied", [(2100, 2000, 256, 250, False), (1500, 1200, 64, 64, True),
-                                           (5000, 4000, 256, 130, False)])
+                                           (5000, 4000, 256, 130, False),
+                                           # round 6, K5 through LDS: waves without a playlist, a full batch, more tiles
+                                           # than workgroups
+                                           (3000, 2500, 256, 37, False), (2100, 2000, 256, 256, False),
+                                           (20000, 16000, 256, 200, False)])
 def test_train_step_bf16_gemms(V, nt, H, B, tied):
     """dae_set_train_dtype(BF16) (BASELINE.json configs[3]): the three GEMMs of the step (forward, gW_dec, dh) run on
     bf16 operands with fp32 accumulate (hidden = 256 / 128: the 4-tile kernels; other sizes keep fp32 backward
