@@ -757,11 +757,12 @@ def _training_row(torch, _lib, ctx, coo_to_csr, pos, ones, W_enc, b_enc, W_dec, 
     rows[0] = None
     ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 0))
     ctx.set_train_dtype(_lib.DAE_DTYPE_F32)
-    # the step's largest kernels against their own roofs: rocprofv3 averages of the committed profiles (scripts/gpu_round4.sh,
-    # scripts/train_top3.py), quoted only for this shape and while csrc/train.hip is the file they were measured on
+    # the step's largest kernels against their own roofs: rocprofv3 averages of the committed profiles (scripts/gpu_round6.sh,
+    # scripts/train_top3.py), quoted only for this shape and while csrc/train.hip and decode_f32.hip (K5) are the files they were measured on
     try:
-        tk = json.load(open(os.path.join(ROOT, "profiles", "r04_train_top3.json")))
-        if tk.get("shape") == [B, V, H] and tk.get("train_hip_sha256_16") == _src_sha("train.hip"):
+        tk = json.load(open(os.path.join(ROOT, "profiles", "r06_train_top3.json")))
+        if (tk.get("shape") == [B, V, H] and tk.get("train_hip_sha256_16") == _src_sha("train.hip")
+                and tk.get("decode_hip_sha256_16") == _src_sha("decode_f32.hip")):
             for name in ("f32", "bf16_gemms", "model_default_bf16"):
                 if name in row and name in tk:
                     row[name]["top_kernels"] = tk[name]
@@ -1209,7 +1210,7 @@ def main():
                                           "note": "ids uniform over the vocabulary (worst case for locality)"}
         del hU, dU
     if True:
-        try:                                  # PMC passes of scripts/gpu_pmc_round4.sh (FETCH_SIZE x2 + WRITE_SIZE per launch)
+        try:                                  # PMC passes of scripts/gpu_pmc_round6.sh (FETCH_SIZE x2 + WRITE_SIZE per launch)
             te = _pmc_json("traffic_encode.json", "encode.hip")
             roofline_encode["traffic"] = te.get("step_batch", {}).get("hbm_bytes_per_launch")
             roofline_encode["kernel"] = te.get("step_batch", {}).get("kernel", roofline_encode["kernel"])
@@ -1249,7 +1250,7 @@ def main():
         out["value_runs_M"] = value_runs     # M playlists/s of four more repetitions of the same K-step region (the spread)
     if roofline.get("traffic") is not None:
         roofline["traffic_source"] = ("profiles/traffic_decode.json: FETCH_SIZE x 2 + WRITE_SIZE of this kernel from separate "
-                                      "rocprofv3 --pmc passes (scripts/gpu_pmc_round4.sh), not counters of this run; quoted only while "
+                                      "rocprofv3 --pmc passes (scripts/gpu_pmc_round6.sh), not counters of this run; quoted only while "
                                       "sha256 of csrc/decode_f32.hip equals the one stamped into that file")
     if sharded:
         # what the collectives of this run really spanned (n_gpus above is WORLD_SIZE from the launcher's environment)

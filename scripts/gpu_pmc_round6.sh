@@ -1,7 +1,7 @@
 # Round-6 counter passes on the SHIPPED kernels (one rocprofv3 --pmc pass per counter set, kernel trace only:
 # MI355X_MICROARCH.md HBM / rocprofv3 section).  Writes gpurun_out/r06_pmc_<cfg>_<set>.csv and the two JSON
 # summaries bench.py reads (copy them to profiles/: traffic_decode.json, traffic_encode.json).
-#   usage: bash scripts/gpu_pmc_round5.sh
+#   usage: bash scripts/gpu_pmc_round6.sh
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 pass() {  # cfg set-name counters... -- bench args

@@ -1,3 +1,4 @@
+# FETCH_SIZE per access width (r06 notes 7): scripts/probe/fetch_calib.hip under rocprofv3 --pmc FETCH_SIZE
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/fc
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/fc -o out -- $GRAFT_REPO_ROOT/scripts/probe/fetch_calib > /tmp/fc.log 2>&1

@@ -1,3 +1,4 @@
+# issue / completion times per step with several batches in flight (r06 notes 1): scripts/time_issue.py
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=32
 o=gpurun_out; mkdir -p $o

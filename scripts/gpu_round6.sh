@@ -1,5 +1,5 @@
 # Round-6 session on the GPU box: tests, the driver's bench command, and the rocprofv3 kernel stats profiles/r06_notes.md quotes
-# (copy gpurun_out/r06_* into profiles/ afterwards).  usage: bash scripts/gpu_round5.sh [notests]
+# (copy gpurun_out/r06_* into profiles/ afterwards).  usage: bash scripts/gpu_round6.sh [notests]
 cd $GRAFT_REPO_ROOT
 export GPU_MAX_HW_QUEUES=32
 o=gpurun_out; mkdir -p $o

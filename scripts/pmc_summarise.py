@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc_round3.sh (round 2: gpu_pmc_round2.sh, prefix r02) into the two JSON files bench.py quotes
+"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc_round6.sh into the two JSON files bench.py quotes
 (`roofline.traffic`, `roofline_encode.traffic`): HBM-side bytes per launch = FETCH_SIZE x 2 (gfx950 correction for
 wide coalesced reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, counters in KB."""
 import collections
@@ -54,7 +54,7 @@ def src_sha(name):
 
 
 sha = {n: src_sha(n) for n in ("decode_f32.hip", "refine.hip", "encode.hip", "train.hip", "dae_internal.h")}
-dec = {"source": "rocprofv3 --kernel-trace --pmc <set>, one pass per counter set (scripts/gpu_pmc_round3.sh): bench.py "
+dec = {"source": "rocprofv3 --kernel-trace --pmc <set>, one pass per counter set (scripts/gpu_pmc_round6.sh): bench.py "
                  "--streams 1 --steps 6, default workload (B=256, V=170000, H=256); raw CSVs profiles/%s_pmc_*.csv" % PFX,
        "fetch_correction": "hbm_bytes_per_launch = FETCH_SIZE x 2 (gfx950: wide coalesced reads are tallied at half) + "
                            "WRITE_SIZE; counters are KB", "kernel_source_sha256_16": sha}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The training step's three largest kernels against their own roofs, from the rocprofv3 kernel stats of
-scripts/gpu_round4.sh (profiles/r04_train_{f32,bf16,default}_kernel_stats.csv) -> profiles/r04_train_top3.json, which
+scripts/gpu_round6.sh (profiles/r06_train_default_kernel_stats.csv, and the f32 / bf16 ones when present) -> profiles/r06_train_top3.json, which
 bench.py attaches to its `training_step` rows.  Algorithmic work per launch at B = 256, V = 170 000, H = 256 (DESIGN.md
 section 4 "Training"): every GEMM 2 B V H FLOP; bytes = what no schedule avoids (W read, dL/dz written / read, Adam state)."""
 import csv
@@ -36,12 +36,13 @@ def short(k):
     return k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
 
 
-out = {"shape": [B, V, H], "source": "rocprofv3 --kernel-trace --stats of scripts/bench_train.py [--bf16 | --default] (scripts/gpu_round4.sh): "
-       "profiles/r04_train_{f32,bf16,default}_kernel_stats.csv; frac = the larger of (FLOP / MFMA peak of the operand type) and "
+out = {"shape": [B, V, H], "source": "rocprofv3 --kernel-trace --stats of scripts/bench_train.py [--bf16 | --default] (scripts/gpu_round6.sh): "
+       "profiles/r06_train_*_kernel_stats.csv; frac = the larger of (FLOP / MFMA peak of the operand type) and "
        "(bytes / 8 TB/s), over the measured average",
-       "train_hip_sha256_16": hashlib.sha256(open(os.path.join(ROOT, "spotify_recsys_challenge_2018_amd", "csrc", "train.hip"), "rb").read()).hexdigest()[:16]}
-for key, fname, bf16, fused in (("f32", "r04_train_f32_kernel_stats.csv", False, False), ("bf16_gemms", "r04_train_bf16_kernel_stats.csv", True, False),
-                                ("model_default_bf16", "r04_train_default_kernel_stats.csv", True, True)):
+       "train_hip_sha256_16": hashlib.sha256(open(os.path.join(ROOT, "spotify_recsys_challenge_2018_amd", "csrc", "train.hip"), "rb").read()).hexdigest()[:16],
+       "decode_hip_sha256_16": hashlib.sha256(open(os.path.join(ROOT, "spotify_recsys_challenge_2018_amd", "csrc", "decode_f32.hip"), "rb").read()).hexdigest()[:16]}
+for key, fname, bf16, fused in (("f32", "r06_train_f32_kernel_stats.csv", False, False), ("bf16_gemms", "r06_train_bf16_kernel_stats.csv", True, False),
+                                ("model_default_bf16", "r06_train_default_kernel_stats.csv", True, True)):
     path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         continue
@@ -65,5 +66,5 @@ for key, fname, bf16, fused in (("f32", "r04_train_f32_kernel_stats.csv", False,
                      "t_mfma_us": round(t_mfma, 1), "t_hbm_us": round(t_hbm, 1), "frac": round(max(t_mfma, t_hbm) / us, 3)})
     rows.sort(key=lambda x: -x["per_step_us"])
     out[key] = rows[:3]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_train_top3.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r06_train_top3.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
