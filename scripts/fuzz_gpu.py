@@ -21,6 +21,8 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     ctx = _lib.Context(0)
+    if os.environ.get("FUZZ_AUDIT"):              # every exact launch audited (64 sampled tiles): an honest image must stay silent
+        ctx.set_exact_audit(1, 64)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     bad = 0
     t0 = time.time()
@@ -85,8 +87,9 @@ def main():
         except Exception as e:                                                   # noqa: BLE001
             bad += 1
             print("ERROR", tag, repr(e))
-    print("fuzz: %d cases, %d bad, %.0f s" % (n_cases, bad, time.time() - t0))
-    return 1 if bad else 0
+    g, a = ctx.exact_guard_read(), ctx.exact_audit_read()
+    print("fuzz: %d cases, %d bad, %.0f s; guard words %s, dropped-column audit %s" % (n_cases, bad, time.time() - t0, g, a))
+    return 1 if (bad or a["violations"]) else 0
 
 
 if __name__ == "__main__":

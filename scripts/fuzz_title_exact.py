@@ -29,6 +29,9 @@ def run(n_cases=24, seed=0, log=print):
         out_scale = float(rng.choice([1.0, 1.0, 10.0, 60.0]))
         m = T._model(tmp / ("c%d" % case), conf, bias, w_scale, title_seed=int(rng.integers(1, 1000)), feat_scale=feat_scale,
                      out_scale=out_scale) if (tmp / ("c%d" % case)).mkdir() is None else None
+        if os.environ.get("FUZZ_AUDIT"):          # every launch audited (64 sampled tiles): an honest image must stay silent
+            m.title_model.ctx.set_exact_audit(1, 64)
+            m.ctx.set_exact_audit(1, 64)
         k = int(rng.choice([1, 10, 100, 500, 777]))
         k = min(k, 1024)
         pos, ones, seeds = T._feed(conf, int(rng.integers(0, 10000)), empty_rows=tuple(int(x) for x in rng.integers(0, conf.batch, 2)))
