@@ -508,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_kernel(const GwP p)
 //     the armed Adam update (dae_arm_decoder_adam) reads and writes W / m / v with the same shape.
 // LDS holds h^T for the workgroup's 128 hidden units as bf16 B fragments in operand order: 4 KB per k-step of 16
 // playlists, 64 KB at B = 256.  gb = dz^T 1 comes out of the matrix pipe as well (a ones fragment as B operand).
-template <int NW>
+template <int NW, bool FULL = false>
 __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
 {
     extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [S][4][64] B fragments
@@ -557,17 +557,19 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
         uint4 qa[RING], qb[RING];
 #pragma unroll
         for (int u = 0; u < RING; ++u) {
-            const int su = u < S ? u : S - 1;
+            const int su = (FULL || u < S) ? u : S - 1;
             qa[u] = *reinterpret_cast<const uint4*>(ra + 16 * su);
             qb[u] = *reinterpret_cast<const uint4*>(rb + 16 * su);
         }
 #pragma unroll
         for (int s_ = 0; s_ < 16; ++s_) {
-            if (s_ < S) {                                              // wave-uniform
+            // (FULL: S == 16, a batch of 241 .. 256, known at compile time -- with the wave-uniform tests in the loop hipcc ends
+            // every step on s_waitcnt vmcnt(0), i.e. on the ring slot it has just requested)
+            if (FULL || s_ < S) {                                      // wave-uniform
                 const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, qa[s_ % RING]);
                 const bf16x8_t fb = __builtin_bit_cast(bf16x8_t, qb[s_ % RING]);
                 if (s_ + RING < 16) {                                  // refill the slot (clamped: values unused past S)
-                    const int sn = s_ + RING < S ? s_ + RING : S - 1;
+                    const int sn = (FULL || s_ + RING < S) ? s_ + RING : S - 1;
                     qa[s_ % RING] = *reinterpret_cast<const uint4*>(ra + 16 * sn);
                     qb[s_ % RING] = *reinterpret_cast<const uint4*>(rb + 16 * sn);
                 }
@@ -645,6 +647,130 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t_kernel(const GwP p)
                         *reinterpret_cast<float4*>(p.gW + (size_t)v * p.H + hc0 + 4 * n) =
                             make_float4(acc[m][0][reg], acc[m][1][reg], acc[m][2][reg], acc[m][3][reg]);
                 }
+        }
+    }
+}
+
+// ---- K6, transposed orientation, the armed-Adam form with its state streams kept in flight (round 6) ---------------------------
+// grad_wdec_t_kernel above runs a tile in two phases -- 160 MFMAs with 4 KB of dz^T requests in flight per wave, then the Adam
+// pass in groups of 12 x 1 KB loads, compute, 12 stores -- and sits at 5.3 TB/s for 1.14 GB with its waves parked 59 % of the time
+// (SQ counters, r06 notes 8): too few bytes in flight, not too many instructions.  At 248 registers it has no room for more.
+// This form halves the tile (32 decoder rows: 64 accumulator registers instead of 128 + 32) and spends the registers on the
+// streams: the first group of p / m / v rows of a tile is requested BEFORE its MFMAs (under which it arrives), and inside the Adam
+// pass group g + 1 is requested before group g is computed and stored (two buffers).  Same operands, same k order per
+// element, same update operations as above: the parameters stay bit-identical to dense Adam.
+template <int NW, bool FULL>
+__global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t32_kernel(const GwP p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];      // [S][4][64] B fragments
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gs = DAE_NUM_XCD * p.n_half;
+    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int half = rem / DAE_NUM_XCD;
+    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int hc0 = half * 128;
+    const int Bp = (p.B + 31) & ~31;
+    const int S = Bp >> 4;
+
+    for (int f = tid; f < S * 4 * 64; f += NW * 64) {
+        const int fl = f & 63, fa = (f >> 6) & 3, fs = f >> 8;
+        const int r0 = 16 * fs + 8 * (fl >> 5);
+        const float* src = p.h + hc0 + 4 * (fl & 31) + fa;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = r0 + e < p.B ? src[(size_t)(r0 + e) * p.H] : 0.0f;
+        ldsq[f] = make_uint4(pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3]), pk_bf16(x[4], x[5]), pk_bf16(x[6], x[7]));
+    }
+    __syncthreads();
+
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const unsigned short* dz = reinterpret_cast<const unsigned short*>(p.dzT);
+    const int n_tiles = (p.V + 31) / 32;
+    const int n_ws = p.nb_half * NW;
+    constexpr int RING = 4;
+    const float b1 = p.ad_b1, b2 = p.ad_b2, eps = p.ad_eps, al = p.ad_alpha;
+    for (int t = bir * NW + wave; t < n_tiles; t += n_ws) {
+        const int v0 = t * 32;
+        const int va = v0 + n;
+        const unsigned short* ra = dz + (size_t)(va < p.V ? va : 0) * p.ldT + 8 * hi;
+        f32x16 acc[4], accg;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accg[e] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
+        uint4 qa[RING];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) qa[u] = *reinterpret_cast<const uint4*>(ra + 16 * ((FULL || u < S) ? u : S - 1));
+        // the Adam pass's rows: register reg of lane (n, hi) is decoder row v0 + (reg & 3) + 8 (reg >> 2) + 4 hi, hidden hc0 + 4 n + a
+        float4 P[2][4], M[2][4], Vv[2][4];
+        size_t off[2][4];
+        bool ok[2][4];
+        auto issue = [&](int buf, int r4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int reg = r4 + u;
+                const int v = v0 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                ok[buf][u] = v < p.V;
+                off[buf][u] = (size_t)(ok[buf][u] ? v : 0) * p.H + hc0 + 4 * n;
+                P[buf][u] = nt_ld4(p.ad_p + off[buf][u]);
+                M[buf][u] = nt_ld4(p.ad_m + off[buf][u]);
+                Vv[buf][u] = nt_ld4(p.ad_v + off[buf][u]);
+            }
+        };
+        issue(0, 0);                                                   // arrives under the MFMAs
+        // (S == 16 -- a batch of 241 .. 256 -- is a template case: with the wave-uniform `s_ < S` tests in the loop hipcc ends every
+        // step on s_waitcnt vmcnt(0), i.e. on the ring slot it has just requested: 16 memory round trips per tile instead of a ring)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            if (FULL || s_ < S) {                                      // wave-uniform
+                const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, qa[s_ % RING]);
+                if (s_ + RING < 16) {
+                    const int sn = (FULL || s_ + RING < S) ? s_ + RING : S - 1;
+                    qa[s_ % RING] = *reinterpret_cast<const uint4*>(ra + 16 * sn);
+                }
+                uint4 bq[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) bq[a] = ldsq[(s_ * 4 + a) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8_t, bq[a]), acc[a], 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, accg, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p.gb && half == 0 && n == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int v = v0 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                if (v < p.V) p.gb[v] = accg[reg];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = g & 1;
+            if (g + 1 < 4) issue(cb ^ 1, 4 * (g + 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int reg = 4 * g + u;
+                float4 pp = P[cb][u], mm = M[cb][u], vv = Vv[cb][u];
+                const float g0 = acc[0][reg], g1 = acc[1][reg], g2 = acc[2][reg], g3 = acc[3][reg];
+#define K6_ADAM(Pq, Mq, Vq, G)                                           \
+                Mq = Mq + (G - Mq) * (1.0f - b1);                        \
+                Vq = Vq + (G * G - Vq) * (1.0f - b2);                    \
+                Pq = Pq - (Mq * al) / (sqrtf(Vq) + eps);
+                K6_ADAM(pp.x, mm.x, vv.x, g0) K6_ADAM(pp.y, mm.y, vv.y, g1)
+                K6_ADAM(pp.z, mm.z, vv.z, g2) K6_ADAM(pp.w, mm.w, vv.w, g3)
+#undef K6_ADAM
+                if (ok[cb][u]) {
+                    nt_st4(p.ad_p + off[cb][u], pp);
+                    nt_st4(p.ad_m + off[cb][u], mm);
+                    nt_st4(p.ad_v + off[cb][u], vv);
+                }
+            }
         }
     }
 }
@@ -824,8 +950,16 @@ __global__ __launch_bounds__(256) void hidden_backward_kernel(const float* __res
     const size_t n = (size_t)B * H;
     for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) {
         float s = 0.f;
-        // fixed order; 8 loads in flight per thread (one dependent load per iteration was 32 us for 33 MB)
+        // fixed order; 32 loads in flight per thread (one dependent load per iteration was 32 us for 33 MB, 8 at a time 11 us:
+        // 65 536 threads x 128 chunk partials is 16 round trips of 8)
         int c = 0;
+        for (; c + 32 <= n_chunk; c += 32) {
+            float q[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) q[u] = part[(size_t)(c + u) * Bpad64 * H + o];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += q[u];
+        }
         for (; c + 8 <= n_chunk; c += 8) {
             float q[8];
 #pragma unroll
@@ -913,10 +1047,14 @@ __global__ __launch_bounds__(256) void scatter_gwenc_kernel(const int32_t* __res
             }
             __syncthreads();
         }
+        // xhat once per entry (the same division, by one thread instead of by every hidden unit's: ~100 IEEE divides per thread)
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) xs[i] = xs[i] / denom;
+        __syncthreads();
         for (int k = tid; k < H; k += 256) {
             const float dv = dpre[(size_t)row * H + k];
             for (int i = 0; i < n; ++i) {
-                const float w = xs[i] / denom;
+                const float w = xs[i];
                 const int c = cs[i];
                 if (w != 0.0f && c >= col_lo && c < col_hi) atomicAdd(&gW[(size_t)(c - col_lo) * H + k], w * dv);
             }
@@ -1123,19 +1261,33 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
     const int row = rows[w];
     if (row < 0 || row >= n_rows) return;
     const int stamp = 2 * step + MODE;
+    // (round 6) Everything that depends on `row` alone is requested TOGETHER: the claim, the row's step and the first 64 float4 of
+    // its state (the whole row at hidden 256) -- the wave was four dependent trips to memory (row, claim, step, state) for one
+    // update, and a launch is ~100 such waves per CU: 27 + 30 us for 95 MB.  A wave that loses the claim has read lines the
+    // winner reads anyway.
+    const bool vec = (row_len & 3) == 0;
+    const bool first_in = vec && lane < (row_len >> 2);
+    const size_t o_first = ((size_t)row * row_len >> 2) + lane;
+    float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), mm0 = pp0, vv0 = pp0, gg0 = pp0;
+    if (first_in) {
+        pp0 = reinterpret_cast<float4*>(p)[o_first]; mm0 = reinterpret_cast<float4*>(m)[o_first];
+        vv0 = reinterpret_cast<float4*>(v)[o_first];
+        if (MODE == 1) gg0 = reinterpret_cast<float4*>(g)[o_first];
+    }
+    const int from = last[row];
     int claimed = 0;
     if (lane == 0) claimed = atomicExch(&mark[row], stamp) != stamp;
     claimed = __shfl(claimed, 0);
     if (!claimed) return;
-    const int from = last[row];
     const int upto = step - 1;
     // four elements per lane at a time: the replay is a sequential recurrence per element (sqrt -> divide -> subtract),
     // so independent chains are the only instruction-level parallelism there is
-    if ((row_len & 3) == 0) {
+    if (vec) {
         for (int c4 = lane; c4 < (row_len >> 2); c4 += 64) {
             const size_t o = ((size_t)row * row_len >> 2) + c4;
-            float4 pp = reinterpret_cast<float4*>(p)[o], mm = reinterpret_cast<float4*>(m)[o],
-                   vv = reinterpret_cast<float4*>(v)[o];
+            const bool pre = c4 == lane;                           // the first round was requested above
+            float4 pp = pre ? pp0 : reinterpret_cast<float4*>(p)[o], mm = pre ? mm0 : reinterpret_cast<float4*>(m)[o],
+                   vv = pre ? vv0 : reinterpret_cast<float4*>(v)[o];
             for (int s_ = from + 1; s_ <= upto; ++s_) {
                 const float a = lr_tab[s_];
                 const float z = 0.0f;
@@ -1143,7 +1295,7 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
                 ADAM_EL(pp.z, mm.z, vv.z, z, a) ADAM_EL(pp.w, mm.w, vv.w, z, a)
             }
             if (MODE == 1) {
-                const float4 gg = reinterpret_cast<float4*>(g)[o];
+                const float4 gg = pre ? gg0 : reinterpret_cast<float4*>(g)[o];
                 ADAM_EL(pp.x, mm.x, vv.x, gg.x, lr_t) ADAM_EL(pp.y, mm.y, vv.y, gg.y, lr_t)
                 ADAM_EL(pp.z, mm.z, vv.z, gg.z, lr_t) ADAM_EL(pp.w, mm.w, vv.w, gg.w, lr_t)
                 reinterpret_cast<float4*>(g)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1385,6 +1537,25 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                 if (dae_first_use(ctx, &k6t_key))
                     DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t_kernel<8>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                static const bool k6_t64 = dae_exp_env("DAE_K6_T64") != nullptr;                       // A/B: the 64-row tile form
+                if (p.ad_m && !k6_t64) {
+                    static const char attr_t32_key = 0;
+                    if (dae_first_use(ctx, &attr_t32_key)) {
+                        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t32_kernel<8, true>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t32_kernel<8, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                    }
+                    if (((B + 31) & ~31) == 256) hipLaunchKernelGGL((grad_wdec_t32_kernel<8, true>), grid, dim3(512), lds_t, st, p);
+                    else hipLaunchKernelGGL((grad_wdec_t32_kernel<8, false>), grid, dim3(512), lds_t, st, p);
+                } else
+                if (((B + 31) & ~31) == 256) {
+                    static const char attr_tf_key = 0;
+                    if (dae_first_use(ctx, &attr_tf_key))
+                        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t_kernel<8, true>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                    hipLaunchKernelGGL((grad_wdec_t_kernel<8, true>), grid, dim3(512), lds_t, st, p);
+                } else
                 hipLaunchKernelGGL((grad_wdec_t_kernel<8>), grid, dim3(512), lds_t, st, p);
             } else if (t.dz16) hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true, true>), grid, dim3(512), lds, st, p);
             else hipLaunchKernelGGL((grad_wdec_kernel<4, 8, true>), grid, dim3(512), lds, st, p);
