@@ -1,8 +1,8 @@
-# A/B of the exact title mix's kernels (experiments build): kernel times per variant
-export GPU_MAX_HW_QUEUES=32
-R=${GRAFT_REPO_ROOT:-$PWD}
-export DAE_LIB_AB=$R/scripts/probe/libdae_hip_exp.so
-for v in "$@"; do
-  echo "== $v"
-  env $v bash $R/scripts/gpu_kprof.sh title_ab 4 python $R/scripts/time_title.py exact_bf16 20 2>&1 | grep -v "^W2026\|amdgpu.ids"
-done
+# the titled loop after a change: tests, kernel times and rates, new / old (scripts/probe/libdae_hip_old.so when present)
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_title_exact.py tests/test_gpu_title.py -x -q 2>&1 | tail -3
+bash scripts/gpu_kprof.sh titleab 5 python $R/scripts/time_title.py exact_bf16
+if [ -f scripts/probe/libdae_hip_old.so ]; then echo "=== old"; DAE_LIB_AB=$R/scripts/probe/libdae_hip_old.so bash scripts/gpu_kprof.sh titleab_old 5 python $R/scripts/time_title.py exact_bf16; fi
+for i in 1 2 3; do python scripts/time_title.py exact_bf16 2>&1 | grep "playlists/s"
+  if [ -f scripts/probe/libdae_hip_old.so ]; then DAE_LIB_AB=$R/scripts/probe/libdae_hip_old.so python scripts/time_title.py exact_bf16 2>&1 | grep "playlists/s" | sed 's/^/OLD /'; fi; done

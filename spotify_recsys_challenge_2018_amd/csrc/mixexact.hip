@@ -162,15 +162,22 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
     const int tv1 = p.list[has ? (it0 + n_ws < n_items ? it0 + n_ws : it0) : 0];
     // filter: the row's threshold (rows beyond B list nothing)
     static_assert(R_TILE <= NTH, "one thread per row");
+    // (every load of this prologue is UNCONDITIONAL, on a clamped row: a guarded load is a branch, and hipcc ends each guarded
+    // group on s_waitcnt vmcnt(0) -- eight dependent trips to memory before the first MFMA, round 6's ISA reading)
     float tau_g = __builtin_inff();
-    if (MODE == 0 && tid < R_TILE && rg * R_TILE + tid < p.B) {
-        const float tau = p.tau[rg * R_TILE + tid];
-        // the compared bound is widened by 2^-20 and rounded twice; tau <= 0 (or -inf: fewer than `need` sample values,
-        // or NaN): every column passes
-        tau_g = tau > 0.0f ? tau * (1.0f - 0x1p-17f) : 0.0f;
-        // a row without input and without title (the padding rows of a reader's last batch, main_challenge.py:75-78): both
-        // weights are 0, y is +0 for every column -- nothing is listed, the refine launch writes its list directly
-        if (p.w_t[rg * R_TILE + tid] == 0.0f && p.w_p[rg * R_TILE + tid] == 0.0f) tau_g = __builtin_inff();
+    if (MODE == 0) {
+        const int rr = rg * R_TILE + (tid < R_TILE ? tid : 0);
+        const int rc = rr < p.B ? rr : p.B - 1;
+        const float tau = p.tau[rc];
+        const float a_t = p.w_t[rc], a_p = p.w_p[rc];
+        if (tid < R_TILE && rr < p.B) {
+            // the compared bound is widened by 2^-20 and rounded twice; tau <= 0 (or -inf: fewer than `need` sample values,
+            // or NaN): every column passes
+            tau_g = tau > 0.0f ? tau * (1.0f - 0x1p-17f) : 0.0f;
+            // a row without input and without title (the padding rows of a reader's last batch, main_challenge.py:75-78): both
+            // weights are 0, y is +0 for every column -- nothing is listed, the refine launch writes its list directly
+            if (a_t == 0.0f && a_p == 0.0f) tau_g = __builtin_inff();
+        }
     }
     int* lcnt = reinterpret_cast<int*>(lds4 + n_h4);
     float* ltau = reinterpret_cast<float*>(lcnt + R_TILE);
@@ -202,9 +209,12 @@ __global__ __launch_bounds__(NW * 64, 1) void mix_bf16_kernel(const MixP p)
     for (int rb = 0; rb < RB; ++rb) {
         const int row = rg * R_TILE + rb * 32 + j;
         const bool in = row < p.B;
-        wt_r[rb] = in ? p.w_t[row] : 0.0f;
-        wp_r[rb] = in ? p.w_p[row] : 0.0f;
-        oy[rb] = hi == 0 ? (0x3F80u | ((in ? p.fhat[row] : 0u) << 16)) : 0u;
+        const int rc = in ? row : p.B - 1;
+        const float a_t = p.w_t[rc], a_p = p.w_p[rc];
+        const unsigned fh = p.fhat[rc];
+        wt_r[rb] = in ? a_t : 0.0f;
+        wp_r[rb] = in ? a_p : 0.0f;
+        oy[rb] = hi == 0 ? (0x3F80u | ((in ? fh : 0u) << 16)) : 0u;
     }
     __builtin_amdgcn_sched_barrier(0);
     int t = __builtin_amdgcn_readfirstlane(tv0), u = __builtin_amdgcn_readfirstlane(tv1);
