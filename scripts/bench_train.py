@@ -25,9 +25,10 @@ names = ["We", "be", "bd"] + ([] if tied else ["Wd"])
 g = {n: torch.zeros_like(t[n]) for n in names}
 mom = {n: (torch.zeros_like(t[n]), torch.zeros_like(t[n])) for n in names}
 cost = torch.zeros(1, device="cuda")
-default = "--default" in sys.argv and not tied      # models/DAEs.py train_step with train_dtype = bf16: the fused / row-sparse Adam forms
+default_f32 = "--default-f32" in sys.argv and not tied      # the same step with train_dtype = f32 (config.ini's default)
+default = ("--default" in sys.argv or default_f32) and not tied      # models/DAEs.py train_step: the fused / row-sparse Adam forms (bf16 GEMMs)
 if default:
-    ctx.set_train_dtype(_lib.DAE_DTYPE_BF16)
+    ctx.set_train_dtype(_lib.DAE_DTYPE_F32 if default_f32 else _lib.DAE_DTYPE_BF16)
     lz = {"state": torch.zeros(2 * V, dtype=torch.int32, device="cuda"), "tab": torch.zeros(1 << 12, dtype=torch.float32, device="cuda"),
           "flushed": 0}
     ctx.check(ctx.lib.dae_set_enc_grad_prezeroed(ctx.h, 1))

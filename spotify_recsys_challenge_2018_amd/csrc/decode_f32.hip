@@ -979,6 +979,153 @@ __global__ __launch_bounds__(512, 1) void decode_loss_shared_bf16_kernel(const L
     }
 }
 
+// ---- K5, fp32 operands, hidden 256, batches of at most 256 playlists: the same shape on v_mfma_f32_32x32x2_f32 (round 6) ----
+// decode_loss_rowmajor_kernel's lanes gather their decoder rows as the 128-row bf16 kernel's did (64 cache lines per load
+// instruction): 219 us for 142 us of fp32 matrix work.  Here: a workgroup = a tile of 32 decoder rows x all playlists, the rows
+// as plain 1 KB reads into LDS (fp32, 1 040-byte rows, two tiles in rotation), a wave = 32 playlists whose hidden row sits in
+// 128 registers, the A fragments from LDS (a float4 = four MFMAs).  The k order inside a dot product is the row-major kernel's
+// (pairs (8 g + c, 8 g + 4 + c)); training compares by tolerance.
+__global__ __launch_bounds__(512, 1) void decode_loss_shared_f32_kernel(const LossRmP p)
+{
+    constexpr int NW = 8, LDW = 260;                                   // dwords per staged decoder row (256 + 4 of padding)
+    extern __shared__ __attribute__((aligned(16))) float wtf[];       // [2][32 * LDW] | wsum[NW]
+    float* const wsum = wtf + 2 * 32 * LDW;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = wave * 32 + j;
+    const int H4 = p.H >> 2;
+    const float4* W4 = reinterpret_cast<const float4*>(p.W);
+    const int n_tiles = (p.V + 31) >> 5;
+    const int nb = gridDim.x;
+
+    // hidden row of the lane's playlist: group g = k 8 g + 4 hi .. + 3 (zeros past the batch)
+    float4 hb[32];
+    {
+        const float4* hr = reinterpret_cast<const float4*>(p.h) + (size_t)(row < p.B ? row : 0) * H4 + hi;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) hb[g] = hr[2 * g];
+        if (row >= p.B) {
+#pragma unroll
+            for (int g = 0; g < 32; ++g) hb[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // the wave's four rows of a tile, lane l holding floats 4 l .. 4 l + 3 of each: four named registers (an array behind a
+    // lambda's reference stayed in scratch here)
+    float4 w0, w1, w2, w3;
+#define K5F_LOAD(T)                                                                            \
+    {                                                                                          \
+        const int v_ = (T) * 32 + 4 * wave;                                                    \
+        w0 = W4[(size_t)(v_ < p.V ? v_ : p.V - 1) * H4 + lane];                                \
+        w1 = W4[(size_t)(v_ + 1 < p.V ? v_ + 1 : p.V - 1) * H4 + lane];                        \
+        w2 = W4[(size_t)(v_ + 2 < p.V ? v_ + 2 : p.V - 1) * H4 + lane];                        \
+        w3 = W4[(size_t)(v_ + 3 < p.V ? v_ + 3 : p.V - 1) * H4 + lane];                        \
+    }
+#define K5F_STAGE(BUF)                                                                         \
+    {                                                                                          \
+        float* d_ = &wtf[(BUF) * 32 * LDW + (4 * wave) * LDW + 4 * lane];                      \
+        *reinterpret_cast<float4*>(d_) = w0;                                                   \
+        *reinterpret_cast<float4*>(d_ + LDW) = w1;                                             \
+        *reinterpret_cast<float4*>(d_ + 2 * LDW) = w2;                                         \
+        *reinterpret_cast<float4*>(d_ + 3 * LDW) = w3;                                         \
+    }
+    // the tile's 32 bias values, one per lane (lane l: column 32 t + (l & 31)); a lane takes its 16 by shuffle when it needs them
+    auto load_bias = [&](int t) -> float {
+        const int c = t * 32 + j;
+        return p.bias[c < p.V ? c : p.V - 1];
+    };
+    float loss_acc = 0.0f;
+    float bl, bl_n = 0.0f;
+    int t = blockIdx.x;
+    // (every request is UNCONDITIONAL, on a tile clamped to the last one: a conditionally written register array goes to scratch,
+    // and the store to scratch waits for the load it has just issued)
+    const int t_last = n_tiles - 1;
+    K5F_LOAD(t < t_last ? t : t_last)
+    bl = load_bias(t < t_last ? t : t_last);
+    K5F_STAGE(0)
+    K5F_LOAD(t + nb < t_last ? t + nb : t_last)
+    __syncthreads();
+    const bool rows_in = wave * 32 + 32 <= p.B;
+    // (Tried: the second wave of each SIMD one tile late with its epilogue, so that one wave's MFMAs run under the other's
+    // epilogue -- 214 against 209 us: the launch is not losing its time to coinciding phases.)
+    auto epilogue = [&](int te, const f32x16& ac, float bv) {
+            float4 bq[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                bq[qd] = make_float4(__shfl(bv, 4 * hi + 8 * qd), __shfl(bv, 4 * hi + 8 * qd + 1), __shfl(bv, 4 * hi + 8 * qd + 2),
+                                     __shfl(bv, 4 * hi + 8 * qd + 3));
+            if (te * 32 + 32 <= p.V && rows_in) {
+                const unsigned lane_off = (unsigned)(4 * hi) * (unsigned)p.ldT + (unsigned)row;
+                float* const d32 = p.dzT + (size_t)te * 32 * p.ldT;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float zz = ac[4 * qd + e] + zb[e];
+                        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                        const float a0 = 1.0f - pr + 1e-10f;
+                        loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
+                        (d32 + (size_t)(8 * qd + e) * p.ldT)[lane_off] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                    }
+                }
+            } else if (row < p.B) {
+                const int tcol0 = te * 32 + 4 * hi;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int lc = tcol0 + 8 * qd;
+                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (lc + e < p.V) {
+                            const float zz = ac[4 * qd + e] + zb[e];
+                            const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                            const float a0 = 1.0f - pr + 1e-10f;
+                            loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
+                            p.dzT[(size_t)(lc + e) * p.ldT + row] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
+                        }
+                    }
+                }
+            }
+    };
+    int buf = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (; t < n_tiles; t += nb, buf ^= 1) {
+        K5F_STAGE(buf ^ 1)                                             // tile t + nb (or a clamped copy nobody reads)
+        bl_n = load_bias(t + nb < t_last ? t + nb : t_last);
+        K5F_LOAD(t + 2 * nb < t_last ? t + 2 * nb : t_last)
+        __builtin_amdgcn_sched_barrier(0);                             // (hipcc sinks these requests below the 128 MFMAs otherwise)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        const float* wl = &wtf[buf * 32 * LDW + j * LDW + 4 * hi];
+        // (one accumulator: a chain of 128 dependent MFMAs per wave, and two -- even / odd groups, summed -- measured the same
+        // 209 - 213 us: with two waves per SIMD the pipe is busy either way; the launch is at the fp32 MFMA rate of its clock)
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(wl + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hb[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hb[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hb[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hb[g].w, acc, 0, 0, 0);
+        }
+        epilogue(t, acc, bl);
+        bl = bl_n;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
+    if (lane == 0) wsum[wave] = loss_acc;
+    __syncthreads();
+    if (tid == 0) {
+        float sm = 0.0f;
+        for (int w = 0; w < NW; ++w) sm += wsum[w];
+        p.loss_part[blockIdx.x] = sm * p.inv_nb;
+    }
+}
+#undef K5F_LOAD
+#undef K5F_STAGE
+
 // ---- fp32, hidden = 256, filter epilogue (phase B of the fused path): the generic kernel above with
 // one addition, TAIL BALANCE.  A launch of n tiles over n_ws wave slots runs floor(n / n_ws) whole rounds
 // and a last round with `rem` tiles; when that round is at most half full (222 of 512 slots at batch 256,
@@ -2504,6 +2651,22 @@ int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, i
         else hipLaunchKernelGGL(decode_loss_shared_bf16_kernel<false>, dim3(g.grid), dim3(512), 0, ctx->stream, p);
         DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_bf16_kernel");
         return DAE_OK;
+    }
+    if (B <= 256) {
+        const size_t lds_s = ((size_t)2 * 32 * 260 + 8) * sizeof(float);
+        static const char rs_key = 0;
+        if (dae_first_use(ctx, &rs_key))
+            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_loss_shared_f32_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+#ifdef DAE_EXPERIMENTS
+        static const bool k5_rowmajor = dae_exp_env("DAE_K5_ROWMAJOR") != nullptr;            // A/B: the row-gathering kernel below
+        if (!k5_rowmajor)
+#endif
+        {
+            hipLaunchKernelGGL(decode_loss_shared_f32_kernel, dim3(g.grid), dim3(512), lds_s, ctx->stream, p);
+            DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_f32_kernel");
+            return DAE_OK;
+        }
     }
     const size_t lds = (size_t)32 * 4 * 64 * sizeof(float4);
     static const char rm_key = 0;

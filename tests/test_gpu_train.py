@@ -39,6 +39,9 @@ def _uniform(seed, stream, rows, cols):
     (1500, 1200, 64, 64, True, 0.0, 1.0, 0.8),
     (900, 700, 32, 10, False, 0.01, 0.6, 1.0),
     (2100, 2000, 256, 250, True, 0.02, 0.75, 0.8),
+    # round 6, fp32 K5 through LDS (hidden 256): waves without a playlist, a full batch with more tiles than workgroups
+    (3000, 2500, 256, 37, False, 0.0, 0.75, 0.8),
+    (20000, 16000, 256, 256, False, 0.0, 1.0, 1.0),
 ])
 def test_train_step_gradients(V, nt, H, B, tied, lam, ikp, kp):
     import torch
