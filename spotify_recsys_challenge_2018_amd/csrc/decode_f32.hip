@@ -607,176 +607,22 @@ __global__ __launch_bounds__(NW * 64, HALF ? 2 : NW / 4) void decode_f32_kernel(
     }
 }
 
-// ---- training forward (K5) straight from the ROW-MAJOR decoder, fp32, hidden = 256 -----------------------------
-// The decoder changes every training step, so the packed image the scoring kernels stream had to be rebuilt every
-// step (65 us for 174 MB) only to be read once.  Here a lane reads its operand from the matrix as it is: lane (i, hi)
-// of a tile takes W[32 t + i][8 g + 4 hi .. + 3] -- one aligned 16-byte load per k-group, the two lane halves reading
-// adjacent 16 bytes -- and the hidden fragments in LDS are cut the same way (k-slot e of lane half hi is 8 g + 4 hi + e),
-// filled from the row-major hidden activations.  A load instruction then touches 32 rows (32 cache lines, each reused
-// by the next 3 groups) instead of 1 KB of contiguous image: ~2 k cycles of address work per tile against 32 k cycles
-// of MFMAs.  The k order of a sum differs from the canonical chain (pairs (e, 4 + e) instead of (2 e, 2 e + 1)): this
-// is the training path, compared by tolerance.  Loss epilogue as EPI_LOSS above (every element a negative; the
-// positives are redone by train.hip's loss_fixup_kernel).
+// ---- training forward (K5) straight from the ROW-MAJOR decoder, hidden = 256 -------------------------------------------
+// The decoder changes every training step, so the packed image the scoring kernels stream had to be rebuilt every step (65 us
+// for 174 MB) only to be read once: K5 reads the matrix as the optimiser leaves it.  Until round 6 a lane read ITS decoder row
+// in 16-byte (fp32) / 32-byte (bf16) pieces -- 32 rows, 64 cache lines per load instruction; the two kernels below take a tile's
+// rows as plain 1 KB reads through LDS instead.  The k order of a sum differs from the canonical chain: this is the training
+// path, compared by tolerance.  Loss epilogue as EPI_LOSS above (every element a negative; the positives are redone by train.hip's
+// loss_fixup_kernel).
 struct LossRmP {
     const float* W; const float* bias; const float* h;       // [V][H], [V], [B][H] row-major
     int V, H, B, n_rg, nb_rg;
     float inv_nb; float* dzT; int64_t ldT; float* loss_part;
 };
 
-__global__ __launch_bounds__(256, 1) void decode_loss_rowmajor_kernel(const LossRmP p)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];       // [G = 32][RB = 4][64]
-    constexpr int RB = 4, G = 32, R_TILE = 128, NW = 4;
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gs = DAE_NUM_XCD * p.n_rg;
-    const int q = blockIdx.x / gs, rem = blockIdx.x % gs;
-    const int rg = rem / DAE_NUM_XCD;
-    const int bir = q * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
-    const int H4 = p.H >> 2;
-
-    // hidden fragments: (g, rb, lane (j, hi)) = h[rg * 128 + 32 rb + j][8 g + 4 hi .. + 3], zero past B
-    {
-        const float4* h4 = reinterpret_cast<const float4*>(p.h);
-        for (int i0 = tid; i0 < G * RB * 64; i0 += 8 * 256) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int f = i0 + u * 256;
-                const int fl = f & 63, frb = (f >> 6) & 3, fg = f >> 8;
-                const int row = rg * R_TILE + frb * 32 + (fl & 31);
-                v[u] = h4[(size_t)(row < p.B ? row : 0) * H4 + 2 * fg + (fl >> 5)];
-                if (row >= p.B) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) lds4[i0 + u * 256] = v[u];
-        }
-    }
-    __syncthreads();
-
-    float loss_acc = 0.0f;
-    const int n_tiles = (p.V + 31) >> 5;
-    const int n_ws = p.nb_rg * NW;
-    const int item0 = wave * p.nb_rg + bir;
-    const float4* W4 = reinterpret_cast<const float4*>(p.W);
-    float4 wb0, wb1, wb2, wb3;
-    float4 bA[RB], bB[RB];
-    auto wrow = [&](int t) {                       // this lane's operand row of tile t (rows past V: the last row)
-        const int v = t * 32 + j;
-        return W4 + (size_t)(v < p.V ? v : p.V - 1) * H4 + hi;
-    };
-    if (item0 < n_tiles) {
-        const float4* w0 = wrow(item0);
-        wb0 = w0[0]; wb1 = w0[2]; wb2 = w0[4]; wb3 = w0[6];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) bA[rb] = lds4[rb * 64 + lane];
-    }
-    for (int t = item0; t < n_tiles; t += n_ws) {
-        const float4* wp = wrow(t);
-        const float4* wn = wrow(t + n_ws < n_tiles ? t + n_ws : t);
-        // bias of the lane's 16 columns: v_local(reg) = (reg & 3) + 8 (reg >> 2) + 4 hi
-        float4 bq[4];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int c = t * 32 + 4 * hi + 8 * qd;
-            bq[qd] = make_float4(c < p.V ? p.bias[c] : 0.f, c + 1 < p.V ? p.bias[c + 1] : 0.f,
-                                 c + 2 < p.V ? p.bias[c + 2] : 0.f, c + 3 < p.V ? p.bias[c + 3] : 0.f);
-        }
-        f32x16 acc[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rb][e] = 0.0f;
-#define RM_STEP(WB, PF, BC, BN, GNEXT)                                                         \
-    {                                                                                          \
-        const float4 a = WB;                                                                   \
-        WB = *(PF);                                                                            \
-        const float4* hl = lds4 + (size_t)(GNEXT) * (RB * 64) + lane;                          \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) BN[rb] = hl[rb * 64];                \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, BC[rb].x, acc[rb], 0, 0, 0);   \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, BC[rb].y, acc[rb], 0, 0, 0);   \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, BC[rb].z, acc[rb], 0, 0, 0);   \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                      \
-            acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, BC[rb].w, acc[rb], 0, 0, 0);   \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-    }
-        int g = 0;
-#pragma unroll
-        for (; g < G - 4; g += 4) {
-            const float4* pf = wp + 2 * (g + 4);
-            RM_STEP(wb0, pf,     bA, bB, g + 1)
-            RM_STEP(wb1, pf + 2, bB, bA, g + 2)
-            RM_STEP(wb2, pf + 4, bA, bB, g + 3)
-            RM_STEP(wb3, pf + 6, bB, bA, g + 4)
-        }
-        RM_STEP(wb0, wn,     bA, bB, g + 1)
-        RM_STEP(wb1, wn + 2, bB, bA, g + 2)
-        RM_STEP(wb2, wn + 4, bA, bB, g + 3)
-        RM_STEP(wb3, wn + 6, bB, bA, 0)
-#undef RM_STEP
-        const int tcol0 = t * 32 + 4 * hi;
-        // a tile that lies wholly inside the matrix and the batch (all but the last tile / row group) takes the
-        // epilogue without per-element bounds tests: 64 exec-mask branches per tile otherwise (233 -> 218 us)
-        if (t * 32 + 32 <= p.V && rg * R_TILE + R_TILE <= p.B) {
-            // (round 6: a wave-uniform column base + one 32-bit lane offset per row block -- a lane-dependent base made every
-            // store a 64-bit multiply; the launcher checks that the offsets fit)
-            const unsigned lane_off0 = (unsigned)(4 * hi) * (unsigned)p.ldT + (unsigned)(rg * R_TILE + j);
-            float* const d32 = p.dzT + (size_t)t * 32 * p.ldT;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const unsigned lane_off = lane_off0 + (unsigned)(rb * 32);
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float zz = acc[rb][4 * qd + e] + zb[e];
-                        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
-                        const float a0 = 1.0f - pr + 1e-10f;
-                        loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
-                        (d32 + (size_t)(8 * qd + e) * p.ldT)[lane_off] = 0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int row = rg * R_TILE + rb * 32 + j;
-            if (row >= p.B) continue;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int lc = tcol0 + 8 * qd;
-                const float zb[4] = {bq[qd].x, bq[qd].y, bq[qd].z, bq[qd].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (lc + e < p.V) {
-                        const float zz = acc[rb][4 * qd + e] + zb[e];
-                        const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
-                        const float a0 = 1.0f - pr + 1e-10f;
-                        loss_acc -= (0.69314718f * 0.55f) * __builtin_amdgcn_logf(a0);
-                        p.dzT[(size_t)(lc + e) * p.ldT + row] =
-                            0.55f * __builtin_amdgcn_rcpf(a0) * pr * (1.0f - pr) * p.inv_nb;
-                    }
-                }
-            }
-        }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
-    __shared__ float wsum[NW];
-    if (lane == 0) wsum[wave] = loss_acc;
-    __syncthreads();
-    if (tid == 0) p.loss_part[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * p.inv_nb;
-}
-
 // ---- K5, bf16 operands, hidden 256, batches of at most 256 playlists: the W tile through LDS (round 6) ---------------
-// Until round 6 this launch had the fp32 kernel's shape (decode_loss_rowmajor_kernel above: a wave = a tile of 32 decoder rows x
-// 128 playlists, every lane reading ITS decoder row in 32-byte pieces): 64 lanes, 32 rows -- 64 different cache lines per load
+// Until round 6 a wave was a tile of 32 decoder rows x 128 playlists, every lane reading ITS decoder row in 32-byte pieces:
+// 64 lanes, 32 rows -- 64 different cache lines per load
 // instruction, one tag lookup each.  Measured (rocprofv3 counters + the launch with one part removed at a time,
 // profiles/r06_notes.md 8): 90 us with, 48 us without the W loads; halving the epilogue's instruction count changed nothing.
 // Here a workgroup of 8 waves takes a tile x ALL playlists (58.8 us):
@@ -980,8 +826,8 @@ __global__ __launch_bounds__(512, 1) void decode_loss_shared_bf16_kernel(const L
 }
 
 // ---- K5, fp32 operands, hidden 256, batches of at most 256 playlists: the same shape on v_mfma_f32_32x32x2_f32 (round 6) ----
-// decode_loss_rowmajor_kernel's lanes gather their decoder rows as the 128-row bf16 kernel's did (64 cache lines per load
-// instruction): 219 us for 142 us of fp32 matrix work.  Here: a workgroup = a tile of 32 decoder rows x all playlists, the rows
+// The row-gathering fp32 kernel it replaces (64 cache lines per load instruction, as the 128-row bf16 kernel's): 219 us for
+// 142 us of fp32 matrix work at the nominal clock; this one 209 us.  Here: a workgroup = a tile of 32 decoder rows x all playlists, the rows
 // as plain 1 KB reads into LDS (fp32, 1 040-byte rows, two tiles in rotation), a wave = 32 playlists whose hidden row sits in
 // 128 registers, the A fragments from LDS (a float4 = four MFMAs).  The k order inside a dot product is the row-major kernel's
 // (pairs (8 g + c, 8 g + 4 + c)); training compares by tolerance.
@@ -2652,29 +2498,14 @@ int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, i
         DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_bf16_kernel");
         return DAE_OK;
     }
-    if (B <= 256) {
-        const size_t lds_s = ((size_t)2 * 32 * 260 + 8) * sizeof(float);
-        static const char rs_key = 0;
-        if (dae_first_use(ctx, &rs_key))
-            DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_loss_shared_f32_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-#ifdef DAE_EXPERIMENTS
-        static const bool k5_rowmajor = dae_exp_env("DAE_K5_ROWMAJOR") != nullptr;            // A/B: the row-gathering kernel below
-        if (!k5_rowmajor)
-#endif
-        {
-            hipLaunchKernelGGL(decode_loss_shared_f32_kernel, dim3(g.grid), dim3(512), lds_s, ctx->stream, p);
-            DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_f32_kernel");
-            return DAE_OK;
-        }
-    }
-    const size_t lds = (size_t)32 * 4 * 64 * sizeof(float4);
-    static const char rm_key = 0;
-    if (dae_first_use(ctx, &rm_key))
-        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_loss_rowmajor_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // + 16 B static
-    hipLaunchKernelGGL(decode_loss_rowmajor_kernel, dim3(g.grid), dim3(256), lds, ctx->stream, p);
-    DAE_CHECK_LAUNCH(ctx, "decode_loss_rowmajor_kernel");
+    if (B > 256) return DAE_ERR_STATE;
+    const size_t lds_s = ((size_t)2 * 32 * 260 + 8) * sizeof(float);
+    static const char rs_key = 0;
+    if (dae_first_use(ctx, &rs_key))
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_loss_shared_f32_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    hipLaunchKernelGGL(decode_loss_shared_f32_kernel, dim3(g.grid), dim3(512), lds_s, ctx->stream, p);
+    DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_f32_kernel");
     return DAE_OK;
 }
 

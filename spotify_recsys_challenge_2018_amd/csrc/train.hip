@@ -775,6 +775,125 @@ __global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t32_kernel(const GwP p)
     }
 }
 
+// ---- K6 with fp32 operands (train_dtype = f32), the armed-Adam form with its state streams kept in flight (round 6) -------------
+// grad_wdec_t32_kernel's plan on v_mfma_f32_32x32x2_f32: a tile of 32 decoder rows, A = dz^T (fp32 rows; a float4 = 4
+// playlists = two k-steps, the lane half hi taking the even / odd one), B = h^T from LDS (one float4 per lane and k-step: the four
+// accumulators' hidden units), 512 MFMAs per tile, the row sums (gb) on the VALU; then the Adam pass of section 12 -- the first
+// group of p / m / v rows requested before the MFMAs, group g + 1 before group g is computed.  The generic kernel it replaces
+// for this case (grad_wdec_kernel<4, 8, false, false, true>) ran its two phases back to back at 12 KB in flight per wave: 349 us
+// for 180 us of matrix work and 1.22 GB.
+template <int NW, bool FULL>
+__global__ __launch_bounds__(NW * 64, 1) void grad_wdec_t32_f32_kernel(const GwP p)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 ldsf[];     // [Bp / 2 k-steps][64 lanes]: h[2 g + hi][hc0 + 4 n .. + 3]
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, n = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gs = DAE_NUM_XCD * p.n_half;
+    const int q_ = blockIdx.x / gs, rem = blockIdx.x % gs;
+    const int half = rem / DAE_NUM_XCD;
+    const int bir = q_ * DAE_NUM_XCD + (rem % DAE_NUM_XCD);
+    const int hc0 = half * 128;
+    const int Bp = (p.B + 31) & ~31;
+    const int Q = Bp >> 2;                                             // float4 of a dz^T row (4 playlists each)
+
+    for (int f = tid; f < (Bp >> 1) * 64; f += NW * 64) {
+        const int fl = f & 63, g = f >> 6;
+        const int r = 2 * g + (fl >> 5);
+        ldsf[f] = r < p.B ? *reinterpret_cast<const float4*>(p.h + (size_t)r * p.H + hc0 + 4 * (fl & 31)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const int n_tiles = (p.V + 31) / 32;
+    const int n_ws = p.nb_half * NW;
+    constexpr int RING = 4;
+    const unsigned himask = hi ? 0xFFFFFFFFu : 0u;
+    // (Tried: the second wave of each SIMD starting 2 .. 16 x 8 k cycles late, so that one wave's MFMAs run under the other's state
+    // streams -- 345 - 352 us at every setting: phases that coincide are not what this launch loses its time to.)
+#define K6F_SEL(A, Bv) __uint_as_float((__float_as_uint(Bv) & himask) | (__float_as_uint(A) & ~himask))
+    const float b1 = p.ad_b1, b2 = p.ad_b2, eps = p.ad_eps, al = p.ad_alpha;
+    for (int t = bir * NW + wave; t < n_tiles; t += n_ws) {
+        const int v0 = t * 32;
+        const int va = v0 + n;
+        const float4* ra = reinterpret_cast<const float4*>(p.dzT + (size_t)(va < p.V ? va : 0) * p.ldT);
+        f32x16 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][e] = 0.0f;
+        float cs = 0.0f;
+        float4 qa[RING];
+#pragma unroll
+        for (int u = 0; u < RING; ++u) qa[u] = ra[(FULL || u < Q) ? u : Q - 1];
+        float4 P[2][4], M[2][4], Vv[2][4];
+        size_t off[2][4];
+        bool ok[2][4];
+        auto issue = [&](int buf, int r4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int reg = r4 + u;
+                const int v = v0 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                ok[buf][u] = v < p.V;
+                off[buf][u] = (size_t)(ok[buf][u] ? v : 0) * p.H + hc0 + 4 * n;
+                P[buf][u] = nt_ld4(p.ad_p + off[buf][u]);
+                M[buf][u] = nt_ld4(p.ad_m + off[buf][u]);
+                Vv[buf][u] = nt_ld4(p.ad_v + off[buf][u]);
+            }
+        };
+        issue(0, 0);                                                   // arrives under the 512 MFMAs
+        const int q_end = FULL ? 64 : Q;
+        for (int q0 = 0; q0 < q_end; q0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int qq = q0 + u;
+                const float4 d4 = qa[u];
+                {
+                    const int qn = qq + RING;
+                    qa[u] = ra[(FULL ? qn < 64 : qn < Q) ? qn : q_end - 1];
+                }
+                const float4 bA = ldsf[(2 * qq) * 64 + lane], bB = ldsf[(2 * qq + 1) * 64 + lane];
+                const float dA = K6F_SEL(d4.x, d4.y), dB = K6F_SEL(d4.z, d4.w);
+                __builtin_amdgcn_sched_barrier(0);
+                cs += dA; cs += dB;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dA, bA.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dA, bA.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dA, bA.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(dA, bA.w, acc[3], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dB, bB.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dB, bB.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dB, bB.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(dB, bB.w, acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        cs += __shfl_xor(cs, 32);                                      // the two lane halves hold the even / odd playlists of the row
+        if (p.gb && half == 0 && hi == 0 && va < p.V) p.gb[va] = cs;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = g & 1;
+            if (g + 1 < 4) issue(cb ^ 1, 4 * (g + 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int reg = 4 * g + u;
+                float4 pp = P[cb][u], mm = M[cb][u], vv = Vv[cb][u];
+                const float g0 = acc[0][reg], g1 = acc[1][reg], g2 = acc[2][reg], g3 = acc[3][reg];
+#define K6_ADAM(Pq, Mq, Vq, G)                                           \
+                Mq = Mq + (G - Mq) * (1.0f - b1);                        \
+                Vq = Vq + (G * G - Vq) * (1.0f - b2);                    \
+                Pq = Pq - (Mq * al) / (sqrtf(Vq) + eps);
+                K6_ADAM(pp.x, mm.x, vv.x, g0) K6_ADAM(pp.y, mm.y, vv.y, g1)
+                K6_ADAM(pp.z, mm.z, vv.z, g2) K6_ADAM(pp.w, mm.w, vv.w, g3)
+#undef K6_ADAM
+                if (ok[cb][u]) {
+                    nt_st4(p.ad_p + off[cb][u], pp);
+                    nt_st4(p.ad_m + off[cb][u], mm);
+                    nt_st4(p.ad_v + off[cb][u], vv);
+                }
+            }
+        }
+    }
+#undef K6F_SEL
+}
+
 // ---- K7: dh partial [chunk][r][hc] = sum_{v in chunk} dzT[v, r] * W[v, hc] -----------------------
 // a wave owns one (hidden half of 128, 64 playlists) output tile for one chunk of V: 8 accumulators;
 // A = W rows (float4 per lane: hc0 + 4 i + a), B = dz^T rows (float2 per lane: r0 + 2 j + b); no LDS.
@@ -1566,6 +1685,21 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             }
             static const bool k6_old32 = dae_exp_env("DAE_K6_ORIENT") && !strcmp(dae_exp_env("DAE_K6_ORIENT"), "hidden");   // A/B
+            static const bool k6_generic = dae_exp_env("DAE_K6_GENERIC") != nullptr;                // A/B: the generic kernel below
+            const int Bp32 = (B + 31) & ~31;
+            if (p.ad_m && H == 256 && !k6_old32 && !k6_generic && (Bp32 & 15) == 0) {
+                // (the ring walks the dz^T row four float4 at a time: whole groups of 16 playlists)
+                const size_t lds_f = (size_t)(Bp32 >> 1) * 64 * sizeof(float4);
+                static const char attr_tf32_key = 0;
+                if (dae_first_use(ctx, &attr_tf32_key)) {
+                    DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t32_f32_kernel<8, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&grad_wdec_t32_f32_kernel<8, false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                }
+                if (Bp32 == 256) hipLaunchKernelGGL((grad_wdec_t32_f32_kernel<8, true>), grid, dim3(512), lds_f, st, p);
+                else hipLaunchKernelGGL((grad_wdec_t32_f32_kernel<8, false>), grid, dim3(512), lds_f, st, p);
+            } else
             if (!k6_old32) {
                 static const char attr8t_key = 0;
                 if (dae_first_use(ctx, &attr8t_key))
