@@ -314,6 +314,9 @@ int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, i
                                     const float* bias, const float* h, float inv_n_batch, float* dzT, int64_t ldT,
                                     float* loss_part, int dtype = DAE_DTYPE_F32, int dz16 = 0);
 
+int dae_launch_decode_loss_dh(dae_ctx* ctx, const dae_rowgeom& g, int B, int V, int H, const float* W, const float* bias,
+                              const float* h, float inv_n_batch, float* dzT, int64_t ldT, float* loss_part, float* part, int Bpad64);
+
 // train.hip
 int dae_train_step_f32(dae_ctx* ctx,
         const int32_t* x_row_ptr, const int32_t* x_col, const float* x_val,

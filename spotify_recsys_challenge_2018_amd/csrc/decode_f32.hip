@@ -825,6 +825,217 @@ __global__ __launch_bounds__(512, 1) void decode_loss_shared_bf16_kernel(const L
     }
 }
 
+// ---- K5 + K7 in one launch (bf16 operands, dz^T as bf16, hidden 256, batches <= 256): dh folded into the forward (round 6) ----
+// K7 (train.hip grad_hidden_kernel) reads the whole decoder a second time and dz^T back from HBM to form dh = dz W_dec.  Here
+// the tile of decoder rows is in LDS already and a lane holds its playlist's 16 dz values of the tile when the epilogue ends:
+// the wave multiplies them (A operand: straight from the epilogue's packed bf16 pairs -- the MFMA's k-slots are assigned to
+// the tile's rows the way the accumulator layout hands them out) by the tile (B operand: a TRANSPOSED bf16 copy of the tile
+// in LDS, [hidden unit][row], the rows permuted the same way) into 8 accumulators = dh[its 32 playlists][256], kept for the
+// whole launch and left as one partial per workgroup (part[blockIdx.x][playlist][hidden]: the fixed-order reduce of
+// hidden_backward_kernel sums them, K7's chunks before).  Every element is still a NEGATIVE here: loss_fixup_kernel<.., CORR>
+// adds (dz_positive - dz_negative) W_dec[v] for the ~25 k positives as one more partial.  Products: bf16(dz) x bf16(W), fp32
+// accumulate, as K7's.  Registers: 128 (dh) + 32 (half of the hidden fragments; the other half in LDS) + the forward's.
+__device__ __forceinline__ unsigned k5d_pk2(float a, float b)
+{
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__global__ __launch_bounds__(512, 1) void decode_loss_dh_bf16_kernel(const LossRmP p, float* __restrict__ part, int Bpad64)
+{
+    constexpr int NW = 8, LDW = 132, LDT = 18;                         // dwords per staged row: forward copy / transposed copy
+    extern __shared__ __attribute__((aligned(16))) unsigned dyn[];
+    unsigned* const wt = dyn;                                          // [2][32 * LDW]          forward copy  [row v][k]
+    unsigned* const wt2 = dyn + 2 * 32 * LDW;                          // [2][256 * LDT]         transposed    [hidden][row, permuted]
+    uint4* const hq = reinterpret_cast<uint4*>(dyn + 2 * 32 * LDW + 2 * 256 * LDT);     // [8 steps][8 waves][64]: steps 8 .. 15
+    float* const wsum = reinterpret_cast<float*>(hq + 8 * 8 * 64);
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, j = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = wave * 32 + j;
+    const int H4 = p.H >> 2;
+    const float4* W4 = reinterpret_cast<const float4*>(p.W);
+    const int n_tiles = (p.V + 31) >> 5;
+    const int nb = gridDim.x;
+    const int t_last = n_tiles - 1;
+
+    // hidden fragments of the lane's playlist: steps 0 .. 7 in registers, 8 .. 15 in LDS (zeros past the batch)
+    uint4 hb[8];
+    {
+        const float4* hr = reinterpret_cast<const float4*>(p.h) + (size_t)(row < p.B ? row : 0) * H4 + 2 * hi;
+        float4 ha[16], hc[16];
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) { ha[s_] = hr[4 * s_]; hc[s_] = hr[4 * s_ + 1]; }
+        const unsigned keep = row < p.B ? 0xFFFFFFFFu : 0u;
+#define K5D_FRAG(A, B) make_uint4((bf16_rne(A.x) | (bf16_rne(A.y) << 16)) & keep, (bf16_rne(A.z) | (bf16_rne(A.w) << 16)) & keep, \
+                                  (bf16_rne(B.x) | (bf16_rne(B.y) << 16)) & keep, (bf16_rne(B.z) | (bf16_rne(B.w) << 16)) & keep)
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) hb[s_] = K5D_FRAG(ha[s_], hc[s_]);
+#pragma unroll
+        for (int s_ = 8; s_ < 16; ++s_) hq[((s_ - 8) * NW + wave) * 64 + lane] = K5D_FRAG(ha[s_], hc[s_]);
+#undef K5D_FRAG
+    }
+    // the wave's four rows of a tile (lane l: floats 4 l .. 4 l + 3 of each), staged twice: as they are ([row][k]) and transposed
+    // ([hidden 4 l + c][the wave's 4 rows]: position of row v = 16 s + 4 h + 8 g + i in its 32: (2 s + h) 8 + 4 g + i, with
+    // (s, g, h) = bits of the wave index -- the k-slot order of the dh MFMAs below)
+    float4 w0, w1, w2, w3;
+    const int tpos = (((wave >> 2) << 1) | (wave & 1)) * 4 + ((wave >> 1) & 1) * 2;          // dwords into a transposed row
+#define K5D_LOAD(T)                                                                            \
+    {                                                                                          \
+        const int v_ = (T) * 32 + 4 * wave;                                                    \
+        w0 = W4[(size_t)(v_ < p.V ? v_ : p.V - 1) * H4 + lane];                                \
+        w1 = W4[(size_t)(v_ + 1 < p.V ? v_ + 1 : p.V - 1) * H4 + lane];                        \
+        w2 = W4[(size_t)(v_ + 2 < p.V ? v_ + 2 : p.V - 1) * H4 + lane];                        \
+        w3 = W4[(size_t)(v_ + 3 < p.V ? v_ + 3 : p.V - 1) * H4 + lane];                        \
+    }
+#define K5D_PK(A, B) k5d_pk2((A), (B))                                       /* v_cvt_pk_bf16_f32 (RNE) */
+#define K5D_STAGE(BUF)                                                                         \
+    {                                                                                          \
+        unsigned* d_ = wt + (BUF) * 32 * LDW + (4 * wave) * LDW + 2 * lane;                    \
+        *reinterpret_cast<uint2*>(d_) = make_uint2(K5D_PK(w0.x, w0.y), K5D_PK(w0.z, w0.w));    \
+        *reinterpret_cast<uint2*>(d_ + LDW) = make_uint2(K5D_PK(w1.x, w1.y), K5D_PK(w1.z, w1.w)); \
+        *reinterpret_cast<uint2*>(d_ + 2 * LDW) = make_uint2(K5D_PK(w2.x, w2.y), K5D_PK(w2.z, w2.w)); \
+        *reinterpret_cast<uint2*>(d_ + 3 * LDW) = make_uint2(K5D_PK(w3.x, w3.y), K5D_PK(w3.z, w3.w)); \
+        unsigned* e_ = wt2 + (BUF) * 256 * LDT + (4 * lane) * LDT + tpos;                      \
+        *reinterpret_cast<uint2*>(e_) = make_uint2(K5D_PK(w0.x, w1.x), K5D_PK(w2.x, w3.x));    \
+        *reinterpret_cast<uint2*>(e_ + LDT) = make_uint2(K5D_PK(w0.y, w1.y), K5D_PK(w2.y, w3.y)); \
+        *reinterpret_cast<uint2*>(e_ + 2 * LDT) = make_uint2(K5D_PK(w0.z, w1.z), K5D_PK(w2.z, w3.z)); \
+        *reinterpret_cast<uint2*>(e_ + 3 * LDT) = make_uint2(K5D_PK(w0.w, w1.w), K5D_PK(w2.w, w3.w)); \
+    }
+    auto load_bias = [&](int t) -> float {
+        const int c = t * 32 + j;
+        return p.bias[c < p.V ? c : p.V - 1];
+    };
+
+    f32x16 dh[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dh[b][e] = 0.0f;
+    float loss_acc = 0.0f;
+    float bl, bl_n = 0.0f;
+    int t = blockIdx.x;
+    K5D_LOAD(t < t_last ? t : t_last)
+    bl = load_bias(t < t_last ? t : t_last);
+    K5D_STAGE(0)
+    K5D_LOAD(t + nb < t_last ? t + nb : t_last)
+    __syncthreads();
+    const float k1 = 0.55f * p.inv_nb;
+    const bool row_in = row < p.B;
+    int buf = 0;
+    for (; t < n_tiles; t += nb, buf ^= 1) {
+        K5D_STAGE(buf ^ 1)                                             // tile t + nb (or a clamped copy nobody reads)
+        bl_n = load_bias(t + nb < t_last ? t + nb : t_last);
+        K5D_LOAD(t + 2 * nb < t_last ? t + 2 * nb : t_last)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        const unsigned* wl = wt + buf * 32 * LDW + j * LDW + 4 * hi;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const uint4 af = *reinterpret_cast<const uint4*>(wl + 8 * s_);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(af), as_bf16x8(hb[s_]), acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s_ = 8; s_ < 16; ++s_) {
+            const uint4 af = *reinterpret_cast<const uint4*>(wl + 8 * s_);
+            const uint4 bf = hq[((s_ - 8) * NW + wave) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(af), as_bf16x8(bf), acc, 0, 0, 0);
+        }
+        // epilogue: lane (j, hi) holds, for playlist `row`, the columns t 32 + 4 hi + 8 qd + e; dz of columns past V and of
+        // playlists past the batch is 0 (and not stored)
+        float dzv[16];
+        float q_min = 1.0f;
+        const int tcol0 = t * 32 + 4 * hi;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float zz = acc[4 * qd + e] + __shfl(bl, 4 * hi + 8 * qd + e);
+                const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                const float q = 1.0f - pr;
+                const bool live = row_in && tcol0 + 8 * qd + e < p.V;
+                loss_acc -= live ? (0.69314718f * 0.55f) * __builtin_amdgcn_logf(q + 1e-10f) : 0.0f;
+                q_min = fminf(q_min, live ? q : 1.0f);
+                // dL/dz = 0.55 y (1 - y) / (1 - y + 1e-10) (DAEs.py:98-99's negatives): the quotient is 1 to 2^-13 unless 1 - y < 1e-6
+                dzv[4 * qd + e] = live ? k1 * pr : 0.0f;
+            }
+        }
+        if (__builtin_expect(__ballot(q_min < 1e-6f) != 0ull, 0)) {   // (a logit above 13.8 somewhere in the wave: the exact form)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float zz = acc[4 * qd + e] + __shfl(bl, 4 * hi + 8 * qd + e);
+                    const float pr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * zz));
+                    const float q = 1.0f - pr;
+                    const bool live = row_in && tcol0 + 8 * qd + e < p.V;
+                    if (live && q < 1e-6f) dzv[4 * qd + e] = k1 * __builtin_amdgcn_rcpf(q + 1e-10f) * pr * q;
+                }
+        }
+        unsigned pk[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) pk[x] = K5D_PK(dzv[2 * x], dzv[2 * x + 1]);
+        if (row_in) {
+            unsigned short* const d16 = reinterpret_cast<unsigned short*>(p.dzT) + (size_t)t * 32 * p.ldT;
+            const unsigned lane_off = (unsigned)(4 * hi) * (unsigned)p.ldT + (unsigned)row;
+            if (t * 32 + 32 <= p.V) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int c = 8 * (x >> 1) + 2 * (x & 1);              // column offset of the pair's first element
+                    (d16 + (size_t)c * p.ldT)[lane_off] = (unsigned short)(pk[x] & 0xFFFFu);
+                    (d16 + (size_t)(c + 1) * p.ldT)[lane_off] = (unsigned short)(pk[x] >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int c = 8 * (x >> 1) + 2 * (x & 1);
+                    if (tcol0 + c < p.V) (d16 + (size_t)c * p.ldT)[lane_off] = (unsigned short)(pk[x] & 0xFFFFu);
+                    if (tcol0 + c + 1 < p.V) (d16 + (size_t)(c + 1) * p.ldT)[lane_off] = (unsigned short)(pk[x] >> 16);
+                }
+            }
+        }
+        // dh[playlist][hidden] += dz[playlist][the tile's rows] W[rows][hidden]: A = dz (k-slot i of lane half hi, step s: row
+        // 16 s + 4 hi + i for i < 4, + 8 + (i - 4) above), B = the transposed tile, block b of 32 hidden units
+        const uint4 a0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), a1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        const unsigned* tl = wt2 + buf * 256 * LDT + j * LDT + 4 * hi;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint2 x0 = *reinterpret_cast<const uint2*>(tl + b * 32 * LDT), x1 = *reinterpret_cast<const uint2*>(tl + b * 32 * LDT + 2);
+            const uint2 y0 = *reinterpret_cast<const uint2*>(tl + b * 32 * LDT + 8), y1 = *reinterpret_cast<const uint2*>(tl + b * 32 * LDT + 10);
+            dh[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(make_uint4(x0.x, x0.y, x1.x, x1.y)), dh[b], 0, 0, 0);
+            dh[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(make_uint4(y0.x, y0.y, y1.x, y1.y)), dh[b], 0, 0, 0);
+        }
+        bl = bl_n;
+        __syncthreads();
+    }
+    // the workgroup's partial of dh: register reg of lane (j, hi), block b = playlist 32 wave + (reg & 3) + 8 (reg >> 2) + 4 hi,
+    // hidden 32 b + j
+    {
+        float* pw = part + (size_t)blockIdx.x * Bpad64 * p.H;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                if (r < Bpad64) pw[(size_t)r * p.H + b * 32 + j] = dh[b][reg];
+            }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) loss_acc += __shfl_xor(loss_acc, d);
+    if (lane == 0) wsum[wave] = loss_acc;
+    __syncthreads();
+    if (tid == 0) {
+        float sm = 0.0f;
+        for (int w = 0; w < NW; ++w) sm += wsum[w];
+        p.loss_part[blockIdx.x] = sm * p.inv_nb;
+    }
+}
+#undef K5D_LOAD
+#undef K5D_PK
+#undef K5D_STAGE
+
 // ---- K5, fp32 operands, hidden 256, batches of at most 256 playlists: the same shape on v_mfma_f32_32x32x2_f32 (round 6) ----
 // The row-gathering fp32 kernel it replaces (64 cache lines per load instruction, as the 128-row bf16 kernel's): 219 us for
 // 142 us of fp32 matrix work at the nominal clock; this one 209 us.  Here: a workgroup = a tile of 32 decoder rows x all playlists, the rows
@@ -2506,6 +2717,25 @@ int dae_launch_decode_loss_rowmajor(dae_ctx* ctx, const dae_rowgeom& g, int B, i
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     hipLaunchKernelGGL(decode_loss_shared_f32_kernel, dim3(g.grid), dim3(512), lds_s, ctx->stream, p);
     DAE_CHECK_LAUNCH(ctx, "decode_loss_shared_f32_kernel");
+    return DAE_OK;
+}
+
+// K5 + K7 fused (decode_loss_dh_bf16_kernel): g.grid partials of dh at `part` ([g.grid][Bpad64][H]); DAE_ERR_STATE when the shape does not apply
+int dae_launch_decode_loss_dh(dae_ctx* ctx, const dae_rowgeom& g, int B, int V, int H, const float* W, const float* bias,
+                              const float* h, float inv_n_batch, float* dzT, int64_t ldT, float* loss_part, float* part, int Bpad64)
+{
+    if (H != 256 || B > 256 || g.R_TILE != 128 || g.waves != 4) return DAE_ERR_STATE;
+    if ((uint64_t)ldT * 4 + (uint64_t)g.Bpad >= (1ull << 30)) return DAE_ERR_STATE;
+    LossRmP p;
+    p.W = W; p.bias = bias; p.h = h; p.V = V; p.H = H; p.B = B; p.n_rg = g.n_rg; p.nb_rg = g.nb_rg;
+    p.inv_nb = inv_n_batch; p.dzT = dzT; p.ldT = ldT; p.loss_part = loss_part;
+    const size_t lds = ((size_t)2 * 32 * 132 + (size_t)2 * 256 * 18) * 4 + (size_t)8 * 8 * 64 * 16 + 64;
+    static const char key = 0;
+    if (dae_first_use(ctx, &key))
+        DAE_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_loss_dh_bf16_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decode_loss_dh_bf16_kernel, dim3(g.grid), dim3(512), lds, ctx->stream, p, part, Bpad64);
+    DAE_CHECK_LAUNCH(ctx, "decode_loss_dh_bf16_kernel");
     return DAE_OK;
 }
 

@@ -71,7 +71,10 @@ __device__ __forceinline__ float bf16_value(float f)
 }
 // BF16: the forward GEMM ran on bf16 operands (dae_set_train_dtype): W and h are rounded the same way here
 // DZ16: dL/dz is kept as bf16 (the bf16 backward GEMMs read it as such)
-template <bool BF16, bool DZ16 = false>
+// CORR (with BF16 and DZ16: the forward launch has already folded dh = dz W_dec into itself with every element a negative):
+// the row's dh correction sum_i (bf16(dz_i) - bf16(dz_i as a negative)) bf16(W_dec[v_i]) goes out as one more partial
+// (corr_out[row][k]); the value the forward launch stored is read back before it is overwritten, so the difference is exact.
+template <bool BF16, bool DZ16 = false, bool CORR = false>
 __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ col,
                                                          const float* __restrict__ val, int B, int H,
@@ -80,10 +83,13 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
                                                          const float* __restrict__ Wd,     // [col_hi - col_lo, H]
                                                          const float* __restrict__ bias,   // local column index
                                                          float inv_nb, float* __restrict__ dzT, int64_t ldT,
-                                                         float* __restrict__ loss_part)
+                                                         float* __restrict__ loss_part, float* __restrict__ corr_out = nullptr)
 {
     __shared__ float4 sh[FIX_MAXH / 4];
     __shared__ float wsum[4];
+    constexpr int CCAP = CORR ? 1024 : 1;
+    __shared__ float cdel[CCAP];
+    __shared__ int ccol[CCAP];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int H4 = H >> 2;
     for (int i = tid; i < H4; i += 256) {
@@ -127,14 +133,62 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
         corr -= 0.69314718f * y * (l1 - 0.55f * l0);
         const float dzv = -(y * __builtin_amdgcn_rcpf(a1) - 0.55f * (1.0f - y) * __builtin_amdgcn_rcpf(a0)) *
                           pr * (1.0f - pr) * inv_nb;
-        if (DZ16) reinterpret_cast<unsigned short*>(dzT)[(size_t)lc * ldT + row] = (unsigned short)(pk_bf16(dzv, 0.0f) & 0xFFFFu);
-        else dzT[(size_t)lc * ldT + row] = dzv;
+        if (DZ16) {
+            unsigned short* dst = reinterpret_cast<unsigned short*>(dzT) + (size_t)lc * ldT + row;
+            const unsigned short nw = (unsigned short)(pk_bf16(dzv, 0.0f) & 0xFFFFu);
+            if (CORR) {
+                const int e = i - row_ptr[row];
+                if (e < CCAP) { cdel[e] = __uint_as_float((unsigned)nw << 16) - __uint_as_float((unsigned)*dst << 16); ccol[e] = lc; }
+            }
+            *dst = nw;
+        } else dzT[(size_t)lc * ldT + row] = dzv;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) corr += __shfl_xor(corr, d);
     if ((tid & 63) == 0) wsum[tid >> 6] = corr;
     __syncthreads();
     if (tid == 0) loss_part[row] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_nb;
+    if (CORR) {
+        // entries outside [col_lo, col_hi) wrote nothing: mark them (a second sweep over the row's entries, in entry order)
+        const int beg = row_ptr[row], n = min(row_ptr[row + 1] - beg, CCAP);
+        __syncthreads();
+        for (int e = tid; e < n; e += 256) { const int c = col[beg + e]; if (c < col_lo || c >= col_hi) { cdel[e] = 0.0f; ccol[e] = 0; } }
+        __syncthreads();
+        // wave g takes the entries g, g + 4, ... (a lane = four hidden units: plain 1 KB row reads, 8 in flight), the four partial
+        // sums meet in LDS and are added in wave order: a fixed order, whatever the timing
+        float4* const cacc = sh;                                    // (the hidden row is no longer needed: [4][H / 4] float4 fit)
+        __syncthreads();
+        const int wv_ = tid >> 6, ln_ = tid & 63;
+        for (int k4 = ln_; k4 < (H >> 2); k4 += 64) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            int e = wv_;
+            for (; e + 28 < n; e += 32) {
+                float4 wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = reinterpret_cast<const float4*>(Wd + (size_t)ccol[e + 4 * u] * H)[k4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d = cdel[e + 4 * u];
+                    a.x = fmaf(d, bf16_value(wv[u].x), a.x); a.y = fmaf(d, bf16_value(wv[u].y), a.y);
+                    a.z = fmaf(d, bf16_value(wv[u].z), a.z); a.w = fmaf(d, bf16_value(wv[u].w), a.w);
+                }
+            }
+            for (; e < n; e += 4) {
+                const float4 w1 = reinterpret_cast<const float4*>(Wd + (size_t)ccol[e] * H)[k4];
+                const float d = cdel[e];
+                a.x = fmaf(d, bf16_value(w1.x), a.x); a.y = fmaf(d, bf16_value(w1.y), a.y);
+                a.z = fmaf(d, bf16_value(w1.z), a.z); a.w = fmaf(d, bf16_value(w1.w), a.w);
+            }
+            cacc[wv_ * (FIX_MAXH / 16) + k4] = a;
+        }
+        __syncthreads();
+        for (int k4 = tid; k4 < (H >> 2); k4 += 256) {
+            const float4 p0 = cacc[k4], p1 = cacc[(FIX_MAXH / 16) + k4], p2 = cacc[2 * (FIX_MAXH / 16) + k4], p3 = cacc[3 * (FIX_MAXH / 16) + k4];
+            reinterpret_cast<float4*>(corr_out + (size_t)row * H)[k4] =
+                make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                            ((p0.w + p1.w) + p2.w) + p3.w);
+        }
+    }
 }
 
 // ---- K6: gW[v, hc] (+)= sum_r dz[r, v] * h[r, hc];  gb[v] = sum_r dz[r, v] ----------------------
@@ -1527,6 +1581,7 @@ namespace {
 // (Vl, H, B), so the stages of a sharded step find h / sg where the earlier stage left them
 struct TrainPlan {
     int NA, G, RB, Bpad64, n_chunk, chunk, n_fix, dtype, dz16, rm;
+    int fuse_dh;        // K5 leaves dh's partials itself (decode_f32.hip decode_loss_dh_bf16_kernel): no K7; n_chunk = g.grid + 1
     dae_rowgeom g;
     size_t bh, hp_bytes;
     float *dzT, *hbuf, *sg, *dpre, *part, *loss_part;
@@ -1564,6 +1619,11 @@ int train_plan(dae_ctx* ctx, int Vl, int H, int B, TrainPlan& t)
     t.chunk = ((Vl + want_chunks - 1) / want_chunks + 15) / 16 * 16;
     if (t.chunk < 16) t.chunk = 16;
     t.n_chunk = (Vl + t.chunk - 1) / t.chunk;
+    {   // bf16 GEMMs with dz^T as bf16 at hidden 256: dh comes out of the forward launch, one partial per workgroup + the positives'
+        static const bool no_fuse = dae_exp_env("DAE_K5_NOFUSE") != nullptr;                   // A/B: K5, then K7
+        t.fuse_dh = (t.rm && t.dtype == DAE_DTYPE_BF16 && t.dz16 && !no_fuse) ? 1 : 0;
+        if (t.fuse_dh) t.n_chunk = t.g.grid + 1;
+    }
     t.bh = (size_t)B * H;
     t.n_fix = B;                                   // loss partials of the positives: one per row
     const size_t c_floats = 3 * t.bh + (size_t)t.n_chunk * t.Bpad64 * H + (size_t)t.g.grid + t.n_fix + 64;
@@ -1591,13 +1651,23 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     if (H > FIX_MAXH) return dae_fail(ctx, DAE_ERR_ARG, "training kernels need H <= %d (H=%d)", FIX_MAXH, H);
     if (t.Bpad64 != B)
         DAE_HIP_CHECK(ctx, hipMemsetAsync(t.dzT, 0, (size_t)Vl * t.Bpad64 * (t.dz16 ? sizeof(unsigned short) : sizeof(float)), st));
-    if (t.rm)
+    float* const corr_part = t.part + (size_t)(t.n_chunk - 1) * t.Bpad64 * H;         // (fuse_dh: the positives' partial, the last one)
+    if (t.fuse_dh) {
+        rc = dae_launch_decode_loss_dh(ctx, t.g, B, Vl, H, Wd, b_dec, t.hbuf, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part,
+                                       t.part, t.Bpad64);
+        if (rc == DAE_ERR_STATE) return dae_fail(ctx, DAE_ERR_STATE, "the fused K5 + K7 launch does not take this shape");
+        if (t.Bpad64 != B) DAE_HIP_CHECK(ctx, hipMemsetAsync(corr_part, 0, (size_t)t.Bpad64 * H * sizeof(float), st));
+    } else if (t.rm)
         rc = dae_launch_decode_loss_rowmajor(ctx, t.g, B, Vl, H, Wd, b_dec, t.hbuf, 1.0f / (float)n_batch, t.dzT, t.Bpad64,
                                              t.loss_part, t.dtype, t.dz16);
     else
         rc = dae_launch_decode_loss_f32(ctx, t.g, B, 1.0f / (float)n_batch, t.dzT, t.Bpad64, t.loss_part, t.dtype, t.dz16);
     if (rc) return rc;
-    if (t.dtype == DAE_DTYPE_BF16 && t.dz16)
+    if (t.fuse_dh)
+        hipLaunchKernelGGL((loss_fixup_kernel<true, true, true>), dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
+                           col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
+                           t.loss_part + t.g.grid, corr_part);
+    else if (t.dtype == DAE_DTYPE_BF16 && t.dz16)
         hipLaunchKernelGGL((loss_fixup_kernel<true, true>), dim3(B), dim3(256), 0, st, y_row_ptr, y_col, y_val, B, H, col_lo,
                            col_hi, t.hbuf, Wd, b_dec, 1.0f / (float)n_batch, t.dzT, (int64_t)t.Bpad64,
                            t.loss_part + t.g.grid);
@@ -1739,13 +1809,13 @@ int train_decode_backward(dae_ctx* ctx, const TrainPlan& t, int Vl, int H, int B
     // the weights the forward pass used: K7 first.
     if (ctx->arm_m) {
         if (NA != 4) { ctx->arm_m = nullptr; return dae_fail(ctx, DAE_ERR_ARG, "the armed decoder Adam needs H %% 128 == 0 (H=%d)", H); }
-        rc = run_k7(); if (rc) return rc;
+        if (!t.fuse_dh) { rc = run_k7(); if (rc) return rc; }
         rc = run_k6();
         ctx->arm_m = nullptr; ctx->arm_v = nullptr;         // one step only
         return rc;
     }
     rc = run_k6(); if (rc) return rc;
-    return run_k7();
+    return t.fuse_dh ? DAE_OK : run_k7();
 }
 
 // cost = sum of the loss partials + lambda * (l2 of the listed tensors)
