@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
     if (tid == 0) loss_part[row] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_nb;
     if (CORR) {
         // entries outside [col_lo, col_hi) wrote nothing: mark them (a second sweep over the row's entries, in entry order)
+        // (a row holds at most CCAP = 1 024 targets here -- a playlist's <= 250 tracks and their artists, spotify_reader.py:84 --;
+        // a longer one poisons its dh row with NaN rather than dropping entries silently)
+        const bool too_long = row_ptr[row + 1] - row_ptr[row] > CCAP;
         const int beg = row_ptr[row], n = min(row_ptr[row + 1] - beg, CCAP);
         __syncthreads();
         for (int e = tid; e < n; e += 256) { const int c = col[beg + e]; if (c < col_lo || c >= col_hi) { cdel[e] = 0.0f; ccol[e] = 0; } }
@@ -185,8 +188,9 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
         for (int k4 = tid; k4 < (H >> 2); k4 += 256) {
             const float4 p0 = cacc[k4], p1 = cacc[(FIX_MAXH / 16) + k4], p2 = cacc[2 * (FIX_MAXH / 16) + k4], p3 = cacc[3 * (FIX_MAXH / 16) + k4];
             reinterpret_cast<float4*>(corr_out + (size_t)row * H)[k4] =
-                make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
-                            ((p0.w + p1.w) + p2.w) + p3.w);
+                too_long ? make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""))
+                         : make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                                       ((p0.w + p1.w) + p2.w) + p3.w);
         }
     }
 }
