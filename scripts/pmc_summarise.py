@@ -114,7 +114,7 @@ f = per_kernel(os.path.join(root, "%s_pmc_train_fetch.csv" % PFX))
 w = per_kernel(os.path.join(root, "%s_pmc_train_write.csv" % PFX))
 trn = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python scripts/bench_train.py --default",
        "fetch_correction": dec["fetch_correction"], "kernel_source_sha256_16": sha}
-for key, sub in (("grad_wdec_adam", "grad_wdec_t"), ("loss_forward", "decode_loss_shared_bf16_kernel"),
+for key, sub in (("grad_wdec_adam", "grad_wdec_t"), ("loss_forward", "decode_loss_"),
                  ("grad_hidden", "grad_hidden_kernel"), ("adam_rows_apply", "adam_rows_kernel<1>"), ("adam_rows_begin", "adam_rows_kernel<0>")):
     kn, fd = find(f, sub)
     _, wd = find(w, sub)

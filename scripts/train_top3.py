@@ -19,6 +19,8 @@ gemm = 2.0 * B * V * H
 def work(kernel, bf16, fused):
     """-> (flop, bytes) of one launch, or None for kernels that are not rated."""
     dz = (2.0 if bf16 else 4.0) * B * V
+    if "decode_loss_dh" in kernel:          # K5 + K7 in one launch: two GEMMs; W once, dz^T written, one dh partial per workgroup
+        return 2 * gemm, mat + dz + 256 * 4.0 * B * H
     if "decode_loss_" in kernel:
         return gemm, mat + dz
     if "grad_wdec" in kernel:
