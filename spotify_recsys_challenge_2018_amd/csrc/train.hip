@@ -107,6 +107,18 @@ __global__ __launch_bounds__(256) void loss_fixup_kernel(const int32_t* __restri
         const float4* w = reinterpret_cast<const float4*>(Wd + (size_t)lc * H);
         float z = 0.0f;
         int k = 0;
+        for (; k + 16 <= H4; k += 16) {                        // (16 loads in flight: the same chain, half the round trips)
+            float4 wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[k + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (BF16) wv[u] = make_float4(bf16_value(wv[u].x), bf16_value(wv[u].y), bf16_value(wv[u].z), bf16_value(wv[u].w));
+                const float4 hv = sh[k + u];
+                z = fmaf(wv[u].x, hv.x, z); z = fmaf(wv[u].y, hv.y, z);
+                z = fmaf(wv[u].z, hv.z, z); z = fmaf(wv[u].w, hv.w, z);
+            }
+        }
         for (; k + 8 <= H4; k += 8) {
             float4 wv[8];
 #pragma unroll
