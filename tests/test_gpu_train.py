@@ -42,6 +42,8 @@ def _uniform(seed, stream, rows, cols):
     # round 6, fp32 K5 through LDS (hidden 256): waves without a playlist, a full batch with more tiles than workgroups
     (3000, 2500, 256, 37, False, 0.0, 0.75, 0.8),
     (20000, 16000, 256, 256, False, 0.0, 1.0, 1.0),
+    (33, 20, 256, 256, False, 0.0, 0.75, 0.8),                   # two tiles, the second with one decoder row
+    (31, 20, 256, 3, False, 0.0, 0.75, 0.8),                     # less than a tile, less than a wave's playlists
 ])
 def test_train_step_gradients(V, nt, H, B, tied, lam, ikp, kp):
     import torch
@@ -246,7 +248,9 @@ def _step(ctx, csr, d, V, H, B, tied, ikp, kp, seed, lam):
                                            # round 6, K5 through LDS: waves without a playlist, a full batch, more tiles
                                            # than workgroups
                                            (3000, 2500, 256, 37, False), (2100, 2000, 256, 256, False),
-                                           (20000, 16000, 256, 200, False)])
+                                           (20000, 16000, 256, 200, False),
+                                           # ... and vocabularies of one or two tiles (the fused K5 + K7 launch's clamps)
+                                           (40, 30, 256, 5, False), (33, 20, 256, 256, False)])
 def test_train_step_bf16_gemms(V, nt, H, B, tied):
     """dae_set_train_dtype(BF16) (BASELINE.json configs[3]): the three GEMMs of the step (forward, gW_dec, dh) run on
     bf16 operands with fp32 accumulate (hidden = 256 / 128: the 4-tile kernels; other sizes keep fp32 backward
