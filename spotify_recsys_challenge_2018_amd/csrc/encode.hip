@@ -191,12 +191,16 @@ __global__ __launch_bounds__(NW * 64) void encode_kernel(const EncP p)
 // Latency mode for small batches: a row is split over HS waves by hidden units (wave q owns units
 // [q*H/HS, (q+1)*H/HS), one or more floats per lane), so HS times more row reads are in flight per
 // playlist.  The per-unit fmaf chain over the non-zeros is unchanged -> same bits as encode_kernel.
-template <int HS>
-__global__ __launch_bounds__(64) void encode_split_kernel(const EncP p)
+// WGW = waves per workgroup (1: a workgroup per (row, quarter); HS: a workgroup per row, its waves the quarters -- the same waves, a
+// quarter of the workgroups to dispatch: round 6's SQ counters showed waves living 6.4 us in a 12.3 us launch of 1 024 one-wave
+// workgroups)
+template <int HS, int WGW = 1>
+__global__ __launch_bounds__(64 * WGW) void encode_split_kernel(const EncP p)
 {
-    const int lane = threadIdx.x;
-    const int row = blockIdx.x / HS;
-    const int q = blockIdx.x % HS;
+    const int lane = threadIdx.x & 63;
+    const int unit = WGW == 1 ? (int)blockIdx.x : (int)blockIdx.x * WGW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row = unit / HS;
+    const int q = unit % HS;
     const int H = p.H;
     const int hq = H / HS;                       // hidden units of this wave (multiple of 4)
     const int hbytes = H * 4;
@@ -376,7 +380,9 @@ int dae_launch_encode(dae_ctx* ctx, const int32_t* row_ptr, const int32_t* col, 
     p.dbg_stop = dbg_stop;
     if (B <= 1024 && (H % 16) == 0 && H >= 64) {
         // small batch: latency bound -> 4 waves per row (by hidden units), 4x the bytes in flight
-        hipLaunchKernelGGL(encode_split_kernel<4>, dim3(B * 4), dim3(64), 0, ctx->stream, p);
+        static const bool enc_wg1 = dae_exp_env("DAE_ENC_WG1") != nullptr;                     // A/B: one wave per workgroup
+        if (enc_wg1) hipLaunchKernelGGL((encode_split_kernel<4, 1>), dim3(B * 4), dim3(64), 0, ctx->stream, p);
+        else hipLaunchKernelGGL((encode_split_kernel<4, 4>), dim3(B), dim3(256), 0, ctx->stream, p);
     } else if (B <= 2048) {
         // few rows: one wave per workgroup spreads the rows over all CUs
         hipLaunchKernelGGL(encode_kernel<1>, dim3(B), dim3(64), 0, ctx->stream, p);
