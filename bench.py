@@ -797,8 +797,14 @@ def main():
     if sim:
         args.force_dist = True
     sharded = world > 1 or args.force_dist
+    saved_stdout_fd = None
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a version banner through C stdio on stdout when the first communicator comes up: file descriptor 1 points at
+        # stderr until the JSON line is due, so that stdout carries that ONE line and nothing else
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "gloo":
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -1716,13 +1722,15 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
-    # the JSON line goes out LAST: RCCL prints its version banner through C stdio, which would
-    # otherwise land after it
+    # the JSON line goes out LAST, on the real stdout (everything C stdio still holds -- RCCL's banner -- is flushed to stderr first)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
+    if saved_stdout_fd is not None:
+        os.dup2(saved_stdout_fd, 1)
+        os.close(saved_stdout_fd)
     if rank == 0:
         verbose = json.dumps(out)
         sys.stderr.write("BENCH_VERBOSE " + verbose + "\n")
